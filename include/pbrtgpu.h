@@ -1,0 +1,234 @@
+/*
+ * pbrtgpu.h -- C ABI of the MI355X path-tracing core (libpbrtgpu.so).
+ *
+ * This is the drop-in boundary for pbrt-r3's per-pixel radiance loop.  pbrt-r3
+ * has no FFI of its own; its extension seams are Rust traits.  Each entry point
+ * below names the reference interface it stands in for (paths relative to the
+ * reference tree):
+ *
+ *   pt_scene_upload      <- what SceneContext::pbrt_shape / make_scene /
+ *                           make_integrator assemble
+ *                           (src/core/api/scene_context/scene_context.rs:1201-1318,
+ *                            :718-729, :675-716) + BVHAccel::new
+ *                           (src/accelerators/bvh/accel/qbvh/qbvh_x86.rs:352-370)
+ *   pt_render            <- Integrator::render (src/core/integrator/integrator.rs:6-9),
+ *                           i.e. SampleIntegratorCore::render
+ *                           (src/core/integrator/sampler.rs:259-325)
+ *   pt_film_*            <- Film::merge_film_tile / write_image
+ *                           (src/core/film/film.rs:219-241, :440-484)
+ *   pt_trace_closest/any <- Scene::intersect / intersect_p
+ *                           (src/core/scene/scene.rs:44-54)
+ *   pt_generate_camera_rays <- Sampler::get_camera_sample +
+ *                           PerspectiveCamera::generate_ray_differential
+ *                           (src/core/sampler/sampler.rs:26-36,
+ *                            src/cameras/perspective.rs:121-183)
+ *   pt_sobol_samples     <- SobolSampler::sample_dimension (src/samplers/sobol.rs:167-185)
+ *   pt_get_counters      <- the stat counters "Intersections/Regular ray intersection
+ *                           tests" / "Shadow ray intersection tests"
+ *                           (src/core/scene/scene.rs:11-12)
+ *
+ * Conventions: plain C, caller-owned host buffers unless a parameter is named
+ * dev_*, every function returns a pt_status, one context per device, contexts
+ * are thread-compatible (not thread-safe).  No torch / HIP types appear here.
+ */
+#ifndef PBRTGPU_H
+#define PBRTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+typedef enum {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = 1,
+    PT_ERR_NO_DEVICE = 2,        /* no HIP device / runtime: there is NO CPU fallback */
+    PT_ERR_DEVICE = 3,           /* a HIP call failed; see pt_last_error */
+    PT_ERR_UNSUPPORTED = 4,      /* feature outside the accelerated path */
+    PT_ERR_NO_SCENE = 5,
+    PT_ERR_OUT_OF_MEMORY = 6
+} pt_status;
+
+typedef struct pt_context pt_context;
+
+/* ---- flattened scene description ------------------------------------- */
+
+/* Material::compute_scattering_functions variants (src/materials/). */
+typedef enum {
+    PT_MATERIAL_NONE = 0,   /* GeometricPrimitive.material == None: ray passes through (path.rs:108-111) */
+    PT_MATERIAL_MATTE = 1   /* materials/matte.rs:25-53 (constant Kd, sigma) */
+} pt_material_type;
+
+typedef struct {
+    int32_t type;           /* pt_material_type */
+    float kd[3];            /* "Kd", default 0.5 */
+    float sigma;            /* "sigma" degrees, clamped to [0,90]; 0 => Lambertian */
+    float reserved[3];
+} pt_material;
+
+/* DiffuseAreaLight parameters shared by every triangle of one emissive shape
+ * (src/lights/diffuse.rs:165-194).  One light is instantiated per triangle. */
+typedef struct {
+    float L[3];             /* "L" * "scale" */
+    int32_t two_sided;      /* "twosided", default 0 */
+} pt_area_light;
+
+/* TriangleMesh flags (src/shapes/triangle.rs:10-22). */
+#define PT_MESH_TWO_SIDED            1u  /* "twosided" shape param, default true (triangle.rs:707) */
+#define PT_MESH_REVERSE_ORIENTATION  2u
+#define PT_MESH_SWAPS_HANDEDNESS     4u
+#define PT_MESH_HAS_N                8u
+#define PT_MESH_HAS_S               16u
+#define PT_MESH_HAS_UV              32u
+
+typedef struct {
+    uint32_t flags;
+    int32_t material;       /* index into materials[], or -1 for none */
+    int32_t area_light;     /* index into area_lights[], or -1 */
+    uint32_t reserved;
+} pt_mesh;
+
+typedef enum { PT_SPLIT_SAH = 0, PT_SPLIT_HLBVH = 1, PT_SPLIT_MIDDLE = 2, PT_SPLIT_EQUAL_COUNTS = 3 } pt_split_method;
+typedef enum { PT_SAMPLER_SOBOL = 0 } pt_sampler_type;
+typedef enum { PT_LIGHTS_UNIFORM = 0, PT_LIGHTS_POWER = 1, PT_LIGHTS_SPATIAL = 2 } pt_light_strategy;
+
+typedef struct {
+    /* ---- geometry: world-space vertices (TriangleMesh::new pre-transforms, triangle.rs:49-66) */
+    uint32_t n_vertices;
+    const float* P;             /* 3*n_vertices */
+    const float* N;             /* 3*n_vertices or NULL; read only where the mesh has PT_MESH_HAS_N */
+    const float* S;             /* 3*n_vertices or NULL */
+    const float* UV;            /* 2*n_vertices or NULL */
+    uint32_t n_triangles;       /* degenerate triangles (area <= 1e-16) already dropped, triangle.rs:726 */
+    const uint32_t* indices;    /* 3*n_triangles, into the vertex arrays */
+    const uint32_t* tri_mesh;   /* n_triangles, index into meshes[] */
+    uint32_t n_meshes;
+    const pt_mesh* meshes;
+    uint32_t n_materials;
+    const pt_material* materials;
+    uint32_t n_area_lights;
+    const pt_area_light* area_lights;
+
+    /* ---- accelerator (accelerators/bvh/create_bvh_accelerator.rs:13-27) */
+    int32_t split_method;       /* pt_split_method, default SAH */
+    int32_t max_node_prims;     /* default 4, clamped to 255 */
+
+    /* ---- camera (cameras/perspective.rs:337-394) */
+    float camera_to_world[16];  /* row-major Transform.m */
+    float fov;                  /* degrees */
+    float screen_window[4];     /* x0 x1 y0 y1 */
+    float lens_radius;
+    float focal_distance;
+    float shutter_open, shutter_close;
+
+    /* ---- film (core/film/film.rs:62-164, :520-580) */
+    int32_t xres, yres;
+    float crop_window[4];       /* x0 x1 y0 y1 in [0,1] */
+    float filter_radius[2];
+    float filter_table[256];    /* 16x16, Film::new's table (film.rs:102-120) */
+    float film_scale;
+    float max_sample_luminance; /* +inf = off */
+
+    /* ---- sampler / integrator (samplers/sobol.rs:16-31, integrators/path.rs:252-271) */
+    int32_t sampler;            /* pt_sampler_type */
+    int32_t spp;                /* "pixelsamples"; Sobol rounds up to a power of two */
+    int32_t max_depth;          /* default 5 */
+    float rr_threshold;         /* default 1 */
+    int32_t light_strategy;     /* pt_light_strategy, default spatial */
+} pt_scene_desc;
+
+/* Axis-aligned block of film *sample* pixels, half-open: the unit the reference
+ * hands to one rayon task (16x16, sampler.rs:271-289). */
+typedef struct { int32_t x0, y0, x1, y1; } pt_tile;
+
+typedef struct {
+    float t;                /* hit distance (undefined when prim < 0) */
+    int32_t prim;           /* index into the caller's triangle list, -1 = miss */
+    float b0, b1;           /* barycentrics of v0, v1 (triangle.rs:321-323) */
+} pt_hit;
+
+typedef struct {
+    uint64_t camera_rays;       /* Integrator/Camera rays traced */
+    uint64_t regular_rays;      /* Scene::intersect calls */
+    uint64_t shadow_rays;       /* Scene::intersect_p calls */
+    uint64_t nodes_visited;     /* interior 4-wide nodes popped */
+    uint64_t tris_tested;       /* Triangle::intersect(_p) calls made by traversal */
+    uint64_t path_vertices;     /* surface interactions shaded */
+    uint64_t trace_launches;    /* launches of the traversal kernel */
+    double   trace_ms;          /* device time in the traversal kernel (HIP events) */
+    double   shade_ms;
+    double   render_ms;         /* first ray-gen launch -> film ready on device */
+} pt_counters;
+
+typedef struct {
+    int32_t sample_bounds[4];   /* x0 y0 x1 y1  Film::get_sample_bounds (film.rs:166-179) */
+    int32_t cropped_bounds[4];  /* x0 y0 x1 y1 */
+    int32_t spp;                /* rounded */
+    uint32_t n_lights;
+    uint32_t n_nodes;           /* 4-wide interior nodes */
+    uint32_t n_leaves;
+    float world_bound[6];
+    double bvh_build_ms;
+    double upload_ms;
+} pt_scene_info;
+
+/* ---- context ---------------------------------------------------------- */
+pt_status pt_context_create(int device, pt_context** out);
+void      pt_context_destroy(pt_context* ctx);
+const char* pt_last_error(const pt_context* ctx);   /* valid until the next call on ctx */
+int       pt_abi_version(void);
+
+/* Path of the Sobol' matrix table (data/sobol_tables.bin).  Must be set before
+ * pt_scene_upload; pt_context_create looks next to the shared library first. */
+pt_status pt_set_data_dir(pt_context* ctx, const char* dir);
+
+/* ---- scene ------------------------------------------------------------ */
+pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* desc);
+pt_status pt_scene_info_get(const pt_context* ctx, pt_scene_info* out);
+
+/* ---- rendering -------------------------------------------------------- */
+/* Zero the device film (RGB sums + weights over the cropped pixel bounds). */
+pt_status pt_film_clear(pt_context* ctx);
+/* Render `n_tiles` tiles (all spp) and accumulate into the device film.  Tiles
+ * must lie inside the sample bounds.  n_tiles == 0 with tiles == NULL renders
+ * every 16x16 tile of the sample bounds (the reference's decomposition). */
+pt_status pt_render(pt_context* ctx, const pt_tile* tiles, uint32_t n_tiles);
+/* Film as {X,Y,Z,weight} float4 per cropped pixel: the quantity
+ * Film::merge_film_tile accumulates and the unit of the multi-GPU sum-reduce. */
+pt_status pt_film_download_xyzw(pt_context* ctx, float* xyzw_out /* 4*W*H */);
+/* Same buffer, device pointer, for an RCCL reduce without a host round trip. */
+pt_status pt_film_device_xyzw(pt_context* ctx, void** dev_ptr, size_t* n_floats);
+/* Tell the context the XYZW buffer (possibly reduced in place) is authoritative. */
+pt_status pt_film_commit_xyzw(pt_context* ctx);
+/* Film::write_image arithmetic: rgb = xyz_to_rgb(xyz)/weight, clamp >=0, *scale. */
+pt_status pt_film_resolve_rgb(pt_context* ctx, float* rgb_out /* 3*W*H */);
+
+/* ---- component hooks (parity tests; also usable by a host integrator) -- */
+/* o,d: 3*n floats (AoS xyz); tmax: n floats. */
+pt_status pt_trace_closest(pt_context* ctx, uint32_t n, const float* o, const float* d,
+                           const float* tmax, pt_hit* out);
+pt_status pt_trace_any(pt_context* ctx, uint32_t n, const float* o, const float* d,
+                       const float* tmax, uint8_t* occluded_out);
+/* Camera rays for pixel (px,py), sample index s: out_o/out_d 3 floats each per ray,
+ * out_pfilm 2 floats per ray. */
+pt_status pt_generate_camera_rays(pt_context* ctx, uint32_t n, const int32_t* pixel_xy,
+                                  const uint32_t* sample_index, float* out_o, float* out_d,
+                                  float* out_pfilm);
+/* out[i] = sampler value for (pixel_xy[i], sample_index[i], dim[i]). */
+pt_status pt_sobol_samples(pt_context* ctx, uint32_t n, const int32_t* pixel_xy,
+                           const uint32_t* sample_index, const uint32_t* dim, float* out);
+/* Per-sample radiance (PathIntegrator::li after validate_radiance_result) for the
+ * pixels of one tile: out is 3 floats per (pixel, sample), pixel-major. */
+pt_status pt_radiance_samples(pt_context* ctx, const pt_tile* tile, float* out_rgb);
+
+pt_status pt_get_counters(pt_context* ctx, pt_counters* out);
+pt_status pt_reset_counters(pt_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBRTGPU_H */
