@@ -225,6 +225,13 @@ pt_status pt_sobol_samples(pt_context* ctx, uint32_t n, const int32_t* pixel_xy,
  * pixels of one tile: out is 3 floats per (pixel, sample), pixel-major. */
 pt_status pt_radiance_samples(pt_context* ctx, const pt_tile* tile, float* out_rgb);
 
+/* Host-only utility (no device, no context): builds the BVH exactly as pt_scene_upload
+ * does and returns the leaf order (order_out[k] = caller's triangle index stored k-th),
+ * the 4-wide node / leaf counts and the traversal stack bound.  Lets a host check the
+ * tree against the reference's ordered_prims (build/node.rs:138-151) without a GPU. */
+pt_status pt_bvh_leaf_order(const pt_scene_desc* desc, uint32_t* order_out /* n_triangles */,
+                            uint32_t* n_nodes, uint32_t* n_leaves, uint32_t* max_stack);
+
 pt_status pt_get_counters(pt_context* ctx, pt_counters* out);
 pt_status pt_reset_counters(pt_context* ctx);
 

@@ -1,0 +1,278 @@
+"""ctypes bindings for include/pbrtgpu.h (libpbrtgpu.so).
+
+Every binding goes through the C ABI; there is no Python or CPU re-implementation
+of any kernel here.  If the shared library is absent, load_library() raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libpbrtgpu.so")
+DATA_DIR = os.path.join(HERE, "data")
+
+PT_MATERIAL_NONE, PT_MATERIAL_MATTE = 0, 1
+PT_MESH_TWO_SIDED, PT_MESH_REVERSE_ORIENTATION, PT_MESH_SWAPS_HANDEDNESS = 1, 2, 4
+PT_MESH_HAS_N, PT_MESH_HAS_S, PT_MESH_HAS_UV = 8, 16, 32
+PT_SPLIT_SAH, PT_SPLIT_HLBVH, PT_SPLIT_MIDDLE, PT_SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
+PT_LIGHTS_UNIFORM, PT_LIGHTS_POWER, PT_LIGHTS_SPATIAL = 0, 1, 2
+
+STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR_DEVICE",
+                4: "PT_ERR_UNSUPPORTED", 5: "PT_ERR_NO_SCENE", 6: "PT_ERR_OUT_OF_MEMORY"}
+
+
+class PtError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), msg))
+        self.status = status
+
+
+class pt_material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("kd", C.c_float * 3), ("sigma", C.c_float), ("reserved", C.c_float * 3)]
+
+
+class pt_area_light(C.Structure):
+    _fields_ = [("L", C.c_float * 3), ("two_sided", C.c_int32)]
+
+
+class pt_mesh(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("material", C.c_int32), ("area_light", C.c_int32), ("reserved", C.c_uint32)]
+
+
+class pt_scene_desc(C.Structure):
+    _fields_ = [
+        ("n_vertices", C.c_uint32), ("P", C.POINTER(C.c_float)), ("N", C.POINTER(C.c_float)),
+        ("S", C.POINTER(C.c_float)), ("UV", C.POINTER(C.c_float)),
+        ("n_triangles", C.c_uint32), ("indices", C.POINTER(C.c_uint32)), ("tri_mesh", C.POINTER(C.c_uint32)),
+        ("n_meshes", C.c_uint32), ("meshes", C.POINTER(pt_mesh)),
+        ("n_materials", C.c_uint32), ("materials", C.POINTER(pt_material)),
+        ("n_area_lights", C.c_uint32), ("area_lights", C.POINTER(pt_area_light)),
+        ("split_method", C.c_int32), ("max_node_prims", C.c_int32),
+        ("camera_to_world", C.c_float * 16), ("fov", C.c_float), ("screen_window", C.c_float * 4),
+        ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+        ("shutter_open", C.c_float), ("shutter_close", C.c_float),
+        ("xres", C.c_int32), ("yres", C.c_int32), ("crop_window", C.c_float * 4),
+        ("filter_radius", C.c_float * 2), ("filter_table", C.c_float * 256),
+        ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
+        ("sampler", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
+        ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
+    ]
+
+
+class pt_tile(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
+
+
+class pt_hit(C.Structure):
+    _fields_ = [("t", C.c_float), ("prim", C.c_int32), ("b0", C.c_float), ("b1", C.c_float)]
+
+
+class pt_counters(C.Structure):
+    _fields_ = [("camera_rays", C.c_uint64), ("regular_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("path_vertices", C.c_uint64),
+                ("trace_launches", C.c_uint64), ("trace_ms", C.c_double), ("shade_ms", C.c_double),
+                ("render_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class pt_scene_info(C.Structure):
+    _fields_ = [("sample_bounds", C.c_int32 * 4), ("cropped_bounds", C.c_int32 * 4), ("spp", C.c_int32),
+                ("n_lights", C.c_uint32), ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32),
+                ("world_bound", C.c_float * 6), ("bvh_build_ms", C.c_double), ("upload_ms", C.c_double)]
+
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<i4"), ("b0", "<f4"), ("b1", "<f4")])
+
+# Every symbol include/pbrtgpu.h declares (tests check the library exports them all).
+SYMBOLS = [
+    "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_abi_version", "pt_set_data_dir",
+    "pt_scene_upload", "pt_scene_info_get", "pt_film_clear", "pt_render", "pt_film_download_xyzw",
+    "pt_film_device_xyzw", "pt_film_commit_xyzw", "pt_film_resolve_rgb", "pt_trace_closest", "pt_trace_any",
+    "pt_generate_camera_rays", "pt_sobol_samples", "pt_radiance_samples", "pt_get_counters", "pt_reset_counters",
+    "pt_bvh_leaf_order",
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libpbrtgpu.so.  Raises (never substitutes another implementation) if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError("libpbrtgpu.so not found at %s -- build it with __graft_entry__.build(); "
+                      "there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    vp, u32, fp = C.c_void_p, C.c_uint32, C.POINTER(C.c_float)
+    lib.pt_context_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.pt_context_destroy.argtypes = [vp]
+    lib.pt_context_destroy.restype = None
+    lib.pt_last_error.argtypes = [vp]
+    lib.pt_last_error.restype = C.c_char_p
+    lib.pt_set_data_dir.argtypes = [vp, C.c_char_p]
+    lib.pt_scene_upload.argtypes = [vp, C.POINTER(pt_scene_desc)]
+    lib.pt_scene_info_get.argtypes = [vp, C.POINTER(pt_scene_info)]
+    lib.pt_film_clear.argtypes = [vp]
+    lib.pt_render.argtypes = [vp, C.POINTER(pt_tile), u32]
+    lib.pt_film_download_xyzw.argtypes = [vp, vp]
+    lib.pt_film_device_xyzw.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.pt_film_commit_xyzw.argtypes = [vp]
+    lib.pt_film_resolve_rgb.argtypes = [vp, vp]
+    lib.pt_trace_closest.argtypes = [vp, u32, vp, vp, vp, vp]
+    lib.pt_trace_any.argtypes = [vp, u32, vp, vp, vp, vp]
+    lib.pt_generate_camera_rays.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+    lib.pt_sobol_samples.argtypes = [vp, u32, vp, vp, vp, vp]
+    lib.pt_radiance_samples.argtypes = [vp, C.POINTER(pt_tile), vp]
+    lib.pt_get_counters.argtypes = [vp, C.POINTER(pt_counters)]
+    lib.pt_reset_counters.argtypes = [vp]
+    lib.pt_bvh_leaf_order.argtypes = [C.POINTER(pt_scene_desc), vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def tiles_array(tiles):
+    arr = (pt_tile * len(tiles))()
+    for i, t in enumerate(tiles):
+        arr[i] = pt_tile(*[int(v) for v in t])
+    return arr
+
+
+def bvh_leaf_order(scene, lib=None):
+    """Host-only BVH build (no GPU): returns (order, n_nodes, n_leaves, max_stack)."""
+    lib = lib or load_library()
+    order = np.empty(scene.desc.n_triangles, np.uint32)
+    nn, nl, ms = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    st = lib.pt_bvh_leaf_order(C.byref(scene.desc), _ptr(order), C.byref(nn), C.byref(nl), C.byref(ms))
+    if st != 0:
+        raise PtError(st, "pt_bvh_leaf_order failed")
+    return order, nn.value, nl.value, ms.value
+
+
+class Context:
+    """One device context (pt_context).  Mirrors the call sequence of the reference's
+    render_scene(): build scene -> integrator.render(scene) -> film.write_image()."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or load_library()
+        self.h = C.c_void_p()
+        st = self.lib.pt_context_create(int(device), C.byref(self.h))
+        if st != 0:
+            raise PtError(st, "pt_context_create(device=%d) failed (no HIP device? there is no CPU fallback)" % device)
+        self._check(self.lib.pt_set_data_dir(self.h, DATA_DIR.encode()))
+        self.info = None
+        self._keep = None
+
+    def _check(self, st):
+        if st != 0:
+            msg = self.lib.pt_last_error(self.h)
+            raise PtError(st, msg.decode() if msg else "")
+
+    def close(self):
+        if self.h:
+            self.lib.pt_context_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene):
+        """scene: scenes.SceneDesc (keeps its numpy buffers alive)."""
+        self._keep = scene
+        self._check(self.lib.pt_scene_upload(self.h, C.byref(scene.desc)))
+        info = pt_scene_info()
+        self._check(self.lib.pt_scene_info_get(self.h, C.byref(info)))
+        self.info = info
+        return info
+
+    @property
+    def film_shape(self):
+        cb = self.info.cropped_bounds
+        return (cb[3] - cb[1], cb[2] - cb[0])
+
+    def film_clear(self):
+        self._check(self.lib.pt_film_clear(self.h))
+
+    def render(self, tiles=None):
+        if tiles is None:
+            self._check(self.lib.pt_render(self.h, None, 0))
+        else:
+            arr = tiles_array(tiles)
+            self._check(self.lib.pt_render(self.h, arr, len(tiles)))
+
+    def film_xyzw(self):
+        h, w = self.film_shape
+        out = np.empty((h, w, 4), np.float32)
+        self._check(self.lib.pt_film_download_xyzw(self.h, _ptr(out)))
+        return out
+
+    def film_device_xyzw(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.pt_film_device_xyzw(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def film_commit_xyzw(self):
+        self._check(self.lib.pt_film_commit_xyzw(self.h))
+
+    def film_rgb(self):
+        h, w = self.film_shape
+        out = np.empty((h, w, 3), np.float32)
+        self._check(self.lib.pt_film_resolve_rgb(self.h, _ptr(out)))
+        return out
+
+    def trace_closest(self, o, d, tmax):
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = len(tmax)
+        out = np.empty(n, HIT_DTYPE)
+        self._check(self.lib.pt_trace_closest(self.h, n, _ptr(o), _ptr(d), _ptr(tmax), _ptr(out)))
+        return out
+
+    def trace_any(self, o, d, tmax):
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = len(tmax)
+        out = np.empty(n, np.uint8)
+        self._check(self.lib.pt_trace_any(self.h, n, _ptr(o), _ptr(d), _ptr(tmax), _ptr(out)))
+        return out
+
+    def generate_camera_rays(self, pixel_xy, sample_index):
+        pixel_xy = np.ascontiguousarray(pixel_xy, np.int32); sample_index = np.ascontiguousarray(sample_index, np.uint32)
+        n = len(sample_index)
+        o = np.empty((n, 3), np.float32); d = np.empty((n, 3), np.float32); pf = np.empty((n, 2), np.float32)
+        self._check(self.lib.pt_generate_camera_rays(self.h, n, _ptr(pixel_xy), _ptr(sample_index), _ptr(o), _ptr(d), _ptr(pf)))
+        return o, d, pf
+
+    def sobol_samples(self, pixel_xy, sample_index, dim):
+        pixel_xy = np.ascontiguousarray(pixel_xy, np.int32); sample_index = np.ascontiguousarray(sample_index, np.uint32)
+        dim = np.ascontiguousarray(dim, np.uint32)
+        n = len(dim)
+        out = np.empty(n, np.float32)
+        self._check(self.lib.pt_sobol_samples(self.h, n, _ptr(pixel_xy), _ptr(sample_index), _ptr(dim), _ptr(out)))
+        return out
+
+    def radiance_samples(self, tile):
+        t = pt_tile(*[int(v) for v in tile])
+        npx = (t.x1 - t.x0) * (t.y1 - t.y0)
+        out = np.empty((npx, self.info.spp, 3), np.float32)
+        self._check(self.lib.pt_radiance_samples(self.h, C.byref(t), _ptr(out)))
+        return out
+
+    def counters(self):
+        c = pt_counters()
+        self._check(self.lib.pt_get_counters(self.h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._check(self.lib.pt_reset_counters(self.h))

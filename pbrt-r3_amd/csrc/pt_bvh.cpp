@@ -1,0 +1,302 @@
+// pt_bvh.cpp -- host-side BVH construction for the gfx950 traversal kernels.
+//
+// The tree topology must be the one pbrt-r3 builds (same leaves, same child order,
+// same split axes), because the traversal order and hence every f32 result depends
+// on it:  src/accelerators/bvh/build/{node,sah,middle,equal_counts}.rs and the
+// two-level collapse of src/accelerators/bvh/accel/qbvh/qbvh_x86.rs:93-176.
+// The implementation is our own: primitives are partitioned in place inside one
+// array (so the final array order IS the leaf order), binary nodes go into a flat
+// vector, large subtrees are built on worker threads, and the output is the 128-byte
+// PtNode / 48-byte PtTri layout of pt_device.h with leaves folded into child refs.
+#include "pt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <limits>
+
+namespace ptbvh {
+
+namespace {
+
+struct Item {            // one primitive during construction (40 bytes, moved physically)
+    float lo[3], hi[3], c[3];
+    uint32_t prim;
+};
+struct BNode {
+    float lo[3], hi[3];
+    int32_t left = -1, right = -1;     // children (indices into the same vector) or -1
+    uint32_t first = 0, count = 0;     // leaf range in the item array
+    uint8_t axis = 0;
+};
+struct Box {
+    float lo[3], hi[3];
+};
+inline float fmin_le(float a, float b) { return a <= b ? a : b; }   // Bounds3::union's comparisons (bounds3.rs:40-46)
+inline float fmax_ge(float a, float b) { return a >= b ? a : b; }
+inline void box_empty(Box& b) {
+    for (int i = 0; i < 3; i++) { b.lo[i] = std::numeric_limits<float>::max(); b.hi[i] = std::numeric_limits<float>::lowest(); }
+}
+inline void box_grow(Box& b, const float* lo, const float* hi) {
+    for (int i = 0; i < 3; i++) { b.lo[i] = fmin_le(b.lo[i], lo[i]); b.hi[i] = fmax_ge(b.hi[i], hi[i]); }
+}
+inline void box_grow_pt(Box& b, const float* p) {
+    for (int i = 0; i < 3; i++) { b.lo[i] = fmin_le(b.lo[i], p[i]); b.hi[i] = fmax_ge(b.hi[i], p[i]); }
+}
+inline float box_area(const Box& b) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return 2.0f * (dx * dy + dx * dz + dy * dz);
+}
+inline int box_max_extent(const Box& b) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    if (dx > dy && dx > dz) return 0;
+    if (dy > dz) return 1;
+    return 2;
+}
+inline float box_offset(const Box& b, const float* p, int dim) {
+    float o = p[dim] - b.lo[dim];
+    if (b.hi[dim] > b.lo[dim]) o = o / (b.hi[dim] - b.lo[dim]);
+    return o;
+}
+
+const int kBuckets = 12;
+inline int bucket_index(const Box& cb, const float* c, int dim) {
+    int b = (int)std::floor((float)kBuckets * box_offset(cb, c, dim));
+    if (b > kBuckets - 1) b = kBuckets - 1;
+    if (b < 0) b = 0;
+    return b;
+}
+
+struct Builder {
+    Item* items;
+    Item* scratch;
+    uint32_t max_prims;
+    int method;
+    size_t par_threshold;
+
+    typedef std::vector<BNode> Tree;
+
+    // Append a finished subtree (root at sub[0], links relative to sub) to dst; returns its new root index.
+    static int32_t splice(Tree& dst, const Tree& sub) {
+        int32_t base = (int32_t)dst.size();
+        for (const BNode& n : sub) {
+            BNode m = n;
+            if (m.left >= 0) m.left += base;
+            if (m.right >= 0) m.right += base;
+            dst.push_back(m);
+        }
+        return base;
+    }
+    static int32_t push_leaf(Tree& t, size_t lo, size_t hi, const Box& b) {
+        BNode n;
+        std::memcpy(n.lo, b.lo, 12); std::memcpy(n.hi, b.hi, 12);
+        n.first = (uint32_t)lo; n.count = (uint32_t)(hi - lo);
+        t.push_back(n);
+        return (int32_t)t.size() - 1;
+    }
+    void stable_sort_axis(size_t lo, size_t hi, int dim) {
+        std::stable_sort(items + lo, items + hi, [dim](const Item& a, const Item& b) { return a.c[dim] < b.c[dim]; });
+    }
+
+    // Builds the subtree over items[lo, hi) into t (appending) and returns its root index.
+    // Large subtrees near the top hand their left half to a worker thread, which builds into
+    // its own vector (no shared storage) that is spliced in afterwards.
+    int32_t build(Tree& t, size_t lo, size_t hi, int depth) {
+        size_t n = hi - lo;
+        Box bounds;
+        std::memcpy(bounds.lo, items[lo].lo, 12); std::memcpy(bounds.hi, items[lo].hi, 12);
+        for (size_t i = lo + 1; i < hi; i++) box_grow(bounds, items[i].lo, items[i].hi);
+        if (n <= max_prims) return push_leaf(t, lo, hi, bounds);
+        Box cb;
+        std::memcpy(cb.lo, items[lo].c, 12); std::memcpy(cb.hi, items[lo].c, 12);
+        for (size_t i = lo + 1; i < hi; i++) box_grow_pt(cb, items[i].c);
+        int dim = box_max_extent(cb);
+        if (cb.lo[dim] == cb.hi[dim]) return push_leaf(t, lo, hi, bounds);
+
+        size_t mid = 0;
+        bool have_split = false;
+        if (method == PT_SPLIT_MIDDLE) {
+            float p_mid = (cb.lo[dim] + cb.hi[dim]) / 2.0f;
+            stable_sort_axis(lo, hi, dim);
+            size_t m = lo;
+            while (m < hi && !(p_mid <= items[m].c[dim])) m++;
+            if (m != lo && m != hi) { mid = m; have_split = true; }
+        } else if (method == PT_SPLIT_SAH) {
+            if (n == 1) return push_leaf(t, lo, hi, bounds);
+            if (n == 2) {
+                stable_sort_axis(lo, hi, dim);
+                mid = lo + 1;
+                have_split = true;
+            } else {
+                int count[kBuckets];
+                Box bb[kBuckets];
+                for (int i = 0; i < kBuckets; i++) { count[i] = 0; box_empty(bb[i]); }
+                for (size_t i = lo; i < hi; i++) {
+                    int b = bucket_index(cb, items[i].c, dim);
+                    count[b]++;
+                    box_grow(bb[b], items[i].lo, items[i].hi);
+                }
+                float cost[kBuckets - 1];
+                const float total_area = box_area(bounds);
+                for (int i = 0; i < kBuckets - 1; i++) {
+                    Box b0 = bb[i], b1 = bb[i + 1];
+                    int c0 = 0, c1 = 0;
+                    for (int j = 0; j <= i; j++) { box_grow(b0, bb[j].lo, bb[j].hi); c0 += count[j]; }
+                    for (int j = i + 1; j < kBuckets; j++) { box_grow(b1, bb[j].lo, bb[j].hi); c1 += count[j]; }
+                    cost[i] = 1.0f + ((float)c0 * box_area(b0) + (float)c1 * box_area(b1)) / total_area;
+                }
+                float min_cost = cost[0];
+                int min_bucket = 0;
+                for (int i = 1; i < kBuckets - 1; i++)
+                    if (cost[i] < min_cost) { min_cost = cost[i]; min_bucket = i; }
+                if (n > max_prims || min_cost < (float)n) {
+                    // stable partition: left part compacts in place, right part detours through scratch
+                    size_t nl = 0, nr = 0;
+                    for (size_t i = lo; i < hi; i++) {
+                        if (bucket_index(cb, items[i].c, dim) <= min_bucket) items[lo + nl++] = items[i];
+                        else scratch[lo + nr++] = items[i];
+                    }
+                    std::memcpy(items + lo + nl, scratch + lo, nr * sizeof(Item));
+                    if (nl != 0 && nr != 0) { mid = lo + nl; have_split = true; }
+                } else {
+                    return push_leaf(t, lo, hi, bounds);
+                }
+            }
+        }
+        if (!have_split) {   // split_equal_counts, also the fallback of the other methods
+            stable_sort_axis(lo, hi, dim);
+            mid = lo + n / 2;
+        }
+        int32_t me = (int32_t)t.size();
+        {
+            BNode nd;
+            nd.axis = (uint8_t)dim;
+            t.push_back(nd);
+        }
+        int32_t l, r;
+        if (n >= par_threshold && depth < 6) {
+            auto fut = std::async(std::launch::async, [this, lo, mid, depth]() {
+                Tree sub;
+                build(sub, lo, mid, depth + 1);
+                return sub;
+            });
+            Tree right_sub;            // keep preorder numbering: left subtree first
+            build(right_sub, mid, hi, depth + 1);
+            Tree left_sub = fut.get();
+            l = splice(t, left_sub);
+            r = splice(t, right_sub);
+        } else {
+            l = build(t, lo, mid, depth + 1);
+            r = build(t, mid, hi, depth + 1);
+        }
+        t[me].left = l; t[me].right = r;
+        for (int i = 0; i < 3; i++) {   // init_interior: union of the two children
+            t[me].lo[i] = fmin_le(t[l].lo[i], t[r].lo[i]);
+            t[me].hi[i] = fmax_ge(t[l].hi[i], t[r].hi[i]);
+        }
+        return me;
+    }
+};
+
+struct Collapser {
+    const std::vector<BNode>& b;
+    Result& out;
+    uint32_t max_depth4 = 0;
+
+    uint32_t leaf_ref(const BNode& n) const { return PT_LEAF_BIT | n.first; }
+
+    // One 4-wide node from a binary node and its two children (a leaf child fills slot 0/2 and
+    // leaves slot 1/3 empty, exactly like flatten_qbvh_tree).  Returns the node index.
+    uint32_t emit(int32_t bi, uint32_t depth) {
+        if (depth > max_depth4) max_depth4 = depth;
+        const BNode& n = b[bi];
+        uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.push_back(PtNode());
+        PtNode nd;
+        std::memset(&nd, 0, sizeof(nd));
+        const BNode& c0 = b[n.left];
+        const BNode& c1 = b[n.right];
+        const BNode* slot[4] = {nullptr, nullptr, nullptr, nullptr};
+        int32_t slot_idx[4] = {-1, -1, -1, -1};
+        if (c0.count > 0) { slot[0] = &c0; slot_idx[0] = n.left; }
+        else { slot[0] = &b[c0.left]; slot_idx[0] = c0.left; slot[1] = &b[c0.right]; slot_idx[1] = c0.right; }
+        if (c1.count > 0) { slot[2] = &c1; slot_idx[2] = n.right; }
+        else { slot[2] = &b[c1.left]; slot_idx[2] = c1.left; slot[3] = &b[c1.right]; slot_idx[3] = c1.right; }
+        for (int k = 0; k < 4; k++) {
+            if (!slot[k]) { nd.child[k] = PT_EMPTY_REF; continue; }   // box stays all-zero as in the reference
+            for (int a = 0; a < 3; a++) { nd.bmin[a][k] = slot[k]->lo[a]; nd.bmax[a][k] = slot[k]->hi[a]; }
+            if (slot[k]->count > 0) nd.child[k] = leaf_ref(*slot[k]);
+            else nd.child[k] = emit(slot_idx[k], depth + 1);
+        }
+        nd.axes = (uint32_t)n.axis | ((uint32_t)c0.axis << 2) | ((uint32_t)c1.axis << 4);
+        out.nodes[me] = nd;
+        return me;
+    }
+};
+
+}  // namespace
+
+bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, int split_method, int max_node_prims,
+           Result* out) {
+    out->nodes.clear(); out->tris.clear(); out->rec_of_prim.clear();
+    out->n_leaves = 0; out->max_stack = 1;
+    if (split_method == PT_SPLIT_HLBVH) return false;   // hlbvh_build (build/hlbvh.rs) is not restated yet
+    if (n_tris == 0) { out->root_ref = PT_EMPTY_REF; return true; }
+    std::vector<Item> items(n_tris), scratch(n_tris);
+    const float eps = std::numeric_limits<float>::epsilon() * 2.0f;   // BOUND_EPS (build/node.rs:13)
+    for (uint32_t t = 0; t < n_tris; t++) {
+        const float* p0 = P + 3 * (size_t)indices[3 * (size_t)t];
+        const float* p1 = P + 3 * (size_t)indices[3 * (size_t)t + 1];
+        const float* p2 = P + 3 * (size_t)indices[3 * (size_t)t + 2];
+        Item& it = items[t];
+        for (int i = 0; i < 3; i++) {
+            float lo = std::fmin(std::fmin(p0[i], p1[i]), p2[i]);   // union3 (triangle.rs:189-200)
+            float hi = std::fmax(std::fmax(p0[i], p1[i]), p2[i]);
+            it.lo[i] = lo - eps;
+            it.hi[i] = hi + eps;
+            it.c[i] = (it.lo[i] + it.hi[i]) * 0.5f;
+        }
+        it.prim = t;
+    }
+    Builder bld;
+    bld.items = items.data();
+    bld.scratch = scratch.data();
+    bld.max_prims = (uint32_t)std::min(std::max(max_node_prims, 0), 255);
+    bld.method = split_method;
+    bld.par_threshold = 32768;
+    std::vector<BNode> tree;
+    tree.reserve((size_t)n_tris);
+    bld.build(tree, 0, n_tris, 0);
+
+    std::memcpy(out->root_lo, tree[0].lo, 12);
+    std::memcpy(out->root_hi, tree[0].hi, 12);
+    // triangle records in final item order; PT_TRI_LAST closes each leaf
+    out->tris.resize(n_tris);
+    out->rec_of_prim.resize(n_tris);
+    for (uint32_t r = 0; r < n_tris; r++) {
+        uint32_t t = items[r].prim;
+        PtTri& tr = out->tris[r];
+        std::memcpy(tr.p0, P + 3 * (size_t)indices[3 * (size_t)t], 12);
+        std::memcpy(tr.p1, P + 3 * (size_t)indices[3 * (size_t)t + 1], 12);
+        std::memcpy(tr.p2, P + 3 * (size_t)indices[3 * (size_t)t + 2], 12);
+        tr.prim = t;
+        tr.flags = tri_flags[t] & ~PT_TRI_LAST;
+        tr.pad = 0;
+        out->rec_of_prim[t] = r;
+    }
+    out->n_leaves = 0;
+    for (const BNode& n : tree)
+        if (n.count > 0) { out->tris[n.first + n.count - 1].flags |= PT_TRI_LAST; out->n_leaves++; }
+    if (tree[0].count > 0) {           // the whole scene is one leaf
+        out->root_ref = PT_LEAF_BIT | tree[0].first;
+        out->max_stack = 1;
+        return true;
+    }
+    Collapser col{tree, *out};
+    out->root_ref = col.emit(0, 1);
+    out->max_stack = 3 * col.max_depth4 + 2;
+    return true;
+}
+
+}  // namespace ptbvh

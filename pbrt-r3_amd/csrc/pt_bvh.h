@@ -1,0 +1,26 @@
+// pt_bvh.h -- host BVH builder producing the device layout of pt_device.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include "pt_device.h"
+#include "../../include/pbrtgpu.h"
+
+namespace ptbvh {
+
+struct Result {
+    std::vector<PtNode> nodes;          // 4-wide interior nodes, root first
+    std::vector<PtTri> tris;            // triangle records in leaf order
+    std::vector<uint32_t> rec_of_prim;  // caller's triangle index -> record index
+    uint32_t root_ref = PT_EMPTY_REF;
+    uint32_t n_leaves = 0;
+    uint32_t max_stack = 1;             // upper bound on traversal stack entries
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+};
+
+// tri_flags[t]: PT_TRI_ONE_SIDED / PT_TRI_FLIP bits of triangle t.  Returns false for an
+// unsupported split method.
+bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, int split_method, int max_node_prims,
+           Result* out);
+
+}  // namespace ptbvh

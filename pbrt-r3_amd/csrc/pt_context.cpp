@@ -1,0 +1,809 @@
+// pt_context.cpp -- host side of libpbrtgpu.so: the C ABI of include/pbrtgpu.h.
+//
+// Plays the role of pbrt-r3's SceneContext::make_scene + make_integrator
+// (src/core/api/scene_context/scene_context.rs:675-729) and of
+// SampleIntegratorCore::render (src/core/integrator/sampler.rs:259-325), re-designed as
+// a wavefront scheduler: camera samples are generated for a pass of S samples per pixel
+// into an SoA path pool in HBM, then every bounce is one traversal launch (continuation
+// rays + the previous bounce's shadow / MIS probe rays) and one shading launch; queues are
+// compacted on the device and no host synchronisation happens inside a pass except one
+// counter read at its end.  There is no CPU rendering path in this library.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pbrtgpu.h"
+#include "pt_bvh.h"
+#include "pt_device.h"
+#include "pt_host_math.h"
+#include "pt_kernels.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+uint32_t round_up_pow2(uint32_t v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
+uint32_t log2int(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+
+}  // namespace
+
+struct pt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err, data_dir;
+    int n_cu = 256;
+
+    // ---- scene
+    bool have_scene = false;
+    PtScene sc;
+    pt_scene_info info;
+    DevBuf d_nodes, d_tris, d_tri_info, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid;
+    std::vector<uint32_t> sobol_m32;
+    std::vector<uint64_t> sobol_vdc, sobol_inv;
+    uint32_t sobol_n_vdc = 0, sobol_n_inv = 0, sobol_msize = 52;
+    uint32_t max_stack = 1;
+    uint32_t film_w = 0, film_h = 0;
+
+    // ---- traversal scratch
+    DevBuf d_spill, d_err, d_counters, d_ticket;
+    uint32_t spill_depth = 0;
+    int grid_trace = 1024, grid_shade = 512, grid_wide = 2048;
+
+    // ---- path pool
+    size_t pool_paths = 0;
+    DevBuf d_pool;          // one slab carved into the SoA arrays of PtPaths
+    PtPaths paths;
+    DevBuf d_qa, d_qb, d_qnee, d_counts, d_pixels;
+    size_t pixels_cap = 0;
+
+    // ---- film
+    DevBuf d_own, d_spillfilm, d_xyzw, d_rgb;
+    bool xyzw_committed = false;
+
+    // ---- timing
+    std::vector<hipEvent_t> ev;
+    double trace_ms = 0, shade_ms = 0, render_ms = 0;
+    uint64_t trace_launches = 0;
+
+    pt_status fail(pt_status st, const std::string& m) { err = m; return st; }
+    pt_status hip_fail(hipError_t e, const char* what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_DEVICE;
+    }
+};
+
+#define PT_HIP(call)                                             \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return ctx->hip_fail(e_, #call);   \
+    } while (0)
+
+namespace {
+
+bool load_sobol(pt_context* ctx) {
+    std::string path = ctx->data_dir + "/sobol_tables.bin";
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[8];
+    uint32_t hdr[4];
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PTSOBOL1", 8) == 0 && std::fread(hdr, 4, 4, f) == 4;
+    if (ok) {
+        ctx->sobol_msize = hdr[1];
+        ctx->sobol_n_vdc = hdr[2];
+        ctx->sobol_n_inv = hdr[3];
+        ctx->sobol_m32.resize((size_t)hdr[0] * hdr[1]);
+        ctx->sobol_vdc.resize((size_t)hdr[2] * hdr[1]);
+        ctx->sobol_inv.resize((size_t)hdr[3] * hdr[1]);
+        ok = std::fread(ctx->sobol_m32.data(), 4, ctx->sobol_m32.size(), f) == ctx->sobol_m32.size() &&
+             std::fread(ctx->sobol_vdc.data(), 8, ctx->sobol_vdc.size(), f) == ctx->sobol_vdc.size() &&
+             std::fread(ctx->sobol_inv.data(), 8, ctx->sobol_inv.size(), f) == ctx->sobol_inv.size();
+    }
+    std::fclose(f);
+    return ok;
+}
+
+template <class T>
+pt_status upload(pt_context* ctx, DevBuf& b, const T* src, size_t n) {
+    PT_HIP(b.alloc(n * sizeof(T)));
+    if (n) PT_HIP(hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+pt_status ensure_pool(pt_context* ctx, size_t n_paths) {
+    if (ctx->pool_paths >= n_paths && ctx->d_pool.p) return PT_OK;
+    // 11 float4 + float2 + u64 + 6 x 4-byte + 1 byte per path
+    const size_t per_path = 11 * 16 + 8 + 8 + 6 * 4 + 4;
+    PT_HIP(ctx->d_pool.alloc(n_paths * per_path + 16384));
+    char* base = ctx->d_pool.as<char>();
+    size_t off = 0;
+    auto carve = [&](size_t elem) { void* p = base + off; off += (n_paths * elem + 255) & ~(size_t)255; return p; };
+    PtPaths& P = ctx->paths;
+    P.ray_o = (float4*)carve(16); P.ray_d = (float4*)carve(16);
+    P.sh_o = (float4*)carve(16); P.sh_d = (float4*)carve(16);
+    P.pr_o = (float4*)carve(16); P.pr_d = (float4*)carve(16);
+    P.beta = (float4*)carve(16); P.L = (float4*)carve(16);
+    P.pendA = (float4*)carve(16); P.pendB = (float4*)carve(16); P.pbeta = (float4*)carve(16);
+    P.p_film = (float2*)carve(8);
+    P.sobol_index = (uint64_t*)carve(8);
+    P.pixel = (uint32_t*)carve(4); P.state = (uint32_t*)carve(4);
+    P.hit_t = (float*)carve(4); P.hit_rec = (int32_t*)carve(4);
+    P.nee = (uint32_t*)carve(4);
+    P.probe_rec = (int32_t*)carve(4);
+    P.occluded = (uint8_t*)carve(1);
+    if (off > ctx->d_pool.bytes) return ctx->fail(PT_ERR_DEVICE, "internal: path pool carve overflow");
+    PT_HIP(ctx->d_qa.alloc(n_paths * 4));
+    PT_HIP(ctx->d_qb.alloc(n_paths * 4));
+    PT_HIP(ctx->d_qnee.alloc(n_paths * 4));
+    ctx->pool_paths = n_paths;
+    return PT_OK;
+}
+
+pt_status ensure_traversal_scratch(pt_context* ctx) {
+    uint32_t need = ctx->max_stack > PT_LDS_STACK ? ctx->max_stack - PT_LDS_STACK : 0;
+    size_t threads = (size_t)std::max(ctx->grid_trace, 2048) * PT_BLOCK;
+    if (!ctx->d_spill.p || ctx->spill_depth < need) {
+        PT_HIP(ctx->d_spill.alloc((size_t)std::max(need, 1u) * threads * 4));
+        ctx->spill_depth = need;
+    }
+    return PT_OK;
+}
+
+hipEvent_t get_event(pt_context* ctx, size_t i) {
+    while (ctx->ev.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->ev.push_back(e);
+    }
+    return ctx->ev[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_abi_version(void) { return PT_ABI_VERSION; }
+
+pt_status pt_context_create(int device, pt_context** out) {
+    if (!out) return PT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PT_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PT_ERR_NO_DEVICE;
+    pt_context* ctx = new pt_context;
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PT_ERR_DEVICE; }
+    std::memset(&ctx->sc, 0, sizeof(ctx->sc));
+    std::memset(&ctx->info, 0, sizeof(ctx->info));
+    std::memset(&ctx->paths, 0, sizeof(ctx->paths));
+    // occupancy-sized persistent grids: blocks per CU from register/LDS use x CU count
+    ctx->grid_trace = ctx->n_cu * 4;
+    ctx->grid_shade = ctx->n_cu * 2;
+    ctx->grid_wide = ctx->n_cu * 8;
+    const char* dd = std::getenv("PBRTGPU_DATA_DIR");
+    if (dd) ctx->data_dir = dd;
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_context_destroy(pt_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* pt_last_error(const pt_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+pt_status pt_set_data_dir(pt_context* ctx, const char* dir) {
+    if (!ctx || !dir) return PT_ERR_INVALID_ARGUMENT;
+    ctx->data_dir = dir;
+    return PT_OK;
+}
+
+pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
+    if (!ctx || !d) return PT_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    ctx->have_scene = false;
+    // ---- validation (the kernels index these arrays unchecked)
+    if (d->n_triangles == 0 || !d->P || !d->indices || !d->tri_mesh || !d->meshes) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no triangles");
+    if (d->xres <= 0 || d->yres <= 0 || d->spp <= 0 || d->max_depth < 0 || d->max_depth > 250) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "bad film / sampler / integrator parameters");
+    if (d->sampler != PT_SAMPLER_SOBOL) return ctx->fail(PT_ERR_UNSUPPORTED, "only the Sobol' sampler is reproducible on a wavefront (SURVEY.md section 2, row 8)");
+    if (d->n_triangles >= 0x7fffffffu) return ctx->fail(PT_ERR_UNSUPPORTED, "too many triangles");
+    for (uint32_t t = 0; t < d->n_triangles; t++) {
+        for (int k = 0; k < 3; k++)
+            if (d->indices[3 * (size_t)t + k] >= d->n_vertices) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "vertex index out of range");
+        if (d->tri_mesh[t] >= d->n_meshes) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "mesh index out of range");
+    }
+    for (uint32_t m = 0; m < d->n_meshes; m++) {
+        if (d->meshes[m].material >= (int32_t)d->n_materials) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "material index out of range");
+        if (d->meshes[m].area_light >= (int32_t)d->n_area_lights) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "area light index out of range");
+        int32_t mi = d->meshes[m].material;
+        if (mi >= 0 && d->materials[mi].type != PT_MATERIAL_NONE && d->materials[mi].type != PT_MATERIAL_MATTE)
+            return ctx->fail(PT_ERR_UNSUPPORTED, "material type not on the accelerated path yet");
+    }
+    if (ctx->sobol_m32.empty() && !load_sobol(ctx)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "cannot read sobol_tables.bin from data dir '" + ctx->data_dir + "'");
+
+    double t0 = now_ms();
+    // ---- BVH (host) ---------------------------------------------------------
+    std::vector<uint32_t> tri_flags(d->n_triangles);
+    for (uint32_t t = 0; t < d->n_triangles; t++) {
+        uint32_t mf = d->meshes[d->tri_mesh[t]].flags, f = 0;
+        if (!(mf & PT_MESH_TWO_SIDED)) f |= PT_TRI_ONE_SIDED;
+        if (((mf & PT_MESH_REVERSE_ORIENTATION) != 0) ^ ((mf & PT_MESH_SWAPS_HANDEDNESS) != 0)) f |= PT_TRI_FLIP;
+        tri_flags[t] = f;
+    }
+    ptbvh::Result bvh;
+    if (!ptbvh::build(d->P, d->indices, tri_flags.data(), d->n_triangles, d->split_method, d->max_node_prims > 0 ? d->max_node_prims : 4, &bvh))
+        return ctx->fail(PT_ERR_UNSUPPORTED, "split method not supported (hlbvh)");
+    double t1 = now_ms();
+    ctx->max_stack = bvh.max_stack;
+
+    // ---- shading records ----------------------------------------------------
+    std::vector<PtTriInfo> tinfo(d->n_triangles);
+    std::vector<PtLight> lights;
+    for (uint32_t t = 0; t < d->n_triangles; t++) {
+        const pt_mesh& m = d->meshes[d->tri_mesh[t]];
+        PtTriInfo& ti = tinfo[t];
+        ti.v[0] = d->indices[3 * (size_t)t]; ti.v[1] = d->indices[3 * (size_t)t + 1]; ti.v[2] = d->indices[3 * (size_t)t + 2];
+        ti.mesh = d->tri_mesh[t];
+        ti.material = m.material;
+        uint32_t mf = m.flags;
+        if (!d->N) mf &= ~PT_MESH_HAS_N;
+        if (!d->S) mf &= ~PT_MESH_HAS_S;
+        if (!d->UV) mf &= ~PT_MESH_HAS_UV;
+        ti.mesh_flags = mf;
+        ti.pad = 0;
+        ti.light = -1;
+        if (m.area_light >= 0) {     // one DiffuseAreaLight per emissive triangle, in primitive order
+            const pt_area_light& al = d->area_lights[m.area_light];
+            PtLight L;
+            std::memset(&L, 0, sizeof(L));
+            const float* p0 = d->P + 3 * (size_t)ti.v[0]; const float* p1 = d->P + 3 * (size_t)ti.v[1]; const float* p2 = d->P + 3 * (size_t)ti.v[2];
+            std::memcpy(L.p0, p0, 12); std::memcpy(L.p1, p1, 12); std::memcpy(L.p2, p2, 12);
+            // Triangle::area (triangle.rs:579-588)
+            float ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
+            float bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
+            float cx = (ay * bz) - (az * by), cy = (az * bx) - (ax * bz), cz = (ax * by) - (ay * bx);
+            L.area = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);
+            L.mesh_flags = mf;
+            L.two_sided = al.two_sided;
+            std::memcpy(L.L, al.L, 12);
+            L.tri_rec = bvh.rec_of_prim[t];
+            L.prim = t;
+            if (mf & PT_MESH_HAS_N) {
+                std::memcpy(L.n0, d->N + 3 * (size_t)ti.v[0], 12); std::memcpy(L.n1, d->N + 3 * (size_t)ti.v[1], 12); std::memcpy(L.n2, d->N + 3 * (size_t)ti.v[2], 12);
+            }
+            ti.light = (int32_t)lights.size();
+            lights.push_back(L);
+        }
+    }
+    if (lights.size() >= (1u << 24)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^24 emissive triangles");
+    std::vector<PtMaterial> mats(std::max<uint32_t>(d->n_materials, 1));
+    std::memset(mats.data(), 0, mats.size() * sizeof(PtMaterial));
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        PtMaterial& m = mats[i];
+        m.type = d->materials[i].type;
+        std::memcpy(m.kd, d->materials[i].kd, 12);
+        m.sigma = d->materials[i].sigma;
+        float sig = m.sigma < 0.0f ? 0.0f : (m.sigma > 90.0f ? 90.0f : m.sigma);
+        const float pi = 3.14159265358979323846f;
+        float sigma = sig * (pi / 180.0f);
+        float sigma2 = sigma * sigma;
+        m.oren_a = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+        m.oren_b = 0.45f * sigma2 / (sigma2 + 0.09f);
+    }
+
+    PtScene& sc = ctx->sc;
+    std::memset(&sc, 0, sizeof(sc));
+    pt_status st;
+    if ((st = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size())) != PT_OK) return st;
+    if ((st = upload(ctx, ctx->d_tris, bvh.tris.data(), bvh.tris.size())) != PT_OK) return st;
+    if ((st = upload(ctx, ctx->d_tri_info, tinfo.data(), tinfo.size())) != PT_OK) return st;
+    if ((st = upload(ctx, ctx->d_materials, mats.data(), mats.size())) != PT_OK) return st;
+    if ((st = upload(ctx, ctx->d_lights, lights.data(), lights.size())) != PT_OK) return st;
+    if (d->N) { if ((st = upload(ctx, ctx->d_N, d->N, 3 * (size_t)d->n_vertices)) != PT_OK) return st; } else ctx->d_N.release();
+    if (d->S) { if ((st = upload(ctx, ctx->d_S, d->S, 3 * (size_t)d->n_vertices)) != PT_OK) return st; } else ctx->d_S.release();
+    if (d->UV) { if ((st = upload(ctx, ctx->d_UV, d->UV, 2 * (size_t)d->n_vertices)) != PT_OK) return st; } else ctx->d_UV.release();
+    sc.nodes = ctx->d_nodes.as<PtNode>();
+    sc.tris = ctx->d_tris.as<PtTri>();
+    sc.tri_info = ctx->d_tri_info.as<PtTriInfo>();
+    sc.N = d->N ? ctx->d_N.as<float>() : nullptr;
+    sc.S = d->S ? ctx->d_S.as<float>() : nullptr;
+    sc.UV = d->UV ? ctx->d_UV.as<float>() : nullptr;
+    sc.materials = ctx->d_materials.as<PtMaterial>();
+    sc.lights = ctx->d_lights.as<PtLight>();
+    sc.n_lights = (uint32_t)lights.size();
+    sc.root_ref = bvh.root_ref;
+    std::memcpy(sc.wb_min, bvh.root_lo, 12);
+    std::memcpy(sc.wb_max, bvh.root_hi, 12);
+    sc.max_depth = d->max_depth;
+    sc.rr_threshold = d->rr_threshold;
+
+    // ---- camera ---------------------------------------------------------------
+    pth::M44 r2c;
+    if (!pth::raster_to_camera(d->fov, d->screen_window, d->xres, d->yres, &r2c)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "singular camera projection");
+    std::memcpy(sc.cam.raster_to_camera, r2c.a, 64);
+    std::memcpy(sc.cam.camera_to_world, d->camera_to_world, 64);
+    sc.cam.lens_radius = d->lens_radius;
+    sc.cam.focal_distance = d->focal_distance;
+
+    // ---- film (Film::new, film.rs:62-100; get_sample_bounds :166-179) ---------
+    PtFilm& fm = sc.film;
+    fm.crop[0] = std::max(0, (int)std::floor((float)d->xres * d->crop_window[0]));
+    fm.crop[1] = std::max(0, (int)std::floor((float)d->yres * d->crop_window[2]));
+    fm.crop[2] = std::min((int)std::ceil((float)d->xres * d->crop_window[1]), d->xres);
+    fm.crop[3] = std::min((int)std::ceil((float)d->yres * d->crop_window[3]), d->yres);
+    if (fm.crop[2] <= fm.crop[0] || fm.crop[3] <= fm.crop[1]) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "empty crop window");
+    fm.filter_radius[0] = d->filter_radius[0]; fm.filter_radius[1] = d->filter_radius[1];
+    fm.inv_filter_radius[0] = 1.0f / d->filter_radius[0]; fm.inv_filter_radius[1] = 1.0f / d->filter_radius[1];
+    fm.sample_bounds[0] = (int)std::floor((float)fm.crop[0] - fm.filter_radius[0]);
+    fm.sample_bounds[1] = (int)std::floor((float)fm.crop[1] - fm.filter_radius[1]);
+    fm.sample_bounds[2] = (int)std::ceil((float)fm.crop[2] + fm.filter_radius[0]);
+    fm.sample_bounds[3] = (int)std::ceil((float)fm.crop[3] + fm.filter_radius[1]);
+    fm.max_sample_luminance = d->max_sample_luminance;
+    fm.scale = d->film_scale;
+    std::memcpy(fm.filter_table, d->filter_table, sizeof(fm.filter_table));
+    ctx->film_w = (uint32_t)(fm.crop[2] - fm.crop[0]);
+    ctx->film_h = (uint32_t)(fm.crop[3] - fm.crop[1]);
+    uint32_t sbw = (uint32_t)(fm.sample_bounds[2] - fm.sample_bounds[0]), sbh = (uint32_t)(fm.sample_bounds[3] - fm.sample_bounds[1]);
+    if (sbw >= 65536 || sbh >= 65536) return ctx->fail(PT_ERR_UNSUPPORTED, "film larger than 65535 pixels on a side");
+
+    // ---- sampler (SobolSampler::new, samplers/sobol.rs:16-31) -----------------
+    PtSobol& sb = sc.sobol;
+    sb.resolution = round_up_pow2(std::max(sbw, sbh));
+    sb.log2_resolution = log2int(sb.resolution);
+    sb.spp = round_up_pow2((uint32_t)d->spp);
+    if (sb.log2_resolution > 0 && (sb.log2_resolution - 1 >= ctx->sobol_n_vdc || sb.log2_resolution - 1 >= ctx->sobol_n_inv))
+        return ctx->fail(PT_ERR_UNSUPPORTED, "film resolution beyond the VdC Sobol' tables");
+    if ((st = upload(ctx, ctx->d_m32, ctx->sobol_m32.data(), ctx->sobol_m32.size())) != PT_OK) return st;
+    size_t row = sb.log2_resolution > 0 ? (size_t)(sb.log2_resolution - 1) * ctx->sobol_msize : 0;
+    if ((st = upload(ctx, ctx->d_vdc, ctx->sobol_vdc.data() + row, ctx->sobol_msize)) != PT_OK) return st;
+    if ((st = upload(ctx, ctx->d_vdc_inv, ctx->sobol_inv.data() + row, ctx->sobol_msize)) != PT_OK) return st;
+    sb.m32 = ctx->d_m32.as<uint32_t>();
+    sb.m32_len = (uint32_t)ctx->sobol_m32.size();
+    sb.vdc = ctx->d_vdc.as<uint64_t>();
+    sb.vdc_inv = ctx->d_vdc_inv.as<uint64_t>();
+
+    // ---- light sampling distribution (create_light_sample_distribution.rs:11-50) -
+    PtLightGrid& g = sc.grid;
+    g.n_lights = sc.n_lights;
+    g.stride = 2 * sc.n_lights + 2;
+    std::memcpy(g.wb_min, sc.wb_min, 12);
+    std::memcpy(g.wb_max, sc.wb_max, 12);
+    int strategy = d->light_strategy;
+    if (strategy == PT_LIGHTS_UNIFORM && sc.n_lights != 1) strategy = PT_LIGHTS_SPATIAL;
+    if (sc.n_lights > 0) {
+        if (strategy == PT_LIGHTS_SPATIAL) {
+            const uint32_t max_voxels = 64;
+            float diag[3] = {sc.wb_max[0] - sc.wb_min[0], sc.wb_max[1] - sc.wb_min[1], sc.wb_max[2] - sc.wb_min[2]};
+            int ext = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);
+            float bmax = diag[ext];
+            size_t nvox = 1;
+            for (int i = 0; i < 3; i++) {
+                float c = std::ceil(diag[i] / bmax * (float)max_voxels);
+                uint32_t v = c > 0.0f ? (c >= 4294967296.0f ? 0xffffffffu : (uint32_t)c) : 0u;
+                v = std::min(std::max(v, 1u), max_voxels);
+                g.voxels[i] = v;
+                nvox *= v;
+            }
+            g.single = 0;
+            size_t bytes = nvox * g.stride * sizeof(float);
+            if (bytes > ((size_t)16 << 30)) return ctx->fail(PT_ERR_UNSUPPORTED, "dense light grid would exceed 16 GiB; lazy per-voxel fill is not implemented yet");
+            PT_HIP(ctx->d_grid.alloc(bytes));
+            g.data = ctx->d_grid.as<float>();
+            PT_HIP(ptk_light_grid(ctx->stream, sc, ctx->d_grid.as<float>(), (uint32_t)nvox));
+            PT_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            // uniform / power: one Distribution1D (lightdistrib/uniform.rs, power.rs:9-17)
+            g.voxels[0] = g.voxels[1] = g.voxels[2] = 1;
+            g.single = 1;
+            uint32_t nl = sc.n_lights;
+            std::vector<float> tab(g.stride);
+            for (uint32_t i = 0; i < nl; i++) {
+                if (strategy == PT_LIGHTS_UNIFORM) tab[i] = 1.0f;
+                else {
+                    float n = lights[i].two_sided ? 2.0f : 1.0f;
+                    float s = n * lights[i].area * 3.14159265358979323846f;
+                    float r = lights[i].L[0] * s, gg = lights[i].L[1] * s, b = lights[i].L[2] * s;
+                    tab[i] = 0.212671f * r + 0.715160f * gg + 0.072169f * b;
+                }
+            }
+            float* cdf = tab.data() + nl;
+            cdf[0] = 0.0f;
+            for (uint32_t i = 1; i < nl + 1; i++) cdf[i] = cdf[i - 1] + tab[i - 1] / (float)nl;
+            float func_int = cdf[nl];
+            if (func_int == 0.0f) for (uint32_t i = 1; i < nl + 1; i++) cdf[i] = (float)i / (float)nl;
+            else for (uint32_t i = 1; i < nl + 1; i++) cdf[i] /= func_int;
+            cdf[nl + 1] = func_int;
+            if ((st = upload(ctx, ctx->d_grid, tab.data(), tab.size())) != PT_OK) return st;
+            g.data = ctx->d_grid.as<float>();
+        }
+    }
+
+    // ---- film + scratch buffers ---------------------------------------------------
+    size_t npx = (size_t)ctx->film_w * ctx->film_h;
+    PT_HIP(ctx->d_own.alloc(npx * 16));
+    PT_HIP(ctx->d_spillfilm.alloc(npx * 16));
+    PT_HIP(ctx->d_xyzw.alloc(npx * 16));
+    PT_HIP(ctx->d_rgb.alloc(npx * 12));
+    PT_HIP(hipMemset(ctx->d_own.p, 0, npx * 16));
+    PT_HIP(hipMemset(ctx->d_spillfilm.p, 0, npx * 16));
+    PT_HIP(hipMemset(ctx->d_xyzw.p, 0, npx * 16));
+    ctx->xyzw_committed = false;
+    if (!ctx->d_counters.p) {
+        PT_HIP(ctx->d_counters.alloc(sizeof(PtCounters)));
+        PT_HIP(hipMemset(ctx->d_counters.p, 0, sizeof(PtCounters)));
+        PT_HIP(ctx->d_err.alloc(16));
+        PT_HIP(hipMemset(ctx->d_err.p, 0, 16));
+        PT_HIP(ctx->d_ticket.alloc(16));
+        PT_HIP(ctx->d_counts.alloc(64));
+    }
+    if ((st = ensure_traversal_scratch(ctx)) != PT_OK) return st;
+    double t2 = now_ms();
+
+    pt_scene_info& inf = ctx->info;
+    std::memset(&inf, 0, sizeof(inf));
+    for (int i = 0; i < 4; i++) { inf.sample_bounds[i] = fm.sample_bounds[i]; inf.cropped_bounds[i] = fm.crop[i]; }
+    inf.spp = (int32_t)sb.spp;
+    inf.n_lights = sc.n_lights;
+    inf.n_nodes = (uint32_t)bvh.nodes.size();
+    inf.n_leaves = bvh.n_leaves;
+    std::memcpy(inf.world_bound, sc.wb_min, 12);
+    std::memcpy(inf.world_bound + 3, sc.wb_max, 12);
+    inf.bvh_build_ms = t1 - t0;
+    inf.upload_ms = t2 - t1;
+    ctx->have_scene = true;
+    return PT_OK;
+}
+
+pt_status pt_scene_info_get(const pt_context* ctx, pt_scene_info* out) {
+    if (!ctx || !out) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return PT_ERR_NO_SCENE;
+    *out = ctx->info;
+    return PT_OK;
+}
+
+pt_status pt_film_clear(pt_context* ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    (void)hipSetDevice(ctx->device);
+    size_t npx = (size_t)ctx->film_w * ctx->film_h;
+    PT_HIP(hipMemsetAsync(ctx->d_own.p, 0, npx * 16, ctx->stream));
+    PT_HIP(hipMemsetAsync(ctx->d_spillfilm.p, 0, npx * 16, ctx->stream));
+    PT_HIP(hipMemsetAsync(ctx->d_xyzw.p, 0, npx * 16, ctx->stream));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->xyzw_committed = false;
+    return PT_OK;
+}
+
+// Renders the listed tiles; radiance_out (device, optional) receives per-sample radiance.
+static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_tiles, float* d_radiance_out) {
+    const PtScene& sc = ctx->sc;
+    const int32_t* sbnd = sc.film.sample_bounds;
+    std::vector<pt_tile> all;
+    if (n_tiles == 0 && tiles == nullptr) {      // the reference's 16x16 decomposition (sampler.rs:266-289)
+        for (int32_t y = sbnd[1]; y < sbnd[3]; y += 16)
+            for (int32_t x = sbnd[0]; x < sbnd[2]; x += 16) {
+                pt_tile t = {x, y, std::min(x + 16, sbnd[2]), std::min(y + 16, sbnd[3])};
+                all.push_back(t);
+            }
+        tiles = all.data();
+        n_tiles = (uint32_t)all.size();
+    }
+    std::vector<uint32_t> pixels;
+    for (uint32_t i = 0; i < n_tiles; i++) {
+        const pt_tile& t = tiles[i];
+        if (t.x0 < sbnd[0] || t.y0 < sbnd[1] || t.x1 > sbnd[2] || t.y1 > sbnd[3] || t.x1 < t.x0 || t.y1 < t.y0)
+            return ctx->fail(PT_ERR_INVALID_ARGUMENT, "tile outside the sample bounds");
+        for (int32_t y = t.y0; y < t.y1; y++)
+            for (int32_t x = t.x0; x < t.x1; x++) pixels.push_back((uint32_t)(x - sbnd[0]) | ((uint32_t)(y - sbnd[1]) << 16));
+    }
+    if (pixels.empty()) return PT_OK;
+    const uint32_t spp = sc.sobol.spp;
+
+    size_t pool_target = (size_t)4 << 20;       // paths in flight per pass
+    if (const char* e = std::getenv("PBRTGPU_POOL_PATHS")) pool_target = std::max<size_t>(65536, std::strtoull(e, nullptr, 10));
+    size_t chunk_pix = std::min(pixels.size(), pool_target);
+    uint32_t S = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, pool_target / chunk_pix));
+    pt_status st;
+    if ((st = ensure_pool(ctx, chunk_pix * S)) != PT_OK) return st;
+    if (ctx->pixels_cap < pixels.size()) {
+        PT_HIP(ctx->d_pixels.alloc(pixels.size() * 4));
+        ctx->pixels_cap = pixels.size();
+    }
+    PT_HIP(hipMemcpyAsync(ctx->d_pixels.p, pixels.data(), pixels.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+
+    PtQueues Q;
+    Q.nee = ctx->d_qnee.as<uint32_t>();
+    Q.counts = ctx->d_counts.as<uint32_t>();
+    PtCounters* cnt = ctx->d_counters.as<PtCounters>();
+    uint32_t* err = ctx->d_err.as<uint32_t>();
+    size_t ev_i = 0;
+    std::vector<std::pair<size_t, int>> spans;   // (event index, kind) kind 0 = trace, 1 = shade
+
+    hipEvent_t ev_begin = get_event(ctx, ev_i++), ev_end = get_event(ctx, ev_i++);
+    PT_HIP(hipEventRecord(ev_begin, ctx->stream));
+
+    for (size_t c0 = 0; c0 < pixels.size(); c0 += chunk_pix) {
+        uint32_t n_pix = (uint32_t)std::min(chunk_pix, pixels.size() - c0);
+        const uint32_t* d_pix = ctx->d_pixels.as<uint32_t>() + c0;
+        for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+            uint32_t ns = std::min(S, spp - s0);
+            uint32_t* qa = ctx->d_qa.as<uint32_t>();
+            uint32_t* qb = ctx->d_qb.as<uint32_t>();
+            Q.cur = qa; Q.next = qb;
+            PT_HIP(ptk_gen(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q, d_pix, n_pix, s0, ns, cnt));
+            if (sc.n_lights > 0) {          // no lights: li() returns zero immediately (path.rs:71-74)
+                auto bounce = [&]() -> pt_status {
+                    hipEvent_t a = get_event(ctx, ev_i), b = get_event(ctx, ev_i + 1), c = get_event(ctx, ev_i + 2);
+                    if (!a || !b || !c) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
+                    spans.push_back({ev_i, 0});
+                    ev_i += 3;
+                    PT_HIP(hipEventRecord(a, ctx->stream));
+                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                    PT_HIP(hipEventRecord(b, ctx->stream));
+                    ctx->trace_launches++;
+                    PT_HIP(ptk_prep(ctx->stream, Q, 0));
+                    PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, cnt));
+                    PT_HIP(ptk_prep(ctx->stream, Q, 1));
+                    PT_HIP(hipEventRecord(c, ctx->stream));
+                    std::swap(Q.cur, Q.next);
+                    return PT_OK;
+                };
+                for (int b = 0; b <= sc.max_depth; b++)
+                    if ((st = bounce()) != PT_OK) return st;
+                // paths can outlive max_depth+1 iterations only by passing through material-less
+                // surfaces; the last SHADE may also have queued NEE work.  One counter read per pass.
+                for (;;) {
+                    uint32_t counts[4];
+                    PT_HIP(hipMemcpyAsync(counts, Q.counts, 16, hipMemcpyDeviceToHost, ctx->stream));
+                    PT_HIP(hipStreamSynchronize(ctx->stream));
+                    if (counts[0] == 0 && counts[2] == 0) break;
+                    if (counts[0] == 0) {     // only NEE resolves left
+                        PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                        ctx->trace_launches++;
+                        PT_HIP(ptk_prep(ctx->stream, Q, 0));
+                    } else if ((st = bounce()) != PT_OK) return st;
+                }
+            }
+            PT_HIP(ptk_film(ctx->stream, ctx->grid_wide, sc, ctx->paths, d_pix, n_pix, ns, ctx->d_own.as<float4>(), ctx->d_spillfilm.as<float4>(),
+                            d_radiance_out ? d_radiance_out + (size_t)c0 * spp * 3 : nullptr, s0, spp));
+        }
+    }
+    PT_HIP(hipEventRecord(ev_end, ctx->stream));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t herr = 0;
+    PT_HIP(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+    if (herr) {
+        PT_HIP(hipMemset(err, 0, 4));
+        return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow (BVH deeper than the computed bound)");
+    }
+    float ms = 0;
+    PT_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
+    ctx->render_ms += ms;
+    for (auto& sp : spans) {
+        float t_ms = 0, s_ms = 0;
+        PT_HIP(hipEventElapsedTime(&t_ms, ctx->ev[sp.first], ctx->ev[sp.first + 1]));
+        PT_HIP(hipEventElapsedTime(&s_ms, ctx->ev[sp.first + 1], ctx->ev[sp.first + 2]));
+        ctx->trace_ms += t_ms;
+        ctx->shade_ms += s_ms;
+    }
+    ctx->xyzw_committed = false;
+    return PT_OK;
+}
+
+pt_status pt_render(pt_context* ctx, const pt_tile* tiles, uint32_t n_tiles) {
+    if (!ctx || (n_tiles > 0 && !tiles)) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    (void)hipSetDevice(ctx->device);
+    return render_tiles(ctx, tiles, n_tiles, nullptr);
+}
+
+static pt_status film_to_xyzw(pt_context* ctx) {
+    if (ctx->xyzw_committed) return PT_OK;
+    uint32_t n = ctx->film_w * ctx->film_h;
+    PT_HIP(ptk_film_xyzw(ctx->stream, ctx->d_own.as<float4>(), ctx->d_spillfilm.as<float4>(), ctx->d_xyzw.as<float4>(), n));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+pt_status pt_film_download_xyzw(pt_context* ctx, float* out) {
+    if (!ctx || !out) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    (void)hipSetDevice(ctx->device);
+    pt_status st = film_to_xyzw(ctx);
+    if (st != PT_OK) return st;
+    PT_HIP(hipMemcpy(out, ctx->d_xyzw.p, (size_t)ctx->film_w * ctx->film_h * 16, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_film_device_xyzw(pt_context* ctx, void** dev_ptr, size_t* n_floats) {
+    if (!ctx || !dev_ptr || !n_floats) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    (void)hipSetDevice(ctx->device);
+    pt_status st = film_to_xyzw(ctx);
+    if (st != PT_OK) return st;
+    *dev_ptr = ctx->d_xyzw.p;
+    *n_floats = (size_t)ctx->film_w * ctx->film_h * 4;
+    return PT_OK;
+}
+
+pt_status pt_film_commit_xyzw(pt_context* ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    ctx->xyzw_committed = true;
+    return PT_OK;
+}
+
+pt_status pt_film_resolve_rgb(pt_context* ctx, float* rgb_out) {
+    if (!ctx || !rgb_out) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    (void)hipSetDevice(ctx->device);
+    pt_status st = film_to_xyzw(ctx);
+    if (st != PT_OK) return st;
+    uint32_t n = ctx->film_w * ctx->film_h;
+    PT_HIP(ptk_film_rgb(ctx->stream, ctx->d_xyzw.as<float4>(), ctx->d_rgb.as<float>(), n, ctx->sc.film.scale));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    PT_HIP(hipMemcpy(rgb_out, ctx->d_rgb.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+static pt_status trace_batch(pt_context* ctx, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out, uint8_t* occ, int any_hit) {
+    if (!ctx || !o || !d || !tmax || (!any_hit && !out) || (any_hit && !occ)) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    DevBuf d_o, d_d, d_t, d_out;
+    PT_HIP(d_o.alloc((size_t)n * 12)); PT_HIP(d_d.alloc((size_t)n * 12)); PT_HIP(d_t.alloc((size_t)n * 4));
+    PT_HIP(d_out.alloc((size_t)n * (any_hit ? 1 : sizeof(pt_hit))));
+    PT_HIP(hipMemcpy(d_o.p, o, (size_t)n * 12, hipMemcpyHostToDevice));
+    PT_HIP(hipMemcpy(d_d.p, d, (size_t)n * 12, hipMemcpyHostToDevice));
+    PT_HIP(hipMemcpy(d_t.p, tmax, (size_t)n * 4, hipMemcpyHostToDevice));
+    PT_HIP(hipMemsetAsync(ctx->d_ticket.p, 0, 16, ctx->stream));
+    hipEvent_t a = get_event(ctx, 0), b = get_event(ctx, 1);
+    PT_HIP(hipEventRecord(a, ctx->stream));
+    PT_HIP(ptk_trace_batch(ctx->stream, ctx->grid_trace, ctx->sc, n, d_o.as<float>(), d_d.as<float>(), d_t.as<float>(), any_hit ? nullptr : d_out.as<pt_hit>(),
+                           any_hit ? d_out.as<uint8_t>() : nullptr, any_hit, ctx->d_ticket.as<uint32_t>(), ctx->d_counters.as<PtCounters>(),
+                           ctx->d_spill.as<uint32_t>(), ctx->spill_depth, ctx->d_err.as<uint32_t>()));
+    PT_HIP(hipEventRecord(b, ctx->stream));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    PT_HIP(hipEventElapsedTime(&ms, a, b));
+    ctx->trace_ms += ms;
+    ctx->trace_launches++;
+    uint32_t herr = 0;
+    PT_HIP(hipMemcpy(&herr, ctx->d_err.p, 4, hipMemcpyDeviceToHost));
+    if (herr) { PT_HIP(hipMemset(ctx->d_err.p, 0, 4)); return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow"); }
+    if (any_hit) PT_HIP(hipMemcpy(occ, d_out.p, n, hipMemcpyDeviceToHost));
+    else PT_HIP(hipMemcpy(out, d_out.p, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_trace_closest(pt_context* ctx, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out) {
+    return trace_batch(ctx, n, o, d, tmax, out, nullptr, 0);
+}
+pt_status pt_trace_any(pt_context* ctx, uint32_t n, const float* o, const float* d, const float* tmax, uint8_t* occluded_out) {
+    return trace_batch(ctx, n, o, d, tmax, nullptr, occluded_out, 1);
+}
+
+pt_status pt_generate_camera_rays(pt_context* ctx, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* out_o, float* out_d,
+                                  float* out_pfilm) {
+    if (!ctx || !pixel_xy || !sample_index || !out_o || !out_d || !out_pfilm) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    DevBuf d_px, d_si, d_o, d_d, d_pf;
+    PT_HIP(d_px.alloc((size_t)n * 8)); PT_HIP(d_si.alloc((size_t)n * 4));
+    PT_HIP(d_o.alloc((size_t)n * 12)); PT_HIP(d_d.alloc((size_t)n * 12)); PT_HIP(d_pf.alloc((size_t)n * 8));
+    PT_HIP(hipMemcpy(d_px.p, pixel_xy, (size_t)n * 8, hipMemcpyHostToDevice));
+    PT_HIP(hipMemcpy(d_si.p, sample_index, (size_t)n * 4, hipMemcpyHostToDevice));
+    PT_HIP(ptk_camera_rays(ctx->stream, ctx->sc, n, d_px.as<int32_t>(), d_si.as<uint32_t>(), d_o.as<float>(), d_d.as<float>(), d_pf.as<float>()));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    PT_HIP(hipMemcpy(out_o, d_o.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(out_d, d_d.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(out_pfilm, d_pf.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_sobol_samples(pt_context* ctx, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim, float* out) {
+    if (!ctx || !pixel_xy || !sample_index || !dim || !out) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    DevBuf d_px, d_si, d_dim, d_out;
+    PT_HIP(d_px.alloc((size_t)n * 8)); PT_HIP(d_si.alloc((size_t)n * 4)); PT_HIP(d_dim.alloc((size_t)n * 4)); PT_HIP(d_out.alloc((size_t)n * 4));
+    PT_HIP(hipMemcpy(d_px.p, pixel_xy, (size_t)n * 8, hipMemcpyHostToDevice));
+    PT_HIP(hipMemcpy(d_si.p, sample_index, (size_t)n * 4, hipMemcpyHostToDevice));
+    PT_HIP(hipMemcpy(d_dim.p, dim, (size_t)n * 4, hipMemcpyHostToDevice));
+    PT_HIP(ptk_sobol_samples(ctx->stream, ctx->sc, n, d_px.as<int32_t>(), d_si.as<uint32_t>(), d_dim.as<uint32_t>(), d_out.as<float>()));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    PT_HIP(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_radiance_samples(pt_context* ctx, const pt_tile* tile, float* out_rgb) {
+    if (!ctx || !tile || !out_rgb) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    (void)hipSetDevice(ctx->device);
+    size_t npx = (size_t)std::max(0, tile->x1 - tile->x0) * (size_t)std::max(0, tile->y1 - tile->y0);
+    if (npx == 0) return PT_OK;
+    size_t n = npx * ctx->sc.sobol.spp * 3;
+    DevBuf d_rad;
+    PT_HIP(d_rad.alloc(n * 4));
+    // the film is left untouched: render into scratch copies
+    size_t fpx = (size_t)ctx->film_w * ctx->film_h;
+    DevBuf keep_own, keep_spill;
+    PT_HIP(keep_own.alloc(fpx * 16)); PT_HIP(keep_spill.alloc(fpx * 16));
+    PT_HIP(hipMemcpy(keep_own.p, ctx->d_own.p, fpx * 16, hipMemcpyDeviceToDevice));
+    PT_HIP(hipMemcpy(keep_spill.p, ctx->d_spillfilm.p, fpx * 16, hipMemcpyDeviceToDevice));
+    pt_status st = render_tiles(ctx, tile, 1, d_rad.as<float>());
+    PT_HIP(hipMemcpy(ctx->d_own.p, keep_own.p, fpx * 16, hipMemcpyDeviceToDevice));
+    PT_HIP(hipMemcpy(ctx->d_spillfilm.p, keep_spill.p, fpx * 16, hipMemcpyDeviceToDevice));
+    if (st != PT_OK) return st;
+    PT_HIP(hipMemcpy(out_rgb, d_rad.p, n * 4, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_bvh_leaf_order(const pt_scene_desc* d, uint32_t* order_out, uint32_t* n_nodes, uint32_t* n_leaves, uint32_t* max_stack) {
+    if (!d || !order_out || !d->P || !d->indices || !d->tri_mesh || !d->meshes || d->n_triangles == 0) return PT_ERR_INVALID_ARGUMENT;
+    std::vector<uint32_t> tri_flags(d->n_triangles, 0);
+    ptbvh::Result bvh;
+    if (!ptbvh::build(d->P, d->indices, tri_flags.data(), d->n_triangles, d->split_method, d->max_node_prims > 0 ? d->max_node_prims : 4, &bvh))
+        return PT_ERR_UNSUPPORTED;
+    for (uint32_t r = 0; r < d->n_triangles; r++) order_out[r] = bvh.tris[r].prim;
+    if (n_nodes) *n_nodes = (uint32_t)bvh.nodes.size();
+    if (n_leaves) *n_leaves = bvh.n_leaves;
+    if (max_stack) *max_stack = bvh.max_stack;
+    return PT_OK;
+}
+
+pt_status pt_get_counters(pt_context* ctx, pt_counters* out) {
+    if (!ctx || !out) return PT_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    std::memset(out, 0, sizeof(*out));
+    if (ctx->d_counters.p) {
+        PtCounters c;
+        PT_HIP(hipMemcpy(&c, ctx->d_counters.p, sizeof(c), hipMemcpyDeviceToHost));
+        out->camera_rays = c.camera_rays; out->regular_rays = c.regular_rays; out->shadow_rays = c.shadow_rays;
+        out->nodes_visited = c.nodes; out->tris_tested = c.tris; out->path_vertices = c.vertices;
+    }
+    out->trace_launches = ctx->trace_launches;
+    out->trace_ms = ctx->trace_ms; out->shade_ms = ctx->shade_ms; out->render_ms = ctx->render_ms;
+    return PT_OK;
+}
+
+pt_status pt_reset_counters(pt_context* ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_counters.p) PT_HIP(hipMemset(ctx->d_counters.p, 0, sizeof(PtCounters)));
+    ctx->trace_launches = 0;
+    ctx->trace_ms = ctx->shade_ms = ctx->render_ms = 0;
+    return PT_OK;
+}
+
+}  // extern "C"

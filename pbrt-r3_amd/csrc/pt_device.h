@@ -1,0 +1,163 @@
+// pt_device.h -- plain-old-data layouts shared by the host side (pt_context.cpp,
+// pt_bvh.cpp) and the gfx950 kernels (pt_kernels.hip).  Everything here lives in
+// HBM; layouts are chosen for 16-byte lane loads and 128-byte node fetches.
+#pragma once
+#include <stdint.h>
+
+#define PT_WAVE 64
+#define PT_BLOCK 256
+#define PT_LDS_STACK 32          // per-lane traversal stack entries kept in LDS
+#define PT_EMPTY_REF 0xffffffffu
+#define PT_LEAF_BIT 0x80000000u
+
+// One 4-wide BVH node = one 128-byte line.  Replaces the reference's 144-byte
+// SIMDBVHNode + separate leaf nodes (qbvh_x86.rs:15-24, :93-176): a child that is
+// a leaf is referenced as PT_LEAF_BIT | first_triangle_record, so leaves cost no
+// node fetch; an empty slot is PT_EMPTY_REF.
+struct PtNode {
+    float bmin[3][4];            // [axis][child]
+    float bmax[3][4];
+    uint32_t child[4];
+    uint32_t axes;               // axis_top | axis_left << 2 | axis_right << 4
+    uint32_t pad[3];
+};
+
+// Triangle record in BVH leaf order (48 bytes = 3 x dwordx4).  The last record of
+// a leaf carries PT_TRI_LAST, so a leaf reference needs no count.
+#define PT_TRI_LAST 1u
+#define PT_TRI_ONE_SIDED 2u      // !two_sided: cull when dot(n, d) >= 0 (triangle.rs:247-251)
+#define PT_TRI_FLIP 4u           // reverse_orientation ^ swaps_handedness
+struct PtTri {
+    float p0[3];
+    uint32_t prim;               // caller's triangle index
+    float p1[3];
+    uint32_t flags;
+    float p2[3];
+    uint32_t pad;
+};
+
+// Per original triangle shading record.
+struct PtTriInfo {
+    uint32_t v[3];               // vertex indices (N / S / UV lookups)
+    uint32_t mesh;
+    int32_t light;               // index into lights[] or -1
+    int32_t material;            // index into materials[] or -1
+    uint32_t mesh_flags;         // PT_MESH_* of include/pbrtgpu.h
+    uint32_t pad;
+};
+
+struct PtMaterial {
+    int32_t type;
+    float kd[3];
+    float sigma;
+    float oren_a, oren_b;        // OrenNayar::new (oren_nayar.rs:16-23), precomputed on the host
+    float pad;
+};
+
+// One DiffuseAreaLight (one emissive triangle).
+struct PtLight {
+    float p0[3]; float area;
+    float p1[3]; uint32_t mesh_flags;
+    float p2[3]; int32_t two_sided;
+    float L[3];  uint32_t tri_rec;   // index of the triangle's PtTri record
+    float n0[3]; uint32_t prim;
+    float n1[3]; uint32_t pad0;
+    float n2[3]; uint32_t pad1;
+};
+
+struct PtCamera {
+    float raster_to_camera[16];
+    float camera_to_world[16];
+    float lens_radius, focal_distance;
+    float pad[2];
+};
+
+struct PtFilm {
+    int32_t crop[4];             // x0 y0 x1 y1
+    int32_t sample_bounds[4];
+    float filter_radius[2];
+    float inv_filter_radius[2];
+    float max_sample_luminance;
+    float scale;
+    int32_t box_unit;            // 1 when every in-pixel sample has a one-pixel footprint of weight 1
+    int32_t pad;
+    float filter_table[256];
+};
+
+struct PtSobol {
+    const uint32_t* m32;         // [n_dims * 52]
+    const uint64_t* vdc;         // row (log2_resolution - 1) of VDC_SOBOL_MATRICES
+    const uint64_t* vdc_inv;     // row (log2_resolution - 1) of VDC_SOBOL_MATRICES_INV
+    uint32_t m32_len;
+    uint32_t log2_resolution;
+    uint32_t resolution;
+    uint32_t spp;                // rounded up to a power of two
+};
+
+struct PtLightGrid {
+    // dense replacement for the reference's lazily filled hash table (spatial.rs:199-260):
+    // voxel v owns floats [v*stride, (v+1)*stride): func[nl], cdf[nl+1], func_int
+    const float* data;
+    uint32_t voxels[3];
+    uint32_t n_lights;
+    uint32_t stride;
+    uint32_t single;             // 1: uniform / power strategy, one table for every point
+    float wb_min[3], wb_max[3];
+};
+
+struct PtCounters {
+    unsigned long long regular_rays, shadow_rays, nodes, tris, vertices, camera_rays;
+};
+
+struct PtScene {
+    const PtNode* nodes;
+    const PtTri* tris;
+    const PtTriInfo* tri_info;
+    const float* N; const float* S; const float* UV;     // per-vertex attributes or null
+    const PtMaterial* materials;
+    const PtLight* lights;
+    uint32_t n_lights;
+    uint32_t root_ref;           // node 0, or a leaf reference when the whole scene is one leaf
+    float wb_min[3], wb_max[3];  // BVH root bounds (Scene::world_bound)
+    int32_t max_depth;
+    float rr_threshold;
+    PtCamera cam;
+    PtFilm film;
+    PtSobol sobol;
+    PtLightGrid grid;
+};
+
+// ---- wavefront path pool (SoA, one slot per in-flight camera sample)
+struct PtPaths {
+    float4* ray_o;       // xyz origin, w = t_max
+    float4* ray_d;       // xyz direction
+    float4* sh_o;        // shadow ray (NEE light sample), w = t_max
+    float4* sh_d;
+    float4* pr_o;        // MIS probe ray, w = t_max (inf)
+    float4* pr_d;
+    float4* beta;        // xyz, w = eta_scale
+    float4* L;           // xyz radiance, w unused
+    float4* pendA;       // light-sample term f*Li*(w/pdf), w = selection pdf
+    float4* pendB;       // BSDF-sample term,              w = beta snapshot index unused
+    float4* pbeta;       // beta at NEE time
+    float2* p_film;
+    uint64_t* sobol_index;
+    uint32_t* pixel;     // x | y << 16 relative to sample_bounds.min
+    uint32_t* state;     // dim (16) | bounces (8) | flags (8)
+    float* hit_t;
+    int32_t* hit_rec;    // triangle record index or -1
+    uint32_t* nee;       // bit0 shadow ray live, bit1 probe live, bits 8.. light index
+    uint8_t* occluded;
+    int32_t* probe_rec;
+};
+
+#define PT_ST_SPECULAR 1u
+#define PT_NEE_SHADOW 1u
+#define PT_NEE_PROBE 2u
+
+struct PtQueues {
+    uint32_t* cur;       // path ids to shade / whose continuation ray is traced
+    uint32_t* next;
+    uint32_t* nee;       // path ids with a pending NEE resolve
+    uint32_t* counts;    // [0]=n_cur [1]=n_next [2]=n_nee [3]=work ticket
+};

@@ -1,0 +1,23 @@
+// pt_kernels.h -- host-callable launchers of the kernels in pt_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pt_device.h"
+#include "../../include/pbrtgpu.h"
+
+hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
+                     uint32_t spill_depth, uint32_t* err);
+hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out,
+                           uint8_t* occ, int any_hit, uint32_t* ticket, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err);
+hipError_t ptk_gen(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const uint32_t* pixels, uint32_t n_pix,
+                   uint32_t s0, uint32_t n_samples, PtCounters* cnt);
+hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode);
+hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt);
+hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,
+                    float4* own, float4* spill, float* radiance_out, uint32_t s0, uint32_t spp_total);
+hipError_t ptk_film_xyzw(hipStream_t st, const float4* own, const float4* spill, float4* xyzw, uint32_t n);
+hipError_t ptk_film_rgb(hipStream_t st, const float4* xyzw, float* rgb, uint32_t n, float scale);
+hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32_t n_vox);
+hipError_t ptk_camera_rays(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* o, float* d,
+                           float* pf);
+hipError_t ptk_sobol_samples(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim,
+                             float* out);

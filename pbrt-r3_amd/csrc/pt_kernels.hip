@@ -1,0 +1,1154 @@
+// pt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the wavefront
+// path tracer.  HBM-bound pointer chasing: no MFMA anywhere.  Layout rules:
+//   * one 4-wide BVH node = one 128-byte line, fetched as 8 x dwordx4 per lane
+//   * triangle records are 48 bytes (3 x dwordx4) in leaf order
+//   * per-lane traversal stack lives in LDS ([entry][lane] => conflict-free at any
+//     depth mix, since 64 lanes x 4 B = two full bank rows), spilling to HBM past
+//     PT_LDS_STACK entries
+//   * queues are SoA index lists; compaction uses wave ballot + one atomic per wave
+//   * persistent grids pull 64-item tickets from a device counter
+// Arithmetic follows the reference operation by operation (-ffp-contract=off):
+//   traversal  src/accelerators/bvh/accel/qbvh/qbvh_x86.rs:26-67, :230-343
+//   triangle   src/shapes/triangle.rs:226-577
+//   shading    src/integrators/path.rs:61-241, src/core/integrator/sample_lights.rs:129-176,:330-453
+//   sampler    src/samplers/sobol.rs, src/core/lowdiscrepancy/sobol/sobol.rs:5-56
+//   camera     src/cameras/perspective.rs:121-183, src/core/transform/transform.rs:184-282
+//   film       src/core/film/film_tile.rs:84-183, film.rs:219-241, :440-484
+#include <hip/hip_runtime.h>
+#include "pt_device.h"
+#include "pt_device_math.h"
+#include "pt_kernels.h"
+#include "../../include/pbrtgpu.h"
+
+// ============================================================ Sobol' sampler
+PT_DEV uint64_t sobol_interval_to_index(const PtSobol& sb, uint64_t frame, int32_t px, int32_t py) {
+    const uint32_t m = sb.log2_resolution;
+    if (m == 0) return 0;
+    uint64_t index = frame << (m << 1);
+    uint64_t delta = 0;
+    for (int c = 0; frame != 0; frame >>= 1, c++)
+        if (frame & 1) delta ^= sb.vdc[c];
+    uint64_t b = ((((uint64_t)(uint32_t)px) << m) | (uint64_t)(int64_t)py) ^ delta;
+    for (int c = 0; b != 0; b >>= 1, c++)
+        if (b & 1) index ^= sb.vdc_inv[c];
+    return index;
+}
+PT_DEV float sobol_sample_float(const PtSobol& sb, uint64_t a, uint32_t dim) {
+    uint32_t v = 0;
+    uint32_t base = dim * 52u;
+    if (base > sb.m32_len - 1u) base = sb.m32_len - 1u;
+    while (a != 0) {
+        uint32_t bit = (uint32_t)__builtin_ctzll(a);
+        uint32_t i = base + bit;
+        if (i >= sb.m32_len) i %= sb.m32_len;
+        v ^= sb.m32[i];
+        a &= a - 1;
+    }
+    float fv = (float)((double)v * 2.3283064365386963e-10);
+    return fminf(fv, PT_ONE_MINUS_EPS);
+}
+// SobolSampler::sample_dimension (samplers/sobol.rs:167-185)
+PT_DEV float sample_dimension(const PtScene& sc, uint64_t index, uint32_t dim, int32_t px, int32_t py) {
+    float s = sobol_sample_float(sc.sobol, index, dim);
+    if (dim == 0 || dim == 1) {
+        int32_t bmin = sc.film.sample_bounds[dim];
+        int32_t pix = dim == 0 ? px : py;
+        s = s * (float)sc.sobol.resolution + (float)bmin;
+        s = clampf(s - (float)pix, 0.0f, PT_ONE_MINUS_EPS);
+        s = s - truncf(s);
+    }
+    return s;
+}
+struct Sampler {
+    uint64_t index;
+    uint32_t dim;
+    int32_t px, py;
+    // no sample arrays are requested by PathIntegrator => array_end_dim == array_start_dim == 5,
+    // and the skip tests of get_1d / get_2d (sobol.rs:95-141) never fire except get_2d at dim 4.
+    PT_DEV float get_1d(const PtScene& sc) { float x = sample_dimension(sc, index, dim, px, py); dim += 1; return x; }
+    PT_DEV V2 get_2d(const PtScene& sc) {
+        float x = sample_dimension(sc, index, dim, px, py);
+        float y = sample_dimension(sc, index, dim + 1, px, py);
+        dim += 2;
+        return mk2(x, y);
+    }
+};
+
+// ============================================================ camera
+PT_DEV V3 xform_point(const float* m, V3 p) {
+    float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    float wp = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (wp == 1.0f) return mk3(xp, yp, zp);
+    return mk3(xp / wp, yp / wp, zp / wp);
+}
+PT_DEV V3 xform_vector(const float* m, V3 v) {
+    return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+PT_DEV void generate_camera_ray(const PtScene& sc, V2 p_film, V2 u_lens, V3* o_out, V3* d_out) {
+    V3 p_camera = xform_point(sc.cam.raster_to_camera, mk3(p_film.x, p_film.y, 0.0f));
+    V3 o = mk3(0.0f, 0.0f, 0.0f);
+    V3 d = normalize(p_camera);
+    if (sc.cam.lens_radius > 0.0f) {
+        V2 dl = concentric_sample_disk(u_lens);
+        V2 p_lens = mk2(dl.x * sc.cam.lens_radius, dl.y * sc.cam.lens_radius);
+        float ft = sc.cam.focal_distance / d.z;
+        V3 p_focus = o + d * ft;
+        o = mk3(p_lens.x, p_lens.y, 0.0f);
+        d = normalize(p_focus - o);
+    }
+    // Transform::transform_ray: nudge the origin along d by the transform's rounding error bound
+    const float* m = sc.cam.camera_to_world;
+    V3 op = xform_point(m, o);
+    float xa = fabsf(m[0] * o.x) + fabsf(m[1] * o.y) + fabsf(m[2] * o.z) + fabsf(m[3]);
+    float ya = fabsf(m[4] * o.x) + fabsf(m[5] * o.y) + fabsf(m[6] * o.z) + fabsf(m[7]);
+    float za = fabsf(m[8] * o.x) + fabsf(m[9] * o.y) + fabsf(m[10] * o.z) + fabsf(m[11]);
+    V3 o_err = PT_GAMMA(3.0f) * mk3(xa, ya, za);
+    V3 dd = xform_vector(m, d);
+    float ls = length_squared(dd);
+    if (ls > 0.0f) {
+        float dt = dot(vabs(dd), o_err) / ls;
+        op = op + dd * dt;
+    }
+    *o_out = op;
+    *d_out = dd;
+}
+
+// ============================================================ ray / triangle
+struct RayPre {          // per-ray constants of the watertight test, hoisted out of the per-triangle code
+    V3 o, d;
+    int kx, ky, kz;
+    float sx, sy, sz;
+    V3 dperm;
+};
+PT_DEV float sel3(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+PT_DEV void ray_precompute(RayPre& r, V3 o, V3 d) {
+    r.o = o; r.d = d;
+    V3 a = vabs(d);
+    int kz = (a.x > a.y) ? ((a.x > a.z) ? 0 : 2) : ((a.y > a.z) ? 1 : 2);   // max_dimension (misc.rs:35-50)
+    int kx = kz == 2 ? 0 : kz + 1;
+    int ky = kx == 2 ? 0 : kx + 1;
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.dperm = mk3(sel3(d, kx), sel3(d, ky), sel3(d, kz));
+    r.sx = -r.dperm.x / r.dperm.z;
+    r.sy = -r.dperm.y / r.dperm.z;
+    r.sz = 1.0f / r.dperm.z;
+}
+struct TriHit { float t, b0, b1, b2; };
+// triangle.rs:240-347 / :466-571 (intersect and intersect_p share this front half)
+PT_DEV bool tri_test(const RayPre& r, V3 p0, V3 p1, V3 p2, uint32_t flags, float t_max, TriHit& h) {
+    if (flags & PT_TRI_ONE_SIDED) {
+        V3 n = cross(p0 - p2, p1 - p2);
+        if (flags & PT_TRI_FLIP) n = n * -1.0f;
+        if (dot(n, r.d) >= 0.0f) return false;
+    }
+    V3 q0 = p0 - r.o, q1 = p1 - r.o, q2 = p2 - r.o;
+    float p0x = sel3(q0, r.kx), p0y = sel3(q0, r.ky), p0z = sel3(q0, r.kz);
+    float p1x = sel3(q1, r.kx), p1y = sel3(q1, r.ky), p1z = sel3(q1, r.kz);
+    float p2x = sel3(q2, r.kx), p2y = sel3(q2, r.ky), p2z = sel3(q2, r.kz);
+    p0x += r.sx * p0z; p0y += r.sy * p0z;
+    p1x += r.sx * p1z; p1y += r.sy * p1z;
+    p2x += r.sx * p2z; p2y += r.sy * p2z;
+    float e0 = p1x * p2y - p1y * p2x;
+    float e1 = p2x * p0y - p2y * p0x;
+    float e2 = p0x * p1y - p0y * p1x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double a0 = (double)p2x * (double)p1y, b0 = (double)p2y * (double)p1x;
+        e0 = (float)(b0 - a0);
+        double a1 = (double)p0x * (double)p2y, b1 = (double)p0y * (double)p2x;
+        e1 = (float)(b1 - a1);
+        double a2 = (double)p1x * (double)p0y, b2 = (double)p1y * (double)p0x;
+        e2 = (float)(b2 - a2);
+    }
+    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0.0f) return false;
+    p0z *= r.sz; p1z *= r.sz; p2z *= r.sz;
+    float t_scaled = e0 * p0z + e1 * p1z + e2 * p2z;
+    if (det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) return false;
+    else if (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)) return false;
+    float inv_det = 1.0f / det;
+    float t = t_scaled * inv_det;
+    float max_zt = max3(fabsf(p0z), fabsf(p1z), fabsf(p2z));
+    float delta_z = PT_GAMMA(3.0f) * max_zt;
+    float max_xt = max3(fabsf(p0x), fabsf(p1x), fabsf(p2x));
+    float max_yt = max3(fabsf(p0y), fabsf(p1y), fabsf(p2y));
+    float delta_x = PT_GAMMA(5.0f) * (max_xt + max_zt);
+    float delta_y = PT_GAMMA(5.0f) * (max_yt + max_zt);
+    float delta_e = 2.0f * (PT_GAMMA(2.0f) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
+    float max_e = max3(fabsf(e0), fabsf(e1), fabsf(e2));
+    float delta_t = 3.0f * (PT_GAMMA(3.0f) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
+    if (t <= delta_t) return false;
+    h.t = t; h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;
+    return true;
+}
+
+struct TriVerts { V3 p0, p1, p2; uint32_t prim, flags; };
+PT_DEV TriVerts load_tri(const PtTri* tris, uint32_t rec) {
+    const float4* q = reinterpret_cast<const float4*>(tris) + (size_t)rec * 3;
+    float4 a = q[0], b = q[1], c = q[2];
+    TriVerts t;
+    t.p0 = mk3(a.x, a.y, a.z); t.prim = __float_as_uint(a.w);
+    t.p1 = mk3(b.x, b.y, b.z); t.flags = __float_as_uint(b.w);
+    t.p2 = mk3(c.x, c.y, c.z);
+    return t;
+}
+
+// ============================================================ BVH traversal
+// _mm_max_ps / _mm_min_ps semantics: second operand when either is NaN
+PT_DEV float sse_max(float a, float b) { return a > b ? a : b; }
+PT_DEV float sse_min(float a, float b) { return a < b ? a : b; }
+
+struct TravCtx {
+    uint32_t* lds;           // &stack[0][tid]; entry e at lds[e * PT_BLOCK]
+    uint32_t* spill;         // &spill[gtid]; entry e (>= PT_LDS_STACK) at spill[(e - PT_LDS_STACK) * spill_stride]
+    uint32_t spill_stride;
+    uint32_t spill_depth;
+    uint32_t n_nodes, n_tris;
+    uint32_t overflow;
+};
+PT_DEV void stk_push(TravCtx& c, uint32_t& sp, uint32_t v) {
+    if (sp < PT_LDS_STACK) c.lds[sp * PT_BLOCK] = v;
+    else if (sp - PT_LDS_STACK < c.spill_depth) c.spill[(size_t)(sp - PT_LDS_STACK) * c.spill_stride] = v;
+    else { c.overflow = 1; return; }
+    sp++;
+}
+PT_DEV uint32_t stk_pop(TravCtx& c, uint32_t& sp) {
+    sp--;
+    if (sp < PT_LDS_STACK) return c.lds[sp * PT_BLOCK];
+    return c.spill[(size_t)(sp - PT_LDS_STACK) * c.spill_stride];
+}
+
+// Bounds3f::intersect_p on the root (bounds3.rs:154-163, intersect.rs:46-65): NaN-ignoring max/min.
+PT_DEV bool root_test(const PtScene& sc, V3 o, V3 idir, uint32_t sbits, float t_max, float& tmin, float& tmax) {
+    float t0 = 0.0f, t1 = t_max;
+    float lo, hi;
+    lo = (sbits & 1) ? sc.wb_max[0] : sc.wb_min[0]; hi = (sbits & 1) ? sc.wb_min[0] : sc.wb_max[0];
+    t0 = fmaxf(t0, (lo - o.x) * idir.x); t1 = fminf(t1, (hi - o.x) * idir.x);
+    lo = (sbits & 2) ? sc.wb_max[1] : sc.wb_min[1]; hi = (sbits & 2) ? sc.wb_min[1] : sc.wb_max[1];
+    t0 = fmaxf(t0, (lo - o.y) * idir.y); t1 = fminf(t1, (hi - o.y) * idir.y);
+    lo = (sbits & 4) ? sc.wb_max[2] : sc.wb_min[2]; hi = (sbits & 4) ? sc.wb_min[2] : sc.wb_max[2];
+    t0 = fmaxf(t0, (lo - o.z) * idir.z); t1 = fminf(t1, (hi - o.z) * idir.z);
+    if (t0 <= t1) { tmin = t0; tmax = t1; return true; }
+    return false;
+}
+
+// One node: 4 slab tests (test_aabb) + ORDER_TABLE in closed form:
+// children are pushed so that pops visit {0,1} before {2,3} iff the ray is non-negative
+// along axis_top, 0 before 1 iff non-negative along axis_left, 2 before 3 iff along axis_right.
+PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t sbits, float tmin, float tmax, TravCtx& c, uint32_t& sp) {
+    const float4* q = reinterpret_cast<const float4*>(nodes + ni);
+    float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
+    uint4 ch = reinterpret_cast<const uint4*>(q)[6];
+    uint32_t axes = reinterpret_cast<const uint4*>(q)[7].x;
+    // near / far planes per axis by ray sign
+    float4 nx = (sbits & 1) ? mxx : mnx, fx = (sbits & 1) ? mnx : mxx;
+    float4 ny = (sbits & 2) ? mxy : mny, fy = (sbits & 2) ? mny : mxy;
+    float4 nz = (sbits & 4) ? mxz : mnz, fz = (sbits & 4) ? mnz : mxz;
+    uint32_t mask = 0;
+#define PT_SLAB(k, C)                                                        \
+    {                                                                        \
+        float a = tmin, b = tmax;                                            \
+        a = sse_max(a, (nx.C - o.x) * idir.x); b = sse_min(b, (fx.C - o.x) * idir.x); \
+        a = sse_max(a, (ny.C - o.y) * idir.y); b = sse_min(b, (fy.C - o.y) * idir.y); \
+        a = sse_max(a, (nz.C - o.z) * idir.z); b = sse_min(b, (fz.C - o.z) * idir.z); \
+        if (b >= a) mask |= (1u << k);                                       \
+    }
+    PT_SLAB(0, x) PT_SLAB(1, y) PT_SLAB(2, z) PT_SLAB(3, w)
+#undef PT_SLAB
+    if (ch.x == PT_EMPTY_REF) mask &= ~1u;
+    if (ch.y == PT_EMPTY_REF) mask &= ~2u;
+    if (ch.z == PT_EMPTY_REF) mask &= ~4u;
+    if (ch.w == PT_EMPTY_REF) mask &= ~8u;
+    if (mask == 0) return;
+    uint32_t s_top = (sbits >> (axes & 3)) & 1, s_left = (sbits >> ((axes >> 2) & 3)) & 1, s_right = (sbits >> ((axes >> 4) & 3)) & 1;
+    // push order = reverse visit order
+    uint32_t l_first = s_left ? ch.x : ch.y, l_second = s_left ? ch.y : ch.x;          // pushed first => visited last
+    uint32_t l_first_bit = s_left ? 1u : 2u, l_second_bit = s_left ? 2u : 1u;
+    uint32_t r_first = s_right ? ch.z : ch.w, r_second = s_right ? ch.w : ch.z;
+    uint32_t r_first_bit = s_right ? 4u : 8u, r_second_bit = s_right ? 8u : 4u;
+    if (!s_top) {
+        if (mask & r_first_bit) stk_push(c, sp, r_first);
+        if (mask & r_second_bit) stk_push(c, sp, r_second);
+        if (mask & l_first_bit) stk_push(c, sp, l_first);
+        if (mask & l_second_bit) stk_push(c, sp, l_second);
+    } else {
+        if (mask & l_first_bit) stk_push(c, sp, l_first);
+        if (mask & l_second_bit) stk_push(c, sp, l_second);
+        if (mask & r_first_bit) stk_push(c, sp, r_first);
+        if (mask & r_second_bit) stk_push(c, sp, r_second);
+    }
+}
+
+// intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
+PT_DEV int32_t trace_closest(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c, float* t_out) {
+    V3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+    float tmin, tmax;
+    if (!root_test(sc, o, idir, sbits, t_max, tmin, tmax)) return -1;
+    RayPre rp;
+    ray_precompute(rp, o, d);
+    int32_t best = -1;
+    float ray_tmax = t_max;
+    uint32_t sp = 0;
+    stk_push(c, sp, sc.root_ref);
+    while (sp > 0) {
+        uint32_t ref = stk_pop(c, sp);
+        if (ref & PT_LEAF_BIT) {
+            uint32_t rec = ref & ~PT_LEAF_BIT;
+            bool leaf_hit = false;
+            for (;;) {
+                TriVerts tv = load_tri(sc.tris, rec);
+                c.n_tris++;
+                TriHit h;
+                if (tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, ray_tmax, h)) { ray_tmax = h.t; best = (int32_t)rec; leaf_hit = true; }
+                if (tv.flags & PT_TRI_LAST) break;
+                rec++;
+            }
+            if (leaf_hit) tmax = ray_tmax;
+        } else {
+            c.n_nodes++;
+            visit_node(sc.nodes, ref, o, idir, sbits, tmin, tmax, c, sp);
+        }
+    }
+    *t_out = ray_tmax;
+    return best;
+}
+// intersect_simd_p (qbvh_x86.rs:289-343): any hit
+PT_DEV bool trace_any(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c) {
+    V3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+    float tmin, tmax;
+    if (!root_test(sc, o, idir, sbits, t_max, tmin, tmax)) return false;
+    RayPre rp;
+    ray_precompute(rp, o, d);
+    uint32_t sp = 0;
+    stk_push(c, sp, sc.root_ref);
+    while (sp > 0) {
+        uint32_t ref = stk_pop(c, sp);
+        if (ref & PT_LEAF_BIT) {
+            uint32_t rec = ref & ~PT_LEAF_BIT;
+            for (;;) {
+                TriVerts tv = load_tri(sc.tris, rec);
+                c.n_tris++;
+                TriHit h;
+                if (tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, t_max, h)) return true;
+                if (tv.flags & PT_TRI_LAST) break;
+                rec++;
+            }
+        } else {
+            c.n_nodes++;
+            visit_node(sc.nodes, ref, o, idir, sbits, tmin, tmax, c, sp);
+        }
+    }
+    return false;
+}
+
+// Block-level counter flush: LDS accumulate, one global atomic per counter per block.
+PT_DEV void flush_counters(PtCounters* g, unsigned long long* s_cnt, unsigned long long regular, unsigned long long shadow,
+                           unsigned long long nodes, unsigned long long tris) {
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (regular) atomicAdd(&s_cnt[0], regular);
+    if (shadow) atomicAdd(&s_cnt[1], shadow);
+    if (nodes) atomicAdd(&s_cnt[2], nodes);
+    if (tris) atomicAdd(&s_cnt[3], tris);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_cnt[0]) atomicAdd(&g->regular_rays, s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&g->shadow_rays, s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(&g->nodes, s_cnt[2]);
+        if (s_cnt[3]) atomicAdd(&g->tris, s_cnt[3]);
+    }
+}
+
+// ------------------------------------------------------------------ wave-level ticket
+PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(ticket, 64u);
+    return __shfl(base, 0, 64);
+}
+
+// ============================================================ K_TRACE (wavefront)
+// Items [0, n_cur) are continuation rays (closest hit -> hit_t / hit_rec).
+// Items [n_cur, n_cur + n_nee) resolve the previous bounce's next-event estimate:
+// shadow ray (any hit), MIS probe ray (closest hit, accepted only if it lands on the
+// sampled light's triangle), then L += beta * ((A + B) / pdf_light)   (path.rs:122-136).
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+                                                              uint32_t spill_depth, uint32_t* err) {
+    __shared__ uint32_t s_stack[PT_LDS_STACK * PT_BLOCK];
+    __shared__ unsigned long long s_cnt[4];
+    TravCtx c;
+    c.lds = &s_stack[threadIdx.x];
+    c.spill_stride = gridDim.x * PT_BLOCK;
+    c.spill = spill + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    c.spill_depth = spill_depth;
+    c.n_nodes = 0; c.n_tris = 0; c.overflow = 0;
+    const uint32_t n_cur = Q.counts[0], n_nee = Q.counts[2];
+    const uint32_t total = n_cur + n_nee;
+    unsigned long long regular = 0, shadow = 0;
+    for (;;) {
+        uint32_t base = wave_ticket(&Q.counts[3]);
+        if (base >= total) break;
+        uint32_t item = base + (threadIdx.x & 63);
+        if (item < n_cur) {
+            uint32_t p = Q.cur[item];
+            float4 ro = P.ray_o[p], rd = P.ray_d[p];
+            float t;
+            int32_t rec = trace_closest(sc, f4_3(ro), f4_3(rd), ro.w, c, &t);
+            P.hit_t[p] = t;
+            P.hit_rec[p] = rec;
+            regular++;
+        } else if (item < total) {
+            uint32_t p = Q.nee[item - n_cur];
+            uint32_t nee = P.nee[p];
+            float4 A = P.pendA[p];
+            V3 ld = mk3(0.0f, 0.0f, 0.0f);
+            if (nee & PT_NEE_SHADOW) {
+                float4 so = P.sh_o[p], sd = P.sh_d[p];
+                shadow++;
+                bool occ = trace_any(sc, f4_3(so), f4_3(sd), so.w, c);
+                if (!occ) ld = ld + mk3(A.x, A.y, A.z);
+            }
+            if (nee & PT_NEE_PROBE) {
+                float4 po = P.pr_o[p], pd = P.pr_d[p];
+                regular++;
+                float t;
+                int32_t rec = trace_closest(sc, f4_3(po), f4_3(pd), po.w, c, &t);
+                if (rec >= 0 && (uint32_t)rec == sc.lights[nee >> 8].tri_rec) {
+                    float4 B = P.pendB[p];
+                    ld = ld + mk3(B.x, B.y, B.z);
+                }
+            }
+            V3 ldn = ld / A.w;
+            float4 pb = P.pbeta[p];
+            float4 L = P.L[p];
+            V3 add = mk3(pb.x, pb.y, pb.z) * ldn;
+            L.x += add.x; L.y += add.y; L.z += add.z;
+            P.L[p] = L;
+        }
+    }
+    if (c.overflow) atomicOr(err, 1u);
+    flush_counters(cnt, s_cnt, regular, shadow, c.n_nodes, c.n_tris);
+}
+
+// ============================================================ hooks: plain ray batches
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace_batch(PtScene sc, uint32_t n, const float* o, const float* d, const float* tmax,
+                                                                    pt_hit* out, uint8_t* occ_out, int any_hit, uint32_t* ticket, PtCounters* cnt,
+                                                                    uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
+    __shared__ uint32_t s_stack[PT_LDS_STACK * PT_BLOCK];
+    __shared__ unsigned long long s_cnt[4];
+    TravCtx c;
+    c.lds = &s_stack[threadIdx.x];
+    c.spill_stride = gridDim.x * PT_BLOCK;
+    c.spill = spill + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    c.spill_depth = spill_depth;
+    c.n_nodes = 0; c.n_tris = 0; c.overflow = 0;
+    unsigned long long regular = 0, shadow = 0;
+    for (;;) {
+        uint32_t base = wave_ticket(ticket);
+        if (base >= n) break;
+        uint32_t i = base + (threadIdx.x & 63);
+        if (i >= n) continue;
+        V3 ro = ld3(o + 3 * (size_t)i), rd = ld3(d + 3 * (size_t)i);
+        if (any_hit) {
+            shadow++;
+            occ_out[i] = trace_any(sc, ro, rd, tmax[i], c) ? 1 : 0;
+        } else {
+            regular++;
+            float t;
+            int32_t rec = trace_closest(sc, ro, rd, tmax[i], c, &t);
+            pt_hit h;
+            h.t = 0.0f; h.prim = -1; h.b0 = 0.0f; h.b1 = 0.0f;
+            if (rec >= 0) {
+                TriVerts tv = load_tri(sc.tris, (uint32_t)rec);
+                RayPre rp;
+                ray_precompute(rp, ro, rd);
+                TriHit th;
+                tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, PT_INF, th);   // same arithmetic => same t, b
+                h.t = t; h.prim = (int32_t)tv.prim; h.b0 = th.b0; h.b1 = th.b1;
+            }
+            out[i] = h;
+        }
+    }
+    if (c.overflow) atomicOr(err, 1u);
+    flush_counters(cnt, s_cnt, regular, shadow, c.n_nodes, c.n_tris);
+}
+
+// ============================================================ K_GEN: camera samples
+// path i of the pass: pixel = pixels[i % n_pix], sample = s0 + i / n_pix
+// (render_tile, sampler.rs:221-251: start_pixel / get_camera_sample / generate_ray_differential)
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_gen(PtScene sc, PtPaths P, PtQueues Q, const uint32_t* pixels, uint32_t n_pix,
+                                                            uint32_t s0, uint32_t n_samples, PtCounters* cnt) {
+    uint32_t n = n_pix * n_samples;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t pk = pixels[i % n_pix];
+        uint32_t s = s0 + i / n_pix;
+        int32_t rx = (int32_t)(pk & 0xffffu), ry = (int32_t)(pk >> 16);
+        int32_t px = rx + sc.film.sample_bounds[0], py = ry + sc.film.sample_bounds[1];
+        Sampler sm;
+        sm.index = sobol_interval_to_index(sc.sobol, s, rx, ry);
+        sm.dim = 0; sm.px = px; sm.py = py;
+        V2 uf = sm.get_2d(sc);
+        V2 p_film = mk2((float)px + uf.x, (float)py + uf.y);
+        V2 u_lens = sm.get_2d(sc);
+        (void)sm.get_1d(sc);   // time
+        V3 o, d;
+        generate_camera_ray(sc, p_film, u_lens, &o, &d);
+        P.ray_o[i] = make_float4(o.x, o.y, o.z, PT_INF);
+        P.ray_d[i] = make_float4(d.x, d.y, d.z, 0.0f);
+        P.beta[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        P.L[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        P.p_film[i] = make_float2(p_film.x, p_film.y);
+        P.sobol_index[i] = sm.index;
+        P.pixel[i] = pk;
+        P.state[i] = sm.dim;          // dim = 5, bounces = 0, flags = 0
+        P.nee[i] = 0;
+        Q.cur[i] = i;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Q.counts[0] = n; Q.counts[1] = 0; Q.counts[2] = 0; Q.counts[3] = 0;
+        atomicAdd(&cnt->camera_rays, (unsigned long long)n);
+    }
+}
+
+// queue bookkeeping between stages (single thread)
+extern "C" __global__ void k_prep(PtQueues Q, int mode) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (mode == 0) {            // before SHADE: nee and next start empty
+            Q.counts[1] = 0; Q.counts[2] = 0; Q.counts[3] = 0;
+        } else {                    // after SHADE: next becomes cur (host swaps the pointers)
+            Q.counts[0] = Q.counts[1]; Q.counts[1] = 0; Q.counts[3] = 0;
+        }
+    }
+}
+
+// ============================================================ shading helpers
+struct Surf {            // what SurfaceInteraction carries for this path (surface_interaction.rs:25-57)
+    V3 p, p_error, n, wo;
+    V3 sh_n, sh_dpdu;
+    uint32_t prim;
+};
+
+// Triangle::get_dpdu_dpdv (triangle.rs:132-186)
+PT_DEV void tri_dpdu(const PtScene& sc, const PtTriInfo& ti, V3 p0, V3 p1, V3 p2, V3* dpdu, V3* dpdv) {
+    V2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);
+    if ((ti.mesh_flags & PT_MESH_HAS_UV) && sc.UV) {
+        uv0 = mk2(sc.UV[2 * ti.v[0]], sc.UV[2 * ti.v[0] + 1]);
+        uv1 = mk2(sc.UV[2 * ti.v[1]], sc.UV[2 * ti.v[1] + 1]);
+        uv2 = mk2(sc.UV[2 * ti.v[2]], sc.UV[2 * ti.v[2] + 1]);
+    }
+    float du02x = uv0.x - uv2.x, du02y = uv0.y - uv2.y, du12x = uv1.x - uv2.x, du12y = uv1.y - uv2.y;
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = du02x * du12y - du02y * du12x;
+    if (!(fabsf(determinant) < 1e-8f)) {
+        float invdet = 1.0f / determinant;
+        V3 du = (du12y * dp02 - du02y * dp12) * invdet;
+        V3 dv = (-du12x * dp02 + du02x * dp12) * invdet;
+        if (!(length_squared(cross(du, dv)) <= 0.0f)) { *dpdu = du; *dpdv = dv; return; }
+    }
+    V3 ng = cross(p2 - p0, p1 - p0);
+    coordinate_system(normalize(ng), dpdu, dpdv);
+}
+
+// Triangle::intersect's back half (triangle.rs:349-449): rebuild the interaction from (ray, record).
+PT_DEV bool make_surf(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, float* t_out) {
+    TriVerts tv = load_tri(sc.tris, rec);
+    RayPre rp;
+    ray_precompute(rp, ro, rd);
+    TriHit h;
+    if (!tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, PT_INF, h)) return false;
+    const PtTriInfo ti = sc.tri_info[tv.prim];
+    V3 n = cross(tv.p0 - tv.p2, tv.p1 - tv.p2);
+    if (tv.flags & PT_TRI_FLIP) n = n * -1.0f;
+    n = normalize(n);
+    V3 dpdu, dpdv;
+    tri_dpdu(sc, ti, tv.p0, tv.p1, tv.p2, &dpdu, &dpdv);
+    float xa = fabsf(h.b0 * tv.p0.x) + fabsf(h.b1 * tv.p1.x) + fabsf(h.b2 * tv.p2.x);
+    float ya = fabsf(h.b0 * tv.p0.y) + fabsf(h.b1 * tv.p1.y) + fabsf(h.b2 * tv.p2.y);
+    float za = fabsf(h.b0 * tv.p0.z) + fabsf(h.b1 * tv.p1.z) + fabsf(h.b2 * tv.p2.z);
+    s.p_error = PT_GAMMA(7.0f) * mk3(xa, ya, za);
+    s.p = h.b0 * tv.p0 + h.b1 * tv.p1 + h.b2 * tv.p2;
+    s.wo = -rd;
+    s.n = n;
+    s.sh_n = n;
+    s.sh_dpdu = dpdu;
+    s.prim = tv.prim;
+    bool has_n = (ti.mesh_flags & PT_MESH_HAS_N) && sc.N, has_s = (ti.mesh_flags & PT_MESH_HAS_S) && sc.S;
+    if (has_n || has_s) {
+        V3 ns = s.n;
+        if (has_n) {
+            V3 nns = h.b0 * ld3(sc.N + 3 * (size_t)ti.v[0]) + h.b1 * ld3(sc.N + 3 * (size_t)ti.v[1]) + h.b2 * ld3(sc.N + 3 * (size_t)ti.v[2]);
+            if (length_squared(nns) > 0.0f) ns = normalize(nns);
+        }
+        V3 ss = normalize(dpdu);
+        if (has_s) {
+            V3 nns = h.b0 * ld3(sc.S + 3 * (size_t)ti.v[0]) + h.b1 * ld3(sc.S + 3 * (size_t)ti.v[1]) + h.b2 * ld3(sc.S + 3 * (size_t)ti.v[2]);
+            if (length_squared(nns) > 0.0f) ss = normalize(nns);
+        }
+        V3 ts = cross(ns, ss);
+        if (length_squared(ts) > 0.0f) {
+            ts = normalize(ts);
+            ss = normalize(cross(ts, ns));
+        } else {
+            coordinate_system(ns, &ss, &ts);
+        }
+        if (ti.mesh_flags & PT_MESH_REVERSE_ORIENTATION) ts = ts * -1.0f;
+        s.sh_n = normalize(cross(ss, ts));          // set_shading_geometry, orientation authoritative
+        s.n = face_forward(s.n, s.sh_n);
+        s.sh_dpdu = ss;
+    }
+    *t_out = h.t;
+    return true;
+}
+
+// ---- BSDF with at most one diffuse-reflection lobe (Matte: Lambertian or OrenNayar)
+struct Bsdf {
+    V3 ns, ng, ss, ts;
+    V3 r;
+    float oa, ob;
+    int n_lobes;     // 0 when Kd is black (matte.rs:41)
+    int oren;
+};
+PT_DEV float sin2_theta(V3 w) { return fmaxf(0.0f, 1.0f - w.z * w.z); }
+PT_DEV float sin_theta(V3 w) { return sqrtf(sin2_theta(w)); }
+PT_DEV float cos_phi(V3 w) { float s = sin_theta(w); return s == 0.0f ? 1.0f : clampf(w.x / s, -1.0f, 1.0f); }
+PT_DEV float sin_phi(V3 w) { float s = sin_theta(w); return s == 0.0f ? 0.0f : clampf(w.y / s, -1.0f, 1.0f); }
+PT_DEV V3 lobe_f(const Bsdf& b, V3 wo, V3 wi) {
+    if (!b.oren) return b.r * PT_INV_PI;
+    float sti = sin_theta(wi), sto = sin_theta(wo);
+    float max_cos = 0.0f;
+    if (sti > 1e-4f && sto > 1e-4f) {
+        float d_cos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo);
+        max_cos = fmaxf(d_cos, 0.0f);
+    }
+    float sin_alpha, tan_beta;
+    if (fabsf(wi.z) > fabsf(wo.z)) { sin_alpha = sto; tan_beta = sti / fabsf(wi.z); }
+    else { sin_alpha = sti; tan_beta = sto / fabsf(wo.z); }
+    return (b.r * PT_INV_PI) * (b.oa + b.ob * max_cos * sin_alpha * tan_beta);
+}
+PT_DEV float lobe_pdf(V3 wo, V3 wi) { return (wo.z * wi.z > 0.0f) ? fabsf(wi.z) * PT_INV_PI : 0.0f; }
+PT_DEV V3 w2l(const Bsdf& b, V3 v) { return mk3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
+PT_DEV V3 l2w(const Bsdf& b, V3 v) {
+    return mk3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z, b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
+}
+PT_DEV bool finite3(V3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
+// BSDF::sample_f (bsdf.rs:92-206) for a single matching lobe (matching_comps == 1: comp = 0, u remap = min(u0, 1-eps))
+PT_DEV bool bsdf_sample_f(const Bsdf& b, V3 wo_w, V2 u, V3* f, V3* wi_w, float* pdf) {
+    if (b.n_lobes == 0) return false;
+    V2 ur = mk2(fminf((u.x * 1.0f) - 0.0f, PT_ONE_MINUS_EPS), u.y);
+    V3 wo = w2l(b, wo_w);
+    if (wo.z == 0.0f || !finite3(wo)) return false;
+    V3 wi = cosine_sample_hemisphere(ur);
+    if (wo.z < 0.0f) wi.z *= -1.0f;
+    float p = lobe_pdf(wo, wi);
+    if (p <= 0.0f) return false;
+    V3 wiw = l2w(b, wi);
+    bool reflect = (dot(wiw, b.ng) * dot(wo_w, b.ng)) > 0.0f;
+    V3 ff = mk3(0.0f, 0.0f, 0.0f);
+    if (reflect) ff = ff + lobe_f(b, wo, wi);
+    *f = ff; *wi_w = wiw; *pdf = p;
+    return true;
+}
+PT_DEV V3 bsdf_f(const Bsdf& b, V3 wo_w, V3 wi_w) {
+    V3 wi = w2l(b, wi_w), wo = w2l(b, wo_w);
+    V3 r = mk3(0.0f, 0.0f, 0.0f);
+    if (wo.z == 0.0f || !finite3(wo)) return r;
+    bool reflect = (dot(wi_w, b.ng) * dot(wo_w, b.ng)) > 0.0f;
+    if (b.n_lobes && reflect) r = r + lobe_f(b, wo, wi);
+    return r;
+}
+PT_DEV float bsdf_pdf(const Bsdf& b, V3 wo_w, V3 wi_w) {
+    V3 wi = w2l(b, wi_w), wo = w2l(b, wo_w);
+    if (wo.z == 0.0f || !finite3(wo)) return 0.0f;
+    if (b.n_lobes == 0) return 0.0f;
+    float p = 0.0f + lobe_pdf(wo, wi);
+    return p / 1.0f;
+}
+
+// ---- lights
+PT_DEV V3 light_L(const PtLight& l, V3 n, V3 w) {     // diffuse.rs:155-163
+    if (l.two_sided || dot(n, w) > 0.0f) return ld3(l.L);
+    return mk3(0.0f, 0.0f, 0.0f);
+}
+// Triangle::sample + sample_from (triangle.rs:590-651) + DiffuseAreaLight::sample_li (diffuse.rs:70-87)
+PT_DEV bool light_sample_li(const PtLight& l, V3 ref_p, V2 u, V3* li, V3* wi, float* pdf, V3* lp, V3* lperr, V3* ln) {
+    V3 p0 = ld3(l.p0), p1 = ld3(l.p1), p2 = ld3(l.p2);
+    V2 b = uniform_sample_triangle(u);
+    float b2 = 1.0f - b.x - b.y;
+    V3 p = b.x * p0 + b.y * p1 + b2 * p2;
+    V3 n = normalize(cross(p1 - p0, p2 - p0));
+    if (l.mesh_flags & PT_MESH_HAS_N) {
+        V3 ns = b.x * ld3(l.n0) + b.y * ld3(l.n1) + b2 * ld3(l.n2);
+        n = face_forward(n, ns);
+    } else if (((l.mesh_flags & PT_MESH_REVERSE_ORIENTATION) != 0) ^ ((l.mesh_flags & PT_MESH_SWAPS_HANDEDNESS) != 0)) {
+        n = n * -1.0f;
+    }
+    V3 pas = vabs(b.x * p0) + vabs(b.y * p1) + vabs(b2 * p2);
+    *lperr = PT_GAMMA6_REF * pas;
+    float pd = 1.0f / l.area;
+    V3 w = p - ref_p;
+    if (length_squared(w) <= 0.0f) return false;
+    w = normalize(w);
+    if (!(l.mesh_flags & PT_MESH_TWO_SIDED)) {
+        if (dot(n, -w) <= 0.0f) return false;
+    }
+    pd = pd * distance_squared(ref_p, p) / abs_dot(n, -w);
+    if (pd <= 0.0f || isinf(pd)) return false;
+    // sample_li
+    if (length_squared(p - ref_p) <= 0.0f) return false;
+    *wi = normalize(p - ref_p);
+    *li = light_L(l, n, -*wi);
+    *pdf = pd; *lp = p; *ln = n;
+    return true;
+}
+
+// ---- light distribution lookup (spatial.rs:84-111 + distribution.rs:12-31, :88-106)
+PT_DEV const float* grid_lookup(const PtLightGrid& g, V3 p) {
+    if (g.single) return g.data;   // uniform / power: one table for every point
+    uint32_t pi[3];
+    float pc[3] = {p.x, p.y, p.z};
+    for (int i = 0; i < 3; i++) {
+        float o = pc[i] - g.wb_min[i];
+        if (g.wb_max[i] > g.wb_min[i]) o = o / (g.wb_max[i] - g.wb_min[i]);
+        o = clampf(o, 0.0f, 1.0f);
+        float f = o * (float)g.voxels[i];
+        uint32_t v = f > 0.0f ? (uint32_t)f : 0u;
+        if (v > g.voxels[i] - 1) v = g.voxels[i] - 1;
+        pi[i] = v;
+    }
+    size_t vox = ((size_t)pi[2] * g.voxels[1] + pi[1]) * g.voxels[0] + pi[0];
+    return g.data + vox * g.stride;
+}
+PT_DEV uint32_t sample_discrete(const float* tab, uint32_t n, float u, float* pdf) {
+    const float* func = tab;
+    const float* cdf = tab + n;
+    float func_int = tab[2 * n + 1];
+    uint32_t first = 0, len = n + 1;
+    while (len > 0) {
+        uint32_t half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    uint32_t idx = first == 0 ? 0 : first - 1;
+    if (idx > n - 1) idx = n - 1;
+    *pdf = func_int > 0.0f ? func[idx] * (1.0f / (float)n) / func_int : 0.0f;
+    return idx;
+}
+
+// ============================================================ K_SHADE
+// One bounce of PathIntegrator::li for every path in Q.cur (path.rs:85-234).
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_shade(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    __shared__ unsigned long long s_vert;
+    if (threadIdx.x == 0) s_vert = 0;
+    __syncthreads();
+    const uint32_t n_cur = Q.counts[0];
+    uint32_t n_vert = 0;
+    const uint32_t lane = threadIdx.x & 63;
+    for (;;) {
+        uint32_t base = wave_ticket(&Q.counts[3]);
+        if (base >= n_cur) break;
+        uint32_t item = base + lane;
+        bool active = item < n_cur;
+        bool cont = false, want_nee = false;
+        uint32_t p = 0;
+        if (active) {
+            p = Q.cur[item];
+            float4 ro4 = P.ray_o[p], rd4 = P.ray_d[p];
+            V3 ro = f4_3(ro4), rd = f4_3(rd4);
+            int32_t rec = P.hit_rec[p];
+            uint32_t st = P.state[p];
+            uint32_t dim = st & 0xffffu, bounces = (st >> 16) & 0xffu, flags = st >> 24;
+            float4 beta4 = P.beta[p];
+            V3 beta = f4_3(beta4);
+            float eta_scale = beta4.w;
+            Surf s;
+            float thit;
+            bool found = rec >= 0 && make_surf(sc, ro, rd, (uint32_t)rec, s, &thit);
+            // emitted radiance at the first vertex / after a specular bounce (path.rs:87-98)
+            if (found && (bounces == 0 || (flags & PT_ST_SPECULAR))) {
+                int32_t li = sc.tri_info[s.prim].light;
+                if (li >= 0) {
+                    V3 le = light_L(sc.lights[li], s.n, -rd);
+                    float4 L = P.L[p];
+                    V3 add = beta * le;
+                    L.x += add.x; L.y += add.y; L.z += add.z;
+                    P.L[p] = L;
+                }
+            }
+            if (found && (int32_t)bounces < sc.max_depth) {
+                const PtTriInfo ti = sc.tri_info[s.prim];
+                if (ti.material < 0 || sc.materials[ti.material].type == PT_MATERIAL_NONE) {
+                    // no BSDF: continue through the surface, same bounce count (path.rs:108-111)
+                    V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
+                    P.ray_o[p] = make_float4(no.x, no.y, no.z, PT_INF);
+                    cont = true;
+                } else {
+                    n_vert++;
+                    const PtMaterial m = sc.materials[ti.material];
+                    Bsdf b;
+                    b.ns = s.sh_n; b.ng = s.n;
+                    b.ss = normalize(s.sh_dpdu);
+                    b.ts = normalize(cross(b.ns, b.ss));
+                    b.r = mk3(m.kd[0], m.kd[1], m.kd[2]);
+                    b.n_lobes = is_black(b.r) ? 0 : 1;
+                    b.oren = clampf(m.sigma, 0.0f, 90.0f) != 0.0f;
+                    b.oa = m.oren_a; b.ob = m.oren_b;
+                    Sampler sm;
+                    sm.index = P.sobol_index[p];
+                    sm.dim = dim;
+                    uint32_t pk = P.pixel[p];
+                    sm.px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0];
+                    sm.py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
+                    // ---- next-event estimation (uniform_sample_one_light_surface, sample_lights.rs:129-176)
+                    if (b.n_lobes > 0 && sc.n_lights > 0) {
+                        const float* tab = grid_lookup(sc.grid, s.p);
+                        float light_pdf;
+                        uint32_t light_num = sample_discrete(tab, sc.n_lights, sm.get_1d(sc), &light_pdf);
+                        if (light_pdf > 0.0f) {
+                            V2 u_light = sm.get_2d(sc);
+                            V2 u_scat = sm.get_2d(sc);
+                            const PtLight& lt = sc.lights[light_num];
+                            uint32_t nee = light_num << 8;
+                            V3 A = mk3(0.0f, 0.0f, 0.0f), B = mk3(0.0f, 0.0f, 0.0f);
+                            V3 li, wi, lp, lperr, ln;
+                            float lpdf;
+                            if (light_sample_li(lt, s.p, u_light, &li, &wi, &lpdf, &lp, &lperr, &ln)) {
+                                if (lpdf > 0.0f && !is_black(li)) {
+                                    V3 f = bsdf_f(b, s.wo, wi) * abs_dot(wi, s.sh_n);
+                                    float spdf = bsdf_pdf(b, s.wo, wi);
+                                    if (!is_black(f)) {
+                                        // VisibilityTester: Interaction::spawn_ray_to (interaction.rs:118-127)
+                                        V3 origin = offset_ray_origin(s.p, s.p_error, s.n, lp - s.p);
+                                        V3 target = offset_ray_origin(lp, lperr, ln, origin - lp);
+                                        V3 sd = target - origin;
+                                        P.sh_o[p] = make_float4(origin.x, origin.y, origin.z, 1.0f - PT_SHADOW_EPS);
+                                        P.sh_d[p] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+                                        float weight = power_heuristic(lpdf, spdf);
+                                        A = f * li * (weight / lpdf);
+                                        nee |= PT_NEE_SHADOW;
+                                    }
+                                }
+                            }
+                            // BSDF sampling half of MIS (sample_lights.rs:393-451)
+                            V3 f2, wi2;
+                            float spdf2;
+                            if (bsdf_sample_f(b, s.wo, u_scat, &f2, &wi2, &spdf2)) {
+                                V3 f = f2 * abs_dot(wi2, s.sh_n);
+                                if (!is_black(f) && spdf2 > 0.0f) {
+                                    // light.pdf_li -> Shape::pdf_from (shape.rs:40-54): one test against the light's own triangle
+                                    V3 po = offset_ray_origin(s.p, s.p_error, s.n, wi2);
+                                    Surf ls;
+                                    float lt_t;
+                                    if (make_surf(sc, po, wi2, lt.tri_rec, ls, &lt_t)) {
+                                        float lp2 = distance_squared(s.p, ls.p) / (abs_dot(ls.n, -wi2) * lt.area);
+                                        if (isinf(lp2)) lp2 = 0.0f;
+                                        if (lp2 != 0.0f) {
+                                            float weight = power_heuristic(spdf2, lp2);
+                                            // if the probe lands on this triangle its interaction is `ls` again
+                                            V3 le = light_L(lt, ls.n, -wi2);
+                                            B = f * le * 1.0f * (weight / spdf2);
+                                            P.pr_o[p] = make_float4(po.x, po.y, po.z, PT_INF);
+                                            P.pr_d[p] = make_float4(wi2.x, wi2.y, wi2.z, 0.0f);
+                                            nee |= PT_NEE_PROBE;
+                                        }
+                                    }
+                                }
+                            }
+                            if (nee & (PT_NEE_SHADOW | PT_NEE_PROBE)) {
+                                P.pendA[p] = make_float4(A.x, A.y, A.z, light_pdf);
+                                P.pendB[p] = make_float4(B.x, B.y, B.z, 0.0f);
+                                P.pbeta[p] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                                P.nee[p] = nee;
+                                want_nee = true;
+                            }
+                        }
+                    }
+                    // ---- continuation (path.rs:139-233)
+                    V2 u = sm.get_2d(sc);
+                    V3 f, wi;
+                    float pdf;
+                    if (bsdf_sample_f(b, s.wo, u, &f, &wi, &pdf) && !(is_black(f) || pdf == 0.0f)) {
+                        beta = beta * (f * (abs_dot(wi, s.sh_n) / pdf));
+                        flags &= ~PT_ST_SPECULAR;          // diffuse lobes only
+                        V3 no = offset_ray_origin(s.p, s.p_error, s.n, wi);
+                        bool alive = true;
+                        V3 rr = beta * eta_scale;
+                        float mx = max3(rr.x, rr.y, rr.z);
+                        if (mx < sc.rr_threshold && bounces > 3) {
+                            float q = fmaxf(0.05f, 1.0f - mx);
+                            if (sm.get_1d(sc) < q) alive = false;
+                            else beta = beta / (1.0f - q);
+                        }
+                        if (alive) {
+                            P.ray_o[p] = make_float4(no.x, no.y, no.z, PT_INF);
+                            P.ray_d[p] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+                            P.beta[p] = make_float4(beta.x, beta.y, beta.z, eta_scale);
+                            bounces++;
+                            cont = true;
+                        }
+                    }
+                    dim = sm.dim;
+                }
+                if (cont) P.state[p] = (dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+            }
+        }
+        // ---- order-preserving wave compaction into the next / nee queues
+        unsigned long long mc = __ballot(cont), mn = __ballot(want_nee);
+        uint32_t bc = 0, bn = 0;
+        if (lane == 0) {
+            if (mc) bc = atomicAdd(&Q.counts[1], (uint32_t)__popcll(mc));
+            if (mn) bn = atomicAdd(&Q.counts[2], (uint32_t)__popcll(mn));
+        }
+        bc = __shfl(bc, 0, 64); bn = __shfl(bn, 0, 64);
+        unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (cont) Q.next[bc + (uint32_t)__popcll(mc & below)] = p;
+        if (want_nee) Q.nee[bn + (uint32_t)__popcll(mn & below)] = p;
+    }
+    if (n_vert) atomicAdd(&s_vert, (unsigned long long)n_vert);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_vert) atomicAdd(&cnt->vertices, s_vert);
+}
+
+// ============================================================ film
+PT_DEV V3 validate_radiance(V3 l) {    // sampler.rs:151-176
+    if (!finite3(l)) return mk3(0.0f, 0.0f, 0.0f);
+    float y = lum_y(l);
+    if (y < -1e-5f) return mk3(0.0f, 0.0f, 0.0f);
+    if (isinf(y)) return mk3(0.0f, 0.0f, 0.0f);
+    return l;
+}
+// FilmTile::add_sample_filter (film_tile.rs:84-183) for one sample.  `own` accumulates the
+// common case (the sample's own pixel gets weight exactly 1) without atomics so that the f32
+// sum runs in sample order exactly like the reference's tile loop; every other footprint goes
+// through float atomics into `spill`.
+PT_DEV float film_weight(const PtFilm& fm, int32_t x, int32_t y, V2 pf) {
+    float dx = fabsf((float)x + 0.5f - pf.x), dy = fabsf((float)y + 0.5f - pf.y);
+    if (!(dx <= fm.filter_radius[0]) || !(dy <= fm.filter_radius[1])) return 0.0f;
+    int ix = min((int)floorf(dx * (fm.inv_filter_radius[0] * 15.0f)), 15);
+    int iy = min((int)floorf(dy * (fm.inv_filter_radius[1] * 15.0f)), 15);
+    return fm.filter_table[iy * 16 + ix];
+}
+PT_DEV void film_add(const PtFilm& fm, float4* spill, int32_t px, int32_t py, V2 pf, V3 l, float4& own_acc) {
+    float ly = lum_y(l);
+    if (ly > fm.max_sample_luminance) l = l * (fm.max_sample_luminance / ly);
+    float rx = fm.filter_radius[0], ry = fm.filter_radius[1];
+    int32_t p0x = (int32_t)floorf(pf.x - rx), p0y = (int32_t)floorf(pf.y - ry);
+    int32_t p1x = (int32_t)ceilf(pf.x + rx), p1y = (int32_t)ceilf(pf.y + ry);
+    p0x = max(p0x, fm.crop[0]); p0y = max(p0y, fm.crop[1]);
+    p1x = min(p1x, fm.crop[2]); p1y = min(p1y, fm.crop[3]);
+    if (p1x - p0x <= 0 || p1y - p0y <= 0) return;
+    // normalise the footprint's weights to sum 1 (reference quirk Q1)
+    float sum = 0.0f;
+    int nz = 0;
+    for (int32_t y = p0y; y < p1y; y++)
+        for (int32_t x = p0x; x < p1x; x++) {
+            float w = film_weight(fm, x, y, pf);
+            sum += w;
+            if (w != 0.0f) nz++;
+        }
+    if (sum <= 0.0f) return;
+    float isum = 1.0f / sum;
+    int32_t width = fm.crop[2] - fm.crop[0];
+    for (int32_t y = p0y; y < p1y; y++)
+        for (int32_t x = p0x; x < p1x; x++) {
+            float w = film_weight(fm, x, y, pf);
+            if (w == 0.0f) continue;      // contributes +0 in the reference
+            w *= isum;
+            V3 cadd = (l * 1.0f) * w;     // l * sample_weight * filter_weight
+            if (nz == 1 && x == px && y == py) {
+                own_acc.x += cadd.x; own_acc.y += cadd.y; own_acc.z += cadd.z; own_acc.w += w;
+            } else {
+                float* dst = reinterpret_cast<float*>(spill + (size_t)(y - fm.crop[1]) * width + (x - fm.crop[0]));
+                atomicAdd(dst + 0, cadd.x); atomicAdd(dst + 1, cadd.y); atomicAdd(dst + 2, cadd.z); atomicAdd(dst + 3, w);
+            }
+        }
+}
+// One thread per pixel of the pass; samples are folded in sample order.
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_film(PtScene sc, PtPaths P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,
+                                                             float4* own, float4* spill, float* radiance_out, uint32_t s0, uint32_t spp_total) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_pix; j += gridDim.x * blockDim.x) {
+        uint32_t pk = pixels[j];
+        int32_t px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0], py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
+        bool inside = px >= sc.film.crop[0] && px < sc.film.crop[2] && py >= sc.film.crop[1] && py < sc.film.crop[3];
+        size_t fidx = inside ? (size_t)(py - sc.film.crop[1]) * (sc.film.crop[2] - sc.film.crop[0]) + (px - sc.film.crop[0]) : 0;
+        float4 acc = inside ? own[fidx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t k = 0; k < n_samples; k++) {
+            size_t path = (size_t)k * n_pix + j;
+            float4 L4 = P.L[path];
+            V3 l = validate_radiance(mk3(L4.x, L4.y, L4.z));
+            if (radiance_out) {
+                float* ro = radiance_out + ((size_t)j * spp_total + (s0 + k)) * 3;
+                ro[0] = l.x; ro[1] = l.y; ro[2] = l.z;
+            }
+            float2 pf = P.p_film[path];
+            film_add(sc.film, spill, inside ? px : -0x7fffffff, py, mk2(pf.x, pf.y), l, acc);
+        }
+        if (inside) own[fidx] = acc;
+    }
+}
+// Film::merge_film_tile's RGB -> XYZ per contribution buffer (film.rs:219-241)
+extern "C" __global__ void k_film_xyzw(const float4* own, const float4* spill, float4* xyzw, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 a = own[i], b = spill[i];
+        V3 xa = rgb_to_xyz(mk3(a.x, a.y, a.z)), xb = rgb_to_xyz(mk3(b.x, b.y, b.z));
+        xyzw[i] = make_float4(xa.x + xb.x, xa.y + xb.y, xa.z + xb.z, a.w + b.w);
+    }
+}
+// Film::write_image (film.rs:440-484)
+extern "C" __global__ void k_film_rgb(const float4* xyzw, float* rgb, uint32_t n, float scale) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 v = xyzw[i];
+        V3 c = xyz_to_rgb(mk3(v.x, v.y, v.z));
+        if (v.w > 0.0f) {
+            float inv = 1.0f / v.w;
+            c = mk3(fmaxf(0.0f, c.x * inv), fmaxf(0.0f, c.y * inv), fmaxf(0.0f, c.z * inv));
+        }
+        rgb[3 * (size_t)i + 0] = (c.x + 0.0f) * scale;
+        rgb[3 * (size_t)i + 1] = (c.y + 0.0f) * scale;
+        rgb[3 * (size_t)i + 2] = (c.z + 0.0f) * scale;
+    }
+}
+
+// ============================================================ light grid
+// SpatialLightDistribution::compute_distribution for every voxel (spatial.rs:113-196) followed
+// by Distribution1D::new (distribution.rs:34-58).  One thread per voxel.
+PT_DEV float radical_inverse_dev(uint32_t base_index, uint64_t a) {   // radical_inverse.rs:38-58
+    if (base_index == 0) {
+        uint64_t r = __brevll(a);
+        return (float)r * 5.4210108624275222e-20f;
+    }
+    const uint64_t primes[5] = {2, 3, 5, 7, 11};
+    uint64_t base = primes[base_index];
+    float inv_base = 1.0f / (float)base;
+    uint64_t rev = 0;
+    float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = a / base;
+        uint64_t digit = a - next * base;
+        rev = rev * base + digit;
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return fminf((float)rev * inv_base_n, PT_ONE_MINUS_EPS);
+}
+extern "C" __global__ void k_light_grid(PtScene sc, float* data, uint32_t n_vox) {
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_vox; v += gridDim.x * blockDim.x) {
+        const PtLightGrid& g = sc.grid;
+        uint32_t pi0 = v % g.voxels[0], pi1 = (v / g.voxels[0]) % g.voxels[1], pi2 = v / (g.voxels[0] * g.voxels[1]);
+        V3 wmin = ld3(g.wb_min), wmax = ld3(g.wb_max);
+        V3 p0 = mk3((float)pi0 / (float)g.voxels[0], (float)pi1 / (float)g.voxels[1], (float)pi2 / (float)g.voxels[2]);
+        V3 p1 = mk3((float)(pi0 + 1) / (float)g.voxels[0], (float)(pi1 + 1) / (float)g.voxels[1], (float)(pi2 + 1) / (float)g.voxels[2]);
+        V3 a = mk3(lerpf(p0.x, wmin.x, wmax.x), lerpf(p0.y, wmin.y, wmax.y), lerpf(p0.z, wmin.z, wmax.z));
+        V3 b = mk3(lerpf(p1.x, wmin.x, wmax.x), lerpf(p1.y, wmin.y, wmax.y), lerpf(p1.z, wmin.z, wmax.z));
+        V3 vmin = mk3(a.x <= b.x ? a.x : b.x, a.y <= b.y ? a.y : b.y, a.z <= b.z ? a.z : b.z);
+        V3 vmax = mk3(a.x >= b.x ? a.x : b.x, a.y >= b.y ? a.y : b.y, a.z >= b.z ? a.z : b.z);
+        const uint32_t nl = g.n_lights;
+        float* func = data + (size_t)v * g.stride;
+        float* cdf = func + nl;
+        for (uint32_t j = 0; j < nl; j++) func[j] = 0.0f;
+        for (uint32_t i = 0; i < 128; i++) {
+            V3 t = mk3(radical_inverse_dev(0, i), radical_inverse_dev(1, i), radical_inverse_dev(2, i));
+            V3 po = mk3(lerpf(t.x, vmin.x, vmax.x), lerpf(t.y, vmin.y, vmax.y), lerpf(t.z, vmin.z, vmax.z));
+            V2 u = mk2(radical_inverse_dev(3, i), radical_inverse_dev(4, i));
+            for (uint32_t j = 0; j < nl; j++) {
+                V3 li, wi, lp, le, ln;
+                float pdf;
+                if (light_sample_li(sc.lights[j], po, u, &li, &wi, &pdf, &lp, &le, &ln))
+                    if (pdf > 0.0f) func[j] += lum_y(li) / pdf;
+            }
+        }
+        float sum = 0.0f;
+        for (uint32_t j = 0; j < nl; j++) sum += func[j];
+        float avg = sum / (float)(128u * nl);
+        float min_contrib = avg > 0.0f ? 0.001f * avg : 1.0f;
+        for (uint32_t j = 0; j < nl; j++) func[j] = fmaxf(min_contrib, func[j]);
+        cdf[0] = 0.0f;
+        for (uint32_t j = 1; j < nl + 1; j++) cdf[j] = cdf[j - 1] + func[j - 1] / (float)nl;
+        float func_int = cdf[nl];
+        if (func_int == 0.0f) for (uint32_t j = 1; j < nl + 1; j++) cdf[j] = (float)j / (float)nl;
+        else for (uint32_t j = 1; j < nl + 1; j++) cdf[j] /= func_int;
+        cdf[nl + 1] = func_int;
+    }
+}
+
+// ============================================================ hooks: sampler / camera
+extern "C" __global__ void k_camera_rays(PtScene sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* out_o, float* out_d,
+                                         float* out_pf) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int32_t px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
+        Sampler sm;
+        sm.index = sobol_interval_to_index(sc.sobol, sample_index[i], px - sc.film.sample_bounds[0], py - sc.film.sample_bounds[1]);
+        sm.dim = 0; sm.px = px; sm.py = py;
+        V2 uf = sm.get_2d(sc);
+        V2 pf = mk2((float)px + uf.x, (float)py + uf.y);
+        V2 ul = sm.get_2d(sc);
+        V3 o, d;
+        generate_camera_ray(sc, pf, ul, &o, &d);
+        out_o[3 * i] = o.x; out_o[3 * i + 1] = o.y; out_o[3 * i + 2] = o.z;
+        out_d[3 * i] = d.x; out_d[3 * i + 1] = d.y; out_d[3 * i + 2] = d.z;
+        out_pf[2 * i] = pf.x; out_pf[2 * i + 1] = pf.y;
+    }
+}
+extern "C" __global__ void k_sobol_samples(PtScene sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim, float* out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int32_t px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
+        uint64_t idx = sobol_interval_to_index(sc.sobol, sample_index[i], px - sc.film.sample_bounds[0], py - sc.film.sample_bounds[1]);
+        out[i] = sample_dimension(sc, idx, dim[i], px, py);
+    }
+}
+
+// ============================================================ launch wrappers (host side of this TU)
+#define PT_LAUNCH_CHECK() hipGetLastError()
+
+hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
+                     uint32_t spill_depth, uint32_t* err) {
+    hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out,
+                           uint8_t* occ, int any_hit, uint32_t* ticket, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
+    hipLaunchKernelGGL(k_trace_batch, dim3(grid), dim3(PT_BLOCK), 0, st, sc, n, o, d, tmax, out, occ, any_hit, ticket, cnt, spill, spill_depth, err);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_gen(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const uint32_t* pixels, uint32_t n_pix,
+                   uint32_t s0, uint32_t n_samples, PtCounters* cnt) {
+    hipLaunchKernelGGL(k_gen, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, pixels, n_pix, s0, n_samples, cnt);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode) {
+    hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, st, Q, mode);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt) {
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,
+                    float4* own, float4* spill, float* radiance_out, uint32_t s0, uint32_t spp_total) {
+    hipLaunchKernelGGL(k_film, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, pixels, n_pix, n_samples, own, spill, radiance_out, s0, spp_total);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_film_xyzw(hipStream_t st, const float4* own, const float4* spill, float4* xyzw, uint32_t n) {
+    hipLaunchKernelGGL(k_film_xyzw, dim3(1024), dim3(PT_BLOCK), 0, st, own, spill, xyzw, n);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_film_rgb(hipStream_t st, const float4* xyzw, float* rgb, uint32_t n, float scale) {
+    hipLaunchKernelGGL(k_film_rgb, dim3(1024), dim3(PT_BLOCK), 0, st, xyzw, rgb, n, scale);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32_t n_vox) {
+    hipLaunchKernelGGL(k_light_grid, dim3((n_vox + 63) / 64), dim3(64), 0, st, sc, data, n_vox);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_camera_rays(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* o, float* d,
+                           float* pf) {
+    hipLaunchKernelGGL(k_camera_rays, dim3((n + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, st, sc, n, pixel_xy, sample_index, o, d, pf);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_sobol_samples(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim,
+                             float* out) {
+    hipLaunchKernelGGL(k_sobol_samples, dim3((n + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, st, sc, n, pixel_xy, sample_index, dim, out);
+    return PT_LAUNCH_CHECK();
+}

@@ -1,0 +1,429 @@
+"""Scene assembly: the host-side mirror of what pbrt-r3's SceneContext does between
+the parser callbacks and Integrator::render, flattened into a pt_scene_desc.
+
+  SceneBuilder.look_at / camera / film / sampler / integrator / accelerator
+      <- pbrt_look_at, pbrt_camera, pbrt_film, pbrt_sampler, pbrt_integrator,
+         pbrt_accelerator (src/core/api/parse_context.rs:5-66) with the defaults of
+         render_options.rs:60-88 where this path supports them
+  SceneBuilder.material / area_light_source / shape_trianglemesh
+      <- pbrt_material, pbrt_area_light_source, pbrt_shape("trianglemesh")
+         (scene_context.rs:1201-1318, shapes/triangle.rs:696-868)
+
+All arithmetic that feeds the renderer is done in float32 in the reference's
+operation order (the reference is f32 throughout, base/types.rs:3-6).
+
+cornell_box() and rt1m() are the two synthetic configs of BASELINE.md.
+"""
+import ctypes as C
+import numpy as np
+
+from . import capi
+
+f32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# PCG32 (src/core/rng.rs:8-67), vectorised: the LCG state after k steps is
+# a^k * s0 + c * (a^(k-1) + ... + 1)  (mod 2^64), so all states come from two
+# wrapping cumulative ops.
+def pcg32_uint32(n, sequence=None):
+    M = np.uint64(0x5851f42d4c957f2d)
+    with np.errstate(over="ignore"):
+        if sequence is None:
+            state0 = np.uint64(0x853c49e6748fea9b)
+            inc = np.uint64(0xda3e39cb94b95bdb)
+        else:
+            inc = np.uint64(((int(sequence) << 1) | 1) & 0xFFFFFFFFFFFFFFFF)
+            s = np.uint64(0)
+            s = s * M + inc                      # first uniform_uint32()
+            s = s + np.uint64(0x853c49e6748fea9b)
+            s = s * M + inc                      # second
+            state0 = s
+        pw = np.full(n, M, np.uint64)
+        pw[0] = np.uint64(1)
+        pw = np.cumprod(pw, dtype=np.uint64)             # a^k, k = 0..n-1
+        geo = np.cumsum(pw, dtype=np.uint64)             # 1 + a + ... + a^k
+        old = np.empty(n, np.uint64)
+        old[0] = state0
+        if n > 1:
+            old[1:] = pw[1:] * state0 + inc * geo[:-1]
+        xorshifted = (((old >> np.uint64(18)) ^ old) >> np.uint64(27)).astype(np.uint32)
+        rot = (old >> np.uint64(59)).astype(np.uint32)
+        return (xorshifted >> rot) | (xorshifted << ((~rot + np.uint32(1)) & np.uint32(31)))
+
+
+def pcg32_uniform_float(n, sequence=None):
+    u = pcg32_uint32(n, sequence)
+    f = u.astype(np.float32) * f32(2.3283064365386963e-10)
+    return np.minimum(f32(0.99999994), f)
+
+
+# --------------------------------------------------------------------------
+# f32 helpers in the reference's operation order
+def _v(x, y, z):
+    return np.array([x, y, z], np.float32)
+
+
+def _dot(a, b):
+    return f32(f32(f32(a[0] * b[0]) + f32(a[1] * b[1])) + f32(a[2] * b[2]))
+
+
+def _cross(a, b):
+    return _v(f32(a[1] * b[2]) - f32(a[2] * b[1]), f32(a[2] * b[0]) - f32(a[0] * b[2]), f32(a[0] * b[1]) - f32(a[1] * b[0]))
+
+
+def _length(a):
+    return np.sqrt(f32(f32(f32(a[0] * a[0]) + f32(a[1] * a[1])) + f32(a[2] * a[2])))
+
+
+def _normalize(a):
+    l = _length(a)
+    return _v(a[0] / l, a[1] / l, a[2] / l)
+
+
+def camera_to_world_look_at(eye, look, up):
+    """Matrix4x4::camera_to_world (src/core/transform/matrix4x4.rs:169-217)."""
+    pos = _v(*eye)
+    lk = _v(*look)
+    upn = _normalize(_v(*up))
+    d = _normalize(lk - pos)
+    right = _cross(upn, d)
+    assert _length(right) != 0
+    right = _normalize(right)
+    new_up = _normalize(_cross(d, right))
+    return np.array([right[0], new_up[0], d[0], pos[0],
+                     right[1], new_up[1], d[1], pos[1],
+                     right[2], new_up[2], d[2], pos[2],
+                     0, 0, 0, 1], np.float32)
+
+
+def _transform_points(m, P):
+    """Matrix4x4::transform_point (matrix4x4.rs:311-324), vectorised, f32."""
+    m = np.asarray(m, np.float32)
+    x, y, z = P[:, 0], P[:, 1], P[:, 2]
+    xp = ((m[0] * x + m[1] * y) + m[2] * z) + m[3]
+    yp = ((m[4] * x + m[5] * y) + m[6] * z) + m[7]
+    zp = ((m[8] * x + m[9] * y) + m[10] * z) + m[11]
+    wp = ((m[12] * x + m[13] * y) + m[14] * z) + m[15]
+    out = np.stack([xp, yp, zp], 1).astype(np.float32)
+    nz = wp != f32(1.0)
+    if np.any(nz):
+        out[nz] = (out[nz] / wp[nz, None]).astype(np.float32)
+    return out
+
+
+def _swaps_handedness(m):
+    m = np.asarray(m, np.float32)
+    det = (m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8])) + m[2] * (m[4] * m[9] - m[5] * m[8])
+    return bool(det < 0)
+
+
+def _tri_areas(P, idx):
+    p0, p1, p2 = P[idx[:, 0]], P[idx[:, 1]], P[idx[:, 2]]
+    a, b = (p1 - p0).astype(np.float32), (p2 - p0).astype(np.float32)
+    cx = a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1]
+    cy = a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2]
+    cz = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+    return f32(0.5) * np.sqrt((cx * cx + cy * cy) + cz * cz)
+
+
+def _is_fillable_uv(idx, n_vertices):
+    """triangle.rs:733-752, sequential exactly as the reference (slot 0 doubles as 'unset')."""
+    check = [0] * n_vertices
+    for face in idx.tolist():
+        for j in range(3):
+            v = face[j]
+            if check[v] == 0 or check[v] == j:
+                check[v] = j
+            else:
+                return False
+    return True
+
+
+class SceneDesc:
+    """A filled pt_scene_desc plus the numpy buffers it points into."""
+
+    def __init__(self):
+        self.desc = capi.pt_scene_desc()
+        self.buffers = {}
+
+    def _set(self, name, arr, ctype):
+        self.buffers[name] = arr
+        setattr(self.desc, name, arr.ctypes.data_as(C.POINTER(ctype)) if arr is not None and arr.size else None)
+
+
+class SceneBuilder:
+    def __init__(self):
+        self.P, self.N, self.S, self.UV = [], [], [], []
+        self.idx, self.tri_mesh = [], []
+        self.meshes, self.materials, self.area_lights = [], [], []
+        self.n_vertices = 0
+        self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, (0.5, 0.5, 0.5), 0.0)   # default matte
+        self.cur_area_light = -1
+        self.reverse_orientation = False
+        # render options (render_options.rs:60-88 where supported)
+        self.camera_to_world = np.eye(4, dtype=np.float32).reshape(-1)
+        self.fov, self.screen_window = 90.0, None
+        self.lens_radius, self.focal_distance = 0.0, 1e6
+        self.shutter = (0.0, 1.0)
+        self.xres, self.yres, self.crop = 1280, 720, (0.0, 1.0, 0.0, 1.0)
+        self.filter_radius, self.filter_table = (0.5, 0.5), np.ones(256, np.float32)
+        self.film_scale, self.max_sample_luminance = 1.0, float("inf")
+        self.spp, self.max_depth, self.rr_threshold = 16, 5, 1.0
+        self.light_strategy = capi.PT_LIGHTS_SPATIAL
+        self.split_method, self.max_node_prims = capi.PT_SPLIT_SAH, 4
+
+    # ---- options
+    def look_at(self, eye, look, up):
+        self.camera_to_world = camera_to_world_look_at(eye, look, up)
+
+    def camera_perspective(self, fov=90.0, lensradius=0.0, focaldistance=1e6, screenwindow=None, frameaspectratio=None,
+                           shutteropen=0.0, shutterclose=1.0):
+        self.fov, self.lens_radius, self.focal_distance = fov, lensradius, focaldistance
+        self.screen_window, self.frameaspectratio = screenwindow, frameaspectratio
+        self.shutter = (min(shutteropen, shutterclose), max(shutteropen, shutterclose))
+
+    def film(self, xresolution=1280, yresolution=720, cropwindow=(0.0, 1.0, 0.0, 1.0), scale=1.0, maxsampleluminance=float("inf")):
+        self.xres, self.yres, self.crop = int(xresolution), int(yresolution), tuple(cropwindow)
+        self.film_scale, self.max_sample_luminance = scale, maxsampleluminance
+
+    def pixel_filter_box(self, xwidth=0.5, ywidth=0.5):
+        """filters/box_filter.rs + Film::new's 16x16 table (film.rs:102-120): BoxFilter::evaluate == 1."""
+        self.filter_radius, self.filter_table = (xwidth, ywidth), np.ones(256, np.float32)
+
+    def sampler_sobol(self, pixelsamples=16):
+        self.spp = int(pixelsamples)
+
+    def integrator_path(self, maxdepth=5, rrthreshold=1.0, lightsamplestrategy="spatial"):
+        self.max_depth, self.rr_threshold = int(maxdepth), float(rrthreshold)
+        self.light_strategy = {"uniform": capi.PT_LIGHTS_UNIFORM, "power": capi.PT_LIGHTS_POWER}.get(lightsamplestrategy, capi.PT_LIGHTS_SPATIAL)
+
+    def accelerator_bvh(self, splitmethod="sah", maxnodeprims=4):
+        self.split_method = {"sah": 0, "hlbvh": 1, "middle": 2, "equal": 3}.get(splitmethod, 0)
+        self.max_node_prims = int(maxnodeprims)
+
+    # ---- graphics state
+    def _add_material(self, typ, kd, sigma):
+        m = capi.pt_material()
+        m.type = typ
+        m.kd[:] = [float(k) for k in kd]
+        m.sigma = float(sigma)
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def material_matte(self, Kd=(0.5, 0.5, 0.5), sigma=0.0):
+        self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, Kd, sigma)
+
+    def material_none(self):
+        self.cur_material = -1
+
+    def area_light_source_diffuse(self, L=(1.0, 1.0, 1.0), scale=(1.0, 1.0, 1.0), twosided=False):
+        al = capi.pt_area_light()
+        al.L[:] = [float(f32(l) * f32(s)) for l, s in zip(L, scale)]
+        al.two_sided = 1 if twosided else 0
+        self.area_lights.append(al)
+        self.cur_area_light = len(self.area_lights) - 1
+
+    def no_area_light(self):
+        self.cur_area_light = -1
+
+    # ---- shapes
+    def shape_trianglemesh(self, P, indices, N=None, S=None, uv=None, twosided=True, object_to_world=None):
+        P = np.asarray(P, np.float32).reshape(-1, 3)
+        idx = np.asarray(indices, np.int64).reshape(-1, 3)
+        nv = len(P)
+        swaps = False
+        if object_to_world is not None:
+            m = np.asarray(object_to_world, np.float32).reshape(-1)
+            P = _transform_points(m, P)
+            swaps = _swaps_handedness(m)
+            if N is not None or S is not None:
+                raise NotImplementedError("transformed N/S: pass world-space attributes")
+        if uv is not None:
+            UV = np.asarray(uv, np.float32).reshape(-1, 2)
+        elif _is_fillable_uv(idx, nv):            # triangle.rs:796-821
+            UV = np.zeros((nv, 2), np.float32)
+            tri_uv = np.array([[0, 0], [1, 0], [1, 1]], np.float32)
+            for i in range(len(idx)):             # sequential, as the reference
+                for j in range(3):
+                    v = idx[i, j]
+                    if UV[v, 0] == 0.0 and UV[v, 1] == 0.0:
+                        UV[v] = tri_uv[j]
+        else:
+            UV = None
+        return self._append_mesh(P, idx, N, S, UV, twosided, swaps)
+
+    def _append_mesh(self, P, idx, N, S, UV, twosided, swaps):
+        nv = len(P)
+        keep = _tri_areas(P, idx) > f32(1e-16)      # triangle.rs:726
+        idx = idx[keep]
+        flags = 0
+        if twosided:
+            flags |= capi.PT_MESH_TWO_SIDED
+        if self.reverse_orientation:
+            flags |= capi.PT_MESH_REVERSE_ORIENTATION
+        if swaps:
+            flags |= capi.PT_MESH_SWAPS_HANDEDNESS
+        if N is not None:
+            flags |= capi.PT_MESH_HAS_N
+        if S is not None:
+            flags |= capi.PT_MESH_HAS_S
+        if UV is not None:
+            flags |= capi.PT_MESH_HAS_UV
+        mesh = capi.pt_mesh(flags, self.cur_material, self.cur_area_light, 0)
+        self.meshes.append(mesh)
+        mid = len(self.meshes) - 1
+        self.P.append(P)
+        self.N.append(np.asarray(N, np.float32).reshape(-1, 3) if N is not None else None)
+        self.S.append(np.asarray(S, np.float32).reshape(-1, 3) if S is not None else None)
+        self.UV.append(UV)
+        self.idx.append((idx + self.n_vertices).astype(np.uint32))
+        self.tri_mesh.append(np.full(len(idx), mid, np.uint32))
+        self.n_vertices += nv
+        return mid
+
+    def shape_trianglemesh_fast(self, P, indices, twosided=True):
+        """Bulk path for meshes whose triangles do not share vertices (indices == arange):
+        identical result to shape_trianglemesh (uv fill = (0,0),(1,0),(1,1) per triangle)."""
+        P = np.asarray(P, np.float32).reshape(-1, 3)
+        idx = np.asarray(indices, np.int64).reshape(-1, 3)
+        assert np.array_equal(idx.reshape(-1), np.arange(len(P)))
+        UV = np.tile(np.array([[0, 0], [1, 0], [1, 1]], np.float32), (len(idx), 1))
+        return self._append_mesh(P, idx, None, None, UV, twosided, False)
+
+    # ---- finish
+    def build(self):
+        sd = SceneDesc()
+        d = sd.desc
+        P = np.ascontiguousarray(np.concatenate(self.P), np.float32) if self.P else np.zeros((0, 3), np.float32)
+
+        def cat(parts, width):
+            if all(p is None for p in parts):
+                return None
+            return np.ascontiguousarray(np.concatenate([p if p is not None else np.zeros((len(pp), width), np.float32)
+                                                        for p, pp in zip(parts, self.P)]), np.float32)
+        N, S, UV = cat(self.N, 3), cat(self.S, 3), cat(self.UV, 2)
+        idx = np.ascontiguousarray(np.concatenate(self.idx), np.uint32) if self.idx else np.zeros((0, 3), np.uint32)
+        tm = np.ascontiguousarray(np.concatenate(self.tri_mesh), np.uint32) if self.tri_mesh else np.zeros(0, np.uint32)
+        d.n_vertices = len(P)
+        sd._set("P", P, C.c_float)
+        sd._set("N", N, C.c_float) if N is not None else None
+        sd._set("S", S, C.c_float) if S is not None else None
+        sd._set("UV", UV, C.c_float) if UV is not None else None
+        d.n_triangles = len(idx)
+        sd._set("indices", idx, C.c_uint32)
+        sd._set("tri_mesh", tm, C.c_uint32)
+        meshes = (capi.pt_mesh * max(1, len(self.meshes)))(*self.meshes)
+        mats = (capi.pt_material * max(1, len(self.materials)))(*self.materials)
+        als = (capi.pt_area_light * max(1, len(self.area_lights)))(*self.area_lights)
+        sd.buffers["meshes"], sd.buffers["materials"], sd.buffers["area_lights"] = meshes, mats, als
+        d.n_meshes, d.meshes = len(self.meshes), meshes
+        d.n_materials, d.materials = len(self.materials), mats
+        d.n_area_lights, d.area_lights = len(self.area_lights), als
+        d.split_method, d.max_node_prims = self.split_method, self.max_node_prims
+        d.camera_to_world[:] = [float(v) for v in self.camera_to_world]
+        d.fov = self.fov
+        # create_perspective_camera (cameras/perspective.rs:337-394)
+        aspect = f32(self.xres) / f32(self.yres)
+        frame = f32(getattr(self, "frameaspectratio", None) or aspect)
+        if self.screen_window is not None:
+            sw = [f32(v) for v in self.screen_window]
+        elif frame > 1.0:
+            sw = [-frame, frame, f32(-1.0), f32(1.0)]
+        else:
+            sw = [f32(-1.0), f32(1.0), f32(-1.0) / frame, f32(1.0) / frame]
+        d.screen_window[:] = [float(v) for v in sw]
+        d.lens_radius, d.focal_distance = self.lens_radius, self.focal_distance
+        d.shutter_open, d.shutter_close = self.shutter
+        d.xres, d.yres = self.xres, self.yres
+        d.crop_window[:] = self.crop
+        d.filter_radius[:] = self.filter_radius
+        d.filter_table[:] = [float(v) for v in self.filter_table]
+        d.film_scale, d.max_sample_luminance = self.film_scale, self.max_sample_luminance
+        d.sampler, d.spp = 0, self.spp
+        d.max_depth, d.rr_threshold, d.light_strategy = self.max_depth, self.rr_threshold, self.light_strategy
+        return sd
+
+
+# --------------------------------------------------------------------------
+def _quad(b, p0, p1, p2, p3, **kw):
+    b.shape_trianglemesh([p0, p1, p2, p3], [0, 1, 2, 0, 2, 3], **kw)
+
+
+def _cuboid(b, top4, height):
+    """Six quads (12 triangles) from the four top corners and a height."""
+    t = [np.array(p, np.float32) for p in top4]
+    bt = [np.array([p[0], p[1] - height, p[2]], np.float32) for p in t]
+    _quad(b, t[0], t[1], t[2], t[3])
+    _quad(b, bt[3], bt[2], bt[1], bt[0])
+    for i in range(4):
+        j = (i + 1) % 4
+        _quad(b, t[i], bt[i], bt[j], t[j])
+
+
+def cornell_box(res=512, spp=64, max_depth=5, light_strategy="spatial"):
+    """BASELINE config 1: 36 triangles, matte walls, one-sided ceiling quad light L=(17,12,4)."""
+    b = SceneBuilder()
+    b.look_at((278, 273, -800), (278, 273, 0), (0, 1, 0))
+    b.camera_perspective(fov=39.3)
+    b.film(xresolution=res, yresolution=res)
+    b.pixel_filter_box()
+    b.sampler_sobol(spp)
+    b.integrator_path(maxdepth=max_depth, lightsamplestrategy=light_strategy)
+    white, red, green = (0.73, 0.73, 0.73), (0.65, 0.05, 0.05), (0.12, 0.45, 0.15)
+    b.material_matte(white)
+    _quad(b, (552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2))                    # floor
+    _quad(b, (556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0))        # ceiling
+    _quad(b, (549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2))      # back
+    b.material_matte(green)
+    _quad(b, (0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2))                    # right
+    b.material_matte(red)
+    _quad(b, (552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0))        # left
+    b.material_matte(white)
+    _cuboid(b, [(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)], 165.0)   # short block
+    _cuboid(b, [(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)], 330.0)  # tall block
+    b.area_light_source_diffuse(L=(17, 12, 4))
+    _quad(b, (343, 548.75, 227), (343, 548.75, 332), (213, 548.75, 332), (213, 548.75, 227))  # light, faces -y
+    return b.build()
+
+
+def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequence=1):
+    """BASELINE config 2 ("RT1M"): 12-triangle enclosure + light, the rest random matte triangles.
+
+    Filler triangle k draws, in order, cx cy cz then v0x..v2z as lerp(uniform_float(), lo, hi)
+    from PCG32 RNG::new_sequence(1) (src/core/rng.rs:21-33, :59-66)."""
+    b = SceneBuilder()
+    b.look_at((0, 0, -3.4), (0, 0, 0), (0, 1, 0))
+    b.camera_perspective(fov=40.0)
+    b.film(xresolution=res, yresolution=res)
+    b.pixel_filter_box()
+    b.sampler_sobol(spp)
+    b.integrator_path(maxdepth=max_depth, rrthreshold=1.0, lightsamplestrategy="spatial")
+    b.accelerator_bvh("sah", 4)
+    b.material_matte((0.5, 0.5, 0.5))
+    _quad(b, (1, -1, -1), (-1, -1, -1), (-1, -1, 1), (1, -1, 1))      # floor
+    _quad(b, (1, 1, -1), (1, 1, 1), (-1, 1, 1), (-1, 1, -1))          # ceiling
+    _quad(b, (1, -1, 1), (-1, -1, 1), (-1, 1, 1), (1, 1, 1))          # back
+    _quad(b, (-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1))      # right
+    _quad(b, (1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1))          # left
+    n_fill = max(0, int(n_triangles) - 12)
+    if n_fill:
+        u = pcg32_uniform_float(12 * n_fill, seed_sequence).reshape(n_fill, 12)
+        one = f32(1.0)
+        c = (one - u[:, 0:3]) * f32(-0.9) + u[:, 0:3] * f32(0.9)                       # lerp(t, lo, hi)
+        off = (one - u[:, 3:12]) * f32(-s) + u[:, 3:12] * f32(s)
+        verts = (np.repeat(c, 3, axis=0).reshape(n_fill, 9) + off).astype(np.float32).reshape(-1, 3)
+        b.shape_trianglemesh_fast(verts, np.arange(3 * n_fill), twosided=True)
+    b.area_light_source_diffuse(L=(17, 12, 4))
+    _quad(b, (0.25, 0.999, -0.25), (0.25, 0.999, 0.25), (-0.25, 0.999, 0.25), (-0.25, 0.999, -0.25))  # faces -y
+    return b.build()
+
+
+def all_tiles(info, tile=16):
+    """The reference's 16x16 decomposition of the sample bounds (sampler.rs:266-289)."""
+    x0, y0, x1, y1 = list(info.sample_bounds)
+    out = []
+    for y in range(y0, y1, tile):
+        for x in range(x0, x1, tile):
+            out.append((x, y, min(x + tile, x1), min(y + tile, y1)))
+    return out
