@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on its headline config.
+
+Workload "RT1M" (BASELINE.md config 2): 1M random matte triangles in a lit box,
+1024x1024 film, Sobol' 256 spp, path depth 8.  One STEP = one full render of that frame
+(every 16x16 tile of the 1026x1026 sample bounds, all 256 spp).  With N ranks the frame's
+tiles are dealt round-robin to the ranks (each GPU holds the whole scene), every rank
+renders its tiles, and the per-rank XYZW films are summed with one RCCL all-reduce over
+xGMI: total work is fixed, so scaling is "strong".
+
+metric  Mrays/s  = rays counted exactly as the reference's "Regular ray intersection tests"
+                   + "Shadow ray intersection tests" (src/core/scene/scene.rs:11-12), summed
+                   over ranks, / wall time of the K timed steps (scene upload + BVH build
+                   excluded; inputs are resident in HBM when timing starts).
+roofline         = the traversal kernel (k_trace): algorithmic bytes per launch
+                   (48 B/closest ray, 36 B/any-hit ray, 128 B/node,
+                   48 B/triangle test) / mean launch duration from HIP events recorded inside
+                   the library on the stream the kernel runs on, vs 8 TB/s.
+cpu_baseline     = the CPU oracle (C++ restatement of the reference; the Rust binary cannot
+                   be built in this image) rendering a bounded sample of the same workload on
+                   the host cores of rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--triangles", type=int, default=1000000)
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--max-depth", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU sample (0 = auto, about 15 s)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = max(args.gpus, world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("pbrt-r3_amd")
+    t0 = time.time()
+    sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth)
+    t_scene = time.time() - t0
+    ctx = pkg.Context(local_rank)
+    info = ctx.upload(sd)
+    tiles = pkg.scenes.all_tiles(info)
+    my_tiles = tiles[rank::world]
+
+    film_ptr, film_n = None, 0
+
+    def step():
+        ctx.film_clear()
+        ctx.render(my_tiles)
+        if world > 1:
+            # the one collective of the path: sum the per-rank XYZW films (disjoint tiles)
+            ptr, n = ctx.film_device_xyzw()
+            t = pkg.dist.wrap_device_floats(ptr, n, local_rank)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()      # the library's next film_clear runs on its own stream
+            ctx.film_commit_xyzw()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.reset_counters()
+    t_start = time.time()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.time() - t_start
+    cnt = ctx.counters()
+
+    stats = torch.tensor([elapsed, cnt["regular_rays"], cnt["shadow_rays"], cnt["nodes_visited"], cnt["tris_tested"],
+                          cnt["path_vertices"], cnt["trace_ms"], cnt["trace_launches"], cnt["camera_rays"], cnt["shade_ms"]],
+                         dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        tot = sm.tolist()
+    else:
+        tot = stats.tolist()
+    rays = tot[1] + tot[2]
+    value = rays / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        # roofline of the dominant kernel, from rank 0's own launches
+        alg_bytes = 48.0 * cnt["regular_rays"] + 36.0 * cnt["shadow_rays"] + 128.0 * cnt["nodes_visited"] + 48.0 * cnt["tris_tested"]
+        launches = max(1, cnt["trace_launches"])
+        avg_launch_s = cnt["trace_ms"] / 1e3 / launches
+        achieved = (alg_bytes / launches) / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        peak = 8000.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
+                    "frac": round(achieved / peak, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1),
+                    "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
+                    "nodes_per_ray": round(cnt["nodes_visited"] / max(1.0, cnt["regular_rays"] + cnt["shadow_rays"]), 2),
+                    "tris_per_ray": round(cnt["tris_tested"] / max(1.0, cnt["regular_rays"] + cnt["shadow_rays"]), 2),
+                    "trace_share_of_render": round(cnt["trace_ms"] / max(1e-9, cnt["render_ms"]), 3)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            import oracle_lib
+            osc = oracle_lib.load().scene(sd)
+            cores = os.cpu_count() or 1
+            ntile = args.cpu_tiles
+            if ntile <= 0:
+                # calibrate on 2 tiles, then size the sample for ~15 s on all cores
+                probe = tiles[len(tiles) // 2: len(tiles) // 2 + 2]
+                _, c0, s0 = osc.render(probe, threads=min(2, cores), want_image=False)
+                per_tile = s0 / 2 * min(2, cores)
+                ntile = int(max(cores, min(len(tiles), 15.0 * cores / max(per_tile, 1e-3))))
+            stride = max(1, len(tiles) // ntile)
+            sample = tiles[::stride][:ntile]
+            _, ccnt, secs = osc.render(sample, threads=cores, want_image=False)
+            crays = ccnt["regular_rays"] + ccnt["shadow_rays"]
+            cpu = {"value": round(crays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "sample": "%d of %d 16x16 tiles (every %dth), all %d spp, %.1f s" % (len(sample), len(tiles), stride, info.spp, secs),
+                   "note": "C++ restatement of the reference (oracle/), not the Rust binary"}
+            osc.close()
+        out = {
+            "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RT1M: %d random matte triangles, %dx%d, Sobol %d spp, path maxdepth %d, BVH sah/4, spatial lights"
+                                   % (sd.desc.n_triangles, args.res, args.res, info.spp, args.max_depth),
+                       "partition": "16x16 film tiles round-robin over %d rank(s), RCCL all-reduce of the XYZW film" % world,
+                       "rays_per_step": int(rays / max(1, args.steps)), "camera_samples_per_step": int(tot[8] / max(1, args.steps)),
+                       "bvh_build_ms": round(info.bvh_build_ms, 1), "upload_ms": round(info.upload_ms, 1),
+                       "scene_gen_s": round(t_scene, 2)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,4 +11,12 @@ The directory name contains a hyphen (it is fixed by the project layout), so
 import it with importlib:  importlib.import_module("pbrt-r3_amd").
 """
 from . import capi, scenes  # noqa: F401
+
+
+def __getattr__(name):
+    if name == "dist":          # imports torch; loaded on demand
+        import importlib
+        return importlib.import_module(__name__ + ".dist")
+    raise AttributeError(name)
+
 from .capi import Context, load_library, PtError  # noqa: F401

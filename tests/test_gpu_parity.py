@@ -157,12 +157,20 @@ def test_image_parity(pair):
 
 def test_tile_subset_and_accumulate(pair):
     """Rendering a subset of tiles touches only their pixels; two disjoint subsets accumulate
-    to the full render (the multi-GPU partition relies on this)."""
+    to the full render (the multi-GPU partition relies on this).  Samples whose footprint is
+    exactly their own pixel (the box-filter norm) are summed in sample order and must agree
+    bit for bit; the few samples that land exactly on a pixel edge are spread with float
+    atomics over 2-4 pixels and may differ in the last bit (the reference is itself
+    order-nondeterministic for such pixels: SURVEY.md quirk Q10)."""
     name, sd, ctx, osc = pair
     tiles = scenes.all_tiles(ctx.info)
     ctx.film_clear(); ctx.render(tiles[0::2]); a = ctx.film_xyzw()
     ctx.film_clear(); ctx.render(tiles[1::2]); b = ctx.film_xyzw()
     ctx.film_clear(); ctx.render(); full = ctx.film_xyzw()
-    assert np.array_equal(bits(a + b), bits(full))
+    assert np.array_equal(bits((a + b)[..., 3]), bits(full[..., 3]))          # weights: exact
+    assert np.allclose(a + b, full, rtol=4e-6, atol=1e-7)
+    exact = np.all(bits(a + b) == bits(full), axis=-1).mean()
+    assert exact > 0.9, exact
     ctx.film_clear(); ctx.render(tiles[0::2]); ctx.render(tiles[1::2]); both = ctx.film_xyzw()
-    assert np.array_equal(bits(both), bits(full))
+    assert np.allclose(both, full, rtol=4e-6, atol=1e-7)
+    assert np.all(bits(both) == bits(full), axis=-1).mean() > 0.9
