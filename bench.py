@@ -32,6 +32,31 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def effective_cores():
+    """Host threads this process may actually use: affinity mask and cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    cap = int(os.environ.get("BENCH_CPU_THREADS", "0"))
+    return min(n, cap) if cap > 0 else n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +85,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    def log(msg):
+        if rank == 0:
+            print("[bench %7.1fs] %s" % (time.time() - t_prog, msg), file=sys.stderr, flush=True)
+
+    t_prog = time.time()
     pkg = importlib.import_module("pbrt-r3_amd")
     t0 = time.time()
     sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth)
@@ -88,13 +118,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log("scene %d tris uploaded (gen %.1fs, bvh %.0f ms), %d tiles for this rank" % (sd.desc.n_triangles, t_scene, info.bvh_build_ms, len(my_tiles)))
+    for i in range(args.warmup):
         step()
+        log("warmup step %d done" % i)
     fence()
     ctx.reset_counters()
     t_start = time.time()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        log("timed step %d done" % i)
     fence()
     elapsed = time.time() - t_start
     cnt = ctx.counters()
@@ -140,17 +173,21 @@ def main():
         if not args.no_cpu_baseline:
             import oracle_lib
             osc = oracle_lib.load().scene(sd)
-            cores = os.cpu_count() or 1
+            cores = min(effective_cores(), 16)      # a 1-GPU box grants 16 host CPUs; BENCH_CPU_THREADS overrides the probe
             ntile = args.cpu_tiles
             if ntile <= 0:
                 # calibrate on 2 tiles, then size the sample for ~15 s on all cores
                 probe = tiles[len(tiles) // 2: len(tiles) // 2 + 2]
+                log("cpu baseline: oracle scene built, calibrating on 2 tiles")
                 _, c0, s0 = osc.render(probe, threads=min(2, cores), want_image=False)
+                log("cpu baseline: 2 tiles took %.1f s" % s0)
                 per_tile = s0 / 2 * min(2, cores)
                 ntile = int(max(cores, min(len(tiles), 15.0 * cores / max(per_tile, 1e-3))))
             stride = max(1, len(tiles) // ntile)
             sample = tiles[::stride][:ntile]
+            log("cpu baseline: rendering %d tiles on %d threads" % (len(sample), cores))
             _, ccnt, secs = osc.render(sample, threads=cores, want_image=False)
+            log("cpu baseline: done in %.1f s" % secs)
             crays = ccnt["regular_rays"] + ccnt["shadow_rays"]
             cpu = {"value": round(crays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                    "sample": "%d of %d 16x16 tiles (every %dth), all %d spp, %.1f s" % (len(sample), len(tiles), stride, info.spp, secs),

@@ -13,6 +13,7 @@
 #include "orc_accel.hpp"
 #include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -210,7 +211,7 @@ struct LightDistribution {
     Distribution1D fixed;          // uniform / power
     uint32_t voxels[3] = {1, 1, 1};
     std::unordered_map<uint64_t, std::unique_ptr<Distribution1D>> table;   // keyed by packed voxel id
-    std::mutex mu;
+    std::shared_mutex mu;      // the reference guards each slot with an RwLock (spatial.rs:199-260)
 
     void init(const Scene* s) {    // create_light_sample_distribution.rs:11-50
         sc = s;
@@ -281,12 +282,12 @@ struct LightDistribution {
         voxel_of(p, pi);
         uint64_t key = ((uint64_t)pi[0] << 40) | ((uint64_t)pi[1] << 20) | (uint64_t)pi[2];
         {
-            std::lock_guard<std::mutex> g(mu);
+            std::shared_lock<std::shared_mutex> g(mu);
             auto it = table.find(key);
             if (it != table.end()) return it->second.get();
         }
         std::unique_ptr<Distribution1D> d = compute_distribution(pi);
-        std::lock_guard<std::mutex> g(mu);
+        std::unique_lock<std::shared_mutex> g(mu);
         auto it = table.find(key);
         if (it != table.end()) return it->second.get();
         const Distribution1D* r = d.get();
