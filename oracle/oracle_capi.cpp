@@ -172,3 +172,18 @@ float orc_sobol_sample_float(int64_t a, uint32_t dim) { return sobol_sample_floa
 uint64_t orc_sobol_interval_to_index(uint32_t m, uint64_t frame, int32_t px, int32_t py) { return sobol_interval_to_index(g_tab, m, frame, px, py); }
 
 }  // extern "C"
+
+// Standalone SobolSampler walk for tests/sampling.rs:137-201 (check_sampler): the first
+// get_2d() of every sample of one pixel.
+extern "C" uint32_t orc_sobol_pixel_first2d(uint32_t spp, const int32_t bounds[4], int32_t px, int32_t py, float* out_xy) {
+    SobolSampler sm;
+    sm.init(&g_tab, spp, bounds);
+    sm.start_pixel(px, py);
+    uint32_t n = 0;
+    do {
+        V2 u = sm.get_2d();
+        out_xy[2 * n] = u.x; out_xy[2 * n + 1] = u.y;
+        n++;
+    } while (sm.start_next_sample());
+    return n;
+}

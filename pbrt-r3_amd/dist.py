@@ -18,6 +18,14 @@ def wrap_device_floats(ptr, n, device_index):
     return torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", device_index))
 
 
+def all_reduce_xyzw(t, group=None):
+    """The path's one collective: element-wise sum of the per-rank {X,Y,Z,weight} films.
+    Works for any backend (RCCL on GPUs, gloo in the CPU tests)."""
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def reduce_film(ctx, device_index, group=None, op="all"):
     """Sum the XYZW film over all ranks in place and mark it authoritative."""
     import torch.distributed as dist

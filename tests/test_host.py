@@ -1,0 +1,118 @@
+"""Host-side logic and the C-ABI boundary, without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import pkg, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """libpbrtgpu.so loads (no device needed) and exports exactly what include/pbrtgpu.h declares."""
+    header = open(os.path.join(ROOT, "include", "pbrtgpu.h")).read()
+    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pt_status"}
+    lib = pkg.capi.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export: " + name
+    assert declared == set(pkg.capi.SYMBOLS), declared ^ set(pkg.capi.SYMBOLS)
+    assert lib.pt_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors of the ABI structs have the C sizes (checked against a tiny C program)."""
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include "pbrtgpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(pt_scene_desc), sizeof(pt_material), sizeof(pt_area_light), sizeof(pt_mesh), sizeof(pt_tile), sizeof(pt_hit), sizeof(pt_counters), sizeof(pt_scene_info));return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(td, "s.c"), "-o", os.path.join(td, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(td, "s")]).split()]
+    c = pkg.capi
+    mine = [C.sizeof(t) for t in (c.pt_scene_desc, c.pt_material, c.pt_area_light, c.pt_mesh, c.pt_tile, c.pt_hit, c.pt_counters, c.pt_scene_info)]
+    assert mine == sizes
+    assert c.HIT_DTYPE.itemsize == C.sizeof(c.pt_hit)
+
+
+def test_no_device_fails_loudly():
+    """There is no CPU fallback: without a HIP device the context cannot be created."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.PtError) as e:
+        pkg.Context(0)
+    assert e.value.status == 2          # PT_ERR_NO_DEVICE
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(OSError):
+        pkg.capi.load_library(str(tmp_path / "libpbrtgpu.so"))
+
+
+@pytest.mark.parametrize("method", ["sah", "middle", "equal"])
+def test_host_bvh_matches_reference_topology(oracle, method):
+    """The product's BVH builder (pt_bvh.cpp, in-place partition, threaded) yields the oracle's
+    (= reference's recursive_build) leaf order and node counts."""
+    for sd_fn in (lambda: scenes.cornell_box(res=16, spp=1), lambda: scenes.rt1m(30000, res=16, spp=1)):
+        b = sd_fn
+        sd = b()
+        sd.desc.split_method = {"sah": 0, "middle": 2, "equal": 3}[method]
+        order, n_nodes, n_leaves, max_stack = pkg.capi.bvh_leaf_order(sd)
+        sc = oracle.scene(sd)
+        assert np.array_equal(order, sc.ordered_prims())
+        assert (n_nodes, n_leaves) == (sc.info.n_nodes, sc.info.n_leaves)
+        assert max_stack >= 1
+        sc.close()
+
+
+def test_hlbvh_is_reported_unsupported():
+    sd = scenes.cornell_box(res=16, spp=1)
+    sd.desc.split_method = 1
+    with pytest.raises(pkg.PtError) as e:
+        pkg.capi.bvh_leaf_order(sd)
+    assert e.value.status == 4
+
+
+def test_scene_builder_mirrors_reference_rules():
+    """pbrt_shape-side rules restated in scenes.py: degenerate triangles dropped (triangle.rs:726),
+    uv auto-fill only for 'fillable' index patterns (triangle.rs:733-821), one light per emissive triangle."""
+    b = scenes.SceneBuilder()
+    b.shape_trianglemesh([(0, 0, 0), (1, 0, 0), (0, 1, 0), (5, 5, 5), (5, 5, 5), (5, 5, 5)], [0, 1, 2, 3, 4, 5])   # second triangle degenerate
+    b.area_light_source_diffuse(L=(2, 2, 2), scale=(0.5, 1, 1))
+    b.shape_trianglemesh([(0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)], [0, 1, 2, 0, 2, 3])
+    sd = b.build()
+    assert sd.desc.n_triangles == 3
+    assert sd.desc.n_meshes == 2
+    m0, m1 = sd.desc.meshes[0], sd.desc.meshes[1]
+    assert m0.flags & pkg.capi.PT_MESH_HAS_UV          # one triangle: fillable
+    assert not (m1.flags & pkg.capi.PT_MESH_HAS_UV)    # quad as 2 triangles sharing vertices in different slots
+    assert m1.area_light == 0 and m0.area_light == -1
+    assert list(sd.desc.area_lights[0].L) == [1.0, 2.0, 2.0]
+    uv = sd.buffers["UV"]
+    assert np.array_equal(uv[:3], np.array([[0, 0], [1, 0], [1, 1]], np.float32))
+    # a vertex reused in a different corner slot makes the mesh non-fillable (the rule runs before the degenerate filter)
+    assert not scenes._is_fillable_uv(np.array([[0, 1, 2], [3, 3, 3]]), 4)
+
+
+def test_rt1m_generator_is_deterministic():
+    a, b = scenes.rt1m(5000, res=16, spp=1), scenes.rt1m(5000, res=16, spp=1)
+    assert np.array_equal(a.buffers["P"], b.buffers["P"])
+    assert a.desc.n_triangles == 5000
+    p = a.buffers["P"]
+    assert p.min() >= -1.0 and p.max() <= 1.0
+
+
+def test_all_tiles_cover_sample_bounds():
+    class I:
+        sample_bounds = [-1, -1, 1025, 1025]
+    t = scenes.all_tiles(I())
+    assert len(t) == 65 * 65                   # 4225 tiles
+    area = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in t)
+    assert area == 1026 * 1026
