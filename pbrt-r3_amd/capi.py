@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libpbrtgpu.so")
+LIB_PATH = os.environ.get("PBRTGPU_LIB") or os.path.join(HERE, "csrc", "libpbrtgpu.so")   # override: tuning builds only
 DATA_DIR = os.path.join(HERE, "data")
 
 PT_MATERIAL_NONE, PT_MATERIAL_MATTE = 0, 1

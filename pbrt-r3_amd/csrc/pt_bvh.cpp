@@ -285,6 +285,12 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
         tr.pad = 0;
         out->rec_of_prim[t] = r;
     }
+    {   // one zero pad record: the kernels fetch triangle records two at a time
+        PtTri pad;
+        std::memset(&pad, 0, sizeof(pad));
+        pad.flags = PT_TRI_LAST;
+        out->tris.push_back(pad);
+    }
     out->n_leaves = 0;
     for (const BNode& n : tree)
         if (n.count > 0) { out->tris[n.first + n.count - 1].flags |= PT_TRI_LAST; out->n_leaves++; }

@@ -10,7 +10,7 @@ namespace ptbvh {
 
 struct Result {
     std::vector<PtNode> nodes;          // 4-wide interior nodes, root first
-    std::vector<PtTri> tris;            // triangle records in leaf order
+    std::vector<PtTri> tris;            // triangle records in leaf order + one zero pad record
     std::vector<uint32_t> rec_of_prim;  // caller's triangle index -> record index
     uint32_t root_ref = PT_EMPTY_REF;
     uint32_t n_leaves = 0;

@@ -200,6 +200,7 @@ pt_status pt_context_create(int device, pt_context** out) {
     std::memset(&ctx->paths, 0, sizeof(ctx->paths));
     // occupancy-sized persistent grids: blocks per CU from register/LDS use x CU count
     ctx->grid_trace = ctx->n_cu * 4;
+    if (const char* e = std::getenv("PBRTGPU_TRACE_BLOCKS_PER_CU")) ctx->grid_trace = ctx->n_cu * std::max(1, std::atoi(e));
     ctx->grid_shade = ctx->n_cu * 2;
     ctx->grid_wide = ctx->n_cu * 8;
     const char* dd = std::getenv("PBRTGPU_DATA_DIR");

@@ -6,7 +6,9 @@
 
 #define PT_WAVE 64
 #define PT_BLOCK 256
+#ifndef PT_LDS_STACK
 #define PT_LDS_STACK 32          // per-lane traversal stack entries kept in LDS
+#endif
 #define PT_EMPTY_REF 0xffffffffu
 #define PT_LEAF_BIT 0x80000000u
 

@@ -281,68 +281,70 @@ PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t
     }
 }
 
+struct LaneRay {
+    V3 o, idir;
+    RayPre rp;
+    float tmin, tmax, ray_tmax;
+    uint32_t sbits, sp;
+    int32_t best;
+};
+PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max, TravCtx& c) {
+    r.o = o;
+    r.idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+    r.best = -1;
+    r.ray_tmax = t_max;
+    r.sp = 0;
+    ray_precompute(r.rp, o, d);
+    if (root_test(sc, o, r.idir, r.sbits, t_max, r.tmin, r.tmax)) stk_push(c, r.sp, sc.root_ref);
+}
+// One pop.  any_hit: stop at the first accepted triangle (sets best, empties the stack).
+PT_DEV void ray_step(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
+    uint32_t ref = stk_pop(c, r.sp);
+    if (ref & PT_LEAF_BIT) {
+        uint32_t rec = ref & ~PT_LEAF_BIT;
+        bool leaf_hit = false;
+        for (;;) {
+            // two records per round trip (the array is padded by one record)
+            TriVerts t0 = load_tri(sc.tris, rec), t1 = load_tri(sc.tris, rec + 1);
+            TriHit h;
+            c.n_tris++;
+            if (tri_test(r.rp, t0.p0, t0.p1, t0.p2, t0.flags, r.ray_tmax, h)) {
+                r.best = (int32_t)rec; leaf_hit = true;
+                if (any_hit) { r.sp = 0; return; }
+                r.ray_tmax = h.t;
+            }
+            if (t0.flags & PT_TRI_LAST) break;
+            c.n_tris++;
+            if (tri_test(r.rp, t1.p0, t1.p1, t1.p2, t1.flags, r.ray_tmax, h)) {
+                r.best = (int32_t)(rec + 1); leaf_hit = true;
+                if (any_hit) { r.sp = 0; return; }
+                r.ray_tmax = h.t;
+            }
+            if (t1.flags & PT_TRI_LAST) break;
+            rec += 2;
+        }
+        if (leaf_hit) r.tmax = r.ray_tmax;
+    } else {
+        c.n_nodes++;
+        visit_node(sc.nodes, ref, r.o, r.idir, r.sbits, r.tmin, r.tmax, c, r.sp);
+    }
+}
+
 // intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
 PT_DEV int32_t trace_closest(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c, float* t_out) {
-    V3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
-    float tmin, tmax;
-    if (!root_test(sc, o, idir, sbits, t_max, tmin, tmax)) return -1;
-    RayPre rp;
-    ray_precompute(rp, o, d);
-    int32_t best = -1;
-    float ray_tmax = t_max;
-    uint32_t sp = 0;
-    stk_push(c, sp, sc.root_ref);
-    while (sp > 0) {
-        uint32_t ref = stk_pop(c, sp);
-        if (ref & PT_LEAF_BIT) {
-            uint32_t rec = ref & ~PT_LEAF_BIT;
-            bool leaf_hit = false;
-            for (;;) {
-                TriVerts tv = load_tri(sc.tris, rec);
-                c.n_tris++;
-                TriHit h;
-                if (tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, ray_tmax, h)) { ray_tmax = h.t; best = (int32_t)rec; leaf_hit = true; }
-                if (tv.flags & PT_TRI_LAST) break;
-                rec++;
-            }
-            if (leaf_hit) tmax = ray_tmax;
-        } else {
-            c.n_nodes++;
-            visit_node(sc.nodes, ref, o, idir, sbits, tmin, tmax, c, sp);
-        }
-    }
-    *t_out = ray_tmax;
-    return best;
+    LaneRay r;
+    ray_begin(sc, r, o, d, t_max, c);
+    while (r.sp > 0) ray_step(sc, r, false, c);
+    *t_out = r.ray_tmax;
+    return r.best;
 }
 // intersect_simd_p (qbvh_x86.rs:289-343): any hit
 PT_DEV bool trace_any(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c) {
-    V3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
-    float tmin, tmax;
-    if (!root_test(sc, o, idir, sbits, t_max, tmin, tmax)) return false;
-    RayPre rp;
-    ray_precompute(rp, o, d);
-    uint32_t sp = 0;
-    stk_push(c, sp, sc.root_ref);
-    while (sp > 0) {
-        uint32_t ref = stk_pop(c, sp);
-        if (ref & PT_LEAF_BIT) {
-            uint32_t rec = ref & ~PT_LEAF_BIT;
-            for (;;) {
-                TriVerts tv = load_tri(sc.tris, rec);
-                c.n_tris++;
-                TriHit h;
-                if (tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, t_max, h)) return true;
-                if (tv.flags & PT_TRI_LAST) break;
-                rec++;
-            }
-        } else {
-            c.n_nodes++;
-            visit_node(sc.nodes, ref, o, idir, sbits, tmin, tmax, c, sp);
-        }
-    }
-    return false;
+    LaneRay r;
+    ray_begin(sc, r, o, d, t_max, c);
+    while (r.sp > 0) ray_step(sc, r, true, c);
+    return r.best >= 0;
 }
 
 // Block-level counter flush: LDS accumulate, one global atomic per counter per block.
@@ -375,7 +377,21 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 // Items [n_cur, n_cur + n_nee) resolve the previous bounce's next-event estimate:
 // shadow ray (any hit), MIS probe ray (closest hit, accepted only if it lands on the
 // sampled light's triangle), then L += beta * ((A + B) / pdf_light)   (path.rs:122-136).
-extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+//
+// Persistent lanes: ray lengths are heavy-tailed (a wave of 64 fresh rays would idle most of
+// its lanes waiting for the slowest one), so every lane runs a small state machine and a wave
+// re-fills its idle lanes from the device-wide ticket as soon as PT_REFILL_MIN of them are free.
+// Each traversal step pops one reference: a 128-byte node (4 slab tests, ordered pushes) or a
+// leaf (48-byte triangle records, fetched two at a time).  The order of pops, tests and t_max
+// updates per ray is exactly the reference's, whatever the interleaving across lanes.
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 24
+#endif
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 4        // waves per SIMD the register allocator must leave room for
+#endif
+
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                               uint32_t spill_depth, uint32_t* err) {
     __shared__ uint32_t s_stack[PT_LDS_STACK * PT_BLOCK];
     __shared__ unsigned long long s_cnt[4];
@@ -387,46 +403,87 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace(PtScene sc, PtPat
     c.n_nodes = 0; c.n_tris = 0; c.overflow = 0;
     const uint32_t n_cur = Q.counts[0], n_nee = Q.counts[2];
     const uint32_t total = n_cur + n_nee;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     unsigned long long regular = 0, shadow = 0;
+
+    // lane job: 0 idle, 1 continuation (closest), 2 shadow (any), 3 MIS probe (closest)
+    int kind = 0;
+    uint32_t p = 0, nee = 0;
+    V3 ld = mk3(0.0f, 0.0f, 0.0f);
+    LaneRay r;
+    r.sp = 0;
+    bool more = total > 0;
     for (;;) {
-        uint32_t base = wave_ticket(&Q.counts[3]);
-        if (base >= total) break;
-        uint32_t item = base + (threadIdx.x & 63);
-        if (item < n_cur) {
-            uint32_t p = Q.cur[item];
-            float4 ro = P.ray_o[p], rd = P.ray_d[p];
-            float t;
-            int32_t rec = trace_closest(sc, f4_3(ro), f4_3(rd), ro.w, c, &t);
-            P.hit_t[p] = t;
-            P.hit_rec[p] = rec;
-            regular++;
-        } else if (item < total) {
-            uint32_t p = Q.nee[item - n_cur];
-            uint32_t nee = P.nee[p];
-            float4 A = P.pendA[p];
-            V3 ld = mk3(0.0f, 0.0f, 0.0f);
-            if (nee & PT_NEE_SHADOW) {
-                float4 so = P.sh_o[p], sd = P.sh_d[p];
-                shadow++;
-                bool occ = trace_any(sc, f4_3(so), f4_3(sd), so.w, c);
-                if (!occ) ld = ld + mk3(A.x, A.y, A.z);
-            }
-            if (nee & PT_NEE_PROBE) {
-                float4 po = P.pr_o[p], pd = P.pr_d[p];
-                regular++;
-                float t;
-                int32_t rec = trace_closest(sc, f4_3(po), f4_3(pd), po.w, c, &t);
-                if (rec >= 0 && (uint32_t)rec == sc.lights[nee >> 8].tri_rec) {
-                    float4 B = P.pendB[p];
-                    ld = ld + mk3(B.x, B.y, B.z);
+        unsigned long long idle = __ballot(kind == 0);
+        int n_idle = __popcll(idle);
+        if (more && (n_idle >= PT_REFILL_MIN || n_idle == 64)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&Q.counts[3], (uint32_t)n_idle);
+            base = __shfl(base, 0, 64);
+            if (base + (uint32_t)n_idle >= total) more = false;
+            uint32_t item = base + (uint32_t)__popcll(idle & below);
+            if (kind == 0 && item < total) {
+                if (item < n_cur) {
+                    p = Q.cur[item];
+                    float4 ro = P.ray_o[p], rd = P.ray_d[p];
+                    kind = 1;
+                    regular++;
+                    ray_begin(sc, r, f4_3(ro), f4_3(rd), ro.w, c);
+                } else {
+                    p = Q.nee[item - n_cur];
+                    nee = P.nee[p];
+                    ld = mk3(0.0f, 0.0f, 0.0f);
+                    if (nee & PT_NEE_SHADOW) {
+                        float4 so = P.sh_o[p], sd = P.sh_d[p];
+                        kind = 2;
+                        shadow++;
+                        ray_begin(sc, r, f4_3(so), f4_3(sd), so.w, c);
+                    } else {
+                        float4 po = P.pr_o[p], pd = P.pr_d[p];
+                        kind = 3;
+                        regular++;
+                        ray_begin(sc, r, f4_3(po), f4_3(pd), po.w, c);
+                    }
                 }
             }
-            V3 ldn = ld / A.w;
-            float4 pb = P.pbeta[p];
-            float4 L = P.L[p];
-            V3 add = mk3(pb.x, pb.y, pb.z) * ldn;
-            L.x += add.x; L.y += add.y; L.z += add.z;
-            P.L[p] = L;
+        }
+        if (__ballot(kind != 0) == 0) {
+            if (!more) break;
+            continue;
+        }
+        if (kind != 0) {
+            if (r.sp > 0) {
+                ray_step(sc, r, kind == 2, c);
+            } else if (kind == 1) {                  // continuation ray finished
+                P.hit_t[p] = r.ray_tmax;
+                P.hit_rec[p] = r.best;
+                kind = 0;
+            } else {
+                bool finish = true;
+                if (kind == 2) {                     // shadow ray finished: unoccluded => light term A
+                    if (r.best < 0) { float4 A = P.pendA[p]; ld = ld + mk3(A.x, A.y, A.z); }
+                    if (nee & PT_NEE_PROBE) {
+                        float4 po = P.pr_o[p], pd = P.pr_d[p];
+                        kind = 3;
+                        regular++;
+                        ray_begin(sc, r, f4_3(po), f4_3(pd), po.w, c);
+                        finish = false;
+                    }
+                } else {                             // probe finished: counts only on the sampled light's triangle
+                    if (r.best >= 0 && (uint32_t)r.best == sc.lights[nee >> 8].tri_rec) { float4 B = P.pendB[p]; ld = ld + mk3(B.x, B.y, B.z); }
+                }
+                if (finish) {
+                    float pdf_sel = P.pendA[p].w;
+                    V3 ldn = ld / pdf_sel;
+                    float4 pb = P.pbeta[p];
+                    float4 L = P.L[p];
+                    V3 add = mk3(pb.x, pb.y, pb.z) * ldn;
+                    L.x += add.x; L.y += add.y; L.z += add.z;
+                    P.L[p] = L;
+                    kind = 0;
+                }
+            }
         }
     }
     if (c.overflow) atomicOr(err, 1u);
