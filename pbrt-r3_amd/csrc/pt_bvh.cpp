@@ -230,6 +230,8 @@ struct Collapser {
             else nd.child[k] = emit(slot_idx[k], depth + 1);
         }
         nd.axes = (uint32_t)n.axis | ((uint32_t)c0.axis << 2) | ((uint32_t)c1.axis << 4);
+        for (int k = 0; k < 4; k++)
+            if (nd.child[k] != PT_EMPTY_REF) nd.axes |= 1u << (8 + k);
         out.nodes[me] = nd;
         return me;
     }

@@ -20,7 +20,7 @@ struct PtNode {
     float bmin[3][4];            // [axis][child]
     float bmax[3][4];
     uint32_t child[4];
-    uint32_t axes;               // axis_top | axis_left << 2 | axis_right << 4
+    uint32_t axes;               // axis_top | axis_left << 2 | axis_right << 4 | occupied-slot mask << 8
     uint32_t pad[3];
 };
 

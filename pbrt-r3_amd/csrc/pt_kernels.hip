@@ -208,16 +208,27 @@ struct TravCtx {
     uint32_t n_nodes, n_tris;
     uint32_t overflow;
 };
-PT_DEV void stk_push(TravCtx& c, uint32_t& sp, uint32_t v) {
+// The top of the stack lives in a register (`top`, PT_EMPTY_REF = empty); LDS/HBM hold the rest.
+// The child pushed last is popped next, so most pushes/pops never touch LDS.
+PT_DEV void stk_store(TravCtx& c, uint32_t& sp, uint32_t v) {
     if (sp < PT_LDS_STACK) c.lds[sp * PT_BLOCK] = v;
     else if (sp - PT_LDS_STACK < c.spill_depth) c.spill[(size_t)(sp - PT_LDS_STACK) * c.spill_stride] = v;
     else { c.overflow = 1; return; }
     sp++;
 }
-PT_DEV uint32_t stk_pop(TravCtx& c, uint32_t& sp) {
-    sp--;
-    if (sp < PT_LDS_STACK) return c.lds[sp * PT_BLOCK];
-    return c.spill[(size_t)(sp - PT_LDS_STACK) * c.spill_stride];
+PT_DEV void stk_push(TravCtx& c, uint32_t& top, uint32_t& sp, uint32_t v) {
+    if (top != PT_EMPTY_REF) stk_store(c, sp, top);
+    top = v;
+}
+PT_DEV uint32_t stk_pop(TravCtx& c, uint32_t& top, uint32_t& sp) {
+    uint32_t v = top;
+    if (sp > 0) {
+        sp--;
+        top = sp < PT_LDS_STACK ? c.lds[sp * PT_BLOCK] : c.spill[(size_t)(sp - PT_LDS_STACK) * c.spill_stride];
+    } else {
+        top = PT_EMPTY_REF;
+    }
+    return v;
 }
 
 // Bounds3f::intersect_p on the root (bounds3.rs:154-163, intersect.rs:46-65): NaN-ignoring max/min.
@@ -237,7 +248,13 @@ PT_DEV bool root_test(const PtScene& sc, V3 o, V3 idir, uint32_t sbits, float t_
 // One node: 4 slab tests (test_aabb) + ORDER_TABLE in closed form:
 // children are pushed so that pops visit {0,1} before {2,3} iff the ray is non-negative
 // along axis_top, 0 before 1 iff non-negative along axis_left, 2 before 3 iff along axis_right.
-PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t sbits, float tmin, float tmax, TravCtx& c, uint32_t& sp) {
+//
+// EXACT selects the slab arithmetic.  _mm_max_ps(a,b) differs from IEEE maxNum only when an
+// operand is NaN, and a NaN can only come from 0*inf, i.e. from a ray with an infinite (or NaN)
+// reciprocal direction component.  Such rays (flagged once per ray) take the compare/select form
+// that reproduces SSE exactly; all others use v_max_f32 / v_min_f32, which then give the same values.
+template <bool EXACT>
+PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t sbits, float tmin, float tmax, TravCtx& c, uint32_t& top, uint32_t& sp) {
     const float4* q = reinterpret_cast<const float4*>(nodes + ni);
     float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
     uint4 ch = reinterpret_cast<const uint4*>(q)[6];
@@ -250,100 +267,112 @@ PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t
 #define PT_SLAB(k, C)                                                        \
     {                                                                        \
         float a = tmin, b = tmax;                                            \
-        a = sse_max(a, (nx.C - o.x) * idir.x); b = sse_min(b, (fx.C - o.x) * idir.x); \
-        a = sse_max(a, (ny.C - o.y) * idir.y); b = sse_min(b, (fy.C - o.y) * idir.y); \
-        a = sse_max(a, (nz.C - o.z) * idir.z); b = sse_min(b, (fz.C - o.z) * idir.z); \
+        if (EXACT) {                                                         \
+            a = sse_max(a, (nx.C - o.x) * idir.x); b = sse_min(b, (fx.C - o.x) * idir.x); \
+            a = sse_max(a, (ny.C - o.y) * idir.y); b = sse_min(b, (fy.C - o.y) * idir.y); \
+            a = sse_max(a, (nz.C - o.z) * idir.z); b = sse_min(b, (fz.C - o.z) * idir.z); \
+        } else {                                                             \
+            a = fmaxf(a, (nx.C - o.x) * idir.x); b = fminf(b, (fx.C - o.x) * idir.x); \
+            a = fmaxf(a, (ny.C - o.y) * idir.y); b = fminf(b, (fy.C - o.y) * idir.y); \
+            a = fmaxf(a, (nz.C - o.z) * idir.z); b = fminf(b, (fz.C - o.z) * idir.z); \
+        }                                                                    \
         if (b >= a) mask |= (1u << k);                                       \
     }
     PT_SLAB(0, x) PT_SLAB(1, y) PT_SLAB(2, z) PT_SLAB(3, w)
 #undef PT_SLAB
-    if (ch.x == PT_EMPTY_REF) mask &= ~1u;
-    if (ch.y == PT_EMPTY_REF) mask &= ~2u;
-    if (ch.z == PT_EMPTY_REF) mask &= ~4u;
-    if (ch.w == PT_EMPTY_REF) mask &= ~8u;
+    mask &= (axes >> 8) & 15u;          // drop empty slots (their boxes are all-zero as in the reference)
     if (mask == 0) return;
     uint32_t s_top = (sbits >> (axes & 3)) & 1, s_left = (sbits >> ((axes >> 2) & 3)) & 1, s_right = (sbits >> ((axes >> 4) & 3)) & 1;
-    // push order = reverse visit order
-    uint32_t l_first = s_left ? ch.x : ch.y, l_second = s_left ? ch.y : ch.x;          // pushed first => visited last
-    uint32_t l_first_bit = s_left ? 1u : 2u, l_second_bit = s_left ? 2u : 1u;
-    uint32_t r_first = s_right ? ch.z : ch.w, r_second = s_right ? ch.w : ch.z;
-    uint32_t r_first_bit = s_right ? 4u : 8u, r_second_bit = s_right ? 8u : 4u;
-    if (!s_top) {
-        if (mask & r_first_bit) stk_push(c, sp, r_first);
-        if (mask & r_second_bit) stk_push(c, sp, r_second);
-        if (mask & l_first_bit) stk_push(c, sp, l_first);
-        if (mask & l_second_bit) stk_push(c, sp, l_second);
-    } else {
-        if (mask & l_first_bit) stk_push(c, sp, l_first);
-        if (mask & l_second_bit) stk_push(c, sp, l_second);
-        if (mask & r_first_bit) stk_push(c, sp, r_first);
-        if (mask & r_second_bit) stk_push(c, sp, r_second);
-    }
+    // push order = reverse visit order: the far pair first, inside a pair the far child first
+    uint32_t l0 = s_left ? ch.x : ch.y, l1 = s_left ? ch.y : ch.x;
+    uint32_t l0b = s_left ? 1u : 2u, l1b = s_left ? 2u : 1u;
+    uint32_t r0 = s_right ? ch.z : ch.w, r1 = s_right ? ch.w : ch.z;
+    uint32_t r0b = s_right ? 4u : 8u, r1b = s_right ? 8u : 4u;
+    uint32_t c0 = s_top ? l0 : r0, c1 = s_top ? l1 : r1, c2 = s_top ? r0 : l0, c3 = s_top ? r1 : l1;
+    uint32_t b0 = s_top ? l0b : r0b, b1 = s_top ? l1b : r1b, b2 = s_top ? r0b : l0b, b3 = s_top ? r1b : l1b;
+    if (mask & b0) stk_push(c, top, sp, c0);
+    if (mask & b1) stk_push(c, top, sp, c1);
+    if (mask & b2) stk_push(c, top, sp, c2);
+    if (mask & b3) stk_push(c, top, sp, c3);
 }
 
+// Per-lane traversal state.  A ray is a small state machine advanced one unit of work at a time:
+// a node visit or a leaf visit.
 struct LaneRay {
     V3 o, idir;
     RayPre rp;
     float tmin, tmax, ray_tmax;
-    uint32_t sbits, sp;
+    uint32_t sbits;              // bits 0-2: direction signs, bit 3: needs the EXACT slab form
+    uint32_t sp, top;            // top == PT_EMPTY_REF: traversal finished
     int32_t best;
 };
-PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max, TravCtx& c) {
+PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max) {
     r.o = o;
     r.idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     r.sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+    if (!(fabsf(r.idir.x) < PT_INF) || !(fabsf(r.idir.y) < PT_INF) || !(fabsf(r.idir.z) < PT_INF)) r.sbits |= 8u;
     r.best = -1;
     r.ray_tmax = t_max;
     r.sp = 0;
+    r.top = PT_EMPTY_REF;
     ray_precompute(r.rp, o, d);
-    if (root_test(sc, o, r.idir, r.sbits, t_max, r.tmin, r.tmax)) stk_push(c, r.sp, sc.root_ref);
+    if (root_test(sc, o, r.idir, r.sbits, t_max, r.tmin, r.tmax)) r.top = sc.root_ref;
 }
-// One pop.  any_hit: stop at the first accepted triangle (sets best, empties the stack).
-PT_DEV void ray_step(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
-    uint32_t ref = stk_pop(c, r.sp);
-    if (ref & PT_LEAF_BIT) {
-        uint32_t rec = ref & ~PT_LEAF_BIT;
-        bool leaf_hit = false;
-        for (;;) {
-            // two records per round trip (the array is padded by one record)
-            TriVerts t0 = load_tri(sc.tris, rec), t1 = load_tri(sc.tris, rec + 1);
-            TriHit h;
-            c.n_tris++;
-            if (tri_test(r.rp, t0.p0, t0.p1, t0.p2, t0.flags, r.ray_tmax, h)) {
-                r.best = (int32_t)rec; leaf_hit = true;
-                if (any_hit) { r.sp = 0; return; }
-                r.ray_tmax = h.t;
-            }
-            if (t0.flags & PT_TRI_LAST) break;
-            c.n_tris++;
-            if (tri_test(r.rp, t1.p0, t1.p1, t1.p2, t1.flags, r.ray_tmax, h)) {
-                r.best = (int32_t)(rec + 1); leaf_hit = true;
-                if (any_hit) { r.sp = 0; return; }
-                r.ray_tmax = h.t;
-            }
-            if (t1.flags & PT_TRI_LAST) break;
-            rec += 2;
+PT_DEV bool ray_done(const LaneRay& r) { return r.top == PT_EMPTY_REF; }
+PT_DEV bool ray_wants_tri(const LaneRay& r) { return r.top != PT_EMPTY_REF && (r.top & PT_LEAF_BIT) != 0; }
+PT_DEV bool ray_wants_node(const LaneRay& r) { return (r.top & PT_LEAF_BIT) == 0; }   // PT_EMPTY_REF has the leaf bit
+// Pop a node: 4 slab tests, ordered pushes.
+PT_DEV void ray_step_node(const PtScene& sc, LaneRay& r, TravCtx& c) {
+    uint32_t ref = stk_pop(c, r.top, r.sp);
+    c.n_nodes++;
+    if (r.sbits & 8u) visit_node<true>(sc.nodes, ref, r.o, r.idir, r.sbits, r.tmin, r.tmax, c, r.top, r.sp);
+    else visit_node<false>(sc.nodes, ref, r.o, r.idir, r.sbits, r.tmin, r.tmax, c, r.top, r.sp);
+}
+// One leaf (entering it from the top of the stack): its 1..max_node_prims triangle records are
+// fetched two per round trip and tested in order.  any_hit: stop at the first accepted triangle
+// (sets best, empties the stack).
+PT_DEV void ray_step_tri(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
+    uint32_t rec = stk_pop(c, r.top, r.sp) & ~PT_LEAF_BIT;
+    bool leaf_hit = false;
+    for (;;) {
+        TriVerts t0 = load_tri(sc.tris, rec), t1 = load_tri(sc.tris, rec + 1);   // array is padded by one record
+        TriHit h;
+        c.n_tris++;
+        if (tri_test(r.rp, t0.p0, t0.p1, t0.p2, t0.flags, r.ray_tmax, h)) {
+            r.best = (int32_t)rec; leaf_hit = true;
+            if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; return; }
+            r.ray_tmax = h.t;                           // GeometricPrimitive::intersect: r.t_max = t_hit
         }
-        if (leaf_hit) r.tmax = r.ray_tmax;
-    } else {
-        c.n_nodes++;
-        visit_node(sc.nodes, ref, r.o, r.idir, r.sbits, r.tmin, r.tmax, c, r.sp);
+        if (t0.flags & PT_TRI_LAST) break;
+        c.n_tris++;
+        if (tri_test(r.rp, t1.p0, t1.p1, t1.p2, t1.flags, r.ray_tmax, h)) {
+            r.best = (int32_t)(rec + 1); leaf_hit = true;
+            if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; return; }
+            r.ray_tmax = h.t;
+        }
+        if (t1.flags & PT_TRI_LAST) break;
+        rec += 2;
     }
+    if (leaf_hit) r.tmax = r.ray_tmax;                  // intersect_simd: tmax shrinks after the whole leaf
+}
+PT_DEV void ray_step(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
+    if (ray_wants_tri(r)) ray_step_tri(sc, r, any_hit, c);
+    else ray_step_node(sc, r, c);
 }
 
 // intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
 PT_DEV int32_t trace_closest(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c, float* t_out) {
     LaneRay r;
-    ray_begin(sc, r, o, d, t_max, c);
-    while (r.sp > 0) ray_step(sc, r, false, c);
+    ray_begin(sc, r, o, d, t_max);
+    while (!ray_done(r)) ray_step(sc, r, false, c);
     *t_out = r.ray_tmax;
     return r.best;
 }
 // intersect_simd_p (qbvh_x86.rs:289-343): any hit
 PT_DEV bool trace_any(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c) {
     LaneRay r;
-    ray_begin(sc, r, o, d, t_max, c);
-    while (r.sp > 0) ray_step(sc, r, true, c);
+    ray_begin(sc, r, o, d, t_max);
+    while (!ray_done(r)) ray_step(sc, r, true, c);
     return r.best >= 0;
 }
 
@@ -385,7 +414,10 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 // leaf (48-byte triangle records, fetched two at a time).  The order of pops, tests and t_max
 // updates per ray is exactly the reference's, whatever the interleaving across lanes.
 #ifndef PT_REFILL_MIN
-#define PT_REFILL_MIN 24
+#define PT_REFILL_MIN 16
+#endif
+#ifndef PT_LEAF_MIN
+#define PT_LEAF_MIN 24
 #endif
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 4        // waves per SIMD the register allocator must leave room for
@@ -413,8 +445,11 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(P
     V3 ld = mk3(0.0f, 0.0f, 0.0f);
     LaneRay r;
     r.sp = 0;
+    r.top = PT_EMPTY_REF;
     bool more = total > 0;
     for (;;) {
+        // ---- which ray does this lane start next (at most one ray_begin site: it is long)
+        int start = 0;                               // 0 none, else the kind to start
         unsigned long long idle = __ballot(kind == 0);
         int n_idle = __popcll(idle);
         if (more && (n_idle >= PT_REFILL_MIN || n_idle == 64)) {
@@ -426,54 +461,29 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(P
             if (kind == 0 && item < total) {
                 if (item < n_cur) {
                     p = Q.cur[item];
-                    float4 ro = P.ray_o[p], rd = P.ray_d[p];
-                    kind = 1;
-                    regular++;
-                    ray_begin(sc, r, f4_3(ro), f4_3(rd), ro.w, c);
+                    start = 1;
                 } else {
                     p = Q.nee[item - n_cur];
                     nee = P.nee[p];
                     ld = mk3(0.0f, 0.0f, 0.0f);
-                    if (nee & PT_NEE_SHADOW) {
-                        float4 so = P.sh_o[p], sd = P.sh_d[p];
-                        kind = 2;
-                        shadow++;
-                        ray_begin(sc, r, f4_3(so), f4_3(sd), so.w, c);
-                    } else {
-                        float4 po = P.pr_o[p], pd = P.pr_d[p];
-                        kind = 3;
-                        regular++;
-                        ray_begin(sc, r, f4_3(po), f4_3(pd), po.w, c);
-                    }
+                    start = (nee & PT_NEE_SHADOW) ? 2 : 3;
                 }
             }
         }
-        if (__ballot(kind != 0) == 0) {
-            if (!more) break;
-            continue;
-        }
-        if (kind != 0) {
-            if (r.sp > 0) {
-                ray_step(sc, r, kind == 2, c);
-            } else if (kind == 1) {                  // continuation ray finished
+        // ---- retire finished rays (rare, divergent)
+        if (kind != 0 && ray_done(r)) {
+            if (kind == 1) {                         // continuation ray finished
                 P.hit_t[p] = r.ray_tmax;
                 P.hit_rec[p] = r.best;
                 kind = 0;
             } else {
-                bool finish = true;
-                if (kind == 2) {                     // shadow ray finished: unoccluded => light term A
+                if (kind == 2) {                     // shadow ray: unoccluded => light term A
                     if (r.best < 0) { float4 A = P.pendA[p]; ld = ld + mk3(A.x, A.y, A.z); }
-                    if (nee & PT_NEE_PROBE) {
-                        float4 po = P.pr_o[p], pd = P.pr_d[p];
-                        kind = 3;
-                        regular++;
-                        ray_begin(sc, r, f4_3(po), f4_3(pd), po.w, c);
-                        finish = false;
-                    }
-                } else {                             // probe finished: counts only on the sampled light's triangle
+                    if (nee & PT_NEE_PROBE) start = 3;
+                } else {                             // probe: counts only on the sampled light's triangle
                     if (r.best >= 0 && (uint32_t)r.best == sc.lights[nee >> 8].tri_rec) { float4 B = P.pendB[p]; ld = ld + mk3(B.x, B.y, B.z); }
                 }
-                if (finish) {
+                if (start == 0) {
                     float pdf_sel = P.pendA[p].w;
                     V3 ldn = ld / pdf_sel;
                     float4 pb = P.pbeta[p];
@@ -481,9 +491,34 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(P
                     V3 add = mk3(pb.x, pb.y, pb.z) * ldn;
                     L.x += add.x; L.y += add.y; L.z += add.z;
                     P.L[p] = L;
-                    kind = 0;
                 }
+                kind = 0;
             }
+        }
+        if (start != 0) {
+            const float4* so = start == 1 ? P.ray_o : (start == 2 ? P.sh_o : P.pr_o);
+            const float4* sd = start == 1 ? P.ray_d : (start == 2 ? P.sh_d : P.pr_d);
+            float4 ro = so[p], rd = sd[p];
+            kind = start;
+            if (start == 2) shadow++; else regular++;
+            ray_begin(sc, r, f4_3(ro), f4_3(rd), ro.w);
+        }
+        if (__ballot(kind != 0) == 0) {
+            if (!more) break;
+            continue;
+        }
+        // ---- one traversal phase for the whole wave.  A node visit (one 128-byte line, 4 slab tests)
+        // and a leaf visit (1-4 watertight triangle tests) are long, different code paths; running both
+        // every iteration would execute each for a fraction of the lanes.  The wave therefore does ONE
+        // kind per iteration: leaves once PT_LEAF_MIN lanes are parked on one (or nobody has a node to
+        // visit), node visits otherwise.
+        bool w_tri = kind != 0 && ray_wants_tri(r);
+        bool w_node = kind != 0 && ray_wants_node(r);
+        unsigned long long m_tri = __ballot(w_tri), m_node = __ballot(w_node);
+        if (m_node != 0 && __popcll(m_tri) < PT_LEAF_MIN) {
+            if (w_node) ray_step_node(sc, r, c);
+        } else {
+            if (w_tri) ray_step_tri(sc, r, kind == 2, c);
         }
     }
     if (c.overflow) atomicOr(err, 1u);
