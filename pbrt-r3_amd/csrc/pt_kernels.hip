@@ -136,12 +136,17 @@ PT_DEV void ray_precompute(RayPre& r, V3 o, V3 d) {
     r.sz = 1.0f / r.dperm.z;
 }
 struct TriHit { float t, b0, b1, b2; };
-// triangle.rs:240-347 / :466-571 (intersect and intersect_p share this front half)
+// triangle.rs:240-347 / :466-571 (intersect and intersect_p share this front half).
+// Written as straight-line predicated code: in a wave some lane nearly always survives each of
+// the reference's early-outs, so branching on them only adds SALU work; the values computed are
+// the reference's, the early-outs become terms of one boolean.  Only the f64 re-evaluation of
+// the edge functions (needed when one is exactly zero) stays behind a branch.
 PT_DEV bool tri_test(const RayPre& r, V3 p0, V3 p1, V3 p2, uint32_t flags, float t_max, TriHit& h) {
+    bool ok = true;
     if (flags & PT_TRI_ONE_SIDED) {
         V3 n = cross(p0 - p2, p1 - p2);
         if (flags & PT_TRI_FLIP) n = n * -1.0f;
-        if (dot(n, r.d) >= 0.0f) return false;
+        ok = !(dot(n, r.d) >= 0.0f);
     }
     V3 q0 = p0 - r.o, q1 = p1 - r.o, q2 = p2 - r.o;
     float p0x = sel3(q0, r.kx), p0y = sel3(q0, r.ky), p0z = sel3(q0, r.kz);
@@ -161,13 +166,17 @@ PT_DEV bool tri_test(const RayPre& r, V3 p0, V3 p1, V3 p2, uint32_t flags, float
         double a2 = (double)p1x * (double)p0y, b2 = (double)p1y * (double)p0x;
         e2 = (float)(b2 - a2);
     }
-    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    bool any_neg = (e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f);
+    bool any_pos = (e0 > 0.0f) | (e1 > 0.0f) | (e2 > 0.0f);
+    ok &= !(any_neg & any_pos);
     float det = e0 + e1 + e2;
-    if (det == 0.0f) return false;
+    ok &= !(det == 0.0f);
     p0z *= r.sz; p1z *= r.sz; p2z *= r.sz;
     float t_scaled = e0 * p0z + e1 * p1z + e2 * p2z;
-    if (det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) return false;
-    else if (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)) return false;
+    float tmd = t_max * det;
+    bool rej_neg = (det < 0.0f) & ((t_scaled >= 0.0f) | (t_scaled < tmd));
+    bool rej_pos = (det > 0.0f) & ((t_scaled <= 0.0f) | (t_scaled > tmd));
+    ok &= !(rej_neg | rej_pos);
     float inv_det = 1.0f / det;
     float t = t_scaled * inv_det;
     float max_zt = max3(fabsf(p0z), fabsf(p1z), fabsf(p2z));
@@ -179,9 +188,9 @@ PT_DEV bool tri_test(const RayPre& r, V3 p0, V3 p1, V3 p2, uint32_t flags, float
     float delta_e = 2.0f * (PT_GAMMA(2.0f) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
     float max_e = max3(fabsf(e0), fabsf(e1), fabsf(e2));
     float delta_t = 3.0f * (PT_GAMMA(3.0f) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
-    if (t <= delta_t) return false;
+    ok &= !(t <= delta_t);
     h.t = t; h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;
-    return true;
+    return ok;
 }
 
 struct TriVerts { V3 p0, p1, p2; uint32_t prim, flags; };
@@ -220,13 +229,23 @@ PT_DEV void stk_push(TravCtx& c, uint32_t& top, uint32_t& sp, uint32_t v) {
     if (top != PT_EMPTY_REF) stk_store(c, sp, top);
     top = v;
 }
+// Same effect as `if (en) stk_push(...)` while sp stays inside the LDS part, without branches:
+// the old top is always written to the slot above the stack and sp advances only if it counted.
+PT_DEV void stk_push_lds(TravCtx& c, uint32_t& top, uint32_t& sp, uint32_t v, bool en) {
+    c.lds[sp * PT_BLOCK] = top;
+    sp += (en && top != PT_EMPTY_REF) ? 1u : 0u;
+    top = en ? v : top;
+}
 PT_DEV uint32_t stk_pop(TravCtx& c, uint32_t& top, uint32_t& sp) {
     uint32_t v = top;
-    if (sp > 0) {
+    if (sp > PT_LDS_STACK) {                       // rare: entry lives in the HBM spill area
         sp--;
-        top = sp < PT_LDS_STACK ? c.lds[sp * PT_BLOCK] : c.spill[(size_t)(sp - PT_LDS_STACK) * c.spill_stride];
+        top = c.spill[(size_t)(sp - PT_LDS_STACK) * c.spill_stride];
     } else {
-        top = PT_EMPTY_REF;
+        uint32_t below = sp > 0 ? sp - 1 : 0;
+        uint32_t e = c.lds[below * PT_BLOCK];
+        top = sp > 0 ? e : PT_EMPTY_REF;
+        sp = below;
     }
     return v;
 }
@@ -255,14 +274,15 @@ PT_DEV bool root_test(const PtScene& sc, V3 o, V3 idir, uint32_t sbits, float t_
 // that reproduces SSE exactly; all others use v_max_f32 / v_min_f32, which then give the same values.
 template <bool EXACT>
 PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t sbits, float tmin, float tmax, TravCtx& c, uint32_t& top, uint32_t& sp) {
-    const float4* q = reinterpret_cast<const float4*>(nodes + ni);
-    float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
-    uint4 ch = reinterpret_cast<const uint4*>(q)[6];
-    uint32_t axes = reinterpret_cast<const uint4*>(q)[7].x;
-    // near / far planes per axis by ray sign
-    float4 nx = (sbits & 1) ? mxx : mnx, fx = (sbits & 1) ? mnx : mxx;
-    float4 ny = (sbits & 2) ? mxy : mny, fy = (sbits & 2) ? mny : mxy;
-    float4 nz = (sbits & 4) ? mxz : mnz, fz = (sbits & 4) ? mnz : mxz;
+    // near / far planes per axis are picked by address (bmin row at +16*axis, bmax row 48 bytes later)
+    // instead of loading both and selecting 24 registers
+    const char* nb = reinterpret_cast<const char*>(nodes) + (size_t)ni * 128u;
+    const uint32_t ox = (sbits & 1u) ? 48u : 0u, oy = (sbits & 2u) ? 48u : 0u, oz = (sbits & 4u) ? 48u : 0u;
+    float4 nx = *reinterpret_cast<const float4*>(nb + ox), fx = *reinterpret_cast<const float4*>(nb + (48u - ox));
+    float4 ny = *reinterpret_cast<const float4*>(nb + 16u + oy), fy = *reinterpret_cast<const float4*>(nb + 16u + (48u - oy));
+    float4 nz = *reinterpret_cast<const float4*>(nb + 32u + oz), fz = *reinterpret_cast<const float4*>(nb + 32u + (48u - oz));
+    uint4 ch = *reinterpret_cast<const uint4*>(nb + 96u);
+    uint32_t axes = *reinterpret_cast<const uint32_t*>(nb + 112u);
     uint32_t mask = 0;
 #define PT_SLAB(k, C)                                                        \
     {                                                                        \
@@ -281,7 +301,6 @@ PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t
     PT_SLAB(0, x) PT_SLAB(1, y) PT_SLAB(2, z) PT_SLAB(3, w)
 #undef PT_SLAB
     mask &= (axes >> 8) & 15u;          // drop empty slots (their boxes are all-zero as in the reference)
-    if (mask == 0) return;
     uint32_t s_top = (sbits >> (axes & 3)) & 1, s_left = (sbits >> ((axes >> 2) & 3)) & 1, s_right = (sbits >> ((axes >> 4) & 3)) & 1;
     // push order = reverse visit order: the far pair first, inside a pair the far child first
     uint32_t l0 = s_left ? ch.x : ch.y, l1 = s_left ? ch.y : ch.x;
@@ -290,10 +309,17 @@ PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t
     uint32_t r0b = s_right ? 4u : 8u, r1b = s_right ? 8u : 4u;
     uint32_t c0 = s_top ? l0 : r0, c1 = s_top ? l1 : r1, c2 = s_top ? r0 : l0, c3 = s_top ? r1 : l1;
     uint32_t b0 = s_top ? l0b : r0b, b1 = s_top ? l1b : r1b, b2 = s_top ? r0b : l0b, b3 = s_top ? r1b : l1b;
-    if (mask & b0) stk_push(c, top, sp, c0);
-    if (mask & b1) stk_push(c, top, sp, c1);
-    if (mask & b2) stk_push(c, top, sp, c2);
-    if (mask & b3) stk_push(c, top, sp, c3);
+    if (__builtin_expect(__ballot(sp + 4u > PT_LDS_STACK) == 0ull, 1)) {   // whole wave stays inside the LDS part
+        stk_push_lds(c, top, sp, c0, (mask & b0) != 0);
+        stk_push_lds(c, top, sp, c1, (mask & b1) != 0);
+        stk_push_lds(c, top, sp, c2, (mask & b2) != 0);
+        stk_push_lds(c, top, sp, c3, (mask & b3) != 0);
+    } else {
+        if (mask & b0) stk_push(c, top, sp, c0);
+        if (mask & b1) stk_push(c, top, sp, c1);
+        if (mask & b2) stk_push(c, top, sp, c2);
+        if (mask & b3) stk_push(c, top, sp, c3);
+    }
 }
 
 // Per-lane traversal state.  A ray is a small state machine advanced one unit of work at a time:
