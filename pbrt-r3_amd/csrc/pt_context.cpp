@@ -58,7 +58,7 @@ struct pt_context {
     bool have_scene = false;
     PtScene sc;
     pt_scene_info info;
-    DevBuf d_nodes, d_tris, d_tri_info, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid;
+    DevBuf d_nodes, d_tris, d_tri_info, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab;
     std::vector<uint32_t> sobol_m32;
     std::vector<uint64_t> sobol_vdc, sobol_inv;
     uint32_t sobol_n_vdc = 0, sobol_n_inv = 0, sobol_msize = 52;
@@ -202,6 +202,7 @@ pt_status pt_context_create(int device, pt_context** out) {
     ctx->grid_trace = ctx->n_cu * 4;
     if (const char* e = std::getenv("PBRTGPU_TRACE_BLOCKS_PER_CU")) ctx->grid_trace = ctx->n_cu * std::max(1, std::atoi(e));
     ctx->grid_shade = ctx->n_cu * 2;
+    if (const char* e = std::getenv("PBRTGPU_SHADE_BLOCKS_PER_CU")) ctx->grid_shade = ctx->n_cu * std::max(1, std::atoi(e));
     ctx->grid_wide = ctx->n_cu * 8;
     const char* dd = std::getenv("PBRTGPU_DATA_DIR");
     if (dd) ctx->data_dir = dd;
@@ -387,6 +388,28 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if ((st = upload(ctx, ctx->d_vdc_inv, ctx->sobol_inv.data() + row, ctx->sobol_msize)) != PT_OK) return st;
     sb.m32 = ctx->d_m32.as<uint32_t>();
     sb.m32_len = (uint32_t)ctx->sobol_m32.size();
+    if (!ctx->d_bytetab.p) {
+        // byte-sliced form of SOBOL_MATRICES_32: T[dim][k][x] = XOR over set bits j of x of column 8k+j,
+        // with the reference's column indexing ((dim*52 + c) % len, sobol.rs:43-52) for c up to 55
+        const uint32_t n_dims = (uint32_t)(ctx->sobol_m32.size() / ctx->sobol_msize);
+        const size_t len = ctx->sobol_m32.size();
+        std::vector<uint32_t> tab((size_t)n_dims * 7 * 256);
+        for (uint32_t dim = 0; dim < n_dims; dim++) {
+            size_t base = std::min((size_t)dim * 52, len - 1);
+            for (uint32_t k = 0; k < 7; k++) {
+                uint32_t* t = &tab[((size_t)dim * 7 + k) * 256];
+                t[0] = 0;
+                for (uint32_t x = 1; x < 256; x++) {
+                    uint32_t low = x & (~x + 1u);              // lowest set bit
+                    uint32_t j = (uint32_t)__builtin_ctz(x);
+                    t[x] = t[x ^ low] ^ ctx->sobol_m32[(base + 8 * k + j) % len];
+                }
+            }
+        }
+        if ((st = upload(ctx, ctx->d_bytetab, tab.data(), tab.size())) != PT_OK) return st;
+    }
+    sb.bytetab = ctx->d_bytetab.as<uint32_t>();
+    sb.n_tab_dims = (uint32_t)(ctx->sobol_m32.size() / ctx->sobol_msize);
     sb.vdc = ctx->d_vdc.as<uint64_t>();
     sb.vdc_inv = ctx->d_vdc_inv.as<uint64_t>();
 

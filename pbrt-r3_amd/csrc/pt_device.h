@@ -91,6 +91,9 @@ struct PtSobol {
     const uint64_t* vdc;         // row (log2_resolution - 1) of VDC_SOBOL_MATRICES
     const uint64_t* vdc_inv;     // row (log2_resolution - 1) of VDC_SOBOL_MATRICES_INV
     uint32_t m32_len;
+    const uint32_t* bytetab;     // [n_tab_dims][7][256]: XOR of the columns selected by one index byte
+    uint32_t n_tab_dims;
+    uint32_t pad;
     uint32_t log2_resolution;
     uint32_t resolution;
     uint32_t spp;                // rounded up to a power of two

@@ -33,8 +33,20 @@ PT_DEV uint64_t sobol_interval_to_index(const PtSobol& sb, uint64_t frame, int32
         if (b & 1) index ^= sb.vdc_inv[c];
     return index;
 }
-PT_DEV float sobol_sample_float(const PtSobol& sb, uint64_t a, uint32_t dim) {
+// sobol_sample_float (sobol.rs:39-56): v = XOR of the generator-matrix columns selected by the set
+// bits of the sample index.  The XOR is linear, so the host folds the 52 columns of each dimension
+// into seven 256-entry tables indexed by one byte of the index: 4 independent loads (issued
+// together) replace a ~15-iteration dependent-load loop.  Integer arithmetic: identical result.
+PT_DEV uint32_t sobol_bits(const PtSobol& sb, uint64_t a, uint32_t dim) {
     uint32_t v = 0;
+    if (dim < sb.n_tab_dims && (a >> 56) == 0) {
+        const uint32_t* T = sb.bytetab + (size_t)dim * (7u * 256u);
+        uint32_t lo = (uint32_t)a;
+        v = T[lo & 255u] ^ T[256u + ((lo >> 8) & 255u)] ^ T[512u + ((lo >> 16) & 255u)] ^ T[768u + (lo >> 24)];
+        uint32_t hi = (uint32_t)(a >> 32);
+        if (hi != 0) v ^= T[1024u + (hi & 255u)] ^ T[1280u + ((hi >> 8) & 255u)] ^ T[1536u + ((hi >> 16) & 255u)];
+        return v;
+    }
     uint32_t base = dim * 52u;
     if (base > sb.m32_len - 1u) base = sb.m32_len - 1u;
     while (a != 0) {
@@ -44,6 +56,10 @@ PT_DEV float sobol_sample_float(const PtSobol& sb, uint64_t a, uint32_t dim) {
         v ^= sb.m32[i];
         a &= a - 1;
     }
+    return v;
+}
+PT_DEV float sobol_sample_float(const PtSobol& sb, uint64_t a, uint32_t dim) {
+    uint32_t v = sobol_bits(sb, a, dim);
     float fv = (float)((double)v * 2.3283064365386963e-10);
     return fminf(fv, PT_ONE_MINUS_EPS);
 }
@@ -857,7 +873,10 @@ PT_DEV uint32_t sample_discrete(const float* tab, uint32_t n, float u, float* pd
 
 // ============================================================ K_SHADE
 // One bounce of PathIntegrator::li for every path in Q.cur (path.rs:85-234).
-extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_shade(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 2
+#endif
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     __shared__ unsigned long long s_vert;
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
