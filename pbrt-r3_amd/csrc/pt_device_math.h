@@ -83,11 +83,57 @@ PT_DEV void coordinate_system(V3 v1, V3* v2, V3* v3) {
     *v3 = normalize(cross(v1, *v2));
 }
 
-// sin/cos: the reference calls libm's sinf/cosf (correctly rounded in all but a
-// handful of cases).  Evaluate in f64 and round once, which is correctly rounded
-// to the same degree, instead of OCML's faster-but-looser f32 polynomial.
-PT_DEV float cos_cr(float x) { return (float)cos((double)x); }
-PT_DEV float sin_cr(float x) { return (float)sin((double)x); }
+// sin/cos.  The reference calls libm's sinf/cosf (Rust f32::sin -> glibc), which is NOT correctly
+// rounded: about 1.2 % of results differ from round(sin(x)) in the last bit, enough to send ~1.5 % of
+// camera samples down a different path.  glibc's algorithm (ARM optimized-routines sincosf: reduce by
+// pi/2 in f64, degree-7/8 f64 polynomials, one final rounding) is restated here with its published
+// coefficients, so the device returns the same bits as the host libm for |x| < 120 (validated
+// against libm.so.6 on >1e6 inputs, tools/check_sincosf_port.py).  Larger / non-finite arguments,
+// which this path never produces, fall back to f64 sin/cos rounded once.
+struct PtSinCosTab { double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+PT_DEV float pt_sincos_poly(double x, double x2, bool neg_cos, int n) {
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    if (neg_cos) { c0 = -c0; c1 = -c1; c2 = -c2; c3 = -c3; c4 = -c4; }     // __sincosf_table[1]
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double t1 = s2 + x2 * s3;
+        double x5 = x3 * x2;
+        double s = x + x3 * s1;
+        return (float)(s + x5 * t1);
+    }
+    double x4 = x2 * x2;
+    double t2 = c3 + x2 * c4;
+    double t1 = c0 + x2 * c1;
+    double x6 = x4 * x2;
+    double c = t1 + x4 * c2;
+    return (float)(c + x6 * t2);
+}
+PT_DEV uint32_t pt_abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
+PT_DEV void pt_sincosf(float y, float* s_out, float* c_out) {
+    const uint32_t top = pt_abstop12(y);
+    double x = (double)y;
+    if (top < 0x3f4u) {                      // |y| < pi/4   (abstop12(0x1.921FB6p-1f))
+        double x2 = x * x;
+        if (top < 0x398u) { *s_out = y; *c_out = 1.0f; return; }      // |y| < 2^-12
+        *s_out = pt_sincos_poly(x, x2, false, 0);
+        *c_out = pt_sincos_poly(x, x2, false, 1);
+        return;
+    }
+    if (top < 0x42fu) {                      // |y| < 120
+        const double hpi_inv = 0x1.45f306dc9c883p+23, hpi = 0x1.921fb54442d18p+0;
+        double r = x * hpi_inv;
+        int n = ((int32_t)r + 0x800000) >> 24;
+        x = x - (double)n * hpi;
+        double sg = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;       // sign[n & 3] = {1,-1,-1,1}
+        bool neg = (n & 2) != 0;
+        *s_out = pt_sincos_poly(x * sg, x * x, neg, n);
+        *c_out = pt_sincos_poly(x * sg, x * x, neg, n ^ 1);
+        return;
+    }
+    *s_out = (float)sin(x);
+    *c_out = (float)cos(x);
+}
 
 // spectrum
 PT_DEV float lum_y(V3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }
@@ -106,12 +152,12 @@ PT_DEV V2 uniform_sample_triangle(V2 u) { float su0 = sqrtf(u.x); return mk2(1.0
 PT_DEV V2 concentric_sample_disk(V2 u) {
     float ox = u.x * 2.0f - 1.0f, oy = u.y * 2.0f - 1.0f;
     if (ox == 0.0f && oy == 0.0f) return mk2(0.0f, 0.0f);
-    if (fabsf(ox) > fabsf(oy)) {
-        float r = ox, theta = PT_PI_OVER_4 * (oy / ox);
-        return mk2(r * cos_cr(theta), r * sin_cr(theta));
-    }
-    float r = oy, theta = PT_PI_OVER_2 - PT_PI_OVER_4 * (ox / oy);
-    return mk2(r * cos_cr(theta), r * sin_cr(theta));
+    float r, theta;
+    if (fabsf(ox) > fabsf(oy)) { r = ox; theta = PT_PI_OVER_4 * (oy / ox); }
+    else { r = oy; theta = PT_PI_OVER_2 - PT_PI_OVER_4 * (ox / oy); }
+    float sn, cs;
+    pt_sincosf(theta, &sn, &cs);
+    return mk2(r * cs, r * sn);
 }
 PT_DEV V3 cosine_sample_hemisphere(V2 u) {
     V2 d = concentric_sample_disk(u);

@@ -21,6 +21,14 @@ from . import capi
 
 f32 = np.float32
 
+_libm = C.CDLL("libm.so.6")
+_libm.expf.argtypes = [C.c_float]
+_libm.expf.restype = C.c_float
+
+
+def _expf(x):
+    return f32(_libm.expf(float(x)))
+
 
 # --------------------------------------------------------------------------
 # PCG32 (src/core/rng.rs:8-67), vectorised: the LCG state after k steps is
@@ -190,6 +198,43 @@ class SceneBuilder:
     def pixel_filter_box(self, xwidth=0.5, ywidth=0.5):
         """filters/box_filter.rs + Film::new's 16x16 table (film.rs:102-120): BoxFilter::evaluate == 1."""
         self.filter_radius, self.filter_table = (xwidth, ywidth), np.ones(256, np.float32)
+
+    def _filter_table(self, radius, evaluate):
+        """Film::new (film.rs:102-120): table[y*16+x] = filter.evaluate(x*rx/15, y*ry/15)."""
+        rx, ry = f32(radius[0]), f32(radius[1])
+        tab = np.empty(256, np.float32)
+        for y in range(16):
+            for x in range(16):
+                tab[y * 16 + x] = evaluate(f32(x) * f32(rx / f32(15)), f32(y) * f32(ry / f32(15)))
+        self.filter_radius, self.filter_table = (float(rx), float(ry)), tab
+
+    def pixel_filter_gaussian(self, xwidth=2.0, ywidth=2.0, alpha=2.0):
+        """filters/gaussian.rs:12-31 (expf through libm, as the reference)."""
+        a = f32(alpha)
+        ex, ey = _expf(-a * f32(xwidth) * f32(xwidth)), _expf(-a * f32(ywidth) * f32(ywidth))
+        g = lambda d, e: max(f32(0.0), f32(_expf(f32(f32(-a * d) * d)) - e))
+        self._filter_table((xwidth, ywidth), lambda x, y: f32(g(x, ex) * g(y, ey)))
+
+    def pixel_filter_triangle(self, xwidth=2.0, ywidth=2.0):
+        """filters/triangle.rs:17-21."""
+        rx, ry = f32(xwidth), f32(ywidth)
+        self._filter_table((xwidth, ywidth), lambda x, y: f32(max(f32(0.0), f32(rx - abs(x))) * max(f32(0.0), f32(ry - abs(y)))))
+
+    def pixel_filter_mitchell(self, xwidth=2.0, ywidth=2.0, B=1.0 / 3.0, C=1.0 / 3.0):
+        """filters/mitchell.rs:20-47."""
+        b, c = f32(B), f32(C)
+
+        def m1(x):
+            x = abs(f32(f32(2.0) * x))
+            if x > 1.0:
+                v = f32(f32(f32(f32(f32(f32(-b - f32(6.0) * c) * x) * x) * x + f32(f32(f32(f32(6.0) * b + f32(30.0) * c) * x) * x)) +
+                            f32(f32(f32(-12.0) * b - f32(48.0) * c) * x)) + f32(f32(8.0) * b + f32(24.0) * c))
+            else:
+                v = f32(f32(f32(f32(f32(f32(12.0) - f32(9.0) * b - f32(6.0) * c) * x) * x) * x +
+                            f32(f32(f32(f32(-18.0) + f32(12.0) * b + f32(6.0) * c) * x) * x)) + f32(f32(6.0) - f32(2.0) * b))
+            return f32(v * f32(f32(1.0) / f32(6.0)))
+        irx, iry = f32(1.0) / f32(xwidth), f32(1.0) / f32(ywidth)
+        self._filter_table((xwidth, ywidth), lambda x, y: f32(m1(f32(x * irx)) * m1(f32(y * iry))))
 
     def sampler_sobol(self, pixelsamples=16):
         self.spp = int(pixelsamples)

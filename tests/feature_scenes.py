@@ -1,0 +1,121 @@
+"""Small scenes that switch on every branch of the accelerated path that the two BASELINE
+scenes leave cold (vertex normals / tangents / uvs, one-sided and reversed meshes, Oren-Nayar,
+black and absent materials, several lights with each sampling strategy, thin lens, wide
+reconstruction filters, crop window, luminance clamp, every BVH split method and leaf size)."""
+import numpy as np
+
+from helpers import pkg, scenes
+
+f32 = np.float32
+
+
+def uv_sphere(center, radius, nt=8, nphi=12):
+    P, N, UV, idx = [], [], [], []
+    for t in range(nt + 1):
+        th = np.pi * t / nt
+        for p in range(nphi):
+            ph = 2 * np.pi * p / nphi
+            n = np.array([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)])
+            P.append(np.array(center) + radius * n); N.append(n); UV.append([p / nphi, t / nt])
+    for t in range(nt):
+        for p in range(nphi):
+            a, b = t * nphi + p, t * nphi + (p + 1) % nphi
+            c, d = a + nphi, b + nphi
+            idx += [a, c, b, b, c, d]
+    return np.array(P, np.float32), np.array(N, np.float32), np.array(UV, np.float32), idx
+
+
+def room(b, size=2.0, light_L=(10, 9, 8), two_sided_light=False):
+    s = size
+    b.material_matte((0.7, 0.7, 0.7))
+    scenes._quad(b, (s, -s, -s), (-s, -s, -s), (-s, -s, s), (s, -s, s))
+    scenes._quad(b, (s, s, -s), (s, s, s), (-s, s, s), (-s, s, -s))
+    scenes._quad(b, (s, -s, s), (-s, -s, s), (-s, s, s), (s, s, s))
+    b.material_matte((0.2, 0.6, 0.3))
+    scenes._quad(b, (-s, -s, s), (-s, -s, -s), (-s, s, -s), (-s, s, s))
+    b.material_matte((0.7, 0.2, 0.2))
+    scenes._quad(b, (s, -s, -s), (s, -s, s), (s, s, s), (s, s, -s))
+    b.material_matte((0.5, 0.5, 0.5))
+    b.area_light_source_diffuse(L=light_L, twosided=two_sided_light)
+    h = 0.999 * s
+    scenes._quad(b, (0.5, h, -0.5), (0.5, h, 0.5), (-0.5, h, 0.5), (-0.5, h, -0.5))
+    b.no_area_light()
+
+
+def base(res=48, spp=8, depth=5):
+    b = scenes.SceneBuilder()
+    b.look_at((0, 0, -6.5), (0, 0, 0), (0, 1, 0))
+    b.camera_perspective(fov=40.0)
+    b.film(xresolution=res, yresolution=res)
+    b.pixel_filter_box()
+    b.sampler_sobol(spp)
+    b.integrator_path(maxdepth=depth)
+    return b
+
+
+def scene_attributes():
+    """Smooth-shaded sphere (N + uv), a tangent-carrying quad (S), a one-sided quad, a reversed one."""
+    b = base()
+    room(b)
+    b.material_matte((0.6, 0.6, 0.8))
+    P, N, UV, idx = uv_sphere((-0.7, -1.2, 0.3), 0.8)
+    b.shape_trianglemesh(P, idx, N=N, uv=UV)
+    b.material_matte((0.8, 0.7, 0.3))
+    q = [(0.3, -2 + 0.01, -0.5), (1.5, -2 + 0.01, -0.5), (1.5, -0.9, 0.6), (0.3, -0.9, 0.6)]
+    S = [(1, 0.2, 0)] * 4
+    b.shape_trianglemesh(q, [0, 1, 2, 0, 2, 3], S=S)
+    b.material_matte((0.3, 0.3, 0.9))
+    b.shape_trianglemesh([(-1.9, 0.2, 1.0), (-0.6, 0.2, 1.5), (-0.6, 1.5, 1.5), (-1.9, 1.5, 1.0)], [0, 1, 2, 0, 2, 3], twosided=False)
+    b.reverse_orientation = True
+    b.shape_trianglemesh([(0.6, 0.2, 1.5), (1.9, 0.2, 1.0), (1.9, 1.5, 1.0), (0.6, 1.5, 1.5)], [0, 1, 2, 0, 2, 3], twosided=False)
+    b.reverse_orientation = False
+    P2, N2, UV2, idx2 = uv_sphere((1.0, 1.0, -0.5), 0.4, 5, 8)
+    b.shape_trianglemesh(P2, idx2, N=N2)            # normals, auto uv rule (not fillable -> default uvs)
+    return b.build()
+
+
+def scene_materials_lights(strategy="spatial"):
+    """Oren-Nayar, a black matte, a material-less occluder, three lights (one two-sided, one mesh light)."""
+    b = base(depth=6)
+    b.integrator_path(maxdepth=6, lightsamplestrategy=strategy)
+    room(b, light_L=(6, 6, 6))
+    b.material_matte((0.7, 0.6, 0.5), sigma=35.0)
+    P, N, UV, idx = uv_sphere((-0.8, -1.2, 0.0), 0.8, 6, 10)
+    b.shape_trianglemesh(P, idx)
+    b.material_matte((0.0, 0.0, 0.0))
+    scenes._cuboid(b, [(0.4, -1.0, -0.4), (0.4, -1.0, 0.6), (1.4, -1.0, 0.6), (1.4, -1.0, -0.4)], 1.0)
+    b.material_none()
+    scenes._quad(b, (-1.5, -0.5, -1.5), (1.5, -0.5, -1.5), (1.5, 1.0, -1.5), (-1.5, 1.0, -1.5))   # invisible pane in front
+    b.material_matte((0.5, 0.5, 0.5))
+    b.area_light_source_diffuse(L=(4, 1, 1), twosided=True)
+    scenes._quad(b, (-1.99, 0.0, -0.3), (-1.99, 0.0, 0.3), (-1.99, 0.6, 0.3), (-1.99, 0.6, -0.3))
+    b.area_light_source_diffuse(L=(0.5, 0.5, 3))
+    P3, N3, UV3, idx3 = uv_sphere((1.2, 1.2, 0.8), 0.25, 3, 5)
+    b.shape_trianglemesh(P3, idx3)                    # 30-triangle mesh light
+    b.no_area_light()
+    return b.build()
+
+
+def scene_camera_film(filt="gaussian"):
+    """Thin lens, wide reconstruction filter, crop window, film scale, luminance clamp."""
+    b = base(res=40, spp=4)
+    b.camera_perspective(fov=40.0, lensradius=0.15, focaldistance=6.0)
+    b.film(xresolution=40, yresolution=32, cropwindow=(0.2, 0.85, 0.1, 0.9), scale=2.0, maxsampleluminance=3.0)
+    if filt == "gaussian":
+        b.pixel_filter_gaussian(2.0, 2.0, 2.0)
+    elif filt == "mitchell":
+        b.pixel_filter_mitchell(2.0, 1.5)
+    else:
+        b.pixel_filter_triangle(1.5, 2.0)
+    room(b)
+    b.material_matte((0.6, 0.6, 0.6))
+    P, N, UV, idx = uv_sphere((0.0, -1.0, 0.0), 1.0, 6, 10)
+    b.shape_trianglemesh(P, idx, N=N)
+    return b.build()
+
+
+def scene_accel(method, leaf):
+    sd = scenes.rt1m(4000, res=32, spp=4, max_depth=4)
+    sd.desc.split_method = {"sah": 0, "middle": 2, "equal": 3}[method]
+    sd.desc.max_node_prims = leaf
+    return sd

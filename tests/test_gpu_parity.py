@@ -1,8 +1,9 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
 seeded inputs.  Integer / index results must be bit-exact; f32 results are compared
-bit-for-bit as well wherever the kernels reproduce the reference's IEEE arithmetic
-(everything except libm sinf/cosf last-ulp differences, which only enter through BSDF
-sampling and are bounded statistically below)."""
+bit-for-bit as well: the kernels reproduce the reference's IEEE arithmetic operation by
+operation (no FMA contraction, IEEE divide/sqrt, glibc's sinf/cosf algorithm), so rays, hits,
+traversal counters and the radiance of every camera sample are identical.  Only the film sum
+of samples that land exactly on a pixel edge (float atomics) may differ in the last bits."""
 import numpy as np
 import pytest
 
@@ -110,8 +111,7 @@ def test_trace_any_exact(pair):
 
 
 def test_radiance_samples(pair):
-    """PathIntegrator::li per camera sample.  Bit-exact unless a libm-vs-f64 sin/cos last-ulp
-    difference occurred somewhere along that path; such paths must be rare and unbiased."""
+    """PathIntegrator::li per camera sample: bit-identical to the oracle."""
     name, sd, ctx, osc = pair
     sb = list(ctx.info.sample_bounds)
     cx, cy = (sb[0] + sb[2]) // 2, (sb[1] + sb[3]) // 2
@@ -124,8 +124,7 @@ def test_radiance_samples(pair):
     print("\n[%s] per-sample radiance: %d samples, %.4f%% not bit-identical, rel-L2 %.3e"
           % (name, same.size, 100 * frac, rel_l2(g, r)))
     assert r.sum() > 0
-    assert frac < 0.02
-    assert abs(float(g.sum()) - float(r.sum())) <= 2e-3 * float(r.sum())
+    assert frac == 0.0
 
 
 def test_image_parity(pair):
@@ -147,10 +146,9 @@ def test_image_parity(pair):
           % (name, err, nbad, orgb.shape[0] * orgb.shape[1], 100 * np.all(bits(grgb) == bits(orgb), axis=-1).mean()))
     assert err <= 1e-3
     assert gc["camera_rays"] == oc["camera_rays"]
-    # ray counts follow the same definition (Scene::intersect / intersect_p calls); paths that
-    # diverged by a last-ulp sin/cos can change them slightly
-    for k in ("regular_rays", "shadow_rays", "path_vertices"):
-        assert abs(gc[k] - oc[k]) <= 2e-3 * oc[k] + 8, (k, gc[k], oc[k])
+    # same paths => same ray counts (Scene::intersect / intersect_p calls), nodes and triangle tests
+    for k in ("regular_rays", "shadow_rays", "path_vertices", "nodes_visited", "tris_tested"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
     # Film::write_image arithmetic on the GPU == oracle's on the same XYZW
     assert np.array_equal(bits(grgb), bits(osc.resolve_rgb(gx)))
 
