@@ -284,7 +284,7 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
         std::memcpy(tr.p2, P + 3 * (size_t)indices[3 * (size_t)t + 2], 12);
         tr.prim = t;
         tr.flags = tri_flags[t] & ~PT_TRI_LAST;
-        tr.pad = 0;
+        tr.light1 = 0;            // filled by the caller once lights are numbered
         out->rec_of_prim[t] = r;
     }
     {   // one zero pad record: the kernels fetch triangle records two at a time

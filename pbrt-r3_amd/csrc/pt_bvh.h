@@ -18,7 +18,7 @@ struct Result {
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
 };
 
-// tri_flags[t]: PT_TRI_ONE_SIDED / PT_TRI_FLIP bits of triangle t.  Returns false for an
+// tri_flags[t]: PT_TRI_ONE_SIDED / PT_TRI_FLIP / PT_TRI_HAS_ATTR bits and the material field of triangle t.  Returns false for an
 // unsupported split method.
 bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, int split_method, int max_node_prims,
            Result* out);

@@ -243,6 +243,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     for (uint32_t m = 0; m < d->n_meshes; m++) {
         if (d->meshes[m].material >= (int32_t)d->n_materials) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "material index out of range");
+        if (d->meshes[m].material >= 65535) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 65534 materials");
         if (d->meshes[m].area_light >= (int32_t)d->n_area_lights) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "area light index out of range");
         int32_t mi = d->meshes[m].material;
         if (mi >= 0 && d->materials[mi].type != PT_MATERIAL_NONE && d->materials[mi].type != PT_MATERIAL_MATTE)
@@ -257,6 +258,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         uint32_t mf = d->meshes[d->tri_mesh[t]].flags, f = 0;
         if (!(mf & PT_MESH_TWO_SIDED)) f |= PT_TRI_ONE_SIDED;
         if (((mf & PT_MESH_REVERSE_ORIENTATION) != 0) ^ ((mf & PT_MESH_SWAPS_HANDEDNESS) != 0)) f |= PT_TRI_FLIP;
+        if (((mf & PT_MESH_HAS_N) && d->N) || ((mf & PT_MESH_HAS_S) && d->S) || ((mf & PT_MESH_HAS_UV) && d->UV)) f |= PT_TRI_HAS_ATTR;
+        int32_t mat = d->meshes[d->tri_mesh[t]].material;
+        if (mat >= 0 && d->materials[mat].type != PT_MATERIAL_NONE) f |= (uint32_t)(mat + 1) << PT_TRI_MATERIAL_SHIFT;
         tri_flags[t] = f;
     }
     ptbvh::Result bvh;
@@ -301,6 +305,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                 std::memcpy(L.n0, d->N + 3 * (size_t)ti.v[0], 12); std::memcpy(L.n1, d->N + 3 * (size_t)ti.v[1], 12); std::memcpy(L.n2, d->N + 3 * (size_t)ti.v[2], 12);
             }
             ti.light = (int32_t)lights.size();
+            bvh.tris[bvh.rec_of_prim[t]].light1 = (uint32_t)lights.size() + 1u;
             lights.push_back(L);
         }
     }
@@ -416,7 +421,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     // ---- light sampling distribution (create_light_sample_distribution.rs:11-50) -
     PtLightGrid& g = sc.grid;
     g.n_lights = sc.n_lights;
-    g.stride = 2 * sc.n_lights + 2;
+    g.stride = (2 * sc.n_lights + 2 + 3) & ~3u;     // rows are 16-byte aligned
     std::memcpy(g.wb_min, sc.wb_min, 12);
     std::memcpy(g.wb_max, sc.wb_max, 12);
     int strategy = d->light_strategy;
@@ -438,7 +443,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             g.single = 0;
             size_t bytes = nvox * g.stride * sizeof(float);
             if (bytes > ((size_t)16 << 30)) return ctx->fail(PT_ERR_UNSUPPORTED, "dense light grid would exceed 16 GiB; lazy per-voxel fill is not implemented yet");
-            PT_HIP(ctx->d_grid.alloc(bytes));
+            PT_HIP(ctx->d_grid.alloc(bytes + 64));
             g.data = ctx->d_grid.as<float>();
             PT_HIP(ptk_light_grid(ctx->stream, sc, ctx->d_grid.as<float>(), (uint32_t)nvox));
             PT_HIP(hipStreamSynchronize(ctx->stream));
@@ -447,7 +452,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             g.voxels[0] = g.voxels[1] = g.voxels[2] = 1;
             g.single = 1;
             uint32_t nl = sc.n_lights;
-            std::vector<float> tab(g.stride);
+            std::vector<float> tab(g.stride + 16);
             for (uint32_t i = 0; i < nl; i++) {
                 if (strategy == PT_LIGHTS_UNIFORM) tab[i] = 1.0f;
                 else {

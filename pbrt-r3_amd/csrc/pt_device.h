@@ -29,13 +29,15 @@ struct PtNode {
 #define PT_TRI_LAST 1u
 #define PT_TRI_ONE_SIDED 2u      // !two_sided: cull when dot(n, d) >= 0 (triangle.rs:247-251)
 #define PT_TRI_FLIP 4u           // reverse_orientation ^ swaps_handedness
+#define PT_TRI_HAS_ATTR 8u       // mesh carries N / S / UV: shading must also read PtTriInfo
+#define PT_TRI_MATERIAL_SHIFT 16 // bits 16..31: material index + 1 (0 = no material)
 struct PtTri {
     float p0[3];
     uint32_t prim;               // caller's triangle index
     float p1[3];
-    uint32_t flags;
+    uint32_t flags;              // PT_TRI_* | (material + 1) << 16: shading needs no second record
     float p2[3];
-    uint32_t pad;
+    uint32_t light1;             // area light index + 1 (0 = not emissive)
 };
 
 // Per original triangle shading record.

@@ -663,12 +663,13 @@ struct Surf {            // what SurfaceInteraction carries for this path (surfa
     V3 p, p_error, n, wo;
     V3 sh_n, sh_dpdu;
     uint32_t prim;
+    int32_t material, light;     // from the triangle record (-1 = none)
 };
 
 // Triangle::get_dpdu_dpdv (triangle.rs:132-186)
-PT_DEV void tri_dpdu(const PtScene& sc, const PtTriInfo& ti, V3 p0, V3 p1, V3 p2, V3* dpdu, V3* dpdv) {
+PT_DEV void tri_dpdu(const PtScene& sc, bool has_attr, const PtTriInfo& ti, V3 p0, V3 p1, V3 p2, V3* dpdu, V3* dpdv) {
     V2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);
-    if ((ti.mesh_flags & PT_MESH_HAS_UV) && sc.UV) {
+    if (has_attr && (ti.mesh_flags & PT_MESH_HAS_UV) && sc.UV) {
         uv0 = mk2(sc.UV[2 * ti.v[0]], sc.UV[2 * ti.v[0] + 1]);
         uv1 = mk2(sc.UV[2 * ti.v[1]], sc.UV[2 * ti.v[1] + 1]);
         uv2 = mk2(sc.UV[2 * ti.v[2]], sc.UV[2 * ti.v[2] + 1]);
@@ -686,19 +687,23 @@ PT_DEV void tri_dpdu(const PtScene& sc, const PtTriInfo& ti, V3 p0, V3 p1, V3 p2
     coordinate_system(normalize(ng), dpdu, dpdv);
 }
 
-// Triangle::intersect's back half (triangle.rs:349-449): rebuild the interaction from (ray, record).
-PT_DEV bool make_surf(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, float* t_out) {
-    TriVerts tv = load_tri(sc.tris, rec);
+// Triangle::intersect's back half (triangle.rs:349-449): rebuild the interaction from the ray and
+// the triangle's vertices.  Everything shading needs for an attribute-less mesh (material, light,
+// orientation) rides in the 48-byte record, so the common case costs one dependent fetch.
+PT_DEV bool make_surf_tv(const PtScene& sc, V3 ro, V3 rd, const TriVerts& tv, uint32_t light1, Surf& s, float* t_out) {
     RayPre rp;
     ray_precompute(rp, ro, rd);
     TriHit h;
     if (!tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, PT_INF, h)) return false;
-    const PtTriInfo ti = sc.tri_info[tv.prim];
+    const bool has_attr = (tv.flags & PT_TRI_HAS_ATTR) != 0;
+    PtTriInfo ti;
+    ti.mesh_flags = 0; ti.v[0] = ti.v[1] = ti.v[2] = 0;
+    if (has_attr) ti = sc.tri_info[tv.prim];
     V3 n = cross(tv.p0 - tv.p2, tv.p1 - tv.p2);
     if (tv.flags & PT_TRI_FLIP) n = n * -1.0f;
     n = normalize(n);
     V3 dpdu, dpdv;
-    tri_dpdu(sc, ti, tv.p0, tv.p1, tv.p2, &dpdu, &dpdv);
+    tri_dpdu(sc, has_attr, ti, tv.p0, tv.p1, tv.p2, &dpdu, &dpdv);
     float xa = fabsf(h.b0 * tv.p0.x) + fabsf(h.b1 * tv.p1.x) + fabsf(h.b2 * tv.p2.x);
     float ya = fabsf(h.b0 * tv.p0.y) + fabsf(h.b1 * tv.p1.y) + fabsf(h.b2 * tv.p2.y);
     float za = fabsf(h.b0 * tv.p0.z) + fabsf(h.b1 * tv.p1.z) + fabsf(h.b2 * tv.p2.z);
@@ -709,7 +714,9 @@ PT_DEV bool make_surf(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, fl
     s.sh_n = n;
     s.sh_dpdu = dpdu;
     s.prim = tv.prim;
-    bool has_n = (ti.mesh_flags & PT_MESH_HAS_N) && sc.N, has_s = (ti.mesh_flags & PT_MESH_HAS_S) && sc.S;
+    s.material = (int32_t)(tv.flags >> PT_TRI_MATERIAL_SHIFT) - 1;
+    s.light = (int32_t)light1 - 1;
+    bool has_n = has_attr && (ti.mesh_flags & PT_MESH_HAS_N) && sc.N, has_s = has_attr && (ti.mesh_flags & PT_MESH_HAS_S) && sc.S;
     if (has_n || has_s) {
         V3 ns = s.n;
         if (has_n) {
@@ -735,6 +742,15 @@ PT_DEV bool make_surf(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, fl
     }
     *t_out = h.t;
     return true;
+}
+PT_DEV bool make_surf(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, float* t_out) {
+    const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)rec * 3;
+    float4 a = q[0], b = q[1], c = q[2];
+    TriVerts tv;
+    tv.p0 = mk3(a.x, a.y, a.z); tv.prim = __float_as_uint(a.w);
+    tv.p1 = mk3(b.x, b.y, b.z); tv.flags = __float_as_uint(b.w);
+    tv.p2 = mk3(c.x, c.y, c.z);
+    return make_surf_tv(sc, ro, rd, tv, __float_as_uint(c.w), s, t_out);
 }
 
 // ---- BSDF with at most one diffuse-reflection lobe (Matte: Lambertian or OrenNayar)
@@ -856,18 +872,42 @@ PT_DEV const float* grid_lookup(const PtLightGrid& g, V3 p) {
     return g.data + vox * g.stride;
 }
 PT_DEV uint32_t sample_discrete(const float* tab, uint32_t n, float u, float* pdf) {
-    const float* func = tab;
-    const float* cdf = tab + n;
-    float func_int = tab[2 * n + 1];
-    uint32_t first = 0, len = n + 1;
-    while (len > 0) {
-        uint32_t half = len >> 1, middle = first + half;
-        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
-        else len = half;
+    uint32_t idx;
+    float f_idx, func_int;
+    if (n <= 3) {
+        // whole row (func[n], cdf[n+1], func_int <= 8 floats, 16-byte aligned) in one round trip;
+        // find_interval_cdf over at most 4 cdf entries unrolls to compares
+        const float4* q = reinterpret_cast<const float4*>(tab);
+        float4 a = q[0], b = q[1];
+        auto get = [&](uint32_t i) -> float {       // register selects, no private-memory array
+            float lo = i == 0 ? a.x : (i == 1 ? a.y : (i == 2 ? a.z : a.w));
+            float hi = i == 4 ? b.x : (i == 5 ? b.y : (i == 6 ? b.z : b.w));
+            return i < 4 ? lo : hi;
+        };
+        uint32_t first = 0, len = n + 1;
+        while (len > 0) {
+            uint32_t half = len >> 1, middle = first + half;
+            if (get(n + middle) <= u) { first = middle + 1; len -= half + 1; }
+            else len = half;
+        }
+        idx = first == 0 ? 0 : first - 1;
+        if (idx > n - 1) idx = n - 1;
+        f_idx = get(idx);
+        func_int = get(2 * n + 1);
+    } else {
+        const float* cdf = tab + n;
+        uint32_t first = 0, len = n + 1;
+        while (len > 0) {
+            uint32_t half = len >> 1, middle = first + half;
+            if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+            else len = half;
+        }
+        idx = first == 0 ? 0 : first - 1;
+        if (idx > n - 1) idx = n - 1;
+        f_idx = tab[idx];
+        func_int = tab[2 * n + 1];
     }
-    uint32_t idx = first == 0 ? 0 : first - 1;
-    if (idx > n - 1) idx = n - 1;
-    *pdf = func_int > 0.0f ? func[idx] * (1.0f / (float)n) / func_int : 0.0f;
+    *pdf = func_int > 0.0f ? f_idx * (1.0f / (float)n) / func_int : 0.0f;
     return idx;
 }
 
@@ -905,7 +945,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
             bool found = rec >= 0 && make_surf(sc, ro, rd, (uint32_t)rec, s, &thit);
             // emitted radiance at the first vertex / after a specular bounce (path.rs:87-98)
             if (found && (bounces == 0 || (flags & PT_ST_SPECULAR))) {
-                int32_t li = sc.tri_info[s.prim].light;
+                int32_t li = s.light;
                 if (li >= 0) {
                     V3 le = light_L(sc.lights[li], s.n, -rd);
                     float4 L = P.L[p];
@@ -915,15 +955,14 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
                 }
             }
             if (found && (int32_t)bounces < sc.max_depth) {
-                const PtTriInfo ti = sc.tri_info[s.prim];
-                if (ti.material < 0 || sc.materials[ti.material].type == PT_MATERIAL_NONE) {
+                if (s.material < 0) {
                     // no BSDF: continue through the surface, same bounce count (path.rs:108-111)
                     V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
                     P.ray_o[p] = make_float4(no.x, no.y, no.z, PT_INF);
                     cont = true;
                 } else {
                     n_vert++;
-                    const PtMaterial m = sc.materials[ti.material];
+                    const PtMaterial m = sc.materials[s.material];
                     Bsdf b;
                     b.ns = s.sh_n; b.ng = s.n;
                     b.ss = normalize(s.sh_dpdu);
@@ -978,7 +1017,18 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
                                     V3 po = offset_ray_origin(s.p, s.p_error, s.n, wi2);
                                     Surf ls;
                                     float lt_t;
-                                    if (make_surf(sc, po, wi2, lt.tri_rec, ls, &lt_t)) {
+                                    bool lhit;
+                                    if (lt.mesh_flags & (PT_MESH_HAS_N | PT_MESH_HAS_S | PT_MESH_HAS_UV)) {
+                                        lhit = make_surf(sc, po, wi2, lt.tri_rec, ls, &lt_t);
+                                    } else {           // the light record already holds the triangle
+                                        TriVerts ltv;
+                                        ltv.p0 = ld3(lt.p0); ltv.p1 = ld3(lt.p1); ltv.p2 = ld3(lt.p2);
+                                        ltv.prim = lt.prim;
+                                        ltv.flags = ((lt.mesh_flags & PT_MESH_TWO_SIDED) ? 0u : PT_TRI_ONE_SIDED) |
+                                                    ((((lt.mesh_flags & PT_MESH_REVERSE_ORIENTATION) != 0) ^ ((lt.mesh_flags & PT_MESH_SWAPS_HANDEDNESS) != 0)) ? PT_TRI_FLIP : 0u);
+                                        lhit = make_surf_tv(sc, po, wi2, ltv, 0u, ls, &lt_t);
+                                    }
+                                    if (lhit) {
                                         float lp2 = distance_squared(s.p, ls.p) / (abs_dot(ls.n, -wi2) * lt.area);
                                         if (isinf(lp2)) lp2 = 0.0f;
                                         if (lp2 != 0.0f) {
