@@ -81,8 +81,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_REDUCE") == "1"     # the latter: rehearse the N>1 code path on one GPU
+    if use_dist:
+        os.environ["NCCL_DEBUG"] = os.environ.get("BENCH_NCCL_DEBUG", "WARN")   # keep RCCL's banner off stdout: one JSON line only
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def log(msg):
@@ -104,7 +110,7 @@ def main():
     def step():
         ctx.film_clear()
         ctx.render(my_tiles)
-        if world > 1:
+        if use_dist:
             # the one collective of the path: sum the per-rank XYZW films (disjoint tiles)
             ptr, n = ctx.film_device_xyzw()
             t = pkg.dist.wrap_device_floats(ptr, n, local_rank)
@@ -114,7 +120,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -135,7 +141,7 @@ def main():
     stats = torch.tensor([elapsed, cnt["regular_rays"], cnt["shadow_rays"], cnt["nodes_visited"], cnt["tris_tested"],
                           cnt["path_vertices"], cnt["trace_ms"], cnt["trace_launches"], cnt["camera_rays"], cnt["shade_ms"]],
                          dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -206,7 +212,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
