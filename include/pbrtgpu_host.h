@@ -1,0 +1,56 @@
+/*
+ * pbrtgpu_host.h -- host-side front end of libpbrtgpu.so: the .pbrt scene-description
+ * parser and the scene context that flattens it into a pt_scene_desc.
+ *
+ * It stands in for (paths relative to the reference tree)
+ *   pbrt_parse_file / pbrt_parse_string     src/core/parser/parser.rs:60-135
+ *   trait ParseContext                      src/core/api/parse_context.rs:5-66
+ *   SceneContext (the ParseContext that builds the scene)
+ *                                           src/core/api/scene_context/scene_context.rs:817-1396
+ * for the subset of the format the accelerated path renders: triangle
+ * meshes, matte materials (incl. named materials and per-shape overrides), diffuse area lights,
+ * perspective camera, box/gaussian/mitchell/triangle filters, Sobol' sampler, path integrator,
+ * BVH accelerator, the full transform / attribute stack and Include.  Anything else is reported
+ * as PT_ERR_UNSUPPORTED with a message naming the directive -- never silently approximated.
+ *
+ * The C++ class interface (ParseContext with the reference's method names) is in
+ * pbrt-r3_amd/csrc/host/pth_parse_context.h; this header is the C ABI over it.
+ */
+#ifndef PBRTGPU_HOST_H
+#define PBRTGPU_HOST_H
+
+#include "pbrtgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pth_scene pth_scene;
+
+/* Parse a .pbrt file (Include resolved relative to the including file).  On failure *out is NULL
+ * and err (if non-NULL) receives a message. */
+pt_status pth_parse_file(const char* filename, pth_scene** out, char* err, size_t err_cap);
+/* Parse scene text; work_dir is the base for Include (may be NULL). */
+pt_status pth_parse_string(const char* text, const char* work_dir, pth_scene** out, char* err, size_t err_cap);
+/* The flattened scene; pointers stay valid until pth_scene_free. */
+const pt_scene_desc* pth_scene_get_desc(const pth_scene* s);
+/* Film "filename" parameter (default "pbrt.exr"). */
+const char* pth_scene_output_filename(const pth_scene* s);
+/* Command-line overrides of the reference CLI (src/bin/pbrt.rs:234-244). */
+void pth_scene_set_pixelsamples(pth_scene* s, int spp);
+/* Non-fatal diagnostics collected while parsing (one per line). */
+const char* pth_scene_warnings(const pth_scene* s);
+void pth_scene_free(pth_scene* s);
+
+/* Parser in isolation: runs `text` through a context that logs every ParseContext callback, one
+ * directive per line (cf. the reference's PrintContext, --cat).  On a syntax error out holds the message. */
+pt_status pth_parse_to_log(const char* text, const char* work_dir, char* out, size_t cap);
+
+/* Linear-RGB float image as PFM (the smallest float format the reference can also write,
+ * src/core/imageio/write_image.rs:59-76). */
+pt_status pth_write_pfm(const char* path, const float* rgb, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

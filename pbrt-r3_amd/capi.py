@@ -146,6 +146,71 @@ def tiles_array(tiles):
     return arr
 
 
+HOST_SYMBOLS = ["pth_parse_file", "pth_parse_string", "pth_scene_get_desc", "pth_scene_output_filename",
+                "pth_scene_set_pixelsamples", "pth_scene_warnings", "pth_scene_free", "pth_write_pfm", "pth_parse_to_log"]
+
+
+class ParsedScene:
+    """A scene parsed from .pbrt text by the C++ front end (include/pbrtgpu_host.h).  Quacks like
+    scenes.SceneDesc (has .desc), so it can be uploaded or handed to the oracle."""
+
+    def __init__(self, text=None, filename=None, work_dir=None, lib=None):
+        self.lib = lib or load_library()
+        L = self.lib
+        L.pth_parse_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.pth_parse_string.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.pth_scene_get_desc.argtypes = [C.c_void_p]
+        L.pth_scene_get_desc.restype = C.POINTER(pt_scene_desc)
+        L.pth_scene_output_filename.argtypes = [C.c_void_p]
+        L.pth_scene_output_filename.restype = C.c_char_p
+        L.pth_scene_warnings.argtypes = [C.c_void_p]
+        L.pth_scene_warnings.restype = C.c_char_p
+        L.pth_scene_set_pixelsamples.argtypes = [C.c_void_p, C.c_int]
+        L.pth_scene_set_pixelsamples.restype = None
+        L.pth_scene_free.argtypes = [C.c_void_p]
+        L.pth_scene_free.restype = None
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(2048)
+        if filename is not None:
+            st = L.pth_parse_file(filename.encode(), C.byref(self.h), err, 2048)
+        else:
+            st = L.pth_parse_string(text.encode(), (work_dir or ".").encode(), C.byref(self.h), err, 2048)
+        if st != 0:
+            raise PtError(st, err.value.decode())
+        self.desc = L.pth_scene_get_desc(self.h).contents
+        self.buffers = {}
+
+    @property
+    def output_filename(self):
+        return self.lib.pth_scene_output_filename(self.h).decode()
+
+    @property
+    def warnings(self):
+        return self.lib.pth_scene_warnings(self.h).decode()
+
+    def set_pixelsamples(self, spp):
+        self.lib.pth_scene_set_pixelsamples(self.h, int(spp))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.pth_scene_free(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def parse_to_log(text, lib=None):
+    """Directive log of the parser alone (pth_parse_to_log); raises PtError on a syntax error."""
+    lib = lib or load_library()
+    lib.pth_parse_to_log.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    out = C.create_string_buffer(1 << 20)
+    st = lib.pth_parse_to_log(text.encode(), b".", out, 1 << 20)
+    if st != 0:
+        raise PtError(st, out.value.decode())
+    return out.value.decode().splitlines()
+
+
 def bvh_leaf_order(scene, lib=None):
     """Host-only BVH build (no GPU): returns (order, n_nodes, n_leaves, max_stack)."""
     lib = lib or load_library()

@@ -1,0 +1,536 @@
+// pth_scene_context.cpp -- the ParseContext that turns a scene description into the flattened
+// pt_scene_desc the device library consumes.  It restates, for the accelerated subset, what the
+// reference's SceneContext does between the parser callbacks and Integrator::render:
+//   transform / attribute stacks, named coordinate systems   scene_context.rs:821-943, :1037-1082
+//   options (Film, Camera, Sampler, ...) + WorldEnd factories  scene_context.rs:953-1016, :606-729
+//   pbrt_shape for "trianglemesh"                              scene_context.rs:1201-1318,
+//                                                             shapes/triangle.rs:696-868
+//   material lookup with per-shape overrides                   scene_context.rs:224-296, materials/matte.rs:56-61
+//   diffuse area lights                                        lights/diffuse.rs:165-194
+// All arithmetic that reaches the renderer (CTM products, vertex transforms, filter tables) is f32 in
+// the reference's operation order.  Unsupported directives set an error naming them.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <sstream>
+
+#include "../../../include/pbrtgpu_host.h"
+#include "../pt_host_math.h"
+#include "pth_parse_context.h"
+
+namespace pth {
+
+namespace {
+
+const float kPi = 3.14159265358979323846f;
+
+struct V3f { float x, y, z; };
+inline V3f sub(V3f a, V3f b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3f crossf(V3f a, V3f b) { return {(a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)}; }
+inline float lenf(V3f a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline V3f normf(V3f a) { float l = lenf(a); return {a.x / l, a.y / l, a.z / l}; }
+
+// Matrix4x4::rotate (matrix4x4.rs:107-131) with transpose as inverse
+Xf xf_rotate(float theta, float x, float y, float z) {
+    V3f a = normf({x, y, z});
+    float r = theta * (kPi / 180.0f);
+    float s = std::sin(r), c = std::cos(r);
+    Xf t;
+    t.m = m_identity();
+    t.m.a[0] = a.x * a.x + (1.0f - a.x * a.x) * c;
+    t.m.a[1] = a.x * a.y * (1.0f - c) - a.z * s;
+    t.m.a[2] = a.x * a.z * (1.0f - c) + a.y * s;
+    t.m.a[4] = a.x * a.y * (1.0f - c) + a.z * s;
+    t.m.a[5] = a.y * a.y + (1.0f - a.y * a.y) * c;
+    t.m.a[6] = a.y * a.z * (1.0f - c) - a.x * s;
+    t.m.a[8] = a.x * a.z * (1.0f - c) - a.y * s;
+    t.m.a[9] = a.y * a.z * (1.0f - c) + a.x * s;
+    t.m.a[10] = a.z * a.z + (1.0f - a.z * a.z) * c;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) t.inv.a[4 * i + j] = t.m.a[4 * j + i];
+    return t;
+}
+// Transform::look_at (transform.rs:68-83): m = world->camera (inverse of the built matrix), minv = camera->world
+bool xf_look_at(const float e[3], const float l[3], const float u[3], Xf* out) {
+    V3f pos = {e[0], e[1], e[2]}, look = {l[0], l[1], l[2]};
+    V3f up = normf({u[0], u[1], u[2]});
+    V3f dir = normf(sub(look, pos));
+    V3f right = crossf(up, dir);
+    if (lenf(right) == 0.0f) return false;
+    right = normf(right);
+    V3f nup = normf(crossf(dir, right));
+    M44 c2w = m_identity();
+    c2w.a[0] = right.x; c2w.a[1] = nup.x; c2w.a[2] = dir.x; c2w.a[3] = pos.x;
+    c2w.a[4] = right.y; c2w.a[5] = nup.y; c2w.a[6] = dir.y; c2w.a[7] = pos.y;
+    c2w.a[8] = right.z; c2w.a[9] = nup.z; c2w.a[10] = dir.z; c2w.a[11] = pos.z;
+    M44 w2c;
+    if (!m_inverse(c2w, &w2c)) return false;
+    out->m = w2c;
+    out->inv = c2w;
+    return true;
+}
+inline void xf_point(const M44& m, const float* p, float* o) {     // matrix4x4.rs:311-324
+    float x = p[0], y = p[1], z = p[2];
+    float xp = m.a[0] * x + m.a[1] * y + m.a[2] * z + m.a[3];
+    float yp = m.a[4] * x + m.a[5] * y + m.a[6] * z + m.a[7];
+    float zp = m.a[8] * x + m.a[9] * y + m.a[10] * z + m.a[11];
+    float wp = m.a[12] * x + m.a[13] * y + m.a[14] * z + m.a[15];
+    if (wp == 1.0f) { o[0] = xp; o[1] = yp; o[2] = zp; }
+    else { o[0] = xp / wp; o[1] = yp / wp; o[2] = zp / wp; }
+}
+inline void xf_vector(const M44& m, const float* v, float* o) {
+    float x = v[0], y = v[1], z = v[2];
+    o[0] = m.a[0] * x + m.a[1] * y + m.a[2] * z;
+    o[1] = m.a[4] * x + m.a[5] * y + m.a[6] * z;
+    o[2] = m.a[8] * x + m.a[9] * y + m.a[10] * z;
+}
+inline void xf_normal(const M44& minv, const float* n, float* o) {  // Transform::transform_normal: transpose of the inverse
+    float x = n[0], y = n[1], z = n[2];
+    o[0] = minv.a[0] * x + minv.a[4] * y + minv.a[8] * z;
+    o[1] = minv.a[1] * x + minv.a[5] * y + minv.a[9] * z;
+    o[2] = minv.a[2] * x + minv.a[6] * y + minv.a[10] * z;
+}
+inline bool swaps_handedness(const M44& m) {
+    float det = m.a[0] * (m.a[5] * m.a[10] - m.a[6] * m.a[9]) - m.a[1] * (m.a[4] * m.a[10] - m.a[6] * m.a[8]) + m.a[2] * (m.a[4] * m.a[9] - m.a[5] * m.a[8]);
+    return det < 0.0f;
+}
+
+struct TransformSet { Xf t[2]; };
+const unsigned kAllBits = 3, kStartBit = 1, kEndBit = 2;
+
+struct MaterialInstance { std::string name; ParamSet params; bool none = false; };
+struct GraphicsState {
+    MaterialInstance material;                                   // default: matte, no params (graphics_state.rs:61-91)
+    std::map<std::string, MaterialInstance> named_materials;
+    std::string area_light_name;
+    ParamSet area_light_params;
+    bool reverse_orientation = false;
+};
+
+}  // namespace
+
+class GpuSceneContext : public ParseContext {
+public:
+    // ---- flattened output
+    std::vector<float> P, N, S, UV;
+    std::vector<uint32_t> indices, tri_mesh;
+    std::vector<pt_mesh> meshes;
+    std::vector<pt_material> materials;
+    std::vector<pt_area_light> area_lights;
+    bool any_n = false, any_s = false, any_uv = false;
+    pt_scene_desc desc;
+    std::string out_filename = "pbrt.exr";
+    std::string error, warnings;
+    bool world_ended = false;
+
+    GpuSceneContext() {
+        TransformSet id;
+        id.t[0].m = id.t[0].inv = id.t[1].m = id.t[1].inv = m_identity();
+        transforms.push_back(id);
+        bits.push_back(kAllBits);
+        gstates.push_back(GraphicsState());
+        gstates.back().material.name = "matte";
+        std::memset(&desc, 0, sizeof(desc));
+    }
+
+    void fail(const std::string& m) { if (error.empty()) error = m; }
+    void warn(const std::string& m) { warnings += m + "\n"; }
+
+    // ---- transforms (scene_context.rs:821-943)
+    void mul(const Xf& t) { for (int i = 0; i < 2; i++) if (bits.back() & (1u << i)) transforms.back().t[i] = xf_mul(transforms.back().t[i], t); }
+    void set(const Xf& t) { for (int i = 0; i < 2; i++) if (bits.back() & (1u << i)) transforms.back().t[i] = t; }
+    void pbrt_identity() override { Xf t; t.m = t.inv = m_identity(); set(t); }
+    void pbrt_translate(float dx, float dy, float dz) override { mul(xf_translate(dx, dy, dz)); }
+    void pbrt_rotate(float angle, float ax, float ay, float az) override { mul(xf_rotate(angle, ax, ay, az)); }
+    void pbrt_scale(float sx, float sy, float sz) override { mul(xf_scale(sx, sy, sz)); }
+    void pbrt_look_at(float ex, float ey, float ez, float lx, float ly, float lz, float ux, float uy, float uz) override {
+        float e[3] = {ex, ey, ez}, l[3] = {lx, ly, lz}, u[3] = {ux, uy, uz};
+        Xf t;
+        if (!xf_look_at(e, l, u, &t)) { fail("LookAt: up vector and viewing direction are parallel"); return; }
+        mul(t);
+    }
+    bool from16(const std::vector<float>& t, Xf* out) {
+        if (t.size() != 16) return false;
+        M44 m;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m.a[4 * i + j] = t[4 * j + i];    // file order is column-major
+        out->m = m;
+        return m_inverse(m, &out->inv);
+    }
+    void pbrt_concat_transform(const std::vector<float>& t) override { Xf x; if (from16(t, &x)) mul(x); else warn("Singular matrix in ConcatTransform"); }
+    void pbrt_transform(const std::vector<float>& t) override { Xf x; if (from16(t, &x)) set(x); else warn("Singular matrix in Transform"); }
+    void pbrt_coordinate_system(const std::string& name) override { named_cs[name] = transforms.back(); }
+    void pbrt_coord_sys_transform(const std::string& name) override {
+        auto it = named_cs.find(name);
+        if (it == named_cs.end()) { warn("Couldn't find named coordinate system \"" + name + "\""); return; }
+        for (int i = 0; i < 2; i++) if (bits.back() & (1u << i)) transforms.back().t[i] = it->second.t[i];
+    }
+    void pbrt_active_transform_all() override { bits.back() = kAllBits; }
+    void pbrt_active_transform_end_time() override { bits.back() = kEndBit; }
+    void pbrt_active_transform_start_time() override { bits.back() = kStartBit; }
+    void pbrt_transform_times(float, float) override {}
+
+    // ---- options
+    void pbrt_pixel_filter(const std::string& name, const ParamSet& p) override { filter_name = name; filter_params = p; }
+    void pbrt_film(const std::string& name, const ParamSet& p) override { film_name = name; film_params = p; }
+    void pbrt_sampler(const std::string& name, const ParamSet& p) override { sampler_name = name; sampler_params = p; }
+    void pbrt_accelerator(const std::string& name, const ParamSet& p) override { accel_name = name; accel_params = p; }
+    void pbrt_integrator(const std::string& name, const ParamSet& p) override { integrator_name = name; integrator_params = p; }
+    void pbrt_camera(const std::string& name, const ParamSet& p) override {
+        camera_name = name; camera_params = p;
+        TransformSet inv;                                          // "camera" = inverse of the CTM (scene_context.rs:1001-1005)
+        for (int i = 0; i < 2; i++) inv.t[i] = xf_inverse(transforms.back().t[i]);
+        named_cs["camera"] = inv;
+        have_camera = true;
+    }
+    void pbrt_make_named_medium(const std::string&, const ParamSet&) override { warn("MakeNamedMedium ignored: PathIntegrator does not handle media (path.rs:128)"); }
+    void pbrt_medium_interface(const std::string&, const std::string&) override { warn("MediumInterface ignored: PathIntegrator does not handle media"); }
+
+    // ---- world block
+    void pbrt_world_begin() override {
+        Xf id; id.m = id.inv = m_identity();
+        transforms.back().t[0] = transforms.back().t[1] = id;
+        bits.back() = kAllBits;
+        named_cs["world"] = transforms.back();
+    }
+    void pbrt_attribute_begin() override { gstates.push_back(gstates.back()); transforms.push_back(transforms.back()); bits.push_back(bits.back()); }
+    void pbrt_attribute_end() override {
+        if (gstates.size() <= 1) { warn("Unmatched AttributeEnd"); return; }
+        gstates.pop_back(); transforms.pop_back(); bits.pop_back();
+    }
+    void pbrt_transform_begin() override { transforms.push_back(transforms.back()); bits.push_back(bits.back()); }
+    void pbrt_transform_end() override {
+        if (transforms.size() <= 1) { warn("Unmatched TransformEnd"); return; }
+        transforms.pop_back(); bits.pop_back();
+    }
+    void pbrt_texture(const std::string& name, const std::string&, const std::string& tex_name, const ParamSet&) override {
+        fail("Texture \"" + name + "\" (" + tex_name + "): textures other than implicit constants are outside the accelerated path");
+    }
+    void pbrt_material(const std::string& name, const ParamSet& p) override {
+        MaterialInstance mi;
+        mi.name = name; mi.params = p;
+        mi.none = name.empty() || name == "none";
+        gstates.back().material = mi;
+    }
+    void pbrt_make_named_material(const std::string& name, const ParamSet& p) override {
+        MaterialInstance mi;
+        mi.name = p.find_one_string("type", "");
+        if (mi.name.empty()) warn("No parameter string \"type\" found in MakeNamedMaterial");
+        mi.params = p;
+        mi.none = mi.name == "none";
+        gstates.back().named_materials[name] = mi;
+    }
+    void pbrt_named_material(const std::string& name) override {
+        auto it = gstates.back().named_materials.find(name);
+        if (it == gstates.back().named_materials.end()) { warn("NamedMaterial \"" + name + "\" unknown."); return; }
+        gstates.back().material = it->second;
+    }
+    void pbrt_light_source(const std::string& name, const ParamSet&) override {
+        fail("LightSource \"" + name + "\": only diffuse area lights are on the accelerated path");
+    }
+    void pbrt_area_light_source(const std::string& name, const ParamSet& p) override {
+        gstates.back().area_light_name = name;
+        gstates.back().area_light_params = p;
+    }
+    void pbrt_reverse_orientation() override { gstates.back().reverse_orientation = !gstates.back().reverse_orientation; }
+    void pbrt_object_begin(const std::string&) override { fail("ObjectBegin: object instancing is outside the accelerated path"); }
+    void pbrt_object_end() override {}
+    void pbrt_object_instance(const std::string&) override { fail("ObjectInstance: object instancing is outside the accelerated path"); }
+
+    // TextureParams lookup order: shape parameters first, then the material's (texture_params.rs:14-120)
+    bool lookup_rgb(const ParamSet& geom, const ParamSet& mat, const std::string& n, float out[3]) {
+        if (geom.textures.count(n) || mat.textures.count(n)) { fail("material parameter \"" + n + "\" bound to a texture: outside the accelerated path"); return false; }
+        if (geom.find_one_rgb(n, out)) return true;
+        return mat.find_one_rgb(n, out);
+    }
+    int material_for_shape(const ParamSet& geom) {
+        const MaterialInstance& mi = gstates.back().material;
+        if (mi.none) return -1;
+        if (mi.name != "matte") { fail("Material \"" + mi.name + "\": only matte is on the accelerated path so far"); return -1; }
+        if (geom.textures.count("bumpmap") || mi.params.textures.count("bumpmap")) { fail("bumpmap: outside the accelerated path"); return -1; }
+        pt_material m;
+        std::memset(&m, 0, sizeof(m));
+        m.type = PT_MATERIAL_MATTE;
+        m.kd[0] = m.kd[1] = m.kd[2] = 0.5f;                       // matte.rs:56
+        lookup_rgb(geom, mi.params, "Kd", m.kd);
+        m.sigma = geom.floats.count("sigma") ? geom.find_one_float("sigma", 0.0f) : mi.params.find_one_float("sigma", 0.0f);
+        for (size_t i = 0; i < materials.size(); i++)
+            if (std::memcmp(&materials[i], &m, sizeof(m)) == 0) return (int)i;
+        materials.push_back(m);
+        return (int)materials.size() - 1;
+    }
+    int area_light_for_shape() {
+        const GraphicsState& gs = gstates.back();
+        if (gs.area_light_name.empty()) return -1;
+        if (gs.area_light_name != "diffuse" && gs.area_light_name != "area") { fail("AreaLightSource \"" + gs.area_light_name + "\" unknown"); return -1; }
+        float L[3] = {1.0f, 1.0f, 1.0f}, sc[3] = {1.0f, 1.0f, 1.0f};
+        gs.area_light_params.find_one_rgb("L", L);
+        gs.area_light_params.find_one_rgb("scale", sc);
+        pt_area_light al;
+        al.L[0] = L[0] * sc[0]; al.L[1] = L[1] * sc[1]; al.L[2] = L[2] * sc[2];
+        al.two_sided = gs.area_light_params.find_one_bool("twosided", false) ? 1 : 0;
+        area_lights.push_back(al);
+        return (int)area_lights.size() - 1;
+    }
+    static bool is_fillable_uv(const std::vector<uint32_t>& vi, size_t nv) {     // triangle.rs:733-752
+        std::vector<int> check(nv, 0);
+        for (size_t f = 0; f + 2 < vi.size(); f += 3)
+            for (int j = 0; j < 3; j++) {
+                uint32_t v = vi[f + j];
+                if (check[v] == 0 || check[v] == j) check[v] = j;
+                else return false;
+            }
+        return true;
+    }
+
+    void pbrt_shape(const std::string& name, const ParamSet& p) override {
+        if (!error.empty()) return;
+        if (name != "trianglemesh") { fail("Shape \"" + name + "\": only trianglemesh is on the accelerated path"); return; }
+        const TransformSet& ts = transforms.back();
+        if (std::memcmp(&ts.t[0].m, &ts.t[1].m, sizeof(M44)) != 0) { fail("animated transforms are outside the accelerated path"); return; }
+        if (p.has("alpha") || p.has("shadowalpha")) { fail("alpha-masked shapes are outside the accelerated path"); return; }
+        const std::vector<int>* vi = p.get_ints("indices");
+        const std::vector<float>* ps = p.get_points("P");
+        if (!vi || !ps || vi->empty() || ps->empty()) { warn("Invalid mesh"); return; }
+        size_t nv = ps->size() / 3;
+        std::vector<uint32_t> idx(vi->size());
+        for (size_t i = 0; i < vi->size(); i++) {
+            if ((*vi)[i] < 0 || (size_t)(*vi)[i] >= nv) { fail("trianglemesh has out-of-bounds vertex index"); return; }
+            idx[i] = (uint32_t)(*vi)[i];
+        }
+        std::vector<float> uv;
+        const std::vector<float>* fuv = p.get_floats("uv");
+        if (!fuv) fuv = p.get_floats("st");
+        if (fuv) uv = *fuv;
+        else if (is_fillable_uv(idx, nv)) {                         // triangle.rs:796-821
+            uv.assign(2 * nv, 0.0f);
+            const float tri_uv[3][2] = {{0, 0}, {1, 0}, {1, 1}};
+            for (size_t f = 0; f + 2 < idx.size(); f += 3)
+                for (int j = 0; j < 3; j++) {
+                    uint32_t v = idx[f + j];
+                    if (uv[2 * v] == 0.0f && uv[2 * v + 1] == 0.0f) { uv[2 * v] = tri_uv[j][0]; uv[2 * v + 1] = tri_uv[j][1]; }
+                }
+        }
+        if (!uv.empty() && uv.size() / 2 < nv) { fail("trianglemesh uv count does not match P"); return; }
+        const std::vector<float>* sv = p.get_points("S");
+        if (!sv) sv = p.get_vectors("S");
+        const std::vector<float>* nn = p.get_points("N");
+        if (!nn) nn = p.get_normals("N");
+        if ((sv && sv->size() / 3 < nv) || (nn && nn->size() / 3 < nv)) { fail("trianglemesh S / N count does not match P"); return; }
+
+        const Xf& o2w = ts.t[0];
+        std::vector<float> wp(3 * nv), wn, ws;                      // TriangleMesh::new pre-transforms (triangle.rs:49-66)
+        for (size_t i = 0; i < nv; i++) xf_point(o2w.m, &(*ps)[3 * i], &wp[3 * i]);
+        if (nn) { wn.resize(3 * nv); for (size_t i = 0; i < nv; i++) xf_normal(o2w.inv, &(*nn)[3 * i], &wn[3 * i]); }
+        if (sv) { ws.resize(3 * nv); for (size_t i = 0; i < nv; i++) xf_vector(o2w.m, &(*sv)[3 * i], &ws[3 * i]); }
+
+        pt_mesh mesh;
+        mesh.flags = 0;
+        if (p.find_one_bool("twosided", true)) mesh.flags |= PT_MESH_TWO_SIDED;
+        if (gstates.back().reverse_orientation) mesh.flags |= PT_MESH_REVERSE_ORIENTATION;
+        if (swaps_handedness(o2w.m)) mesh.flags |= PT_MESH_SWAPS_HANDEDNESS;
+        if (nn) mesh.flags |= PT_MESH_HAS_N;
+        if (sv) mesh.flags |= PT_MESH_HAS_S;
+        if (!uv.empty()) mesh.flags |= PT_MESH_HAS_UV;
+        mesh.material = material_for_shape(p);
+        mesh.area_light = area_light_for_shape();
+        mesh.reserved = 0;
+        if (!error.empty()) return;
+
+        uint32_t base = (uint32_t)(P.size() / 3);
+        uint32_t mesh_id = (uint32_t)meshes.size();
+        size_t kept = 0;
+        for (size_t f = 0; f + 2 < idx.size(); f += 3) {            // drop triangles with area <= 1e-16 (triangle.rs:726)
+            const float* a = &wp[3 * idx[f]]; const float* b = &wp[3 * idx[f + 1]]; const float* c = &wp[3 * idx[f + 2]];
+            V3f e1 = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2 = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            float area = 0.5f * lenf(crossf(e1, e2));
+            if (!(area > 1e-16f)) continue;
+            indices.push_back(base + idx[f]); indices.push_back(base + idx[f + 1]); indices.push_back(base + idx[f + 2]);
+            tri_mesh.push_back(mesh_id);
+            kept++;
+        }
+        (void)kept;
+        meshes.push_back(mesh);
+        size_t old_nv = P.size() / 3;
+        P.insert(P.end(), wp.begin(), wp.end());
+        auto grow = [&](std::vector<float>& dst, const std::vector<float>& src, int width, bool& any) {
+            if (!src.empty() && !any) { dst.assign(old_nv * width, 0.0f); any = true; }
+            if (any) { if (src.empty()) dst.insert(dst.end(), nv * width, 0.0f); else dst.insert(dst.end(), src.begin(), src.begin() + nv * width); }
+        };
+        grow(N, wn, 3, any_n);
+        grow(S, ws, 3, any_s);
+        grow(UV, uv, 2, any_uv);
+    }
+
+    // ---- WorldEnd: the factories of scene_context.rs:606-729 reduced to parameter capture
+    float gaussian1(float d, float alpha, float expv) { return std::fmax(0.0f, std::exp(-alpha * d * d) - expv); }
+    float mitchell1(float x, float b, float c) {
+        x = std::fabs(2.0f * x);
+        if (x > 1.0f) return ((-b - 6.0f * c) * x * x * x + (6.0f * b + 30.0f * c) * x * x + (-12.0f * b - 48.0f * c) * x + (8.0f * b + 24.0f * c)) * (1.0f / 6.0f);
+        return ((12.0f - 9.0f * b - 6.0f * c) * x * x * x + (-18.0f + 12.0f * b + 6.0f * c) * x * x + (6.0f - 2.0f * b)) * (1.0f / 6.0f);
+    }
+    bool make_filter() {
+        float rx, ry;
+        const ParamSet& fp = filter_params;
+        int kind;
+        if (filter_name == "box") { kind = 0; rx = fp.find_one_float("xwidth", 0.5f); ry = fp.find_one_float("ywidth", 0.5f); }
+        else if (filter_name == "gaussian") { kind = 1; rx = fp.find_one_float("xwidth", 2.0f); ry = fp.find_one_float("ywidth", 2.0f); }
+        else if (filter_name == "mitchell") { kind = 2; rx = fp.find_one_float("xwidth", 2.0f); ry = fp.find_one_float("ywidth", 2.0f); }
+        else if (filter_name == "triangle") { kind = 3; rx = fp.find_one_float("xwidth", 2.0f); ry = fp.find_one_float("ywidth", 2.0f); }
+        else { fail("PixelFilter \"" + filter_name + "\" is not supported"); return false; }
+        float alpha = fp.find_one_float("alpha", 2.0f), B = fp.find_one_float("B", 1.0f / 3.0f), C = fp.find_one_float("C", 1.0f / 3.0f);
+        float ex = std::exp(-alpha * rx * rx), ey = std::exp(-alpha * ry * ry);
+        desc.filter_radius[0] = rx; desc.filter_radius[1] = ry;
+        for (int y = 0; y < 16; y++)                                 // Film::new's table (film.rs:102-120)
+            for (int x = 0; x < 16; x++) {
+                float xx = (float)x * (rx / 15.0f), yy = (float)y * (ry / 15.0f), v = 1.0f;
+                if (kind == 1) v = gaussian1(xx, alpha, ex) * gaussian1(yy, alpha, ey);
+                else if (kind == 2) v = mitchell1(xx * (1.0f / rx), B, C) * mitchell1(yy * (1.0f / ry), B, C);
+                else if (kind == 3) v = std::fmax(0.0f, rx - std::fabs(xx)) * std::fmax(0.0f, ry - std::fabs(yy));
+                desc.filter_table[y * 16 + x] = v;
+            }
+        return true;
+    }
+
+    void pbrt_world_end() override {
+        world_ended = true;
+        if (!error.empty()) return;
+        if (indices.empty()) { fail("scene has no triangles"); return; }
+        // film (film.rs:520-580)
+        if (film_name != "image") warn("Film \"" + film_name + "\" treated as \"image\"");
+        desc.xres = film_params.find_one_int("xresolution", 1280);
+        desc.yres = film_params.find_one_int("yresolution", 720);
+        desc.crop_window[0] = 0.0f; desc.crop_window[1] = 1.0f; desc.crop_window[2] = 0.0f; desc.crop_window[3] = 1.0f;
+        if (const std::vector<float>* cw = film_params.get_floats("cropwindow")) {
+            if (cw->size() != 4) { fail("\"cropwindow\" expects 4 values"); return; }
+            for (int i = 0; i < 4; i++) desc.crop_window[i] = (*cw)[i];
+        }
+        desc.film_scale = film_params.find_one_float("scale", 1.0f);
+        desc.max_sample_luminance = film_params.find_one_float("maxsampleluminance", std::numeric_limits<float>::infinity());
+        out_filename = film_params.find_one_string("filename", "pbrt.exr");
+        if (!make_filter()) return;
+        // camera (cameras/perspective.rs:337-394)
+        if (camera_name != "perspective") { fail("Camera \"" + camera_name + "\": only perspective is on the accelerated path"); return; }
+        TransformSet c2w;
+        if (have_camera) c2w = named_cs["camera"];
+        else { c2w.t[0].m = c2w.t[0].inv = c2w.t[1].m = c2w.t[1].inv = m_identity(); }
+        if (std::memcmp(&c2w.t[0].m, &c2w.t[1].m, sizeof(M44)) != 0) { fail("animated camera transforms are outside the accelerated path"); return; }
+        std::memcpy(desc.camera_to_world, c2w.t[0].m.a, 64);
+        float so = camera_params.find_one_float("shutteropen", 0.0f), sc = camera_params.find_one_float("shutterclose", 1.0f);
+        if (sc < so) std::swap(so, sc);
+        desc.shutter_open = so; desc.shutter_close = sc;
+        desc.lens_radius = camera_params.find_one_float("lensradius", 0.0f);
+        desc.focal_distance = camera_params.find_one_float("focaldistance", 1e6f);
+        float aspect = (float)desc.xres / (float)desc.yres;
+        float frame = camera_params.find_one_float("frameaspectratio", aspect);
+        if (const std::vector<float>* sw = camera_params.get_floats("screenwindow")) {
+            if (sw->size() < 4) { fail("\"screenwindow\" should have four values"); return; }
+            for (int i = 0; i < 4; i++) desc.screen_window[i] = (*sw)[i];
+        } else if (frame > 1.0f) {
+            desc.screen_window[0] = -frame; desc.screen_window[1] = frame; desc.screen_window[2] = -1.0f; desc.screen_window[3] = 1.0f;
+        } else {
+            desc.screen_window[0] = -1.0f; desc.screen_window[1] = 1.0f; desc.screen_window[2] = -1.0f / frame; desc.screen_window[3] = 1.0f / frame;
+        }
+        desc.fov = camera_params.find_one_float("fov", 90.0f);
+        float halffov = camera_params.find_one_float("halffov", -1.0f);
+        if (halffov > 0.0f) desc.fov = 2.0f * halffov;
+        // sampler (render_options.rs:71: the default is halton)
+        if (sampler_name != "sobol") {
+            fail("Sampler \"" + sampler_name + "\": only \"sobol\" is reproducible on a wavefront (the reference's default, halton, is not restated yet)");
+            return;
+        }
+        desc.sampler = PT_SAMPLER_SOBOL;
+        desc.spp = sampler_params.find_one_int("pixelsamples", 16);
+        // integrator (integrators/path.rs:252-271)
+        if (integrator_name != "path") { fail("Integrator \"" + integrator_name + "\": only path is on the accelerated path"); return; }
+        desc.max_depth = integrator_params.find_one_int("maxdepth", 5);
+        desc.rr_threshold = integrator_params.find_one_float("rrthreshold", 1.0f);
+        std::string ls = integrator_params.find_one_string("lightsamplestrategy", "spatial");
+        desc.light_strategy = ls == "uniform" ? PT_LIGHTS_UNIFORM : (ls == "power" ? PT_LIGHTS_POWER : PT_LIGHTS_SPATIAL);
+        // accelerator (accelerators/bvh/create_bvh_accelerator.rs:13-27)
+        if (accel_name != "bvh") { fail("Accelerator \"" + accel_name + "\": only bvh is on the accelerated path"); return; }
+        std::string sm = accel_params.find_one_string("splitmethod", "sah");
+        desc.split_method = sm == "hlbvh" ? PT_SPLIT_HLBVH : (sm == "middle" ? PT_SPLIT_MIDDLE : (sm == "equal" ? PT_SPLIT_EQUAL_COUNTS : PT_SPLIT_SAH));
+        desc.max_node_prims = accel_params.find_one_int("maxnodeprims", 4);
+        // geometry
+        desc.n_vertices = (uint32_t)(P.size() / 3);
+        desc.P = P.data();
+        desc.N = any_n ? N.data() : nullptr;
+        desc.S = any_s ? S.data() : nullptr;
+        desc.UV = any_uv ? UV.data() : nullptr;
+        desc.n_triangles = (uint32_t)(indices.size() / 3);
+        desc.indices = indices.data();
+        desc.tri_mesh = tri_mesh.data();
+        desc.n_meshes = (uint32_t)meshes.size();
+        desc.meshes = meshes.data();
+        desc.n_materials = (uint32_t)materials.size();
+        desc.materials = materials.data();
+        desc.n_area_lights = (uint32_t)area_lights.size();
+        desc.area_lights = area_lights.data();
+    }
+
+private:
+    std::vector<TransformSet> transforms;
+    std::vector<unsigned> bits;
+    std::vector<GraphicsState> gstates;
+    std::map<std::string, TransformSet> named_cs;
+    std::string filter_name = "box", film_name = "image", sampler_name = "halton", accel_name = "bvh", integrator_name = "path", camera_name = "perspective";
+    ParamSet filter_params, film_params, sampler_params, accel_params, integrator_params, camera_params;
+    bool have_camera = false;
+};
+
+}  // namespace pth
+
+struct pth_scene {
+    pth::GpuSceneContext ctx;
+};
+
+static pt_status finish(pth_scene* s, bool parsed, const std::string& perr, pth_scene** out, char* err, size_t cap) {
+    std::string msg;
+    pt_status st = PT_OK;
+    if (!parsed) { msg = perr; st = PT_ERR_INVALID_ARGUMENT; }
+    else if (!s->ctx.error.empty()) { msg = s->ctx.error; st = PT_ERR_UNSUPPORTED; }
+    else if (!s->ctx.world_ended) { msg = "scene description has no WorldEnd"; st = PT_ERR_INVALID_ARGUMENT; }
+    if (st != PT_OK) {
+        if (err && cap) { std::snprintf(err, cap, "%s", msg.c_str()); }
+        delete s;
+        *out = nullptr;
+        return st;
+    }
+    *out = s;
+    return PT_OK;
+}
+
+extern "C" {
+
+pt_status pth_parse_file(const char* filename, pth_scene** out, char* err, size_t err_cap) {
+    if (!filename || !out) return PT_ERR_INVALID_ARGUMENT;
+    pth_scene* s = new pth_scene;
+    std::string perr;
+    bool ok = pth::pbrt_parse_file(filename, s->ctx, &perr);
+    return finish(s, ok, perr, out, err, err_cap);
+}
+pt_status pth_parse_string(const char* text, const char* work_dir, pth_scene** out, char* err, size_t err_cap) {
+    if (!text || !out) return PT_ERR_INVALID_ARGUMENT;
+    pth_scene* s = new pth_scene;
+    std::string perr;
+    bool ok = pth::pbrt_parse_string(text, work_dir ? work_dir : ".", s->ctx, &perr);
+    return finish(s, ok, perr, out, err, err_cap);
+}
+const pt_scene_desc* pth_scene_get_desc(const pth_scene* s) { return s ? &s->ctx.desc : nullptr; }
+const char* pth_scene_output_filename(const pth_scene* s) { return s ? s->ctx.out_filename.c_str() : ""; }
+void pth_scene_set_pixelsamples(pth_scene* s, int spp) { if (s && spp > 0) s->ctx.desc.spp = spp; }
+const char* pth_scene_warnings(const pth_scene* s) { return s ? s->ctx.warnings.c_str() : ""; }
+void pth_scene_free(pth_scene* s) { delete s; }
+
+pt_status pth_write_pfm(const char* path, const float* rgb, int w, int h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return PT_ERR_INVALID_ARGUMENT;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return PT_ERR_INVALID_ARGUMENT;
+    std::fprintf(f, "PF\n%d %d\n-1.0\n", w, h);                  // little-endian, bottom row first
+    for (int y = h - 1; y >= 0; y--) std::fwrite(rgb + (size_t)y * w * 3, sizeof(float), (size_t)w * 3, f);
+    std::fclose(f);
+    return PT_OK;
+}
+
+}  // extern "C"

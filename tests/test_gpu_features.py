@@ -175,3 +175,25 @@ def test_baseline_size_properties(gpu_ctx, oracle):
     gs, rs = gpu_ctx.radiance_samples(tile), osc.radiance_samples(tile)
     assert np.array_equal(bits(gs), bits(rs))
     osc.close()
+
+
+def test_cli_renders_pbrt_file(oracle, tmp_path):
+    """`pbrt_gpu -i scene.pbrt` (the `pbrt-r3 -i` counterpart): parse -> upload -> render -> PFM,
+    compared with the oracle's render of the same parsed scene."""
+    exe = os.path.join(ROOT, "pbrt-r3_amd", "csrc", "pbrt_gpu")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "pbrt-r3_amd", "csrc"), "pbrt_gpu"])
+    scene = os.path.join(ROOT, "tests", "scenes", "cornell.pbrt")
+    out = tmp_path / "cornell.pfm"
+    r = subprocess.run([exe, "-i", scene, "--outfile", str(out), "--pixelsamples", "8"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    raw = open(out, "rb").read()
+    header, rest = raw.split(b"\n", 3)[:3], raw.split(b"\n", 3)[3]
+    assert header[0] == b"PF" and header[1] == b"64 64"
+    img = np.frombuffer(rest, "<f4").reshape(64, 64, 3)[::-1]
+    ps = pkg.capi.ParsedScene(filename=scene)
+    ps.set_pixelsamples(8)
+    osc = oracle.scene(ps)
+    ox, _, _ = osc.render(threads=8)
+    assert rel_l2(img, osc.resolve_rgb(ox)) <= 1e-3
+    osc.close()

@@ -1,0 +1,165 @@
+"""The .pbrt front end (include/pbrtgpu_host.h): parser known-answer tests restated from the
+reference's own parser tests, and scene-context parity (a .pbrt Cornell box must flatten to a scene
+that renders bit-identically to the programmatic one).  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import bits, pkg, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+capi = pkg.capi
+
+
+def test_host_symbols_exported():
+    lib = capi.load_library()
+    for s in capi.HOST_SYMBOLS:
+        assert hasattr(lib, s), s
+
+
+def test_parse_ops_001():
+    """src/core/parser/parser.rs:757-770."""
+    log = capi.parse_to_log('Integrator "path" \n\n        WorldBegin')
+    assert log[0].startswith('Integrator "path"') and log[1] == "WorldBegin"
+
+
+def test_parse_ops_002():
+    """parser.rs:771-823: argument counts of Translate / Rotate / LookAt / Transform / Texture."""
+    log = capi.parse_to_log('''
+            Translate 0 0 -140
+            Rotate 0 1 2 3
+            LookAt 0 1 2 3 4 5 6 7 8
+
+            Transform [0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15]
+            Texture "a" "b" "c"
+        ''')
+    assert log[0] == "Translate 0 0 -140"
+    assert log[1] == "Rotate 0 1 2 3"
+    assert log[2] == "LookAt 0 1 2 3 4 5 6 7 8"
+    assert log[3] == "Transform [ 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 ]"
+    assert log[4] == 'Texture "a" "b" "c"'
+
+
+def test_parse_ops_003():
+    """parser.rs:825-852 (the killeroo-simple Film line)."""
+    log = capi.parse_to_log('''
+        Film "image" "integer xresolution" [700] "integer yresolution" [700]
+            "string filename" "killeroo-simple.exr"
+        ''')
+    assert log == ['Film "image" "integer xresolution" [ 700 ] "integer yresolution" [ 700 ] "string filename" [ "killeroo-simple.exr" ]']
+
+
+def test_parse_ops_004():
+    """parser.rs:854-910: comments, colour / point / float / integer arrays."""
+    log = capi.parse_to_log('''
+        AttributeBegin # A
+            Material "matte" "color Kd" [.5 .5 .8]
+            Translate 0 0 -140
+            Shape "trianglemesh" "point P" [ -1000 -1000 0 1000 -1000 0 1000 1000 0 -1000 1000 0 ]
+                "float uv" [ 0 0 5 0 5 5 0 5 ]
+                "integer indices" [ 0 1 2 2 3 0]
+            Shape "trianglemesh" "point P" [ -400 -1000 -1000   -400 1000 -1000   -400 1000 1000 -400 -1000 1000 ]
+                "float uv" [ 0 0 5 0 5 5 0 5 ]
+                "integer indices" [ 0 1 2 2 3 0]
+        AttributeEnd
+        ''')
+    assert [l.split()[0] for l in log] == ["AttributeBegin", "Material", "Translate", "Shape", "Shape", "AttributeEnd"]
+    assert log[1] == 'Material "matte" "rgb Kd" [ 0.5 0.5 0.800000012 ]'
+    assert '"point P" [ -1000 -1000 0 1000 -1000 0 1000 1000 0 -1000 1000 0 ]' in log[3]
+    assert '"float uv" [ 0 0 5 0 5 5 0 5 ]' in log[3] and '"integer indices" [ 0 1 2 2 3 0 ]' in log[3]
+
+
+def test_syntax_errors_are_reported():
+    for bad in ('Translate 1 2', 'Shape "trianglemesh" "point P" [ 1 2 3', 'Frobnicate 1', 'Film "image" "quux x" [1]'):
+        with pytest.raises(capi.PtError) as e:
+            capi.parse_to_log(bad)
+        assert e.value.status == 1
+
+
+@pytest.mark.parametrize("text,needle", [
+    ('Sampler "sobol"\nWorldBegin\nShape "sphere" "float radius" 1\nWorldEnd', "sphere"),
+    ('WorldBegin\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "halton"),
+    ('Sampler "sobol"\nWorldBegin\nLightSource "point"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "LightSource"),
+    ('Sampler "sobol"\nWorldBegin\nMaterial "glass"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "glass"),
+])
+def test_out_of_scope_features_fail_loudly(text, needle):
+    """Nothing outside the accelerated path is silently approximated."""
+    with pytest.raises(capi.PtError) as e:
+        capi.ParsedScene(text=text)
+    assert e.value.status == 4 and needle in str(e.value)
+
+
+def test_cornell_pbrt_equals_programmatic_scene(oracle):
+    """tests/scenes/cornell.pbrt through the C++ parser + scene context renders (oracle) to exactly the
+    film of scenes.cornell_box(): transforms, camera, named materials, Include, area lights all agree."""
+    ps = capi.ParsedScene(filename=os.path.join(ROOT, "tests", "scenes", "cornell.pbrt"))
+    assert ps.output_filename == "cornell.exr"
+    d = ps.desc
+    ref = scenes.cornell_box(res=64, spp=16)
+    assert (d.n_triangles, d.xres, d.yres, d.spp, d.max_depth) == (36, 64, 64, 16, 5)
+    assert np.array_equal(bits(list(d.camera_to_world)), bits(list(ref.desc.camera_to_world)))
+    assert np.array_equal(bits(list(d.screen_window)), bits(list(ref.desc.screen_window)))
+    assert np.array_equal(bits(np.ctypeslib.as_array(d.P, (d.n_vertices * 3,))), bits(ref.buffers["P"].reshape(-1)))
+    a = oracle.scene(ps)
+    b = oracle.scene(ref)
+    xa, ca, _ = a.render(threads=4)
+    xb, cb, _ = b.render(threads=4)
+    assert np.array_equal(bits(xa), bits(xb))
+    assert ca["regular_rays"] == cb["regular_rays"] and ca["shadow_rays"] == cb["shadow_rays"]
+    a.close(); b.close()
+
+
+def test_transform_stack_and_overrides(oracle):
+    """CTM products (Translate/Scale/Rotate/ConcatTransform), TransformBegin/End, CoordSysTransform,
+    ReverseOrientation, per-shape material overrides and --pixelsamples."""
+    text = '''
+    LookAt 0 0 -5  0 0 0  0 1 0
+    Camera "perspective" "float fov" 45
+    Film "image" "integer xresolution" 24 "integer yresolution" 16 "float cropwindow" [0.1 0.9 0 1]
+    Sampler "sobol" "integer pixelsamples" 4
+    PixelFilter "gaussian" "float xwidth" 1.5 "float ywidth" 1.5
+    WorldBegin
+      CoordinateSystem "base"
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [4 4 4] "bool twosided" "true"
+        Translate 0 1.9 0
+        Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 0 -1  1 0 -1  1 0 1  -1 0 1]
+      AttributeEnd
+      AttributeBegin
+        Material "matte" "rgb Kd" [0.2 0.2 0.2]
+        Scale 2 1 2
+        Rotate 30 0 1 0
+        TransformBegin
+          ConcatTransform [1 0 0 0  0 1 0 0  0 0 1 0  0 -2 0 1]
+          Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 0 -1  -1 0 1  1 0 1  1 0 -1] "rgb Kd" [0.8 0.3 0.1] "float sigma" 20
+        TransformEnd
+        ReverseOrientation
+        Scale -1 1 1
+        Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 -1 0.5  1 0 0.5  -1 0 0.5] "bool twosided" "false"
+        CoordSysTransform "base"
+        Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 -1.5 2  1.5 0.5 2  -1.5 0.5 2]
+      AttributeEnd
+    WorldEnd
+    '''
+    ps = capi.ParsedScene(text=text)
+    d = ps.desc
+    assert d.n_triangles == 6 and d.n_meshes == 4
+    m = [d.meshes[i] for i in range(4)]
+    assert m[0].area_light == 0 and m[1].area_light == -1
+    assert d.materials[m[1].material].sigma == 20.0 and abs(d.materials[m[1].material].kd[0] - 0.8) < 1e-6      # shape overrides
+    assert abs(d.materials[m[2].material].kd[0] - 0.2) < 1e-6
+    f2 = m[2].flags
+    assert (f2 & capi.PT_MESH_REVERSE_ORIENTATION) and (f2 & capi.PT_MESH_SWAPS_HANDEDNESS) and not (f2 & capi.PT_MESH_TWO_SIDED)
+    assert not (m[3].flags & capi.PT_MESH_SWAPS_HANDEDNESS)                 # CoordSysTransform restored the base CTM
+    P = np.ctypeslib.as_array(d.P, (d.n_vertices * 3,)).reshape(-1, 3)
+    assert np.allclose(P[:4, 1], 1.9)                                          # Translate
+    assert np.allclose(P[4:8, 1], -2.0) and np.abs(P[4:8, 0]).max() > 1.5     # ConcatTransform after Scale * Rotate
+    assert np.allclose(P[-3:], [[0, -1.5, 2], [1.5, 0.5, 2], [-1.5, 0.5, 2]])
+    sc = oracle.scene(ps)
+    x, _, _ = sc.render(threads=2)
+    assert x.shape[:2] == (16, 20) and np.isfinite(x).all() and x[..., :3].max() > 0
+    ps.set_pixelsamples(8)
+    sc2 = oracle.scene(ps)
+    assert sc2.info.spp == 8
+    sc.close(); sc2.close()
