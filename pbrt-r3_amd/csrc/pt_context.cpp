@@ -10,6 +10,8 @@
 // counter read at its end.  There is no CPU rendering path in this library.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -204,8 +206,17 @@ pt_status pt_context_create(int device, pt_context** out) {
     ctx->grid_shade = ctx->n_cu * 2;
     if (const char* e = std::getenv("PBRTGPU_SHADE_BLOCKS_PER_CU")) ctx->grid_shade = ctx->n_cu * std::max(1, std::atoi(e));
     ctx->grid_wide = ctx->n_cu * 8;
+    // Sobol' tables: $PBRTGPU_DATA_DIR, else <directory of this shared library>/../data
     const char* dd = std::getenv("PBRTGPU_DATA_DIR");
     if (dd) ctx->data_dir = dd;
+    else {
+        Dl_info di;
+        if (dladdr((const void*)&pt_abi_version, &di) && di.dli_fname) {
+            std::string so = di.dli_fname;
+            size_t slash = so.find_last_of('/');
+            ctx->data_dir = (slash == std::string::npos ? std::string(".") : so.substr(0, slash)) + "/../data";
+        }
+    }
     *out = ctx;
     return PT_OK;
 }
