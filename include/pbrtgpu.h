@@ -93,7 +93,10 @@ typedef struct {
 } pt_mesh;
 
 typedef enum { PT_SPLIT_SAH = 0, PT_SPLIT_HLBVH = 1, PT_SPLIT_MIDDLE = 2, PT_SPLIT_EQUAL_COUNTS = 3 } pt_split_method;
-typedef enum { PT_SAMPLER_SOBOL = 0 } pt_sampler_type;
+typedef enum {
+    PT_SAMPLER_SOBOL = 0,   /* samplers/sobol.rs */
+    PT_SAMPLER_HALTON = 1   /* samplers/halton.rs (the reference's default sampler) */
+} pt_sampler_type;
 typedef enum { PT_LIGHTS_UNIFORM = 0, PT_LIGHTS_POWER = 1, PT_LIGHTS_SPATIAL = 2 } pt_light_strategy;
 
 typedef struct {
@@ -135,10 +138,12 @@ typedef struct {
 
     /* ---- sampler / integrator (samplers/sobol.rs:16-31, integrators/path.rs:252-271) */
     int32_t sampler;            /* pt_sampler_type */
-    int32_t spp;                /* "pixelsamples"; Sobol rounds up to a power of two */
+    int32_t spp;                /* "pixelsamples"; Sobol' rounds up to a power of two, Halton takes it as given */
     int32_t max_depth;          /* default 5 */
     float rr_threshold;         /* default 1 */
     int32_t light_strategy;     /* pt_light_strategy, default spatial */
+    int32_t halton_sample_at_center;  /* Halton "samplepixelcenter", default 0 */
+    int32_t reserved[3];
 } pt_scene_desc;
 
 /* Axis-aligned block of film *sample* pixels, half-open: the unit the reference

@@ -107,7 +107,7 @@ void orc_trace_exhaustive(const orc_scene* s, uint32_t n, const float* o, const 
 
 void orc_generate_camera_rays(const orc_scene* s, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* out_o, float* out_d, float* out_pfilm) {
     SobolSampler sm;
-    sm.init(&s->sc.sobol, (uint32_t)s->sc.spp, s->sc.sample_bounds);
+    s->sc.init_sampler(sm);
     for (uint32_t i = 0; i < n; i++) {
         sm.start_pixel(pixel_xy[2 * i], pixel_xy[2 * i + 1]);
         sm.set_sample_number(sample_index[i]);
@@ -123,7 +123,7 @@ void orc_generate_camera_rays(const orc_scene* s, uint32_t n, const int32_t* pix
 }
 void orc_sobol_samples(const orc_scene* s, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim, float* out) {
     SobolSampler sm;
-    sm.init(&s->sc.sobol, (uint32_t)s->sc.spp, s->sc.sample_bounds);
+    s->sc.init_sampler(sm);
     for (uint32_t i = 0; i < n; i++) {
         sm.start_pixel(pixel_xy[2 * i], pixel_xy[2 * i + 1]);
         sm.set_sample_number(sample_index[i]);
@@ -186,4 +186,31 @@ extern "C" uint32_t orc_sobol_pixel_first2d(uint32_t spp, const int32_t bounds[4
         n++;
     } while (sm.start_next_sample());
     return n;
+}
+
+// Standalone HaltonSampler walk: every sample's first get_2d() of one pixel (tests/sampling.rs style checks)
+extern "C" uint32_t orc_halton_pixel_first2d(uint32_t spp, const int32_t bounds[4], int32_t px, int32_t py, float* out_xy) {
+    SobolSampler sm;
+    sm.init_halton(spp, bounds, false);
+    sm.start_pixel(px, py);
+    uint32_t n = 0;
+    do {
+        V2 u = sm.get_2d();
+        out_xy[2 * n] = u.x; out_xy[2 * n + 1] = u.y;
+        n++;
+    } while (sm.start_next_sample());
+    return n;
+}
+// scrambled radical inverse with a caller-supplied permutation (tests/sampling.rs:24-64)
+extern "C" float orc_scrambled_radical_inverse(uint32_t base, const uint16_t* perm, uint64_t a) { return scrambled_radical_inverse(base, perm, a); }
+extern "C" float orc_halton_dimension(uint32_t dim, uint64_t index) {
+    const HaltonTables& H = HaltonTables::get();
+    return scrambled_radical_inverse(H.primes[dim], &H.perms[H.prime_sums[dim]], index);
+}
+extern "C" uint64_t orc_prime(uint32_t i) { return HaltonTables::get().primes[i]; }
+extern "C" int64_t orc_halton_index(const int32_t bounds[4], int32_t px, int32_t py, int64_t sample_num) {
+    SobolSampler sm;
+    sm.init_halton(1, bounds, false);
+    sm.pixel[0] = px; sm.pixel[1] = py;
+    return sm.get_index_for_sample(sample_num);
 }

@@ -185,6 +185,12 @@ struct Scene {
     // sampler / integrator
     SobolTables sobol;
     int32_t spp = 1, max_depth = 5, light_strategy = PT_LIGHTS_SPATIAL;
+    int32_t sampler_kind = PT_SAMPLER_SOBOL;
+    bool halton_at_center = false;
+    void init_sampler(SobolSampler& sm) const {
+        if (sampler_kind == PT_SAMPLER_HALTON) sm.init_halton((uint32_t)spp, sample_bounds, halton_at_center);
+        else sm.init(&sobol, (uint32_t)spp, sample_bounds);
+    }
     Float rr_threshold = 1.0f;
 
     bool build(const pt_scene_desc& d, const std::string& data_dir, std::string* err);
@@ -606,7 +612,7 @@ struct Film {
 // non-null it receives validate(L) per (pixel, sample), pixel-major.
 inline void render_tile(const Scene& sc, LightDistribution& ldist, const int32_t tb[4], Film* film, Float* radiance_out, RayCounters& rc) {
     SobolSampler sampler;
-    sampler.init(&sc.sobol, (uint32_t)sc.spp, sc.sample_bounds);
+    sc.init_sampler(sampler);
     FilmTile tile(&sc, tb);
     size_t k = 0;
     for (int32_t yy = tb[1]; yy < tb[3]; yy++)
@@ -727,7 +733,10 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
     std::memcpy(camera_to_world.m, d.camera_to_world, sizeof(camera_to_world.m));
     lens_radius = d.lens_radius; focal_distance = d.focal_distance;
     shutter_open = d.shutter_open; shutter_close = d.shutter_close;
-    spp = (int32_t)round_up_pow2((uint32_t)std::max(1, d.spp));
+    sampler_kind = d.sampler;
+    halton_at_center = d.halton_sample_at_center != 0;
+    // Sobol' rounds the sample count up to a power of two (sobol.rs:23); Halton takes it as given
+    spp = sampler_kind == PT_SAMPLER_HALTON ? std::max(1, d.spp) : (int32_t)round_up_pow2((uint32_t)std::max(1, d.spp));
     max_depth = d.max_depth; rr_threshold = d.rr_threshold; light_strategy = d.light_strategy;
     return true;
 }

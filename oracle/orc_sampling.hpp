@@ -5,6 +5,7 @@
 //           src/core/sampling/{sampling,distribution}.rs
 #pragma once
 #include "orc_math.hpp"
+#include <algorithm>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -76,6 +77,75 @@ inline Float radical_inverse(uint32_t base_index, uint64_t a) {
     return radical_inverse_specialized(primes[base_index], a);
 }
 
+// ---- Halton machinery (core/lowdiscrepancy/radical_inverse.rs:60-109, primes.rs, sampling.rs:4-15)
+struct HaltonTables {
+    std::vector<uint64_t> primes;        // PRIMES: the first 1000 primes (primes.rs:1)
+    std::vector<uint64_t> prime_sums;    // prefix sums (primes.rs:68 PRIME_SUMS)
+    std::vector<uint16_t> perms;         // compute_radical_inverse_permutations with the default-state RNG (halton.rs:12-20)
+    HaltonTables() {
+        std::vector<bool> comp(8200, false);
+        for (uint64_t i = 2; primes.size() < 1000; i++) {
+            if (comp[i]) continue;
+            primes.push_back(i);
+            for (uint64_t j = i * i; j < comp.size(); j += i) comp[j] = true;
+        }
+        prime_sums.resize(primes.size() + 1, 0);
+        for (size_t i = 0; i < primes.size(); i++) prime_sums[i + 1] = prime_sums[i] + primes[i];
+        perms.resize(prime_sums.back());
+        RNG rng;
+        size_t offset = 0;
+        for (size_t i = 0; i < primes.size(); i++) {
+            size_t len = primes[i];
+            for (size_t j = 0; j < len; j++) perms[offset + j] = (uint16_t)j;
+            // shuffle_array(&mut perms[offset..], len, 1, rng)
+            for (size_t j = 0; j < len; j++) {
+                size_t other = j + rng.uniform_uint32_threshold((uint32_t)(len - j));
+                std::swap(perms[offset + j], perms[offset + other]);
+            }
+            offset += len;
+        }
+    }
+    static const HaltonTables& get() { static HaltonTables t; return t; }
+};
+inline uint64_t inverse_radical_inverse(uint64_t base, uint64_t inverse, size_t ndigits) {
+    uint64_t index = 0;
+    for (size_t i = 0; i < ndigits; i++) {
+        uint64_t digit = inverse % base;
+        inverse /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+inline Float scrambled_radical_inverse(uint64_t base, const uint16_t* perm, uint64_t a) {
+    Float inv_base = 1.0f / (Float)base;
+    uint64_t reverse_digits = 0;
+    Float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = a / base;
+        uint64_t digit = a - next * base;
+        reverse_digits = reverse_digits * base + perm[digit];
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return fmin_(inv_base_n * ((Float)reverse_digits + inv_base * (Float)perm[0] / (1.0f - inv_base)), kOneMinusEpsilon);
+}
+inline uint64_t math_mod(int64_t a, int64_t b) {     // halton.rs:22-29
+    int64_t result = a - (a / b) * b;
+    return result < 0 ? (uint64_t)(result + b) : (uint64_t)result;
+}
+inline void extended_gcd(uint64_t a, uint64_t b, int64_t* x, int64_t* y) {   // halton.rs:31-38
+    if (b == 0) { *x = 1; *y = 0; return; }
+    int64_t d = (int64_t)(a / b), xp, yp;
+    extended_gcd(b, a % b, &xp, &yp);
+    *x = yp;
+    *y = xp - (d * yp);
+}
+inline uint64_t multiplicative_inverse(int64_t a, int64_t n) {
+    int64_t x, y;
+    extended_gcd((uint64_t)a, (uint64_t)n, &x, &y);
+    return math_mod(x, n);
+}
+
 // ---- Sobol' tables (data file written by tools/extract_sobol_tables.py)
 struct SobolTables {
     uint32_t n_dims = 0, msize = 0, n_vdc = 0, n_inv = 0;
@@ -138,6 +208,11 @@ inline uint32_t log2int(uint32_t v) { return 31 - (uint32_t)__builtin_clz(v); }
 // samplers/sobol.rs:7-190 with core/sampler/global_sampler.rs (no sample arrays are
 // requested by PathIntegrator, so array_end_dim == array_start_dim == 5).
 struct SobolSampler {
+    // kind 0: SobolSampler (samplers/sobol.rs); kind 1: HaltonSampler (samplers/halton.rs:46-273, with the
+    // per-pixel offset evaluated as the pure function it is meant to be -- quirk Q9)
+    int kind = 0;
+    int32_t base_scales[2] = {1, 1}, base_exponents[2] = {0, 0}, sample_stride = 1, mult_inverse[2] = {0, 0};
+    bool sample_at_center = false;
     const SobolTables* T = nullptr;
     int32_t bmin[2] = {0, 0}, bmax[2] = {0, 0};
     uint32_t resolution = 0, log2_resolution = 0, spp = 0;
@@ -148,7 +223,25 @@ struct SobolSampler {
     static const uint32_t array_start_dim = 5;
     uint32_t array_end_dim = 5;
 
+    void init_halton(uint32_t samples_per_pixel, const int32_t sb[4], bool at_center) {   // halton.rs:57-112
+        kind = 1;
+        bmin[0] = sb[0]; bmin[1] = sb[1]; bmax[0] = sb[2]; bmax[1] = sb[3];
+        spp = samples_per_pixel;
+        sample_at_center = at_center;
+        const int32_t res[2] = {bmax[0] - bmin[0], bmax[1] - bmin[1]};
+        const int32_t bases[2] = {2, 3};
+        for (int i = 0; i < 2; i++) {
+            int32_t scale = 1, exp = 0;
+            while (scale < std::min(res[i], 128)) { scale *= bases[i]; exp += 1; }
+            base_scales[i] = scale;
+            base_exponents[i] = exp;
+        }
+        sample_stride = base_scales[0] * base_scales[1];
+        mult_inverse[0] = (int32_t)multiplicative_inverse(base_scales[1], base_scales[0]);
+        mult_inverse[1] = (int32_t)multiplicative_inverse(base_scales[0], base_scales[1]);
+    }
     void init(const SobolTables* t, uint32_t samples_per_pixel, const int32_t sb[4]) {
+        kind = 0;
         T = t;
         bmin[0] = sb[0]; bmin[1] = sb[1]; bmax[0] = sb[2]; bmax[1] = sb[3];
         uint32_t dx = (uint32_t)(bmax[0] - bmin[0]), dy = (uint32_t)(bmax[1] - bmin[1]);
@@ -157,9 +250,29 @@ struct SobolSampler {
         spp = round_up_pow2(samples_per_pixel);
     }
     int64_t get_index_for_sample(int64_t sample_num) const {
+        if (kind == 1) {                              // halton.rs:115-147
+            int64_t offset = 0;
+            if (sample_stride > 1) {
+                const uint64_t pm[2] = {math_mod(pixel[0], 128), math_mod(pixel[1], 128)};
+                const uint64_t bases[2] = {2, 3};
+                for (int i = 0; i < 2; i++) {
+                    uint64_t dim_offset = inverse_radical_inverse(bases[i], pm[i], (size_t)base_exponents[i]);
+                    offset += (int64_t)(dim_offset * (uint64_t)((sample_stride / base_scales[i]) * mult_inverse[i]));
+                }
+                offset %= sample_stride;
+            }
+            return offset + sample_num * sample_stride;
+        }
         return (int64_t)sobol_interval_to_index(*T, log2_resolution, (uint64_t)sample_num, pixel[0] - bmin[0], pixel[1] - bmin[1]);
     }
     Float sample_dimension(int64_t index, uint32_t dim) const {
+        if (kind == 1) {                              // halton.rs:149-162
+            if (sample_at_center && (dim == 0 || dim == 1)) return 0.5f;
+            if (dim == 0) return radical_inverse(0, (uint64_t)(index >> base_exponents[0]));
+            if (dim == 1) return radical_inverse(1, (uint64_t)(index / base_scales[1]));
+            const HaltonTables& H = HaltonTables::get();
+            return scrambled_radical_inverse(H.primes[dim], &H.perms[H.prime_sums[dim]], (uint64_t)index);
+        }
         Float s = sobol_sample_float(*T, index, dim, 0);
         if (dim == 0 || dim == 1) {
             s = s * (Float)resolution + (Float)bmin[dim];

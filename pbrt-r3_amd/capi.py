@@ -16,6 +16,7 @@ PT_MESH_TWO_SIDED, PT_MESH_REVERSE_ORIENTATION, PT_MESH_SWAPS_HANDEDNESS = 1, 2,
 PT_MESH_HAS_N, PT_MESH_HAS_S, PT_MESH_HAS_UV = 8, 16, 32
 PT_SPLIT_SAH, PT_SPLIT_HLBVH, PT_SPLIT_MIDDLE, PT_SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
 PT_LIGHTS_UNIFORM, PT_LIGHTS_POWER, PT_LIGHTS_SPATIAL = 0, 1, 2
+PT_SAMPLER_SOBOL, PT_SAMPLER_HALTON = 0, 1
 
 STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID_ARGUMENT", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR_DEVICE",
                 4: "PT_ERR_UNSUPPORTED", 5: "PT_ERR_NO_SCENE", 6: "PT_ERR_OUT_OF_MEMORY"}
@@ -56,6 +57,7 @@ class pt_scene_desc(C.Structure):
         ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
         ("sampler", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
         ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
+        ("halton_sample_at_center", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 

@@ -435,11 +435,15 @@ public:
         float halffov = camera_params.find_one_float("halffov", -1.0f);
         if (halffov > 0.0f) desc.fov = 2.0f * halffov;
         // sampler (render_options.rs:71: the default is halton)
-        if (sampler_name != "sobol") {
-            fail("Sampler \"" + sampler_name + "\": only \"sobol\" is reproducible on a wavefront (the reference's default, halton, is not restated yet)");
+        if (sampler_name == "sobol") {
+            desc.sampler = PT_SAMPLER_SOBOL;
+        } else if (sampler_name == "halton") {          // samplers/halton.rs:275-299
+            desc.sampler = PT_SAMPLER_HALTON;
+            desc.halton_sample_at_center = sampler_params.find_one_bool("samplepixelcenter", false) ? 1 : 0;
+        } else {
+            fail("Sampler \"" + sampler_name + "\": only the index-addressed samplers (halton, sobol) are reproducible on a wavefront");
             return;
         }
-        desc.sampler = PT_SAMPLER_SOBOL;
         desc.spp = sampler_params.find_one_int("pixelsamples", 16);
         // integrator (integrators/path.rs:252-271)
         if (integrator_name != "path") { fail("Integrator \"" + integrator_name + "\": only path is on the accelerated path"); return; }

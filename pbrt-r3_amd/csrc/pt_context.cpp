@@ -60,7 +60,7 @@ struct pt_context {
     bool have_scene = false;
     PtScene sc;
     pt_scene_info info;
-    DevBuf d_nodes, d_tris, d_tri_info, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab;
+    DevBuf d_nodes, d_tris, d_tri_info, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab, d_hdims, d_hperms;
     std::vector<uint32_t> sobol_m32;
     std::vector<uint64_t> sobol_vdc, sobol_inv;
     uint32_t sobol_n_vdc = 0, sobol_n_inv = 0, sobol_msize = 52;
@@ -238,6 +238,82 @@ pt_status pt_set_data_dir(pt_context* ctx, const char* dir) {
     return PT_OK;
 }
 
+namespace {
+// PCG32 with the reference's default state (core/rng.rs:8-67) -- only the bounded draw that
+// shuffle_array (core/sampling/sampling.rs:4-15) needs
+struct Pcg32 {
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    uint32_t next() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27), rot = (uint32_t)(old >> 59);
+        return (xs >> rot) | (xs << ((32u - rot) & 31u));
+    }
+    uint32_t below(uint32_t b) {
+        uint32_t threshold = (0u - b) % b;
+        for (;;) {
+            uint32_t r = next();
+            if (r >= threshold) return r % b;
+        }
+    }
+};
+int64_t floor_mod(int64_t a, int64_t b) { int64_t r = a % b; return r < 0 ? r + b : r; }
+// x with a*x = 1 (mod n), by the extended Euclid recursion of halton.rs:31-44
+int64_t mod_inverse(int64_t a, int64_t n) {
+    int64_t r0 = a, r1 = n, x0 = 1, x1 = 0;
+    while (r1 != 0) {
+        int64_t q = r0 / r1, t = r0 - q * r1;
+        r0 = r1; r1 = t;
+        t = x0 - q * x1;
+        x0 = x1; x1 = t;
+    }
+    return floor_mod(x0, n);
+}
+// HaltonSampler::new (samplers/halton.rs:57-112) + compute_radical_inverse_permutations (:12-20)
+pt_status setup_halton(pt_context* ctx, PtSobol& sb, int32_t res_x, int32_t res_y, bool at_center) {
+    constexpr uint32_t kDims = 1000;          // PRIMES / PRIME_SUMS hold 1000 entries (primes.rs)
+    if (!ctx->d_hdims.p) {
+        std::vector<uint32_t> primes;
+        std::vector<uint8_t> composite(8000, 0);
+        for (uint32_t i = 2; primes.size() < kDims; i++) {
+            if (composite[i]) continue;
+            primes.push_back(i);
+            for (uint32_t j = i * i; j < composite.size(); j += i) composite[j] = 1;
+        }
+        std::vector<uint32_t> dims(4 * (size_t)kDims);
+        std::vector<uint16_t> perms;
+        Pcg32 rng;
+        for (uint32_t i = 0; i < kDims; i++) {
+            const uint32_t p = primes[i], off = (uint32_t)perms.size();
+            for (uint32_t j = 0; j < p; j++) perms.push_back((uint16_t)j);
+            for (uint32_t j = 0; j < p; j++) std::swap(perms[off + j], perms[off + j + rng.below(p - j)]);
+            const uint64_t magic = ~0ull / p + 1;           // floor(2^64 / p) + 1 for p not a power of two; p = 2 is never divided this way
+            dims[4 * i] = p; dims[4 * i + 1] = off; dims[4 * i + 2] = (uint32_t)magic; dims[4 * i + 3] = (uint32_t)(magic >> 32);
+        }
+        pt_status st;
+        if ((st = upload(ctx, ctx->d_hdims, dims.data(), dims.size())) != PT_OK) return st;
+        if ((st = upload(ctx, ctx->d_hperms, perms.data(), perms.size())) != PT_OK) return st;
+    }
+    sb.h_dims = ctx->d_hdims.as<uint4>();
+    sb.h_perms = ctx->d_hperms.as<uint16_t>();
+    sb.h_n_dims = kDims;
+    sb.h_center = at_center ? 1u : 0u;
+    const int32_t res[2] = {res_x, res_y}, bases[2] = {2, 3};
+    int32_t scale[2], exp[2];
+    for (int i = 0; i < 2; i++) {
+        scale[i] = 1; exp[i] = 0;
+        while (scale[i] < std::min(res[i], 128)) { scale[i] *= bases[i]; exp[i]++; }
+    }
+    const int32_t stride = scale[0] * scale[1];
+    sb.h_exp[0] = (uint32_t)exp[0]; sb.h_exp[1] = (uint32_t)exp[1];
+    sb.h_scale1 = (uint32_t)scale[1];
+    sb.h_stride = (uint32_t)stride;
+    sb.h_mul[0] = (uint32_t)((stride / scale[0]) * (int32_t)mod_inverse(scale[1], scale[0]));
+    sb.h_mul[1] = (uint32_t)((stride / scale[1]) * (int32_t)mod_inverse(scale[0], scale[1]));
+    return PT_OK;
+}
+}  // namespace
+
 pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (!ctx || !d) return PT_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(ctx->device);
@@ -245,7 +321,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     // ---- validation (the kernels index these arrays unchecked)
     if (d->n_triangles == 0 || !d->P || !d->indices || !d->tri_mesh || !d->meshes) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no triangles");
     if (d->xres <= 0 || d->yres <= 0 || d->spp <= 0 || d->max_depth < 0 || d->max_depth > 250) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "bad film / sampler / integrator parameters");
-    if (d->sampler != PT_SAMPLER_SOBOL) return ctx->fail(PT_ERR_UNSUPPORTED, "only the Sobol' sampler is reproducible on a wavefront (SURVEY.md section 2, row 8)");
+    if (d->sampler != PT_SAMPLER_SOBOL && d->sampler != PT_SAMPLER_HALTON)
+        return ctx->fail(PT_ERR_UNSUPPORTED, "sampler not on the accelerated path: only the index-addressed samplers (sobol, halton) are reproducible on a wavefront");
     if (d->n_triangles >= 0x7fffffffu) return ctx->fail(PT_ERR_UNSUPPORTED, "too many triangles");
     for (uint32_t t = 0; t < d->n_triangles; t++) {
         for (int k = 0; k < 3; k++)
@@ -395,7 +472,13 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     PtSobol& sb = sc.sobol;
     sb.resolution = round_up_pow2(std::max(sbw, sbh));
     sb.log2_resolution = log2int(sb.resolution);
-    sb.spp = round_up_pow2((uint32_t)d->spp);
+    sb.kind = (uint32_t)d->sampler;
+    sb.spp = sb.kind == PT_SAMPLER_HALTON ? (uint32_t)d->spp : round_up_pow2((uint32_t)d->spp);
+    if (sb.kind == PT_SAMPLER_HALTON) {
+        if ((st = setup_halton(ctx, sb, (int32_t)sbw, (int32_t)sbh, d->halton_sample_at_center != 0)) != PT_OK) return st;
+        sb.resolution = 1;
+        sb.log2_resolution = 0;      // the Sobol' index tables are not consulted
+    }
     if (sb.log2_resolution > 0 && (sb.log2_resolution - 1 >= ctx->sobol_n_vdc || sb.log2_resolution - 1 >= ctx->sobol_n_inv))
         return ctx->fail(PT_ERR_UNSUPPORTED, "film resolution beyond the VdC Sobol' tables");
     if ((st = upload(ctx, ctx->d_m32, ctx->sobol_m32.data(), ctx->sobol_m32.size())) != PT_OK) return st;

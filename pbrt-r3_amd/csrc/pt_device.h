@@ -98,7 +98,18 @@ struct PtSobol {
     uint32_t pad;
     uint32_t log2_resolution;
     uint32_t resolution;
-    uint32_t spp;                // rounded up to a power of two
+    uint32_t spp;                // Sobol': rounded up to a power of two; Halton: as given
+    // ---- HaltonSampler (samplers/halton.rs:46-162); kind selects the sampler
+    uint32_t kind;               // PT_SAMPLER_SOBOL / PT_SAMPLER_HALTON
+    uint32_t h_center;           // "samplepixelcenter"
+    uint32_t h_exp[2];           // base_exponents
+    uint32_t h_scale1;           // base_scales[1]
+    uint32_t h_stride;           // sample_stride
+    uint32_t h_mul[2];           // (sample_stride / base_scales[i]) * mult_inverse[i]
+    const uint4* h_dims;         // per dimension: {prime, offset into perms, magic lo, magic hi}; magic = floor(2^64/prime)+1
+    const uint16_t* h_perms;     // radical-inverse digit permutations (halton.rs:12-20)
+    uint32_t h_n_dims;
+    uint32_t pad2;
 };
 
 struct PtLightGrid {

@@ -11,7 +11,8 @@
 //   traversal  src/accelerators/bvh/accel/qbvh/qbvh_x86.rs:26-67, :230-343
 //   triangle   src/shapes/triangle.rs:226-577
 //   shading    src/integrators/path.rs:61-241, src/core/integrator/sample_lights.rs:129-176,:330-453
-//   sampler    src/samplers/sobol.rs, src/core/lowdiscrepancy/sobol/sobol.rs:5-56
+//   sampler    src/samplers/sobol.rs, src/core/lowdiscrepancy/sobol/sobol.rs:5-56,
+//              src/samplers/halton.rs, src/core/lowdiscrepancy/radical_inverse.rs
 //   camera     src/cameras/perspective.rs:121-183, src/core/transform/transform.rs:184-282
 //   film       src/core/film/film_tile.rs:84-183, film.rs:219-241, :440-484
 #include <hip/hip_runtime.h>
@@ -63,8 +64,64 @@ PT_DEV float sobol_sample_float(const PtSobol& sb, uint64_t a, uint32_t dim) {
     float fv = (float)((double)v * 2.3283064365386963e-10);
     return fminf(fv, PT_ONE_MINUS_EPS);
 }
+// ============================================================ Halton sampler (samplers/halton.rs)
+// a / base for a < 2^32 is mulhi(a, floor(2^64/base)+1) exactly (Lemire & Kaser, "Faster remainder by
+// direct computation", theorem 1 with N = 32); larger indices take the 64-bit division.
+PT_DEV uint64_t div_small(uint64_t a, uint32_t base, uint64_t magic) { return (a >> 32) == 0 ? __umul64hi(a, magic) : a / base; }
+// scrambled_radical_inverse (radical_inverse.rs:83-109); perm == nullptr is radical_inverse_specialized (:36-48)
+PT_DEV float halton_radical_inverse(uint32_t base, uint64_t magic, const uint16_t* perm, uint64_t a) {
+    const float inv_base = 1.0f / (float)base;
+    uint64_t rev = 0;
+    float inv_base_n = 1.0f;
+    while (a != 0) {
+        uint64_t next = div_small(a, base, magic);
+        uint32_t digit = (uint32_t)(a - next * base);
+        rev = rev * base + (perm ? (uint32_t)perm[digit] : digit);
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    if (!perm) return fminf((float)rev * inv_base_n, PT_ONE_MINUS_EPS);
+    return fminf(inv_base_n * ((float)rev + inv_base * (float)perm[0] / (1.0f - inv_base)), PT_ONE_MINUS_EPS);
+}
+// HaltonSampler::get_index_for_sample (halton.rs:115-147), evaluated per path instead of cached per pixel
+PT_DEV uint64_t halton_index_for_sample(const PtSobol& sb, uint64_t sample_num, int32_t px, int32_t py) {
+    uint64_t offset = 0;
+    if (sb.h_stride > 1) {
+        const int32_t pix[2] = {px, py};
+        const uint32_t bases[2] = {2u, 3u};
+        for (int i = 0; i < 2; i++) {
+            int32_t r = pix[i] % 128;
+            uint32_t inv = (uint32_t)(r < 0 ? r + 128 : r);       // math_mod (halton.rs:22-29)
+            uint32_t dim_offset = 0;                                // inverse_radical_inverse (radical_inverse.rs:69-81)
+            for (uint32_t k = 0; k < sb.h_exp[i]; k++) {
+                uint32_t digit = inv % bases[i];
+                inv /= bases[i];
+                dim_offset = dim_offset * bases[i] + digit;
+            }
+            offset += (uint64_t)dim_offset * sb.h_mul[i];
+        }
+        offset %= sb.h_stride;
+    }
+    return offset + sample_num * sb.h_stride;
+}
+PT_DEV float halton_sample_dimension(const PtSobol& sb, uint64_t index, uint32_t dim) {   // halton.rs:149-162
+    if (dim < 2) {
+        if (sb.h_center) return 0.5f;
+        if (dim == 0) return (float)__brevll(index >> sb.h_exp[0]) * 5.4210108624275222e-20f;
+        return halton_radical_inverse(3u, 0x5555555555555556ull, nullptr, index / sb.h_scale1);
+    }
+    if (dim >= sb.h_n_dims) dim = sb.h_n_dims - 1;   // the reference indexes PRIMES out of bounds here (panic)
+    uint4 e = sb.h_dims[dim];
+    return halton_radical_inverse(e.x, (uint64_t)e.z | ((uint64_t)e.w << 32), sb.h_perms + e.y, index);
+}
+// GlobalSampler::get_index_for_sample for the scene's sampler; (px, py) is the absolute pixel
+PT_DEV uint64_t sampler_index(const PtScene& sc, uint64_t sample_num, int32_t px, int32_t py) {
+    if (sc.sobol.kind == PT_SAMPLER_HALTON) return halton_index_for_sample(sc.sobol, sample_num, px, py);
+    return sobol_interval_to_index(sc.sobol, sample_num, px - sc.film.sample_bounds[0], py - sc.film.sample_bounds[1]);
+}
 // SobolSampler::sample_dimension (samplers/sobol.rs:167-185)
 PT_DEV float sample_dimension(const PtScene& sc, uint64_t index, uint32_t dim, int32_t px, int32_t py) {
+    if (sc.sobol.kind == PT_SAMPLER_HALTON) return halton_sample_dimension(sc.sobol, index, dim);
     float s = sobol_sample_float(sc.sobol, index, dim);
     if (dim == 0 || dim == 1) {
         int32_t bmin = sc.film.sample_bounds[dim];
@@ -622,7 +679,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_gen(PtScene sc, PtPaths
         int32_t rx = (int32_t)(pk & 0xffffu), ry = (int32_t)(pk >> 16);
         int32_t px = rx + sc.film.sample_bounds[0], py = ry + sc.film.sample_bounds[1];
         Sampler sm;
-        sm.index = sobol_interval_to_index(sc.sobol, s, rx, ry);
+        sm.index = sampler_index(sc, s, px, py);
         sm.dim = 0; sm.px = px; sm.py = py;
         V2 uf = sm.get_2d(sc);
         V2 p_film = mk2((float)px + uf.x, (float)py + uf.y);
@@ -1266,7 +1323,7 @@ extern "C" __global__ void k_camera_rays(PtScene sc, uint32_t n, const int32_t* 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int32_t px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
         Sampler sm;
-        sm.index = sobol_interval_to_index(sc.sobol, sample_index[i], px - sc.film.sample_bounds[0], py - sc.film.sample_bounds[1]);
+        sm.index = sampler_index(sc, sample_index[i], px, py);
         sm.dim = 0; sm.px = px; sm.py = py;
         V2 uf = sm.get_2d(sc);
         V2 pf = mk2((float)px + uf.x, (float)py + uf.y);
@@ -1281,7 +1338,7 @@ extern "C" __global__ void k_camera_rays(PtScene sc, uint32_t n, const int32_t* 
 extern "C" __global__ void k_sobol_samples(PtScene sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim, float* out) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int32_t px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
-        uint64_t idx = sobol_interval_to_index(sc.sobol, sample_index[i], px - sc.film.sample_bounds[0], py - sc.film.sample_bounds[1]);
+        uint64_t idx = sampler_index(sc, sample_index[i], px, py);
         out[i] = sample_dimension(sc, idx, dim[i], px, py);
     }
 }

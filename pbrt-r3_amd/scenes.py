@@ -237,7 +237,11 @@ class SceneBuilder:
         self._filter_table((xwidth, ywidth), lambda x, y: f32(m1(f32(x * irx)) * m1(f32(y * iry))))
 
     def sampler_sobol(self, pixelsamples=16):
-        self.spp = int(pixelsamples)
+        self.spp, self.sampler = int(pixelsamples), capi.PT_SAMPLER_SOBOL
+
+    def sampler_halton(self, pixelsamples=16, samplepixelcenter=False):
+        """samplers/halton.rs:275-299 (the reference's default sampler)."""
+        self.spp, self.sampler, self.halton_center = int(pixelsamples), capi.PT_SAMPLER_HALTON, bool(samplepixelcenter)
 
     def integrator_path(self, maxdepth=5, rrthreshold=1.0, lightsamplestrategy="spatial"):
         self.max_depth, self.rr_threshold = int(maxdepth), float(rrthreshold)
@@ -385,7 +389,8 @@ class SceneBuilder:
         d.filter_radius[:] = self.filter_radius
         d.filter_table[:] = [float(v) for v in self.filter_table]
         d.film_scale, d.max_sample_luminance = self.film_scale, self.max_sample_luminance
-        d.sampler, d.spp = 0, self.spp
+        d.sampler, d.spp = getattr(self, "sampler", capi.PT_SAMPLER_SOBOL), self.spp
+        d.halton_sample_at_center = 1 if getattr(self, "halton_center", False) else 0
         d.max_depth, d.rr_threshold, d.light_strategy = self.max_depth, self.rr_threshold, self.light_strategy
         return sd
 
@@ -406,14 +411,14 @@ def _cuboid(b, top4, height):
         _quad(b, t[i], bt[i], bt[j], t[j])
 
 
-def cornell_box(res=512, spp=64, max_depth=5, light_strategy="spatial"):
+def cornell_box(res=512, spp=64, max_depth=5, light_strategy="spatial", sampler="sobol"):
     """BASELINE config 1: 36 triangles, matte walls, one-sided ceiling quad light L=(17,12,4)."""
     b = SceneBuilder()
     b.look_at((278, 273, -800), (278, 273, 0), (0, 1, 0))
     b.camera_perspective(fov=39.3)
     b.film(xresolution=res, yresolution=res)
     b.pixel_filter_box()
-    b.sampler_sobol(spp)
+    b.sampler_sobol(spp) if sampler == "sobol" else b.sampler_halton(spp)
     b.integrator_path(maxdepth=max_depth, lightsamplestrategy=light_strategy)
     white, red, green = (0.73, 0.73, 0.73), (0.65, 0.05, 0.05), (0.12, 0.45, 0.15)
     b.material_matte(white)
@@ -432,7 +437,7 @@ def cornell_box(res=512, spp=64, max_depth=5, light_strategy="spatial"):
     return b.build()
 
 
-def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequence=1):
+def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequence=1, sampler="sobol"):
     """BASELINE config 2 ("RT1M"): 12-triangle enclosure + light, the rest random matte triangles.
 
     Filler triangle k draws, in order, cx cy cz then v0x..v2z as lerp(uniform_float(), lo, hi)
@@ -442,7 +447,7 @@ def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequ
     b.camera_perspective(fov=40.0)
     b.film(xresolution=res, yresolution=res)
     b.pixel_filter_box()
-    b.sampler_sobol(spp)
+    b.sampler_sobol(spp) if sampler == "sobol" else b.sampler_halton(spp)
     b.integrator_path(maxdepth=max_depth, rrthreshold=1.0, lightsamplestrategy="spatial")
     b.accelerator_bvh("sah", 4)
     b.material_matte((0.5, 0.5, 0.5))

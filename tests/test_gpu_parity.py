@@ -14,6 +14,9 @@ pytestmark = pytest.mark.gpu
 SCENES = {
     "cornell": lambda: scenes.cornell_box(res=64, spp=16),
     "rt20k": lambda: scenes.rt1m(20000, res=64, spp=8),
+    # the reference's default sampler (samplers/halton.rs); sample counts need not be powers of two
+    "cornell_halton": lambda: scenes.cornell_box(res=64, spp=12, sampler="halton"),
+    "rt20k_halton": lambda: scenes.rt1m(20000, res=72, spp=6, sampler="halton"),
 }
 
 
@@ -45,7 +48,11 @@ def test_sobol_samples_exact(pair):
     si = rng.integers(0, ctx.info.spp, n).astype(np.uint32)
     dim = rng.integers(0, 80, n).astype(np.uint32)
     dim[:64] = np.arange(64) % 2           # the remapped pixel dimensions
-    dim[64:80] = 1023 + np.arange(16)      # clamp / wrap-around branch of sobol_sample_float
+    if name.endswith("halton"):
+        dim[64:80] = 984 + np.arange(16)   # the last primes of the table (PRIMES has 1000 entries)
+        si[80:96] = (1 << 31) + np.arange(16, dtype=np.uint32) * 77777   # index >= 2^32: 64-bit division path
+    else:
+        dim[64:80] = 1023 + np.arange(16)  # clamp / wrap-around branch of sobol_sample_float
     g = ctx.sobol_samples(px, si, dim)
     o = osc.sobol_samples(px, si, dim)
     assert np.array_equal(bits(g), bits(o))

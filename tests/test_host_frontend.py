@@ -79,7 +79,7 @@ def test_syntax_errors_are_reported():
 
 @pytest.mark.parametrize("text,needle", [
     ('Sampler "sobol"\nWorldBegin\nShape "sphere" "float radius" 1\nWorldEnd', "sphere"),
-    ('WorldBegin\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "halton"),
+    ('Sampler "stratified"\nWorldBegin\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "stratified"),
     ('Sampler "sobol"\nWorldBegin\nLightSource "point"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "LightSource"),
     ('Sampler "sobol"\nWorldBegin\nMaterial "glass"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "glass"),
 ])
