@@ -382,6 +382,144 @@ struct BVHBuilder {
         }
         return leaf(pi, n, bounds);
     }
+
+    // ---- HLBVH (build/hlbvh.rs) -------------------------------------------------------------
+    struct MortonPrim { uint32_t prim, code; };
+    bool failed = false;          // the reference panics (index out of bounds) on these inputs
+    static uint32_t left_shift3(uint32_t x) {          // hlbvh.rs:23-40 (input 1024 is clamped to 1023)
+        if (x >= 1024u) x = 1023u;
+        x = (x | (x << 16)) & 0x30000ffu;
+        x = (x | (x << 8)) & 0x300f00fu;
+        x = (x | (x << 4)) & 0x30c30c3u;
+        x = (x | (x << 2)) & 0x9249249u;
+        return x;
+    }
+    static uint32_t f2u_sat(Float f) {                 // Rust `as u32`: saturating, NaN -> 0
+        if (!(f > 0.0f)) return 0;
+        if (f >= 4294967296.0f) return 0xffffffffu;
+        return (uint32_t)f;
+    }
+    static uint32_t encode_morton3(const Float v[3]) { // hlbvh.rs:42-47: note the ceil
+        uint32_t x = f2u_sat(std::ceil(v[0])), y = f2u_sat(std::ceil(v[1])), z = f2u_sat(std::ceil(v[2]));
+        return (left_shift3(z) << 2) | (left_shift3(y) << 1) | left_shift3(x);
+    }
+    static Float clamp01(Float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }   // f32::clamp keeps NaN
+    std::unique_ptr<BuildNode> morton_leaf(const MortonPrim* mp, size_t n, const PrimInfo* info) {
+        std::unique_ptr<BuildNode> nd(new BuildNode);
+        nd->first = ordered.size();
+        nd->n_prims = n;
+        Bounds3 b = info[mp[0].prim].bounds;
+        ordered.push_back(mp[0].prim);
+        for (size_t i = 1; i < n; i++) {
+            ordered.push_back(mp[i].prim);
+            b = bunion(b, info[mp[i].prim].bounds);
+        }
+        nd->bounds = b;
+        n_leaf++;
+        return nd;
+    }
+    // hlbvh.rs:102-157: median split on centroids once the Morton bits are exhausted
+    std::unique_ptr<BuildNode> split_node(MortonPrim* mp, size_t n, const PrimInfo* info, int dim) {
+        if (n <= max_prims) return morton_leaf(mp, n, info);
+        std::stable_sort(mp, mp + n, [&](const MortonPrim& a, const MortonPrim& b) { return info[a.prim].centroid[dim] < info[b.prim].centroid[dim]; });
+        int next_dim = (dim + 3 - 1) % 3;
+        size_t split = n / 2;
+        auto c0 = split_node(mp, split, info, next_dim);
+        auto c1 = split_node(mp + split, n - split, info, next_dim);
+        return interior(dim, std::move(c0), std::move(c1));
+    }
+    // hlbvh.rs:159-246
+    std::unique_ptr<BuildNode> emit_lbvh(const MortonPrim* mp, size_t n, const PrimInfo* info, int bit_index) {
+        if (n <= max_prims) return morton_leaf(mp, n, info);
+        if (bit_index == -1) {
+            std::vector<MortonPrim> copy(mp, mp + n);
+            return split_node(copy.data(), n, info, 2);
+        }
+        uint32_t mask = 1u << bit_index;
+        if ((mp[0].code & mask) == (mp[n - 1].code & mask)) return emit_lbvh(mp, n, info, bit_index - 1);
+        size_t search_start = 0, search_end = n - 1;
+        while (search_start + 1 != search_end) {
+            size_t mid = (search_start + search_end) / 2;
+            if ((mp[search_start].code & mask) == (mp[mid].code & mask)) search_start = mid;
+            else search_end = mid;
+        }
+        size_t split = search_end;
+        auto c0 = emit_lbvh(mp, split, info, bit_index - 1);
+        auto c1 = emit_lbvh(mp + split, n - split, info, bit_index - 1);
+        return interior(bit_index % 3, std::move(c0), std::move(c1));
+    }
+    static size_t upper_bucket(const Bounds3& b, const Bounds3& cb, int dim) {
+        Float c = (b.min[dim] + b.max[dim]) * 0.5f;
+        Float f = 12.0f * ((c - cb.min[dim]) / (cb.max[dim] - cb.min[dim]));
+        size_t bk = !(f > 0.0f) ? 0 : (f >= 1.8446744e19f ? ~(size_t)0 : (size_t)f);     // `as usize`
+        return bk < 11 ? bk : 11;
+    }
+    // hlbvh.rs:254-352.  The cost loop is the reference's own: b0 starts from bucket i but count0 leaves
+    // bucket i out, count1 starts at 1, and the constant is 0.125.
+    std::unique_ptr<BuildNode> build_upper_sah(std::vector<std::unique_ptr<BuildNode>>& roots) {
+        if (roots.empty()) { failed = true; return nullptr; }
+        if (roots.size() == 1) return std::move(roots[0]);
+        Bounds3 bounds = roots[0]->bounds;
+        for (size_t i = 1; i < roots.size(); i++) bounds = bunion(bounds, roots[i]->bounds);
+        V3 center = (roots[0]->bounds.min + roots[0]->bounds.max) * 0.5f;
+        Bounds3 cb(center, center);
+        for (size_t i = 1; i < roots.size(); i++) cb = bunion_p(cb, (roots[i]->bounds.min + roots[i]->bounds.max) * 0.5f);
+        int dim = cb.maximum_extent();
+        const int NB = 12;
+        uint32_t count[NB];
+        Bounds3 bb[NB];
+        for (int i = 0; i < NB; i++) count[i] = 0;
+        for (size_t i = 0; i < roots.size(); i++) {
+            size_t b = upper_bucket(roots[i]->bounds, cb, dim);
+            count[b] += 1;
+            bb[b] = count[b] == 1 ? roots[i]->bounds : bunion(bb[b], roots[i]->bounds);
+        }
+        Float cost[NB - 1];
+        for (int i = 0; i < NB - 1; i++) {
+            Bounds3 b0 = bb[i], b1 = bb[i];
+            uint32_t count0 = 0, count1 = 1;
+            for (int j = 0; j < i; j++) { b0 = bunion(b0, bb[j]); count0 += count[j]; }
+            for (int j = i + 1; j < NB; j++) { b1 = bunion(b1, bb[j]); count1 += count[j]; }
+            cost[i] = 0.125f + (((Float)count0 * b0.surface_area() + (Float)count1 * b1.surface_area()) / bounds.surface_area());
+        }
+        Float min_cost = cost[0];
+        size_t min_bucket = 0;
+        for (int i = 1; i < NB - 1; i++)
+            if (cost[i] < min_cost) { min_cost = cost[i]; min_bucket = (size_t)i; }
+        std::vector<std::unique_ptr<BuildNode>> r0, r1;
+        for (auto& r : roots) {
+            if (upper_bucket(r->bounds, cb, dim) <= min_bucket) r0.push_back(std::move(r));
+            else r1.push_back(std::move(r));
+        }
+        auto c0 = build_upper_sah(r0);
+        auto c1 = build_upper_sah(r1);
+        if (!c0 || !c1) { failed = true; return nullptr; }
+        return interior(dim, std::move(c0), std::move(c1));
+    }
+    // hlbvh.rs:354-428
+    std::unique_ptr<BuildNode> hlbvh_build(const PrimInfo* info, size_t n) {
+        Bounds3 bounds = info[0].bounds;
+        for (size_t i = 1; i < n; i++) bounds = bunion(bounds, info[i].bounds);
+        std::vector<MortonPrim> mp(n), tmp(n);
+        for (size_t i = 0; i < n; i++) {
+            mp[i].prim = (uint32_t)info[i].prim;
+            V3 o = bounds.offset(info[i].centroid);
+            Float sc[3] = {clamp01(o.x) * 1024.0f, clamp01(o.y) * 1024.0f, clamp01(o.z) * 1024.0f};
+            mp[i].code = encode_morton3(sc);
+        }
+        // radix_sort (hlbvh.rs:49-100) is a stable LSD sort on the 30-bit code
+        std::stable_sort(mp.begin(), mp.end(), [](const MortonPrim& a, const MortonPrim& b) { return a.code < b.code; });
+        std::vector<std::unique_ptr<BuildNode>> treelets;
+        const uint32_t MASK = 0x3ffc0000u;
+        size_t start = 0;
+        for (size_t end = 1; end <= n; end++) {
+            if (end == n || (mp[start].code & MASK) != (mp[end].code & MASK)) {
+                treelets.push_back(emit_lbvh(&mp[start], end - start, info, 29 - 12));
+                start = end;
+            }
+        }
+        return build_upper_sah(treelets);
+    }
 };
 
 // ------------------------------------------------- 4-wide node + traversal
@@ -467,7 +605,7 @@ struct QBVH {
     }
 
     // QBVHAccel::new (qbvh_x86.rs:352-370) + create_bvh_node (build/node.rs:107-151)
-    void build(const Geometry* g, size_t max_prims_in_node, SplitMethod method) {
+    bool build(const Geometry* g, size_t max_prims_in_node, SplitMethod method) {
         geom = g;
         size_t n = g->n_tris();
         const Float eps = std::numeric_limits<Float>::epsilon() * 2.0f;  // BOUND_EPS node.rs:13
@@ -485,12 +623,14 @@ struct QBVH {
         BVHBuilder bld;
         bld.max_prims = max_prims_in_node < 255 ? max_prims_in_node : 255;
         bld.method = method;
-        std::unique_ptr<BuildNode> root = bld.recursive_build(info.data(), n);
+        std::unique_ptr<BuildNode> root = method == SPLIT_HLBVH ? bld.hlbvh_build(info.data(), n) : bld.recursive_build(info.data(), n);
+        if (!root || bld.failed) return false;
         prims.swap(bld.ordered);
         nodes.clear();
         flatten(root.get());
         bounds = root->bounds;
         // iterative destruction is unnecessary: depth is O(log n) for these builders
+        return true;
     }
 
     static int get_sign(Float x) { return std::signbit(x) ? 1 : 0; }

@@ -707,7 +707,10 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
             lights.push_back(al);
         }
     }
-    bvh.build(&geom, (size_t)(d.max_node_prims > 0 ? d.max_node_prims : 4), (SplitMethod)d.split_method);
+    if (!bvh.build(&geom, (size_t)(d.max_node_prims > 0 ? d.max_node_prims : 4), (SplitMethod)d.split_method)) {
+        if (err) *err = "hlbvh: degenerate treelet centroids (the reference panics here)";
+        return false;
+    }
     world_bound = bvh.bounds;
     // film (film.rs:62-100, :166-179)
     xres = d.xres; yres = d.yres;

@@ -2,7 +2,7 @@
 //
 // The tree topology must be the one pbrt-r3 builds (same leaves, same child order,
 // same split axes), because the traversal order and hence every f32 result depends
-// on it:  src/accelerators/bvh/build/{node,sah,middle,equal_counts}.rs and the
+// on it:  src/accelerators/bvh/build/{node,sah,middle,equal_counts,hlbvh}.rs and the
 // two-level collapse of src/accelerators/bvh/accel/qbvh/qbvh_x86.rs:93-176.
 // The implementation is our own: primitives are partitioned in place inside one
 // array (so the final array order IS the leaf order), binary nodes go into a flat
@@ -199,6 +199,155 @@ struct Builder {
     }
 };
 
+// ---- HLBVH (src/accelerators/bvh/build/hlbvh.rs) ----------------------------------------------
+// Items are radix-sorted by the 30-bit Morton code of their centroid, cut into treelets on the top
+// 12 bits, each treelet is split on successive code bits (falling back to centroid medians below the
+// last bit), and the treelet roots are joined by a 12-bucket SAH.  Leaves only ever cover consecutive
+// items, so -- as for the other builders -- the item array ends up in leaf order.
+struct Hlbvh {
+    Item* items;
+    const uint32_t* code;      // Morton code of items[i] (valid until a median fallback reorders a range)
+    uint32_t max_prims;
+    std::vector<BNode>& t;
+    bool failed = false;
+
+    static uint32_t spread3(uint32_t x) {          // left_shift3 (hlbvh.rs:23-40); 1024 is clamped to 1023
+        if (x >= 1024u) x = 1023u;
+        x = (x | (x << 16)) & 0x030000ffu;
+        x = (x | (x << 8)) & 0x0300f00fu;
+        x = (x | (x << 4)) & 0x030c30c3u;
+        x = (x | (x << 2)) & 0x09249249u;
+        return x;
+    }
+    static uint32_t grid_coord(float offset) {     // clamp to [0,1], scale by 2^10, ceil, saturating cast (hlbvh.rs:42-47, :367-373)
+        float c = offset < 0.0f ? 0.0f : (offset > 1.0f ? 1.0f : offset);
+        float f = std::ceil(c * 1024.0f);
+        return f > 0.0f ? (uint32_t)f : 0u;        // NaN -> 0
+    }
+    int32_t leaf(size_t lo, size_t hi) {
+        Box b;
+        std::memcpy(b.lo, items[lo].lo, 12); std::memcpy(b.hi, items[lo].hi, 12);
+        for (size_t i = lo + 1; i < hi; i++) box_grow(b, items[i].lo, items[i].hi);
+        return Builder::push_leaf(t, lo, hi, b);
+    }
+    int32_t join(int axis, int32_t l, int32_t r) {
+        BNode nd;
+        nd.axis = (uint8_t)axis; nd.left = l; nd.right = r;
+        for (int i = 0; i < 3; i++) { nd.lo[i] = fmin_le(t[l].lo[i], t[r].lo[i]); nd.hi[i] = fmax_ge(t[l].hi[i], t[r].hi[i]); }
+        t.push_back(nd);
+        return (int32_t)t.size() - 1;
+    }
+    int32_t median_split(size_t lo, size_t hi, int dim) {        // split_node (hlbvh.rs:102-157)
+        if (hi - lo <= max_prims) return leaf(lo, hi);
+        std::stable_sort(items + lo, items + hi, [dim](const Item& a, const Item& b) { return a.c[dim] < b.c[dim]; });
+        size_t mid = lo + (hi - lo) / 2;
+        int next = (dim + 2) % 3;
+        int32_t l = median_split(lo, mid, next);
+        int32_t r = median_split(mid, hi, next);
+        return join(dim, l, r);
+    }
+    int32_t emit(size_t lo, size_t hi, int bit) {                 // emit_lbvh (hlbvh.rs:159-246)
+        for (;;) {
+            if (hi - lo <= max_prims) return leaf(lo, hi);
+            if (bit < 0) return median_split(lo, hi, 2);
+            const uint32_t mask = 1u << bit;
+            if ((code[lo] & mask) != (code[hi - 1] & mask)) break;
+            bit--;
+        }
+        const uint32_t mask = 1u << bit;
+        size_t a = lo, b = hi - 1;                 // first item whose bit differs from the range's first item
+        while (a + 1 != b) {
+            size_t m = (a + b) / 2;
+            if ((code[a] & mask) == (code[m] & mask)) a = m; else b = m;
+        }
+        int32_t l = emit(lo, b, bit - 1);
+        int32_t r = emit(b, hi, bit - 1);
+        return join(bit % 3, l, r);
+    }
+    static size_t sah_bucket(const BNode& n, const Box& cb, int dim) {
+        float c = (n.lo[dim] + n.hi[dim]) * 0.5f;
+        float f = (float)kBuckets * ((c - cb.lo[dim]) / (cb.hi[dim] - cb.lo[dim]));
+        size_t b = f > 0.0f ? (f >= 1.8446744e19f ? ~(size_t)0 : (size_t)f) : 0;    // Rust's saturating `as usize`, NaN -> 0
+        return b < (size_t)kBuckets - 1 ? b : (size_t)kBuckets - 1;
+    }
+    // build_upper_sah (hlbvh.rs:254-352), including its own cost bookkeeping: the left box includes bucket i
+    // but the left count does not, the right count starts at one, and the traversal constant is 1/8.
+    int32_t upper(const std::vector<int32_t>& roots) {
+        if (roots.empty()) { failed = true; return -1; }          // the reference indexes an empty slice here
+        if (roots.size() == 1) return roots[0];
+        Box bounds, cb;
+        box_empty(bounds);
+        for (int32_t r : roots) box_grow(bounds, t[r].lo, t[r].hi);
+        bool first = true;
+        for (int32_t r : roots) {
+            float c[3];
+            for (int i = 0; i < 3; i++) c[i] = (t[r].lo[i] + t[r].hi[i]) * 0.5f;
+            if (first) { std::memcpy(cb.lo, c, 12); std::memcpy(cb.hi, c, 12); first = false; }
+            else box_grow_pt(cb, c);
+        }
+        const int dim = box_max_extent(cb);
+        uint32_t count[kBuckets];
+        Box bb[kBuckets];
+        for (int i = 0; i < kBuckets; i++) { count[i] = 0; box_empty(bb[i]); }
+        for (int32_t r : roots) {
+            size_t b = sah_bucket(t[r], cb, dim);
+            if (count[b]++ == 0) { std::memcpy(bb[b].lo, t[r].lo, 12); std::memcpy(bb[b].hi, t[r].hi, 12); }
+            else box_grow(bb[b], t[r].lo, t[r].hi);
+        }
+        const float total = box_area(bounds);
+        float best = 0.0f;
+        size_t best_bucket = 0;
+        for (int i = 0; i < kBuckets - 1; i++) {
+            Box b0 = bb[i], b1 = bb[i];
+            uint32_t c0 = 0, c1 = 1;
+            for (int j = 0; j < i; j++) { box_grow(b0, bb[j].lo, bb[j].hi); c0 += count[j]; }
+            for (int j = i + 1; j < kBuckets; j++) { box_grow(b1, bb[j].lo, bb[j].hi); c1 += count[j]; }
+            float cost = 0.125f + (((float)c0 * box_area(b0) + (float)c1 * box_area(b1)) / total);
+            if (i == 0 || cost < best) { best = cost; best_bucket = (size_t)i; }
+        }
+        std::vector<int32_t> left, right;
+        for (int32_t r : roots) (sah_bucket(t[r], cb, dim) <= best_bucket ? left : right).push_back(r);
+        int32_t l = upper(left);
+        int32_t r = upper(right);
+        if (l < 0 || r < 0) { failed = true; return -1; }
+        return join(dim, l, r);
+    }
+};
+
+// Morton codes of the item centroids, then a stable LSD radix sort of the items by code (3 passes of 10 bits).
+void morton_sort(std::vector<Item>& items, std::vector<Item>& scratch, std::vector<uint32_t>& code) {
+    const size_t n = items.size();
+    Box bounds;
+    std::memcpy(bounds.lo, items[0].lo, 12); std::memcpy(bounds.hi, items[0].hi, 12);
+    for (size_t i = 1; i < n; i++) box_grow(bounds, items[i].lo, items[i].hi);
+    code.resize(n);
+    std::vector<uint32_t> code2(n);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t g[3];
+        for (int a = 0; a < 3; a++) g[a] = Hlbvh::grid_coord(box_offset(bounds, items[i].c, a));
+        code[i] = (Hlbvh::spread3(g[2]) << 2) | (Hlbvh::spread3(g[1]) << 1) | Hlbvh::spread3(g[0]);
+    }
+    Item* src = items.data(); Item* dst = scratch.data();
+    uint32_t* csrc = code.data(); uint32_t* cdst = code2.data();
+    for (int pass = 0; pass < 3; pass++) {
+        const int shift = 10 * pass;
+        std::vector<size_t> start(1025, 0);
+        for (size_t i = 0; i < n; i++) start[((csrc[i] >> shift) & 1023u) + 1]++;
+        for (int b = 0; b < 1024; b++) start[b + 1] += start[b];
+        for (size_t i = 0; i < n; i++) {
+            size_t o = start[(csrc[i] >> shift) & 1023u]++;
+            dst[o] = src[i];
+            cdst[o] = csrc[i];
+        }
+        std::swap(src, dst);
+        std::swap(csrc, cdst);
+    }
+    if (src != items.data()) {       // odd number of passes: the result sits in scratch
+        std::memcpy(items.data(), src, n * sizeof(Item));
+        std::memcpy(code.data(), csrc, n * 4);
+    }
+}
+
 struct Collapser {
     const std::vector<BNode>& b;
     Result& out;
@@ -243,7 +392,6 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
            Result* out) {
     out->nodes.clear(); out->tris.clear(); out->rec_of_prim.clear();
     out->n_leaves = 0; out->max_stack = 1;
-    if (split_method == PT_SPLIT_HLBVH) return false;   // hlbvh_build (build/hlbvh.rs) is not restated yet
     if (n_tris == 0) { out->root_ref = PT_EMPTY_REF; return true; }
     std::vector<Item> items(n_tris), scratch(n_tris);
     const float eps = std::numeric_limits<float>::epsilon() * 2.0f;   // BOUND_EPS (build/node.rs:13)
@@ -269,10 +417,27 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
     bld.par_threshold = 32768;
     std::vector<BNode> tree;
     tree.reserve((size_t)n_tris);
-    bld.build(tree, 0, n_tris, 0);
+    int32_t root = 0;
+    if (split_method == PT_SPLIT_HLBVH) {
+        std::vector<uint32_t> code;
+        morton_sort(items, scratch, code);
+        Hlbvh h{items.data(), code.data(), bld.max_prims, tree};
+        std::vector<int32_t> treelets;
+        const uint32_t top12 = 0x3ffc0000u;
+        for (size_t start = 0, end = 1; end <= n_tris; end++) {
+            if (end == n_tris || (code[start] & top12) != (code[end] & top12)) {
+                treelets.push_back(h.emit(start, end, 29 - 12));
+                start = end;
+            }
+        }
+        root = h.upper(treelets);
+        if (h.failed || root < 0) return false;
+    } else {
+        bld.build(tree, 0, n_tris, 0);
+    }
 
-    std::memcpy(out->root_lo, tree[0].lo, 12);
-    std::memcpy(out->root_hi, tree[0].hi, 12);
+    std::memcpy(out->root_lo, tree[root].lo, 12);
+    std::memcpy(out->root_hi, tree[root].hi, 12);
     // triangle records in final item order; PT_TRI_LAST closes each leaf
     out->tris.resize(n_tris);
     out->rec_of_prim.resize(n_tris);
@@ -296,13 +461,13 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
     out->n_leaves = 0;
     for (const BNode& n : tree)
         if (n.count > 0) { out->tris[n.first + n.count - 1].flags |= PT_TRI_LAST; out->n_leaves++; }
-    if (tree[0].count > 0) {           // the whole scene is one leaf
-        out->root_ref = PT_LEAF_BIT | tree[0].first;
+    if (tree[root].count > 0) {           // the whole scene is one leaf
+        out->root_ref = PT_LEAF_BIT | tree[root].first;
         out->max_stack = 1;
         return true;
     }
     Collapser col{tree, *out};
-    out->root_ref = col.emit(0, 1);
+    out->root_ref = col.emit(root, 1);
     out->max_stack = 3 * col.max_depth4 + 2;
     return true;
 }

@@ -353,7 +353,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     ptbvh::Result bvh;
     if (!ptbvh::build(d->P, d->indices, tri_flags.data(), d->n_triangles, d->split_method, d->max_node_prims > 0 ? d->max_node_prims : 4, &bvh))
-        return ctx->fail(PT_ERR_UNSUPPORTED, "split method not supported (hlbvh)");
+        return ctx->fail(PT_ERR_INVALID_ARGUMENT, "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)");
     double t1 = now_ms();
     ctx->max_stack = bvh.max_stack;
 

@@ -116,6 +116,6 @@ def scene_camera_film(filt="gaussian"):
 
 def scene_accel(method, leaf):
     sd = scenes.rt1m(4000, res=32, spp=4, max_depth=4)
-    sd.desc.split_method = {"sah": 0, "middle": 2, "equal": 3}[method]
+    sd.desc.split_method = {"sah": 0, "hlbvh": 1, "middle": 2, "equal": 3}[method]
     sd.desc.max_node_prims = leaf
     return sd

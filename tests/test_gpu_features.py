@@ -56,6 +56,8 @@ def _compare(ctx, osc, exact_film, frac_limit=0.0):
     ("accel_middle_1", lambda: fs.scene_accel("middle", 1), True),
     ("accel_equal_8", lambda: fs.scene_accel("equal", 8), True),
     ("accel_sah_2", lambda: fs.scene_accel("sah", 2), True),
+    ("accel_hlbvh_4", lambda: fs.scene_accel("hlbvh", 4), True),
+    ("accel_hlbvh_1", lambda: fs.scene_accel("hlbvh", 1), True),
 ])
 def test_feature_scene(gpu_ctx, oracle, name, make, exact):
     sd = make()

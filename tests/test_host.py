@@ -56,14 +56,14 @@ def test_missing_library_fails_loudly(tmp_path):
         pkg.capi.load_library(str(tmp_path / "libpbrtgpu.so"))
 
 
-@pytest.mark.parametrize("method", ["sah", "middle", "equal"])
+@pytest.mark.parametrize("method", ["sah", "middle", "equal", "hlbvh"])
 def test_host_bvh_matches_reference_topology(oracle, method):
     """The product's BVH builder (pt_bvh.cpp, in-place partition, threaded) yields the oracle's
     (= reference's recursive_build) leaf order and node counts."""
     for sd_fn in (lambda: scenes.cornell_box(res=16, spp=1), lambda: scenes.rt1m(30000, res=16, spp=1)):
         b = sd_fn
         sd = b()
-        sd.desc.split_method = {"sah": 0, "middle": 2, "equal": 3}[method]
+        sd.desc.split_method = {"sah": 0, "hlbvh": 1, "middle": 2, "equal": 3}[method]
         order, n_nodes, n_leaves, max_stack = pkg.capi.bvh_leaf_order(sd)
         sc = oracle.scene(sd)
         assert np.array_equal(order, sc.ordered_prims())
@@ -72,12 +72,33 @@ def test_host_bvh_matches_reference_topology(oracle, method):
         sc.close()
 
 
-def test_hlbvh_is_reported_unsupported():
-    sd = scenes.cornell_box(res=16, spp=1)
+def test_hlbvh_morton_fallback_and_duplicates(oracle):
+    """hlbvh.rs:102-157, :183-192: more than maxnodeprims primitives in one Morton cell fall back to
+    centroid-median splits (start axis z, then y, x); coincident triangles stay in input order."""
+    b = scenes.SceneBuilder()
+    b.look_at((0, 0, -5), (0, 0, 0), (0, 1, 0)); b.camera_perspective(fov=40.0)
+    b.film(xresolution=16, yresolution=16); b.pixel_filter_box(); b.sampler_sobol(1); b.integrator_path(maxdepth=1)
+    b.material_matte((0.5, 0.5, 0.5))
+    rng = np.random.default_rng(2)
+    # a tight cluster (all in one 1/1024 cell of the scene box), 40 exact duplicates, and a sparse shell
+    for k in range(60):
+        c = np.array([0.3, 0.2, 0.1]) + rng.random(3) * 1e-5
+        b.shape_trianglemesh([tuple(c), tuple(c + [1e-6, 0, 0]), tuple(c + [0, 1e-6, 0])], [0, 1, 2])
+    for k in range(40):
+        b.shape_trianglemesh([(-0.5, -0.5, 0.5), (-0.4, -0.5, 0.5), (-0.5, -0.4, 0.5)], [0, 1, 2])
+    for k in range(200):
+        c = rng.random(3) * 4 - 2
+        b.shape_trianglemesh([tuple(c), tuple(c + [0.05, 0, 0]), tuple(c + [0, 0.05, 0.02])], [0, 1, 2])
+    sd = b.build()
     sd.desc.split_method = 1
-    with pytest.raises(pkg.PtError) as e:
-        pkg.capi.bvh_leaf_order(sd)
-    assert e.value.status == 4
+    for leaf in (1, 4, 16):
+        sd.desc.max_node_prims = leaf
+        order, n_nodes, n_leaves, max_stack = pkg.capi.bvh_leaf_order(sd)
+        sc = oracle.scene(sd)
+        assert np.array_equal(order, sc.ordered_prims())
+        assert (n_nodes, n_leaves) == (sc.info.n_nodes, sc.info.n_leaves)
+        assert sorted(order) == list(range(300))
+        sc.close()
 
 
 def test_scene_builder_mirrors_reference_rules():
