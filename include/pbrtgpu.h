@@ -23,6 +23,7 @@
  *                           (src/core/sampler/sampler.rs:26-36,
  *                            src/cameras/perspective.rs:121-183)
  *   pt_sobol_samples     <- SobolSampler::sample_dimension (src/samplers/sobol.rs:167-185)
+ *   pt_bsdf_eval/sample  <- BSDF::f / pdf / sample_f (src/core/reflection/bsdf.rs:92-270)
  *   pt_get_counters      <- the stat counters "Intersections/Regular ray intersection
  *                           tests" / "Shadow ray intersection tests"
  *                           (src/core/scene/scene.rs:11-12)
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 typedef enum {
     PT_OK = 0,
@@ -57,16 +58,38 @@ typedef struct pt_context pt_context;
 
 /* ---- flattened scene description ------------------------------------- */
 
-/* Material::compute_scattering_functions variants (src/materials/). */
+/* Material::compute_scattering_functions variants (src/materials/).  All parameter textures are
+ * constant (core/texture/constant.rs); bump maps are outside the accelerated path. */
 typedef enum {
-    PT_MATERIAL_NONE = 0,   /* GeometricPrimitive.material == None: ray passes through (path.rs:108-111) */
-    PT_MATERIAL_MATTE = 1   /* materials/matte.rs:25-53 (constant Kd, sigma) */
+    PT_MATERIAL_NONE = 0,      /* GeometricPrimitive.material == None: ray passes through (path.rs:108-111) */
+    PT_MATERIAL_MATTE = 1,     /* materials/matte.rs:25-53      Kd, sigma */
+    PT_MATERIAL_PLASTIC = 2,   /* materials/plastic.rs:31-71    Kd, Ks, roughness, remaproughness */
+    PT_MATERIAL_MIRROR = 3,    /* materials/mirror.rs:19-41     Kr */
+    PT_MATERIAL_GLASS = 4,     /* materials/glass.rs:46-110     Kr, Kt, eta, uroughness, vroughness, remaproughness */
+    PT_MATERIAL_METAL = 5,     /* materials/metal.rs:51-85      eta (spectrum -> RGB), k, roughness | uroughness/vroughness */
+    PT_MATERIAL_UBER = 6,      /* materials/uber.rs:63-127      Kd, Ks, Kr, Kt, opacity, eta, roughness | u/v roughness */
+    PT_MATERIAL_SUBSTRATE = 7  /* materials/substrate.rs:34-68  Kd, Ks, uroughness, vroughness */
 } pt_material_type;
 
+#define PT_ROUGHNESS_UNSET (-1.0f)   /* "uroughness"/"vroughness" not given: Metal and Uber fall back to "roughness" */
+
+/* Field defaults are the reference's create_*_material defaults; a field a material type does not
+ * read is ignored.  128 bytes. */
 typedef struct {
     int32_t type;           /* pt_material_type */
-    float kd[3];            /* "Kd", default 0.5 */
-    float sigma;            /* "sigma" degrees, clamped to [0,90]; 0 => Lambertian */
+    float kd[3];            /* "Kd": matte 0.5, plastic/uber 0.25, substrate 0.5 */
+    float sigma;            /* matte "sigma" degrees, clamped to [0,90]; 0 => Lambertian */
+    float ks[3];            /* "Ks": plastic/uber 0.25, substrate 0.5 */
+    float kr[3];            /* "Kr": mirror 0.9, glass 1, uber 0 */
+    float kt[3];            /* "Kt": glass 1, uber 0 */
+    float opacity[3];       /* uber "opacity", default 1 */
+    float eta;              /* glass/uber "eta" (alias "index"), default 1.5 */
+    float roughness;        /* plastic 0.1, metal 0.01, uber 0.1 */
+    float uroughness;       /* glass 0, substrate 0.1; metal/uber: PT_ROUGHNESS_UNSET unless given */
+    float vroughness;
+    int32_t remap_roughness;/* "remaproughness", default true */
+    float metal_eta[3];     /* metal "eta" as RGB (the reference's default is the copper SPD) */
+    float metal_k[3];       /* metal "k" as RGB */
     float reserved[3];
 } pt_material;
 
@@ -226,6 +249,15 @@ pt_status pt_generate_camera_rays(pt_context* ctx, uint32_t n, const int32_t* pi
 /* out[i] = sampler value for (pixel_xy[i], sample_index[i], dim[i]). */
 pt_status pt_sobol_samples(pt_context* ctx, uint32_t n, const int32_t* pixel_xy,
                            const uint32_t* sample_index, const uint32_t* dim, float* out);
+/* BSDF of material `material` of the uploaded scene on the canonical frame ns = ng = (0,0,1),
+ * ss = (1,0,0): BSDF::f and BSDF::pdf (src/core/reflection/bsdf.rs:208-270) for n direction pairs
+ * (world = local here), flags = BxDFType mask.  f_out 3 floats, pdf_out 1 float per pair. */
+pt_status pt_bsdf_eval(pt_context* ctx, uint32_t material, uint32_t n, const float* wo, const float* wi,
+                       uint32_t flags, float* f_out, float* pdf_out);
+/* BSDF::sample_f (bsdf.rs:92-206): u is 2 floats per sample; type_out[i] = sampled BxDFType, or 0
+ * when sample_f returns None (f/wi/pdf are then zero). */
+pt_status pt_bsdf_sample(pt_context* ctx, uint32_t material, uint32_t n, const float* wo, const float* u,
+                         uint32_t flags, float* f_out, float* wi_out, float* pdf_out, uint32_t* type_out);
 /* Per-sample radiance (PathIntegrator::li after validate_radiance_result) for the
  * pixels of one tile: out is 3 floats per (pixel, sample), pixel-major. */
 pt_status pt_radiance_samples(pt_context* ctx, const pt_tile* tile, float* out_rgb);

@@ -214,3 +214,37 @@ extern "C" int64_t orc_halton_index(const int32_t bounds[4], int32_t px, int32_t
     sm.pixel[0] = px; sm.pixel[1] = py;
     return sm.get_index_for_sample(sample_num);
 }
+
+// BSDF of one material on the canonical frame ns = ng = (0,0,1), ss = (1,0,0)  (bsdf.rs:92-270)
+static bool canonical_bsdf(const orc_scene* s, uint32_t material, BSDF* b) {
+    SurfHit si;
+    si.n = V3(0.0f, 0.0f, 1.0f); si.sh_n = si.n;
+    si.sh_dpdu = V3(1.0f, 0.0f, 0.0f);
+    return make_bsdf_from_material(s->sc.materials[material], si, b);
+}
+extern "C" void orc_bsdf_eval(const orc_scene* s, uint32_t material, uint32_t n, const float* wo, const float* wi, uint32_t flags, float* f_out, float* pdf_out) {
+    BSDF b;
+    bool have = canonical_bsdf(s, material, &b);
+    for (uint32_t i = 0; i < n; i++) {
+        V3 o(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), w(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+        RGB f = have ? b.f(o, w, flags) : RGB();
+        f_out[3 * i] = f.c[0]; f_out[3 * i + 1] = f.c[1]; f_out[3 * i + 2] = f.c[2];
+        pdf_out[i] = have ? b.pdf(o, w, flags) : 0.0f;
+    }
+}
+extern "C" void orc_bsdf_sample(const orc_scene* s, uint32_t material, uint32_t n, const float* wo, const float* u, uint32_t flags, float* f_out, float* wi_out,
+                                float* pdf_out, uint32_t* type_out) {
+    BSDF b;
+    bool have = canonical_bsdf(s, material, &b);
+    for (uint32_t i = 0; i < n; i++) {
+        RGB f; V3 wi(0.0f, 0.0f, 0.0f); Float pdf = 0.0f; uint32_t t = 0;
+        if (!have || !b.sample_f(V3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), V2(u[2 * i], u[2 * i + 1]), flags, &f, &wi, &pdf, &t)) {
+            f = RGB(); wi = V3(0.0f, 0.0f, 0.0f); pdf = 0.0f; t = 0;
+        }
+        f_out[3 * i] = f.c[0]; f_out[3 * i + 1] = f.c[1]; f_out[3 * i + 2] = f.c[2];
+        wi_out[3 * i] = wi.x; wi_out[3 * i + 1] = wi.y; wi_out[3 * i + 2] = wi.z;
+        pdf_out[i] = pdf;
+        type_out[i] = t;
+    }
+}
+extern "C" float orc_roughness_to_alpha(float r) { return TRDist::roughness_to_alpha(r); }

@@ -1,9 +1,9 @@
 // ORACLE -- test infrastructure only (see orc_math.hpp).
-// orc_render.hpp: scene, camera, lights, light distributions, Matte BSDF,
+// orc_render.hpp: scene, camera, lights, light distributions, materials -> BSDF,
 // PathIntegrator::li, film and the tile render driver.
 //   follows src/cameras/perspective.rs, src/core/camera/projective.rs,
 //           src/core/interaction/{surface_interaction,interaction}.rs,
-//           src/materials/matte.rs, src/core/reflection/{bsdf,bxdf,lambertian,oren_nayar}.rs,
+//           src/materials/{matte,plastic,mirror,glass,metal,uber,substrate}.rs, src/core/reflection/bsdf.rs,
 //           src/lights/diffuse.rs, src/core/light/visibility_tester.rs,
 //           src/core/lightdistrib/{spatial,power,uniform,create_light_sample_distribution}.rs,
 //           src/core/integrator/{sample_lights,sampler}.rs, src/integrators/path.rs,
@@ -11,6 +11,7 @@
 #pragma once
 #include "../include/pbrtgpu.h"
 #include "orc_accel.hpp"
+#include "orc_bxdf.hpp"
 #include <atomic>
 #include <mutex>
 #include <shared_mutex>
@@ -19,30 +20,13 @@
 
 namespace orc {
 
-// ---- BxDF flags (core/reflection/bxdf.rs:8-14)
-enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
-
-struct Lobe {
-    int kind = 0;        // 0 = LambertianReflection, 1 = OrenNayar
-    RGB r;
-    Float a = 0, b = 0;  // OrenNayar coefficients
-    uint32_t type() const { return BSDF_REFLECTION | BSDF_DIFFUSE; }
-    bool matches(uint32_t t) const { uint32_t tp = type(); return (tp & t) == tp; }
-};
-
-inline bool same_hemisphere(V3 w, V3 wp) { return w.z * wp.z > 0.0f; }
-inline Float abs_cos_theta(V3 w) { return std::fabs(w.z); }
-inline Float sin2_theta(V3 w) { return fmax_(0.0f, 1.0f - w.z * w.z); }
-inline Float sin_theta(V3 w) { return std::sqrt(sin2_theta(w)); }
-inline Float cos_phi(V3 w) { Float s = sin_theta(w); return s == 0.0f ? 1.0f : clampf(w.x / s, -1.0f, 1.0f); }
-inline Float sin_phi(V3 w) { Float s = sin_theta(w); return s == 0.0f ? 0.0f : clampf(w.y / s, -1.0f, 1.0f); }
-
 // core/reflection/bsdf.rs
 struct BSDF {
     Float eta = 1.0f;
     V3 ns, ng, ss, ts;
-    Lobe lobes[2];
+    Lobe lobes[8];               // MAX_BXDFS
     int n_lobes = 0;
+    Lobe& add() { return lobes[n_lobes++]; }
     void init(const SurfHit& si, Float eta_) {   // bsdf.rs:40-53
         eta = eta_;
         ns = si.sh_n;
@@ -55,38 +39,6 @@ struct BSDF {
     V3 world_to_local(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
     V3 local_to_world(V3 v) const {
         return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
-    }
-    static RGB lobe_f(const Lobe& l, V3 wo, V3 wi) {
-        if (l.kind == 0) return l.r * kInvPi;       // lambertian.rs:17-19
-        // oren_nayar.rs:26-52
-        Float sin_theta_i = sin_theta(wi), sin_theta_o = sin_theta(wo);
-        Float max_cos = 0.0f;
-        if (sin_theta_i > 1e-4f && sin_theta_o > 1e-4f) {
-            Float sin_phi_i = sin_phi(wi), cos_phi_i = cos_phi(wi);
-            Float sin_phi_o = sin_phi(wo), cos_phi_o = cos_phi(wo);
-            Float d_cos = cos_phi_i * cos_phi_o + sin_phi_i * sin_phi_o;
-            max_cos = fmax_(0.0f, d_cos);
-        }
-        Float sin_alpha, tan_beta;
-        if (abs_cos_theta(wi) > abs_cos_theta(wo)) {
-            sin_alpha = sin_theta_o;
-            tan_beta = sin_theta_i / abs_cos_theta(wi);
-        } else {
-            sin_alpha = sin_theta_i;
-            tan_beta = sin_theta_o / abs_cos_theta(wo);
-        }
-        return (l.r * kInvPi) * (l.a + l.b * max_cos * sin_alpha * tan_beta);
-    }
-    static Float lobe_pdf(const Lobe&, V3 wo, V3 wi) {   // bxdf.rs:88-94
-        return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0.0f;
-    }
-    // bxdf.rs:74-86 (sample_f_default: never returns None)
-    static void lobe_sample_f(const Lobe& l, V3 wo, V2 u, RGB* f, V3* wi, Float* pdf) {
-        V3 w = cosine_sample_hemisphere(u);
-        if (wo.z < 0.0f) w.z *= -1.0f;
-        *pdf = lobe_pdf(l, wo, w);
-        *f = lobe_f(l, wo, w);
-        *wi = w;
     }
     static bool finite3(V3 v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); }
     // bsdf.rs:92-206
@@ -109,9 +61,10 @@ struct BSDF {
         RGB f;
         V3 wi;
         Float pdf;
-        lobe_sample_f(lb, wo, remapped, &f, &wi, &pdf);
+        uint32_t t = 0;
+        if (!lobe_sample_f(lb, wo, remapped, &f, &wi, &pdf, &t)) return false;
         if (pdf <= 0.0f) return false;
-        uint32_t sampled_type = lb.type();
+        uint32_t sampled_type = t != 0 ? t : lb.type();
         V3 wi_world = local_to_world(wi);
         if ((lb.type() & BSDF_SPECULAR) == 0 && matching > 1)
             for (int i = 0; i < n_lobes; i++)
@@ -338,30 +291,121 @@ inline Ray generate_ray(const Scene& sc, const CameraSample& s) {
 
 struct RayCounters { uint64_t camera = 0, regular = 0, shadow = 0, nodes = 0, tris = 0, vertices = 0; };
 
-// ---- Matte::compute_scattering_functions (materials/matte.rs:25-53).
-// Returns false when the primitive has no material (bsdf stays None).
+// ---- Material::compute_scattering_functions with constant textures, mode = Radiance,
+// allow_multiple_lobes = true (path.rs:106).  Returns false when the interaction gets no BSDF.
+inline void add_microfacet_refl(BSDF* b, RGB r, Float ax, Float ay, int fresnel, Float eta_i, Float eta_t) {
+    Lobe& l = b->add();
+    l.kind = LOBE_MF_REFL; l.r = r; l.dist.init(ax, ay);
+    l.fresnel = fresnel; l.fr_eta_i = eta_i; l.fr_eta_t = eta_t;
+}
+inline bool make_bsdf_from_material(const pt_material& m, const SurfHit& si, BSDF* b) {
+    if (m.type == PT_MATERIAL_NONE) return false;
+    auto rgb = [](const float* c) { return RGB(c[0], c[1], c[2]); };
+    auto pick = [](Float specific, Float general) { return specific == PT_ROUGHNESS_UNSET ? general : specific; };
+    switch (m.type) {
+        case PT_MATERIAL_MATTE: {                      // materials/matte.rs:25-53
+            b->init(si, 1.0f);
+            RGB r = rgb(m.kd);                         // no clamp_zero here, unlike the other materials
+            Float sig = clampf(m.sigma, 0.0f, 90.0f);
+            if (!r.is_black()) {
+                Lobe& l = b->add();
+                l.r = r;
+                if (sig == 0.0f) {
+                    l.kind = LOBE_LAMBERT;
+                } else {                               // oren_nayar.rs:12-24
+                    l.kind = LOBE_OREN_NAYAR;
+                    Float sigma = radians(sig);
+                    Float sigma2 = sigma * sigma;
+                    l.a = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+                    l.b = 0.45f * sigma2 / (sigma2 + 0.09f);
+                }
+            }
+            return true;
+        }
+        case PT_MATERIAL_PLASTIC: {                    // materials/plastic.rs:31-71
+            b->init(si, 1.0f);
+            RGB kd = rgb_clamp_zero(rgb(m.kd));
+            if (!kd.is_black()) { Lobe& l = b->add(); l.kind = LOBE_LAMBERT; l.r = kd; }
+            RGB ks = rgb_clamp_zero(rgb(m.ks));
+            if (!ks.is_black()) {
+                Float rough = m.roughness;
+                if (m.remap_roughness) rough = TRDist::roughness_to_alpha(rough);
+                add_microfacet_refl(b, ks, rough, rough, FR_DIELECTRIC, 1.5f, 1.0f);
+            }
+            return true;
+        }
+        case PT_MATERIAL_MIRROR: {                     // materials/mirror.rs:19-41
+            b->init(si, 1.0f);
+            RGB r = rgb_clamp_zero(rgb(m.kr));
+            if (!r.is_black()) { Lobe& l = b->add(); l.kind = LOBE_SPEC_REFL; l.r = r; l.fresnel = FR_NOOP; }
+            return true;
+        }
+        case PT_MATERIAL_GLASS: {                      // materials/glass.rs:46-110
+            Float eta = m.eta, u_rough = m.uroughness, v_rough = m.vroughness;
+            RGB r = rgb(m.kr), t = rgb(m.kt);
+            if (r.is_black() && t.is_black()) return false;
+            b->init(si, eta);
+            bool is_specular = u_rough == 0.0f && v_rough == 0.0f;
+            if (is_specular) {                         // allow_multiple_lobes
+                Lobe& l = b->add();
+                l.kind = LOBE_FRESNEL_SPEC; l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta;
+            } else {
+                if (m.remap_roughness) { u_rough = TRDist::roughness_to_alpha(u_rough); v_rough = TRDist::roughness_to_alpha(v_rough); }
+                if (!r.is_black()) add_microfacet_refl(b, r, u_rough, v_rough, FR_DIELECTRIC, 1.0f, eta);
+                if (!t.is_black()) {
+                    Lobe& l = b->add();
+                    l.kind = LOBE_MF_TRANS; l.r = t; l.dist.init(u_rough, v_rough); l.eta_a = 1.0f; l.eta_b = eta;
+                }
+            }
+            return true;
+        }
+        case PT_MATERIAL_METAL: {                      // materials/metal.rs:51-85
+            b->init(si, 1.0f);
+            Float u_rough = pick(m.uroughness, m.roughness), v_rough = pick(m.vroughness, m.roughness);
+            if (m.remap_roughness) { u_rough = TRDist::roughness_to_alpha(u_rough); v_rough = TRDist::roughness_to_alpha(v_rough); }
+            Lobe& l = b->add();
+            l.kind = LOBE_MF_REFL; l.r = RGB(1.0f); l.dist.init(u_rough, v_rough);
+            l.fresnel = FR_CONDUCTOR; l.fr_cond_eta = rgb(m.metal_eta); l.fr_cond_k = rgb(m.metal_k);
+            return true;
+        }
+        case PT_MATERIAL_UBER: {                       // materials/uber.rs:63-127
+            Float e = m.eta;
+            RGB op = rgb(m.opacity);
+            RGB t = rgb_clamp_zero(RGB(1.0f) - op);
+            b->init(si, !t.is_black() ? 1.0f : e);
+            if (!t.is_black()) { Lobe& l = b->add(); l.kind = LOBE_SPEC_TRANS; l.r = t; l.eta_a = 1.0f; l.eta_b = 1.0f; }
+            RGB kd = op * rgb_clamp_zero(rgb(m.kd));
+            if (!kd.is_black()) { Lobe& l = b->add(); l.kind = LOBE_LAMBERT; l.r = kd; }
+            RGB ks = op * rgb_clamp_zero(rgb(m.ks));
+            if (!ks.is_black()) {
+                Float u_rough = pick(m.uroughness, m.roughness), v_rough = pick(m.vroughness, m.roughness);
+                if (m.remap_roughness) { u_rough = TRDist::roughness_to_alpha(u_rough); v_rough = TRDist::roughness_to_alpha(v_rough); }
+                add_microfacet_refl(b, ks, u_rough, v_rough, FR_DIELECTRIC, 1.0f, e);
+            }
+            RGB kr = op * rgb_clamp_zero(rgb(m.kr));
+            if (!kr.is_black()) { Lobe& l = b->add(); l.kind = LOBE_SPEC_REFL; l.r = kr; l.fresnel = FR_DIELECTRIC; l.fr_eta_i = 1.0f; l.fr_eta_t = e; }
+            RGB kt = op * rgb_clamp_zero(rgb(m.kt));
+            if (!kt.is_black()) { Lobe& l = b->add(); l.kind = LOBE_SPEC_TRANS; l.r = kt; l.eta_a = 1.0f; l.eta_b = e; }
+            return true;
+        }
+        case PT_MATERIAL_SUBSTRATE: {                  // materials/substrate.rs:34-68
+            b->init(si, 1.0f);
+            RGB d = rgb_clamp_zero(rgb(m.kd)), s = rgb_clamp_zero(rgb(m.ks));
+            if (!d.is_black() && !s.is_black()) {
+                Float u_rough = m.uroughness, v_rough = m.vroughness;
+                if (m.remap_roughness) { u_rough = TRDist::roughness_to_alpha(u_rough); v_rough = TRDist::roughness_to_alpha(v_rough); }
+                Lobe& l = b->add();
+                l.kind = LOBE_FRESNEL_BLEND; l.r = d; l.t = s; l.dist.init(u_rough, v_rough);
+            }
+            return true;
+        }
+    }
+    return false;
+}
 inline bool make_bsdf(const Scene& sc, const SurfHit& si, BSDF* b) {
     int32_t mid = sc.mesh_material[sc.geom.tri_mesh[si.prim]];
     if (mid < 0) return false;
-    const pt_material& m = sc.materials[mid];
-    if (m.type == PT_MATERIAL_NONE) return false;
-    b->init(si, 1.0f);
-    RGB r(m.kd[0], m.kd[1], m.kd[2]);
-    Float sig = clampf(m.sigma, 0.0f, 90.0f);
-    if (!r.is_black()) {
-        Lobe& l = b->lobes[b->n_lobes++];
-        l.r = r;
-        if (sig == 0.0f) {
-            l.kind = 0;
-        } else {                       // oren_nayar.rs:12-24
-            l.kind = 1;
-            Float sigma = radians(sig);
-            Float sigma2 = sigma * sigma;
-            l.a = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
-            l.b = 0.45f * sigma2 / (sigma2 + 0.09f);
-        }
-    }
-    return true;
+    return make_bsdf_from_material(sc.materials[mid], si, b);
 }
 
 // SurfaceInteraction::le (surface_interaction.rs:297-306)

@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRTGPU_LIB") or os.path.join(HERE, "csrc", "libpbrtgpu.so")   # override: tuning builds only
 DATA_DIR = os.path.join(HERE, "data")
 
-PT_MATERIAL_NONE, PT_MATERIAL_MATTE = 0, 1
+PT_MATERIAL_NONE, PT_MATERIAL_MATTE, PT_MATERIAL_PLASTIC, PT_MATERIAL_MIRROR = 0, 1, 2, 3
+PT_MATERIAL_GLASS, PT_MATERIAL_METAL, PT_MATERIAL_UBER, PT_MATERIAL_SUBSTRATE = 4, 5, 6, 7
+PT_ROUGHNESS_UNSET = -1.0
 PT_MESH_TWO_SIDED, PT_MESH_REVERSE_ORIENTATION, PT_MESH_SWAPS_HANDEDNESS = 1, 2, 4
 PT_MESH_HAS_N, PT_MESH_HAS_S, PT_MESH_HAS_UV = 8, 16, 32
 PT_SPLIT_SAH, PT_SPLIT_HLBVH, PT_SPLIT_MIDDLE, PT_SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
@@ -29,7 +31,10 @@ class PtError(RuntimeError):
 
 
 class pt_material(C.Structure):
-    _fields_ = [("type", C.c_int32), ("kd", C.c_float * 3), ("sigma", C.c_float), ("reserved", C.c_float * 3)]
+    _fields_ = [("type", C.c_int32), ("kd", C.c_float * 3), ("sigma", C.c_float), ("ks", C.c_float * 3), ("kr", C.c_float * 3),
+                ("kt", C.c_float * 3), ("opacity", C.c_float * 3), ("eta", C.c_float), ("roughness", C.c_float),
+                ("uroughness", C.c_float), ("vroughness", C.c_float), ("remap_roughness", C.c_int32),
+                ("metal_eta", C.c_float * 3), ("metal_k", C.c_float * 3), ("reserved", C.c_float * 3)]
 
 
 class pt_area_light(C.Structure):
@@ -93,7 +98,7 @@ SYMBOLS = [
     "pt_scene_upload", "pt_scene_info_get", "pt_film_clear", "pt_render", "pt_film_download_xyzw",
     "pt_film_device_xyzw", "pt_film_commit_xyzw", "pt_film_resolve_rgb", "pt_trace_closest", "pt_trace_any",
     "pt_generate_camera_rays", "pt_sobol_samples", "pt_radiance_samples", "pt_get_counters", "pt_reset_counters",
-    "pt_bvh_leaf_order",
+    "pt_bvh_leaf_order", "pt_bsdf_eval", "pt_bsdf_sample",
 ]
 
 _lib = None
@@ -129,6 +134,8 @@ def load_library(path=None):
     lib.pt_generate_camera_rays.argtypes = [vp, u32, vp, vp, vp, vp, vp]
     lib.pt_sobol_samples.argtypes = [vp, u32, vp, vp, vp, vp]
     lib.pt_radiance_samples.argtypes = [vp, C.POINTER(pt_tile), vp]
+    lib.pt_bsdf_eval.argtypes = [vp, u32, u32, vp, vp, u32, vp, vp]
+    lib.pt_bsdf_sample.argtypes = [vp, u32, u32, vp, vp, u32, vp, vp, vp, vp]
     lib.pt_get_counters.argtypes = [vp, C.POINTER(pt_counters)]
     lib.pt_reset_counters.argtypes = [vp]
     lib.pt_bvh_leaf_order.argtypes = [C.POINTER(pt_scene_desc), vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
@@ -328,6 +335,23 @@ class Context:
         out = np.empty(n, np.float32)
         self._check(self.lib.pt_sobol_samples(self.h, n, _ptr(pixel_xy), _ptr(sample_index), _ptr(dim), _ptr(out)))
         return out
+
+    def bsdf_eval(self, material, wo, wi, flags=31):
+        """BSDF::f / pdf of one material on the canonical frame (local == world)."""
+        wo = np.ascontiguousarray(wo, np.float32); wi = np.ascontiguousarray(wi, np.float32)
+        n = len(wo)
+        f = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32)
+        self._check(self.lib.pt_bsdf_eval(self.h, C.c_uint32(material), C.c_uint32(n), _ptr(wo), _ptr(wi), C.c_uint32(flags), _ptr(f), _ptr(pdf)))
+        return f, pdf
+
+    def bsdf_sample(self, material, wo, u, flags=31):
+        """BSDF::sample_f; type 0 = None."""
+        wo = np.ascontiguousarray(wo, np.float32); u = np.ascontiguousarray(u, np.float32)
+        n = len(wo)
+        f = np.empty((n, 3), np.float32); wi = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32); t = np.empty(n, np.uint32)
+        self._check(self.lib.pt_bsdf_sample(self.h, C.c_uint32(material), C.c_uint32(n), _ptr(wo), _ptr(u), C.c_uint32(flags), _ptr(f), _ptr(wi),
+                                            _ptr(pdf), _ptr(t)))
+        return f, wi, pdf, t
 
     def radiance_samples(self, tile):
         t = pt_tile(*[int(v) for v in tile])

@@ -64,6 +64,7 @@ struct pt_context {
     std::vector<uint32_t> sobol_m32;
     std::vector<uint64_t> sobol_vdc, sobol_inv;
     uint32_t sobol_n_vdc = 0, sobol_n_inv = 0, sobol_msize = 52;
+    uint32_t n_materials = 0;
     uint32_t max_stack = 1;
     uint32_t film_w = 0, film_h = 0;
 
@@ -239,6 +240,145 @@ pt_status pt_set_data_dir(pt_context* ctx, const char* dir) {
 }
 
 namespace {
+// ---- Material::compute_scattering_functions for constant parameter textures (src/materials/*.rs), evaluated
+// once per material: the list of BxDFs the BSDF receives, in the order the material adds them.
+const uint32_t kRefl = 1, kTrans = 2, kDiffuse = 4, kGlossy = 8, kSpecular = 16;    // bxdf.rs:8-14
+float clamp_zero(float v) { return v < 0.0f ? 0.0f : v; }                            // Spectrum::clamp_zero per channel
+bool black(const float* c) { return c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f; }
+float roughness_to_alpha(float roughness) {                                           // trowbridge_reitz.rs:104-113
+    roughness = roughness > 1e-3f ? roughness : 1e-3f;
+    float x = std::log(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+PtLobe* push_lobe(PtMaterial& m, uint32_t kind, uint32_t type, const float* r) {
+    PtLobe* l = &m.lobes[m.n_lobes++];
+    l->kind = kind; l->type = type;
+    l->r[0] = r[0]; l->r[1] = r[1]; l->r[2] = r[2];
+    l->eta_a = l->eta_b = l->fr_eta_i = l->fr_eta_t = 1.0f;
+    l->ax = l->ay = 0.001f;
+    return l;
+}
+void set_distribution(PtLobe* l, float ax, float ay) {                               // TrowbridgeReitzDistribution::new
+    l->ax = 0.001f > ax ? 0.001f : ax;     // f32::max: a NaN roughness becomes 0.001
+    l->ay = 0.001f > ay ? 0.001f : ay;
+    if (ax != ax) l->ax = 0.001f;
+    if (ay != ay) l->ay = 0.001f;
+}
+void build_lobes(const pt_material& in, PtMaterial& m) {
+    std::memset(&m, 0, sizeof(m));
+    m.type = in.type;
+    std::memcpy(m.kd, in.kd, 12);
+    m.sigma = in.sigma;
+    m.bsdf_eta = 1.0f;
+    m.has_bsdf = in.type != PT_MATERIAL_NONE;
+    auto pick = [](float specific, float general) { return specific == PT_ROUGHNESS_UNSET ? general : specific; };
+    auto remap = [&](float r) { return in.remap_roughness ? roughness_to_alpha(r) : r; };
+    auto cz = [](const float* c, float* out) { for (int i = 0; i < 3; i++) out[i] = clamp_zero(c[i]); };
+    auto mul = [](const float* a, const float* b, float* out) { for (int i = 0; i < 3; i++) out[i] = a[i] * b[i]; };
+    switch (in.type) {
+        case PT_MATERIAL_MATTE: {                       // matte.rs:25-53 (Kd is not clamped here)
+            float sig = in.sigma < 0.0f ? 0.0f : (in.sigma > 90.0f ? 90.0f : in.sigma);
+            const float pi = 3.14159265358979323846f;
+            float sigma = sig * (pi / 180.0f);
+            float sigma2 = sigma * sigma;
+            m.oren_a = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+            m.oren_b = 0.45f * sigma2 / (sigma2 + 0.09f);
+            if (!black(in.kd)) {
+                PtLobe* l = push_lobe(m, sig == 0.0f ? PT_LOBE_LAMBERT : PT_LOBE_OREN_NAYAR, kRefl | kDiffuse, in.kd);
+                l->oa = m.oren_a; l->ob = m.oren_b;
+            }
+            break;
+        }
+        case PT_MATERIAL_PLASTIC: {                     // plastic.rs:31-71
+            float kd[3], ks[3];
+            cz(in.kd, kd); cz(in.ks, ks);
+            if (!black(kd)) push_lobe(m, PT_LOBE_LAMBERT, kRefl | kDiffuse, kd);
+            if (!black(ks)) {
+                float rough = remap(in.roughness);
+                PtLobe* l = push_lobe(m, PT_LOBE_MF_REFL, kRefl | kGlossy, ks);
+                set_distribution(l, rough, rough);
+                l->fresnel = PT_FR_DIELECTRIC; l->fr_eta_i = 1.5f; l->fr_eta_t = 1.0f;
+            }
+            break;
+        }
+        case PT_MATERIAL_MIRROR: {                      // mirror.rs:19-41
+            float kr[3];
+            cz(in.kr, kr);
+            if (!black(kr)) push_lobe(m, PT_LOBE_SPEC_REFL, kRefl | kSpecular, kr)->fresnel = PT_FR_NOOP;
+            break;
+        }
+        case PT_MATERIAL_GLASS: {                       // glass.rs:46-110 (Kr, Kt unclamped; allow_multiple_lobes = true)
+            if (black(in.kr) && black(in.kt)) { m.has_bsdf = 0; break; }
+            m.bsdf_eta = in.eta;
+            if (in.uroughness == 0.0f && in.vroughness == 0.0f) {
+                PtLobe* l = push_lobe(m, PT_LOBE_FRESNEL_SPEC, kRefl | kTrans | kSpecular, in.kr);
+                std::memcpy(l->t, in.kt, 12);
+                l->eta_a = 1.0f; l->eta_b = in.eta;
+            } else {
+                float ur = remap(in.uroughness), vr = remap(in.vroughness);
+                if (!black(in.kr)) {
+                    PtLobe* l = push_lobe(m, PT_LOBE_MF_REFL, kRefl | kGlossy, in.kr);
+                    set_distribution(l, ur, vr);
+                    l->fresnel = PT_FR_DIELECTRIC; l->fr_eta_i = 1.0f; l->fr_eta_t = in.eta;
+                }
+                if (!black(in.kt)) {
+                    PtLobe* l = push_lobe(m, PT_LOBE_MF_TRANS, kTrans | kGlossy, in.kt);
+                    set_distribution(l, ur, vr);
+                    l->eta_a = 1.0f; l->eta_b = in.eta;
+                }
+            }
+            break;
+        }
+        case PT_MATERIAL_METAL: {                       // metal.rs:51-85
+            const float one[3] = {1.0f, 1.0f, 1.0f};
+            PtLobe* l = push_lobe(m, PT_LOBE_MF_REFL, kRefl | kGlossy, one);
+            set_distribution(l, remap(pick(in.uroughness, in.roughness)), remap(pick(in.vroughness, in.roughness)));
+            l->fresnel = PT_FR_CONDUCTOR;
+            std::memcpy(l->t, in.metal_eta, 12);
+            std::memcpy(l->k, in.metal_k, 12);
+            break;
+        }
+        case PT_MATERIAL_UBER: {                        // uber.rs:63-127
+            float t[3], c[3], tmp[3];
+            for (int i = 0; i < 3; i++) t[i] = clamp_zero(1.0f - in.opacity[i]);
+            m.bsdf_eta = !black(t) ? 1.0f : in.eta;
+            if (!black(t)) push_lobe(m, PT_LOBE_SPEC_TRANS, kTrans | kSpecular, t);       // eta_a = eta_b = 1
+            cz(in.kd, tmp); mul(in.opacity, tmp, c);
+            if (!black(c)) push_lobe(m, PT_LOBE_LAMBERT, kRefl | kDiffuse, c);
+            cz(in.ks, tmp); mul(in.opacity, tmp, c);
+            if (!black(c)) {
+                PtLobe* l = push_lobe(m, PT_LOBE_MF_REFL, kRefl | kGlossy, c);
+                set_distribution(l, remap(pick(in.uroughness, in.roughness)), remap(pick(in.vroughness, in.roughness)));
+                l->fresnel = PT_FR_DIELECTRIC; l->fr_eta_i = 1.0f; l->fr_eta_t = in.eta;
+            }
+            cz(in.kr, tmp); mul(in.opacity, tmp, c);
+            if (!black(c)) {
+                PtLobe* l = push_lobe(m, PT_LOBE_SPEC_REFL, kRefl | kSpecular, c);
+                l->fresnel = PT_FR_DIELECTRIC; l->fr_eta_i = 1.0f; l->fr_eta_t = in.eta;
+            }
+            cz(in.kt, tmp); mul(in.opacity, tmp, c);
+            if (!black(c)) {
+                PtLobe* l = push_lobe(m, PT_LOBE_SPEC_TRANS, kTrans | kSpecular, c);
+                l->eta_a = 1.0f; l->eta_b = in.eta;
+            }
+            break;
+        }
+        case PT_MATERIAL_SUBSTRATE: {                   // substrate.rs:34-68
+            float d[3], s[3];
+            cz(in.kd, d); cz(in.ks, s);
+            if (!black(d) && !black(s)) {
+                PtLobe* l = push_lobe(m, PT_LOBE_FRESNEL_BLEND, kRefl | kGlossy, d);
+                std::memcpy(l->t, s, 12);
+                set_distribution(l, remap(in.uroughness), remap(in.vroughness));
+            }
+            break;
+        }
+        default: break;
+    }
+    for (uint32_t i = 0; i < m.n_lobes; i++)
+        if (!(m.lobes[i].type & kSpecular)) m.nonspecular++;
+}
+
 // PCG32 with the reference's default state (core/rng.rs:8-67) -- only the bounded draw that
 // shuffle_array (core/sampling/sampling.rs:4-15) needs
 struct Pcg32 {
@@ -334,8 +474,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (d->meshes[m].material >= 65535) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 65534 materials");
         if (d->meshes[m].area_light >= (int32_t)d->n_area_lights) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "area light index out of range");
         int32_t mi = d->meshes[m].material;
-        if (mi >= 0 && d->materials[mi].type != PT_MATERIAL_NONE && d->materials[mi].type != PT_MATERIAL_MATTE)
-            return ctx->fail(PT_ERR_UNSUPPORTED, "material type not on the accelerated path yet");
+        if (mi >= 0 && (d->materials[mi].type < PT_MATERIAL_NONE || d->materials[mi].type > PT_MATERIAL_SUBSTRATE))
+            return ctx->fail(PT_ERR_UNSUPPORTED, "material type not on the accelerated path");
     }
     if (ctx->sobol_m32.empty() && !load_sobol(ctx)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "cannot read sobol_tables.bin from data dir '" + ctx->data_dir + "'");
 
@@ -400,17 +540,10 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (lights.size() >= (1u << 24)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^24 emissive triangles");
     std::vector<PtMaterial> mats(std::max<uint32_t>(d->n_materials, 1));
     std::memset(mats.data(), 0, mats.size() * sizeof(PtMaterial));
+    bool general_materials = false;
     for (uint32_t i = 0; i < d->n_materials; i++) {
-        PtMaterial& m = mats[i];
-        m.type = d->materials[i].type;
-        std::memcpy(m.kd, d->materials[i].kd, 12);
-        m.sigma = d->materials[i].sigma;
-        float sig = m.sigma < 0.0f ? 0.0f : (m.sigma > 90.0f ? 90.0f : m.sigma);
-        const float pi = 3.14159265358979323846f;
-        float sigma = sig * (pi / 180.0f);
-        float sigma2 = sigma * sigma;
-        m.oren_a = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
-        m.oren_b = 0.45f * sigma2 / (sigma2 + 0.09f);
+        build_lobes(d->materials[i], mats[i]);
+        if (d->materials[i].type != PT_MATERIAL_NONE && d->materials[i].type != PT_MATERIAL_MATTE) general_materials = true;
     }
 
     PtScene& sc = ctx->sc;
@@ -431,6 +564,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     sc.S = d->S ? ctx->d_S.as<float>() : nullptr;
     sc.UV = d->UV ? ctx->d_UV.as<float>() : nullptr;
     sc.materials = ctx->d_materials.as<PtMaterial>();
+    sc.general_materials = general_materials ? 1u : 0u;
+    ctx->n_materials = d->n_materials;
     sc.lights = ctx->d_lights.as<PtLight>();
     sc.n_lights = (uint32_t)lights.size();
     sc.root_ref = bvh.root_ref;
@@ -850,6 +985,45 @@ pt_status pt_generate_camera_rays(pt_context* ctx, uint32_t n, const int32_t* pi
     PT_HIP(hipMemcpy(out_o, d_o.p, (size_t)n * 12, hipMemcpyDeviceToHost));
     PT_HIP(hipMemcpy(out_d, d_d.p, (size_t)n * 12, hipMemcpyDeviceToHost));
     PT_HIP(hipMemcpy(out_pfilm, d_pf.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_bsdf_eval(pt_context* ctx, uint32_t material, uint32_t n, const float* wo, const float* wi, uint32_t flags, float* f_out, float* pdf_out) {
+    if (!ctx || !wo || !wi || !f_out || !pdf_out) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    if (material >= ctx->n_materials) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "material index out of range");
+    if (n == 0) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    DevBuf d_wo, d_wi, d_f, d_pdf;
+    PT_HIP(d_wo.alloc((size_t)n * 12)); PT_HIP(d_wi.alloc((size_t)n * 12)); PT_HIP(d_f.alloc((size_t)n * 12)); PT_HIP(d_pdf.alloc((size_t)n * 4));
+    PT_HIP(hipMemcpy(d_wo.p, wo, (size_t)n * 12, hipMemcpyHostToDevice));
+    PT_HIP(hipMemcpy(d_wi.p, wi, (size_t)n * 12, hipMemcpyHostToDevice));
+    PT_HIP(ptk_bsdf_eval(ctx->stream, ctx->sc, material, n, d_wo.as<float>(), d_wi.as<float>(), flags, d_f.as<float>(), d_pdf.as<float>()));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    PT_HIP(hipMemcpy(f_out, d_f.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(pdf_out, d_pdf.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+pt_status pt_bsdf_sample(pt_context* ctx, uint32_t material, uint32_t n, const float* wo, const float* u, uint32_t flags, float* f_out, float* wi_out,
+                         float* pdf_out, uint32_t* type_out) {
+    if (!ctx || !wo || !u || !f_out || !wi_out || !pdf_out || !type_out) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    if (material >= ctx->n_materials) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "material index out of range");
+    if (n == 0) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    DevBuf d_wo, d_u, d_f, d_wi, d_pdf, d_t;
+    PT_HIP(d_wo.alloc((size_t)n * 12)); PT_HIP(d_u.alloc((size_t)n * 8)); PT_HIP(d_f.alloc((size_t)n * 12)); PT_HIP(d_wi.alloc((size_t)n * 12));
+    PT_HIP(d_pdf.alloc((size_t)n * 4)); PT_HIP(d_t.alloc((size_t)n * 4));
+    PT_HIP(hipMemcpy(d_wo.p, wo, (size_t)n * 12, hipMemcpyHostToDevice));
+    PT_HIP(hipMemcpy(d_u.p, u, (size_t)n * 8, hipMemcpyHostToDevice));
+    PT_HIP(ptk_bsdf_sample(ctx->stream, ctx->sc, material, n, d_wo.as<float>(), d_u.as<float>(), flags, d_f.as<float>(), d_wi.as<float>(), d_pdf.as<float>(),
+                           d_t.as<uint32_t>()));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    PT_HIP(hipMemcpy(f_out, d_f.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(wi_out, d_wi.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(pdf_out, d_pdf.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(type_out, d_t.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -50,12 +50,37 @@ struct PtTriInfo {
     uint32_t pad;
 };
 
+// One BxDF of a material's BSDF.  With constant textures Material::compute_scattering_functions adds
+// the same BxDFs at every hit, so the host evaluates it once per material (pt_context.cpp build_lobes).
+enum { PT_LOBE_LAMBERT = 0, PT_LOBE_OREN_NAYAR = 1, PT_LOBE_SPEC_REFL = 2, PT_LOBE_SPEC_TRANS = 3, PT_LOBE_FRESNEL_SPEC = 4,
+       PT_LOBE_MF_REFL = 5, PT_LOBE_MF_TRANS = 6, PT_LOBE_FRESNEL_BLEND = 7 };
+enum { PT_FR_NOOP = 0, PT_FR_DIELECTRIC = 1, PT_FR_CONDUCTOR = 2 };
+struct PtLobe {                  // 80 bytes
+    uint32_t kind;               // PT_LOBE_*
+    uint32_t type;               // BxDFType bits (bxdf.rs:8-14)
+    uint32_t fresnel;            // PT_FR_* of SpecularReflection / MicrofacetReflection
+    float ax;                    // TrowbridgeReitz alpha_x (after max(0.001, .))
+    float r[3];                  // R / T / Kd / Rd
+    float ay;
+    float t[3];                  // FresnelSpecular T, FresnelBlend Rs, conductor eta
+    float eta_a;
+    float k[3];                  // conductor k
+    float eta_b;
+    float fr_eta_i, fr_eta_t;    // FresnelDielectric
+    float oa, ob;                // OrenNayar A, B
+};
+#define PT_MAX_LOBES 5           // UberMaterial adds at most five BxDFs
 struct PtMaterial {
     int32_t type;
     float kd[3];
     float sigma;
     float oren_a, oren_b;        // OrenNayar::new (oren_nayar.rs:16-23), precomputed on the host
-    float pad;
+    uint32_t n_lobes;
+    uint32_t has_bsdf;           // 0: compute_scattering_functions leaves bsdf = None (glass with Kr = Kt = 0)
+    uint32_t nonspecular;        // num_components(BSDF_ALL & !BSDF_SPECULAR)
+    float bsdf_eta;              // BSDF::eta
+    uint32_t pad;
+    PtLobe lobes[PT_MAX_LOBES];
 };
 
 // One DiffuseAreaLight (one emissive triangle).
@@ -128,6 +153,7 @@ struct PtCounters {
 };
 
 struct PtScene {
+    uint32_t general_materials;  // 1 when any material is not Matte: k_shade_general runs instead of k_shade
     const PtNode* nodes;
     const PtTri* tris;
     const PtTriInfo* tri_info;

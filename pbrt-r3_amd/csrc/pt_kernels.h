@@ -19,5 +19,9 @@ hipError_t ptk_film_rgb(hipStream_t st, const float4* xyzw, float* rgb, uint32_t
 hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32_t n_vox);
 hipError_t ptk_camera_rays(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* o, float* d,
                            float* pf);
+hipError_t ptk_bsdf_eval(hipStream_t st, const PtScene& sc, uint32_t material, uint32_t n, const float* wo, const float* wi, uint32_t flags, float* f,
+                         float* pdf);
+hipError_t ptk_bsdf_sample(hipStream_t st, const PtScene& sc, uint32_t material, uint32_t n, const float* wo, const float* u, uint32_t flags, float* f,
+                           float* wi, float* pdf, uint32_t* type);
 hipError_t ptk_sobol_samples(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim,
                              float* out);

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include "pt_device.h"
 #include "pt_device_math.h"
+#include "pt_bxdf.h"
 #include "pt_kernels.h"
 #include "../../include/pbrtgpu.h"
 
@@ -973,7 +974,10 @@ PT_DEV uint32_t sample_discrete(const float* tab, uint32_t n, float u, float* pd
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
 #endif
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+// GENERAL = false: every material is Matte (at most one diffuse lobe; the RT1M / Cornell fast path).
+// GENERAL = true: BSDFs are the per-material lobe lists of pt_bxdf.h (specular bounces, eta_scale, glass without a BSDF).
+template <bool GENERAL>
+PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt) {
     __shared__ unsigned long long s_vert;
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
@@ -1012,22 +1016,49 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
                 }
             }
             if (found && (int32_t)bounces < sc.max_depth) {
-                if (s.material < 0) {
+                bool no_bsdf = s.material < 0;
+                if constexpr (GENERAL) { if (!no_bsdf) no_bsdf = sc.materials[s.material].has_bsdf == 0; }
+                if (no_bsdf) {
                     // no BSDF: continue through the surface, same bounce count (path.rs:108-111)
                     V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
                     P.ray_o[p] = make_float4(no.x, no.y, no.z, PT_INF);
                     cont = true;
                 } else {
                     n_vert++;
-                    const PtMaterial m = sc.materials[s.material];
                     Bsdf b;
-                    b.ns = s.sh_n; b.ng = s.n;
-                    b.ss = normalize(s.sh_dpdu);
-                    b.ts = normalize(cross(b.ns, b.ss));
-                    b.r = mk3(m.kd[0], m.kd[1], m.kd[2]);
-                    b.n_lobes = is_black(b.r) ? 0 : 1;
-                    b.oren = clampf(m.sigma, 0.0f, 90.0f) != 0.0f;
-                    b.oa = m.oren_a; b.ob = m.oren_b;
+                    GBsdf gb;
+                    bool nonspecular;
+                    float bsdf_eta = 1.0f;
+                    if constexpr (GENERAL) {
+                        const PtMaterial& m = sc.materials[s.material];
+                        gb.ns = s.sh_n; gb.ng = s.n;
+                        gb.ss = normalize(s.sh_dpdu);
+                        gb.ts = normalize(cross(gb.ns, gb.ss));
+                        gb.lobes = m.lobes; gb.n_lobes = m.n_lobes;
+                        nonspecular = m.nonspecular > 0;
+                        bsdf_eta = m.bsdf_eta;
+                    } else {
+                        const PtMaterial& m = sc.materials[s.material];
+                        b.ns = s.sh_n; b.ng = s.n;
+                        b.ss = normalize(s.sh_dpdu);
+                        b.ts = normalize(cross(b.ns, b.ss));
+                        b.r = mk3(m.kd[0], m.kd[1], m.kd[2]);
+                        b.n_lobes = is_black(b.r) ? 0 : 1;
+                        b.oren = clampf(m.sigma, 0.0f, 90.0f) != 0.0f;
+                        b.oa = m.oren_a; b.ob = m.oren_b;
+                        nonspecular = b.n_lobes > 0;
+                    }
+                    const uint32_t kNoSpec = PT_BSDF_ALL & ~PT_BSDF_SPECULAR;
+                    auto eval_f = [&](V3 wo_w, V3 wi_w) -> V3 {
+                        if constexpr (GENERAL) return gbsdf_f(gb, wo_w, wi_w, kNoSpec); else return bsdf_f(b, wo_w, wi_w);
+                    };
+                    auto eval_pdf = [&](V3 wo_w, V3 wi_w) -> float {
+                        if constexpr (GENERAL) return gbsdf_pdf(gb, wo_w, wi_w, kNoSpec); else return bsdf_pdf(b, wo_w, wi_w);
+                    };
+                    auto sample_bsdf = [&](V3 wo_w, V2 uu, uint32_t fl, V3* f_o, V3* wi_o, float* pdf_o, uint32_t* type_o) -> bool {
+                        if constexpr (GENERAL) return gbsdf_sample_f(gb, wo_w, uu, fl, f_o, wi_o, pdf_o, type_o);
+                        else { *type_o = PT_BSDF_REFLECTION | PT_BSDF_DIFFUSE; return bsdf_sample_f(b, wo_w, uu, f_o, wi_o, pdf_o); }
+                    };
                     Sampler sm;
                     sm.index = P.sobol_index[p];
                     sm.dim = dim;
@@ -1035,7 +1066,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
                     sm.px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0];
                     sm.py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
                     // ---- next-event estimation (uniform_sample_one_light_surface, sample_lights.rs:129-176)
-                    if (b.n_lobes > 0 && sc.n_lights > 0) {
+                    if (nonspecular && sc.n_lights > 0) {
                         const float* tab = grid_lookup(sc.grid, s.p);
                         float light_pdf;
                         uint32_t light_num = sample_discrete(tab, sc.n_lights, sm.get_1d(sc), &light_pdf);
@@ -1049,8 +1080,8 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
                             float lpdf;
                             if (light_sample_li(lt, s.p, u_light, &li, &wi, &lpdf, &lp, &lperr, &ln)) {
                                 if (lpdf > 0.0f && !is_black(li)) {
-                                    V3 f = bsdf_f(b, s.wo, wi) * abs_dot(wi, s.sh_n);
-                                    float spdf = bsdf_pdf(b, s.wo, wi);
+                                    V3 f = eval_f(s.wo, wi) * abs_dot(wi, s.sh_n);
+                                    float spdf = eval_pdf(s.wo, wi);
                                     if (!is_black(f)) {
                                         // VisibilityTester: Interaction::spawn_ray_to (interaction.rs:118-127)
                                         V3 origin = offset_ray_origin(s.p, s.p_error, s.n, lp - s.p);
@@ -1067,7 +1098,8 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
                             // BSDF sampling half of MIS (sample_lights.rs:393-451)
                             V3 f2, wi2;
                             float spdf2;
-                            if (bsdf_sample_f(b, s.wo, u_scat, &f2, &wi2, &spdf2)) {
+                            uint32_t type2;      // never specular: the flags exclude BSDF_SPECULAR (sample_lights.rs:343-347)
+                            if (sample_bsdf(s.wo, u_scat, kNoSpec, &f2, &wi2, &spdf2, &type2)) {
                                 V3 f = f2 * abs_dot(wi2, s.sh_n);
                                 if (!is_black(f) && spdf2 > 0.0f) {
                                     // light.pdf_li -> Shape::pdf_from (shape.rs:40-54): one test against the light's own triangle
@@ -1113,9 +1145,12 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
                     V2 u = sm.get_2d(sc);
                     V3 f, wi;
                     float pdf;
-                    if (bsdf_sample_f(b, s.wo, u, &f, &wi, &pdf) && !(is_black(f) || pdf == 0.0f)) {
+                    uint32_t stype;
+                    if (sample_bsdf(s.wo, u, PT_BSDF_ALL, &f, &wi, &pdf, &stype) && !(is_black(f) || pdf == 0.0f)) {
                         beta = beta * (f * (abs_dot(wi, s.sh_n) / pdf));
-                        flags &= ~PT_ST_SPECULAR;          // diffuse lobes only
+                        if (stype & PT_BSDF_SPECULAR) flags |= PT_ST_SPECULAR; else flags &= ~PT_ST_SPECULAR;
+                        if ((stype & PT_BSDF_SPECULAR) && (stype & PT_BSDF_TRANSMISSION))     // path.rs:157-168
+                            eta_scale *= dot(s.wo, s.n) > 0.0f ? bsdf_eta * bsdf_eta : 1.0f / (bsdf_eta * bsdf_eta);
                         V3 no = offset_ray_origin(s.p, s.p_error, s.n, wi);
                         bool alive = true;
                         V3 rr = beta * eta_scale;
@@ -1153,6 +1188,12 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
     if (n_vert) atomicAdd(&s_vert, (unsigned long long)n_vert);
     __syncthreads();
     if (threadIdx.x == 0 && s_vert) atomicAdd(&cnt->vertices, s_vert);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<false>(sc, P, Q, cnt);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true>(sc, P, Q, cnt);
 }
 
 // ============================================================ film
@@ -1343,6 +1384,40 @@ extern "C" __global__ void k_sobol_samples(PtScene sc, uint32_t n, const int32_t
     }
 }
 
+// ---- hooks: BSDF on the canonical frame
+PT_DEV GBsdf canonical_bsdf(const PtScene& sc, uint32_t material) {
+    GBsdf gb;
+    gb.ns = mk3(0.0f, 0.0f, 1.0f); gb.ng = gb.ns;
+    gb.ss = normalize(mk3(1.0f, 0.0f, 0.0f));
+    gb.ts = normalize(cross(gb.ns, gb.ss));
+    gb.lobes = sc.materials[material].lobes;
+    gb.n_lobes = sc.materials[material].n_lobes;
+    return gb;
+}
+extern "C" __global__ void k_bsdf_eval(PtScene sc, uint32_t material, uint32_t n, const float* wo, const float* wi, uint32_t flags, float* f, float* pdf) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        GBsdf gb = canonical_bsdf(sc, material);
+        V3 o = ld3(wo + 3 * i), w = ld3(wi + 3 * i);
+        V3 r = gbsdf_f(gb, o, w, flags);
+        f[3 * i] = r.x; f[3 * i + 1] = r.y; f[3 * i + 2] = r.z;
+        pdf[i] = gbsdf_pdf(gb, o, w, flags);
+    }
+}
+extern "C" __global__ void k_bsdf_sample(PtScene sc, uint32_t material, uint32_t n, const float* wo, const float* u, uint32_t flags, float* f, float* wi,
+                                         float* pdf, uint32_t* type) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        GBsdf gb = canonical_bsdf(sc, material);
+        V3 r = mk3(0.0f, 0.0f, 0.0f), w = r;
+        float p = 0.0f;
+        uint32_t t = 0;
+        if (!gbsdf_sample_f(gb, ld3(wo + 3 * i), mk2(u[2 * i], u[2 * i + 1]), flags, &r, &w, &p, &t)) { r = mk3(0.0f, 0.0f, 0.0f); w = r; p = 0.0f; t = 0; }
+        f[3 * i] = r.x; f[3 * i + 1] = r.y; f[3 * i + 2] = r.z;
+        wi[3 * i] = w.x; wi[3 * i + 1] = w.y; wi[3 * i + 2] = w.z;
+        pdf[i] = p;
+        type[i] = t;
+    }
+}
+
 // ============================================================ launch wrappers (host side of this TU)
 #define PT_LAUNCH_CHECK() hipGetLastError()
 
@@ -1366,7 +1441,8 @@ hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode) {
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+    if (sc.general_materials) hipLaunchKernelGGL(k_shade_general, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+    else hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,
@@ -1389,6 +1465,16 @@ hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32
 hipError_t ptk_camera_rays(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* o, float* d,
                            float* pf) {
     hipLaunchKernelGGL(k_camera_rays, dim3((n + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, st, sc, n, pixel_xy, sample_index, o, d, pf);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_bsdf_eval(hipStream_t st, const PtScene& sc, uint32_t material, uint32_t n, const float* wo, const float* wi, uint32_t flags, float* f,
+                         float* pdf) {
+    hipLaunchKernelGGL(k_bsdf_eval, dim3((n + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, st, sc, material, n, wo, wi, flags, f, pdf);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_bsdf_sample(hipStream_t st, const PtScene& sc, uint32_t material, uint32_t n, const float* wo, const float* u, uint32_t flags, float* f,
+                           float* wi, float* pdf, uint32_t* type) {
+    hipLaunchKernelGGL(k_bsdf_sample, dim3((n + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, st, sc, material, n, wo, u, flags, f, wi, pdf, type);
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_sobol_samples(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim,

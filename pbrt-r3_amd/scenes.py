@@ -252,16 +252,59 @@ class SceneBuilder:
         self.max_node_prims = int(maxnodeprims)
 
     # ---- graphics state
-    def _add_material(self, typ, kd, sigma):
+    def _add_material(self, typ, kd=(0.0, 0.0, 0.0), sigma=0.0, **kw):
         m = capi.pt_material()
         m.type = typ
         m.kd[:] = [float(k) for k in kd]
         m.sigma = float(sigma)
+        m.opacity[:] = [1.0, 1.0, 1.0]
+        m.eta, m.remap_roughness = 1.5, 1
+        m.uroughness = m.vroughness = capi.PT_ROUGHNESS_UNSET
+        for k, v in kw.items():
+            if isinstance(v, (tuple, list)):
+                getattr(m, k)[:] = [float(x) for x in v]
+            else:
+                setattr(m, k, v)
         self.materials.append(m)
         return len(self.materials) - 1
 
     def material_matte(self, Kd=(0.5, 0.5, 0.5), sigma=0.0):
         self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, Kd, sigma)
+
+    # defaults below are the reference's create_*_material defaults
+    def material_plastic(self, Kd=(0.25,) * 3, Ks=(0.25,) * 3, roughness=0.1, remaproughness=True):
+        """materials/plastic.rs:73-86."""
+        self.cur_material = self._add_material(capi.PT_MATERIAL_PLASTIC, Kd, ks=Ks, roughness=float(roughness), remap_roughness=int(remaproughness))
+
+    def material_mirror(self, Kr=(0.9,) * 3):
+        """materials/mirror.rs:43-47."""
+        self.cur_material = self._add_material(capi.PT_MATERIAL_MIRROR, kr=Kr)
+
+    def material_glass(self, Kr=(1.0,) * 3, Kt=(1.0,) * 3, eta=1.5, uroughness=0.0, vroughness=0.0, remaproughness=True):
+        """materials/glass.rs:124-143."""
+        self.cur_material = self._add_material(capi.PT_MATERIAL_GLASS, kr=Kr, kt=Kt, eta=float(eta), uroughness=float(uroughness),
+                                               vroughness=float(vroughness), remap_roughness=int(remaproughness))
+
+    def material_metal(self, eta, k, roughness=0.01, uroughness=None, vroughness=None, remaproughness=True):
+        """materials/metal.rs:127-149; eta and k as RGB (the reference's default is the copper SPD converted to RGB)."""
+        self.cur_material = self._add_material(
+            capi.PT_MATERIAL_METAL, metal_eta=eta, metal_k=k, roughness=float(roughness), remap_roughness=int(remaproughness),
+            uroughness=capi.PT_ROUGHNESS_UNSET if uroughness is None else float(uroughness),
+            vroughness=capi.PT_ROUGHNESS_UNSET if vroughness is None else float(vroughness))
+
+    def material_uber(self, Kd=(0.25,) * 3, Ks=(0.25,) * 3, Kr=(0.0,) * 3, Kt=(0.0,) * 3, opacity=(1.0,) * 3, eta=1.5, roughness=0.1,
+                      uroughness=None, vroughness=None, remaproughness=True):
+        """materials/uber.rs:142-168."""
+        self.cur_material = self._add_material(
+            capi.PT_MATERIAL_UBER, Kd, ks=Ks, kr=Kr, kt=Kt, opacity=opacity, eta=float(eta), roughness=float(roughness),
+            remap_roughness=int(remaproughness),
+            uroughness=capi.PT_ROUGHNESS_UNSET if uroughness is None else float(uroughness),
+            vroughness=capi.PT_ROUGHNESS_UNSET if vroughness is None else float(vroughness))
+
+    def material_substrate(self, Kd=(0.5,) * 3, Ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remaproughness=True):
+        """materials/substrate.rs:70-86."""
+        self.cur_material = self._add_material(capi.PT_MATERIAL_SUBSTRATE, Kd, ks=Ks, uroughness=float(uroughness),
+                                               vroughness=float(vroughness), remap_roughness=int(remaproughness))
 
     def material_none(self):
         self.cur_material = -1

@@ -119,3 +119,74 @@ def scene_accel(method, leaf):
     sd.desc.split_method = {"sah": 0, "hlbvh": 1, "middle": 2, "equal": 3}[method]
     sd.desc.max_node_prims = leaf
     return sd
+
+
+# ---- materials beyond matte (SURVEY.md section 8, rows a10/a11 "later")
+MATERIAL_KINDS = ["plastic", "mirror", "glass", "glass_rough", "glass_reflect_only", "glass_black", "metal", "metal_aniso",
+                  "uber", "uber_translucent", "substrate", "substrate_aniso", "plastic_noremap"]
+
+
+def apply_material(b, kind):
+    if kind == "plastic":
+        b.material_plastic(Kd=(0.3, 0.1, 0.1), Ks=(0.4, 0.4, 0.4), roughness=0.15)
+    elif kind == "plastic_noremap":
+        b.material_plastic(Kd=(0.0, 0.0, 0.0), Ks=(0.6, 0.5, 0.4), roughness=0.2, remaproughness=False)
+    elif kind == "mirror":
+        b.material_mirror(Kr=(0.9, 0.85, 0.8))
+    elif kind == "glass":
+        b.material_glass(eta=1.5)
+    elif kind == "glass_rough":
+        b.material_glass(Kr=(0.9, 0.9, 0.9), Kt=(0.8, 0.9, 0.8), eta=1.33, uroughness=0.1, vroughness=0.2)
+    elif kind == "glass_reflect_only":
+        b.material_glass(Kr=(1.0, 1.0, 1.0), Kt=(0.0, 0.0, 0.0), eta=1.5, uroughness=0.05, vroughness=0.05)
+    elif kind == "glass_black":
+        b.material_glass(Kr=(0.0, 0.0, 0.0), Kt=(0.0, 0.0, 0.0))
+    elif kind == "metal":
+        b.material_metal(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=0.05)
+    elif kind == "metal_aniso":
+        b.material_metal(eta=(0.14, 0.37, 1.44), k=(3.98, 2.38, 1.6), uroughness=0.02, vroughness=0.2)
+    elif kind == "uber":
+        b.material_uber(Kd=(0.3, 0.3, 0.5), Ks=(0.2, 0.2, 0.2), Kr=(0.1, 0.1, 0.1), Kt=(0.2, 0.2, 0.2), eta=1.4, roughness=0.1)
+    elif kind == "uber_translucent":
+        b.material_uber(Kd=(0.5, 0.4, 0.3), Ks=(0.3, 0.3, 0.3), opacity=(0.6, 0.7, 0.8), uroughness=0.05, vroughness=0.15)
+    elif kind == "substrate":
+        b.material_substrate(Kd=(0.4, 0.2, 0.1), Ks=(0.3, 0.3, 0.3), uroughness=0.1, vroughness=0.1)
+    elif kind == "substrate_aniso":
+        b.material_substrate(Kd=(0.1, 0.3, 0.4), Ks=(0.5, 0.5, 0.5), uroughness=0.02, vroughness=0.3)
+    else:
+        raise ValueError(kind)
+
+
+def scene_material_palette():
+    """One small triangle per material kind: the scene only carries the material table for the BSDF hooks."""
+    b = base(res=16, spp=1)
+    room(b)
+    index = {}
+    for k, kind in enumerate(MATERIAL_KINDS):
+        apply_material(b, kind)
+        index[kind] = b.cur_material
+        x = -1.8 + 0.25 * k
+        b.shape_trianglemesh([(x, -1.9, 0), (x + 0.2, -1.9, 0), (x, -1.7, 0)], [0, 1, 2])
+    index["matte"] = 1
+    b.material_matte((0.5, 0.4, 0.3), sigma=25.0)
+    index["oren_nayar"] = b.cur_material
+    b.shape_trianglemesh([(1.6, -1.9, 0), (1.8, -1.9, 0), (1.6, -1.7, 0)], [0, 1, 2])
+    sd = b.build()
+    sd.material_index = index
+    return sd
+
+
+def scene_materials_render(kinds, res=40, spp=8, depth=6, sampler="sobol"):
+    """Room with a sphere and two slabs carrying the given materials (smooth-shaded sphere: shading != geometric normal)."""
+    b = base(res=res, spp=spp, depth=depth)
+    if sampler == "halton":
+        b.sampler_halton(spp)
+    room(b)
+    apply_material(b, kinds[0])
+    P, N, UV, idx = uv_sphere((-0.6, -1.1, 0.2), 0.9, 10, 16)
+    b.shape_trianglemesh(P, idx, N=N, uv=UV)
+    apply_material(b, kinds[1 % len(kinds)])
+    b.shape_trianglemesh([(0.3, -1.99, -0.8), (1.7, -1.99, -0.8), (1.7, -0.6, 0.9), (0.3, -0.6, 0.9)], [0, 1, 2, 0, 2, 3])
+    apply_material(b, kinds[2 % len(kinds)])
+    b.shape_trianglemesh([(-1.9, 0.0, 1.2), (-0.5, 0.0, 1.6), (-0.5, 1.4, 1.6), (-1.9, 1.4, 1.2)], [0, 1, 2, 0, 2, 3])
+    return b.build()

@@ -47,6 +47,12 @@ class Oracle:
         lib.orc_generate_camera_rays.restype = None
         lib.orc_sobol_samples.argtypes = [vp, u32, vp, vp, vp, vp]
         lib.orc_sobol_samples.restype = None
+        lib.orc_bsdf_eval.argtypes = [vp, u32, u32, vp, vp, u32, vp, vp]
+        lib.orc_bsdf_eval.restype = None
+        lib.orc_bsdf_sample.argtypes = [vp, u32, u32, vp, vp, u32, vp, vp, vp, vp]
+        lib.orc_bsdf_sample.restype = None
+        lib.orc_roughness_to_alpha.argtypes = [C.c_float]
+        lib.orc_roughness_to_alpha.restype = C.c_float
         lib.orc_light_distribution.argtypes = [vp, vp, vp, vp]
         lib.orc_light_distribution.restype = u32
         lib.orc_light_voxels.argtypes = [vp, vp]
@@ -171,6 +177,20 @@ class OracleScene:
         out = np.empty(len(dim), np.float32)
         self.lib.orc_sobol_samples(self.h, len(dim), _p(pixel_xy), _p(sample_index), _p(dim), _p(out))
         return out
+
+    def bsdf_eval(self, material, wo, wi, flags=31):
+        wo = np.ascontiguousarray(wo, np.float32); wi = np.ascontiguousarray(wi, np.float32)
+        n = len(wo)
+        f = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32)
+        self.lib.orc_bsdf_eval(self.h, C.c_uint32(material), C.c_uint32(n), _p(wo), _p(wi), C.c_uint32(flags), _p(f), _p(pdf))
+        return f, pdf
+
+    def bsdf_sample(self, material, wo, u, flags=31):
+        wo = np.ascontiguousarray(wo, np.float32); u = np.ascontiguousarray(u, np.float32)
+        n = len(wo)
+        f = np.empty((n, 3), np.float32); wi = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32); t = np.empty(n, np.uint32)
+        self.lib.orc_bsdf_sample(self.h, C.c_uint32(material), C.c_uint32(n), _p(wo), _p(u), C.c_uint32(flags), _p(f), _p(wi), _p(pdf), _p(t))
+        return f, wi, pdf, t
 
     def light_distribution(self, p):
         n = self.info.n_lights
