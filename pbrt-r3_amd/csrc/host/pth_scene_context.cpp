@@ -243,17 +243,78 @@ public:
         if (geom.find_one_rgb(n, out)) return true;
         return mat.find_one_rgb(n, out);
     }
+    // TextureParams::get_float_texture(_or_null) for constant values (texture_params.rs:107-124): shape first, then material
+    bool lookup_float(const ParamSet& geom, const ParamSet& mat, const std::string& n, float* out) {
+        if (geom.textures.count(n) || mat.textures.count(n)) { fail("material parameter \"" + n + "\" bound to a texture: outside the accelerated path"); return false; }
+        if (geom.floats.count(n)) { *out = geom.find_one_float(n, *out); return true; }
+        if (mat.floats.count(n)) { *out = mat.find_one_float(n, *out); return true; }
+        return false;
+    }
     int material_for_shape(const ParamSet& geom) {
         const MaterialInstance& mi = gstates.back().material;
         if (mi.none) return -1;
-        if (mi.name != "matte") { fail("Material \"" + mi.name + "\": only matte is on the accelerated path so far"); return -1; }
         if (geom.textures.count("bumpmap") || mi.params.textures.count("bumpmap")) { fail("bumpmap: outside the accelerated path"); return -1; }
+        const ParamSet& mp = mi.params;
         pt_material m;
         std::memset(&m, 0, sizeof(m));
-        m.type = PT_MATERIAL_MATTE;
-        m.kd[0] = m.kd[1] = m.kd[2] = 0.5f;                       // matte.rs:56
-        lookup_rgb(geom, mi.params, "Kd", m.kd);
-        m.sigma = geom.floats.count("sigma") ? geom.find_one_float("sigma", 0.0f) : mi.params.find_one_float("sigma", 0.0f);
+        auto set3 = [](float* c, float v) { c[0] = c[1] = c[2] = v; };
+        set3(m.opacity, 1.0f);
+        m.eta = 1.5f;
+        m.uroughness = m.vroughness = PT_ROUGHNESS_UNSET;
+        m.remap_roughness = geom.find_one_bool("remaproughness", mp.find_one_bool("remaproughness", true)) ? 1 : 0;
+        auto eta_or_index = [&]() {                              // get_float_texture_helper(&["eta", "index"], 1.5)
+            if (!lookup_float(geom, mp, "eta", &m.eta)) lookup_float(geom, mp, "index", &m.eta);
+        };
+        if (mi.name == "matte") {                                   // matte.rs:56-61
+            m.type = PT_MATERIAL_MATTE;
+            set3(m.kd, 0.5f);
+            lookup_rgb(geom, mp, "Kd", m.kd);
+            lookup_float(geom, mp, "sigma", &m.sigma);
+        } else if (mi.name == "plastic") {                          // plastic.rs:73-86
+            m.type = PT_MATERIAL_PLASTIC;
+            set3(m.kd, 0.25f); set3(m.ks, 0.25f); m.roughness = 0.1f;
+            lookup_rgb(geom, mp, "Kd", m.kd); lookup_rgb(geom, mp, "Ks", m.ks);
+            lookup_float(geom, mp, "roughness", &m.roughness);
+        } else if (mi.name == "mirror") {                           // mirror.rs:43-47
+            m.type = PT_MATERIAL_MIRROR;
+            set3(m.kr, 0.9f);
+            lookup_rgb(geom, mp, "Kr", m.kr);
+        } else if (mi.name == "glass") {                            // glass.rs:124-143
+            m.type = PT_MATERIAL_GLASS;
+            set3(m.kr, 1.0f); set3(m.kt, 1.0f); m.uroughness = m.vroughness = 0.0f;
+            lookup_rgb(geom, mp, "Kr", m.kr); lookup_rgb(geom, mp, "Kt", m.kt);
+            lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
+            eta_or_index();
+        } else if (mi.name == "metal") {                            // metal.rs:127-149
+            m.type = PT_MATERIAL_METAL;
+            m.roughness = 0.01f;
+            bool have_eta = lookup_rgb(geom, mp, "eta", m.metal_eta), have_k = lookup_rgb(geom, mp, "k", m.metal_k);
+            if (!have_eta || !have_k) {
+                fail("Material \"metal\": \"eta\" and \"k\" must be given as rgb -- the default copper spectrum and \"spectrum\" parameters "
+                     "need the SPD -> RGB conversion, which is outside the accelerated path so far");
+                return -1;
+            }
+            lookup_float(geom, mp, "roughness", &m.roughness);
+            lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
+        } else if (mi.name == "uber") {                             // uber.rs:142-168
+            m.type = PT_MATERIAL_UBER;
+            set3(m.kd, 0.25f); set3(m.ks, 0.25f); m.roughness = 0.1f;
+            lookup_rgb(geom, mp, "Kd", m.kd); lookup_rgb(geom, mp, "Ks", m.ks);
+            lookup_rgb(geom, mp, "Kr", m.kr); lookup_rgb(geom, mp, "Kt", m.kt);
+            lookup_rgb(geom, mp, "opacity", m.opacity);
+            lookup_float(geom, mp, "roughness", &m.roughness);
+            lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
+            eta_or_index();
+        } else if (mi.name == "substrate") {                        // substrate.rs:70-86
+            m.type = PT_MATERIAL_SUBSTRATE;
+            set3(m.kd, 0.5f); set3(m.ks, 0.5f); m.uroughness = m.vroughness = 0.1f;
+            lookup_rgb(geom, mp, "Kd", m.kd); lookup_rgb(geom, mp, "Ks", m.ks);
+            lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
+        } else {
+            fail("Material \"" + mi.name + "\": outside the accelerated path (matte, plastic, mirror, glass, metal, uber, substrate are supported)");
+            return -1;
+        }
+        if (!error.empty()) return -1;
         for (size_t i = 0; i < materials.size(); i++)
             if (std::memcmp(&materials[i], &m, sizeof(m)) == 0) return (int)i;
         materials.push_back(m);

@@ -81,7 +81,7 @@ def test_syntax_errors_are_reported():
     ('Sampler "sobol"\nWorldBegin\nShape "sphere" "float radius" 1\nWorldEnd', "sphere"),
     ('Sampler "stratified"\nWorldBegin\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "stratified"),
     ('Sampler "sobol"\nWorldBegin\nLightSource "point"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "LightSource"),
-    ('Sampler "sobol"\nWorldBegin\nMaterial "glass"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "glass"),
+    ('Sampler "sobol"\nWorldBegin\nMaterial "disney"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "disney"),
 ])
 def test_out_of_scope_features_fail_loudly(text, needle):
     """Nothing outside the accelerated path is silently approximated."""
@@ -163,3 +163,63 @@ def test_transform_stack_and_overrides(oracle):
     sc2 = oracle.scene(ps)
     assert sc2.info.spp == 8
     sc.close(); sc2.close()
+
+
+def test_materials_from_pbrt_text():
+    """Material / MakeNamedMaterial for every supported type: parameters, defaults (create_*_material) and the
+    shape-parameter-overrides-material rule (TextureParams, core/param_set/texture_params.rs)."""
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]'
+    text = '''
+    Sampler "sobol" "integer pixelsamples" 1
+    WorldBegin
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [1 1 1]
+        %(tri)s
+      AttributeEnd
+      Material "plastic"
+      %(tri)s
+      Material "plastic" "rgb Kd" [0.1 0.2 0.3] "rgb Ks" [0.4 0.5 0.6] "float roughness" 0.3 "bool remaproughness" "false"
+      %(tri)s
+      Material "mirror"
+      %(tri)s "rgb Kr" [0.5 0.6 0.7]
+      Material "glass" "float index" 1.33 "float uroughness" 0.05
+      %(tri)s
+      Material "glass" "float eta" 1.7 "float index" 1.2
+      %(tri)s
+      Material "metal" "rgb eta" [0.2 0.9 1.1] "rgb k" [3.9 2.4 2.1] "float vroughness" 0.2
+      %(tri)s
+      MakeNamedMaterial "u" "string type" "uber" "rgb Kt" [0.1 0.1 0.1] "rgb opacity" [0.5 0.5 0.5] "float roughness" 0.25
+      NamedMaterial "u"
+      %(tri)s
+      Material "substrate" "float uroughness" 0.3
+      %(tri)s
+    WorldEnd
+    ''' % {"tri": tri}
+    ps = capi.ParsedScene(text=text)
+    d = ps.desc
+    mats = [d.materials[d.meshes[i].material] for i in range(d.n_meshes)]
+    T = capi
+    m = mats[1]
+    assert m.type == T.PT_MATERIAL_PLASTIC and list(m.kd) == [0.25] * 3 and list(m.ks) == [0.25] * 3
+    assert abs(m.roughness - 0.1) < 1e-7 and m.remap_roughness == 1
+    m = mats[2]
+    assert np.allclose(list(m.kd), [0.1, 0.2, 0.3]) and np.allclose(list(m.ks), [0.4, 0.5, 0.6]) and abs(m.roughness - 0.3) < 1e-7 and m.remap_roughness == 0
+    assert mats[3].type == T.PT_MATERIAL_MIRROR and np.allclose(list(mats[3].kr), [0.5, 0.6, 0.7])       # shape parameter wins
+    m = mats[4]
+    assert m.type == T.PT_MATERIAL_GLASS and abs(m.eta - 1.33) < 1e-6 and abs(m.uroughness - 0.05) < 1e-7 and m.vroughness == 0.0
+    assert list(m.kr) == [1.0] * 3 and list(m.kt) == [1.0] * 3
+    assert abs(mats[5].eta - 1.7) < 1e-6                                                                   # "eta" before "index"
+    m = mats[6]
+    assert m.type == T.PT_MATERIAL_METAL and np.allclose(list(m.metal_k), [3.9, 2.4, 2.1]) and abs(m.roughness - 0.01) < 1e-8
+    assert m.uroughness == T.PT_ROUGHNESS_UNSET and abs(m.vroughness - 0.2) < 1e-7
+    m = mats[7]
+    assert m.type == T.PT_MATERIAL_UBER and np.allclose(list(m.opacity), [0.5] * 3) and np.allclose(list(m.kt), [0.1] * 3)
+    assert list(m.kr) == [0.0] * 3 and abs(m.roughness - 0.25) < 1e-7 and abs(m.eta - 1.5) < 1e-7
+    m = mats[8]
+    assert m.type == T.PT_MATERIAL_SUBSTRATE and abs(m.uroughness - 0.3) < 1e-7 and abs(m.vroughness - 0.1) < 1e-7 and list(m.kd) == [0.5] * 3
+
+
+def test_metal_without_rgb_spectra_is_refused():
+    with pytest.raises(capi.PtError) as e:
+        capi.ParsedScene(text='Sampler "sobol"\nWorldBegin\nMaterial "metal"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd')
+    assert e.value.status == 4 and "copper" in str(e.value)
