@@ -128,7 +128,7 @@ def test_bsdf_sampling_matches_pdf_chi2(palette, kind):
     """The sampled directions of every non-specular BSDF follow its pdf (the reference's own acceptance test
     for BxDF sampling, bsdfs.rs:482-606, here through the material -> BSDF path)."""
     sd, sc = palette
-    rng = np.random.default_rng(abs(hash(kind)) % 1000 + 7)
+    rng = np.random.default_rng(sum(ord(c) for c in kind) + 7)      # fixed per kind: the test is deterministic
     pval, alpha = chi2_bsdf(sc, sd.material_index[kind], rng)
     assert pval > alpha, (kind, pval, alpha)
 
