@@ -77,7 +77,7 @@ struct pt_context {
     size_t pool_paths = 0;
     DevBuf d_pool;          // one slab carved into the SoA arrays of PtPaths
     PtPaths paths;
-    DevBuf d_qa, d_qb, d_qnee, d_counts, d_pixels;
+    DevBuf d_qa, d_qb, d_qnee, d_qsorted, d_counts, d_pixels;
     size_t pixels_cap = 0;
 
     // ---- film
@@ -158,6 +158,7 @@ pt_status ensure_pool(pt_context* ctx, size_t n_paths) {
     PT_HIP(ctx->d_qa.alloc(n_paths * 4));
     PT_HIP(ctx->d_qb.alloc(n_paths * 4));
     PT_HIP(ctx->d_qnee.alloc(n_paths * 4));
+    PT_HIP(ctx->d_qsorted.alloc(n_paths * 4));
     ctx->pool_paths = n_paths;
     return PT_OK;
 }
@@ -541,9 +542,14 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     std::vector<PtMaterial> mats(std::max<uint32_t>(d->n_materials, 1));
     std::memset(mats.data(), 0, mats.size() * sizeof(PtMaterial));
     bool general_materials = false;
+    uint32_t n_matte_bins = 0, n_general_bins = 0;
     for (uint32_t i = 0; i < d->n_materials; i++) {
         build_lobes(d->materials[i], mats[i]);
-        if (d->materials[i].type != PT_MATERIAL_NONE && d->materials[i].type != PT_MATERIAL_MATTE) general_materials = true;
+        const bool general = d->materials[i].type != PT_MATERIAL_NONE && d->materials[i].type != PT_MATERIAL_MATTE;
+        if (general) general_materials = true;
+        // shade-queue bin: one per material while they last, the remainder of a class shares its last bin
+        mats[i].sort_bin = general ? PT_SORT_GENERAL0 + std::min(n_general_bins++, PT_SORT_BINS - PT_SORT_GENERAL0 - 1u)
+                                   : std::min(n_matte_bins++, PT_SORT_GENERAL0 - 1u);
     }
 
     PtScene& sc = ctx->sc;
@@ -719,7 +725,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         PT_HIP(ctx->d_err.alloc(16));
         PT_HIP(hipMemset(ctx->d_err.p, 0, 16));
         PT_HIP(ctx->d_ticket.alloc(16));
-        PT_HIP(ctx->d_counts.alloc(64));
+        PT_HIP(ctx->d_counts.alloc(PT_COUNTS_WORDS * 4));
+        PT_HIP(hipMemset(ctx->d_counts.p, 0, PT_COUNTS_WORDS * 4));
     }
     if ((st = ensure_traversal_scratch(ctx)) != PT_OK) return st;
     double t2 = now_ms();
@@ -799,10 +806,12 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     PtQueues Q;
     Q.nee = ctx->d_qnee.as<uint32_t>();
     Q.counts = ctx->d_counts.as<uint32_t>();
+    Q.sorted = ctx->d_qsorted.as<uint32_t>();
     PtCounters* cnt = ctx->d_counters.as<PtCounters>();
     uint32_t* err = ctx->d_err.as<uint32_t>();
     size_t ev_i = 0;
     std::vector<std::pair<size_t, int>> spans;   // (event index, kind) kind 0 = trace, 1 = shade
+    const bool no_events = std::getenv("PBRTGPU_NO_EVENTS") != nullptr;   // experiment: cost of the per-bounce event records
 
     hipEvent_t ev_begin = get_event(ctx, ev_i++), ev_end = get_event(ctx, ev_i++);
     PT_HIP(hipEventRecord(ev_begin, ctx->stream));
@@ -818,18 +827,22 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
             PT_HIP(ptk_gen(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q, d_pix, n_pix, s0, ns, cnt));
             if (sc.n_lights > 0) {          // no lights: li() returns zero immediately (path.rs:71-74)
                 auto bounce = [&]() -> pt_status {
-                    hipEvent_t a = get_event(ctx, ev_i), b = get_event(ctx, ev_i + 1), c = get_event(ctx, ev_i + 2);
-                    if (!a || !b || !c) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
-                    spans.push_back({ev_i, 0});
-                    ev_i += 3;
-                    PT_HIP(hipEventRecord(a, ctx->stream));
+                    const bool timed = !no_events;
+                    hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+                    if (timed) {
+                        a = get_event(ctx, ev_i); b = get_event(ctx, ev_i + 1); c = get_event(ctx, ev_i + 2);
+                        if (!a || !b || !c) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
+                        spans.push_back({ev_i, 0});
+                        ev_i += 3;
+                        PT_HIP(hipEventRecord(a, ctx->stream));
+                    }
                     PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
-                    PT_HIP(hipEventRecord(b, ctx->stream));
+                    if (timed) PT_HIP(hipEventRecord(b, ctx->stream));
                     ctx->trace_launches++;
                     PT_HIP(ptk_prep(ctx->stream, Q, 0));
                     PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, cnt));
                     PT_HIP(ptk_prep(ctx->stream, Q, 1));
-                    PT_HIP(hipEventRecord(c, ctx->stream));
+                    if (timed) PT_HIP(hipEventRecord(c, ctx->stream));
                     std::swap(Q.cur, Q.next);
                     return PT_OK;
                 };

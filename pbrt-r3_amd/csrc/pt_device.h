@@ -79,7 +79,7 @@ struct PtMaterial {
     uint32_t has_bsdf;           // 0: compute_scattering_functions leaves bsdf = None (glass with Kr = Kt = 0)
     uint32_t nonspecular;        // num_components(BSDF_ALL & !BSDF_SPECULAR)
     float bsdf_eta;              // BSDF::eta
-    uint32_t pad;
+    uint32_t sort_bin;           // shade-queue bin: [0,128) Matte materials, [128,256) the others
     PtLobe lobes[PT_MAX_LOBES];
 };
 
@@ -203,5 +203,13 @@ struct PtQueues {
     uint32_t* cur;       // path ids to shade / whose continuation ray is traced
     uint32_t* next;
     uint32_t* nee;       // path ids with a pending NEE resolve
-    uint32_t* counts;    // [0]=n_cur [1]=n_next [2]=n_nee [3]=work ticket
+    uint32_t* counts;    // [0]=n_cur [1]=n_next [2]=n_nee [3]=work ticket; material sort: [4]=ticket of the general
+                         // segment [5]=end of the Matte segment [6]=end of the general segment,
+                         // [PT_SORT_COUNT0, +256) bin counts, [PT_SORT_CURSOR0, +256) bin cursors
+    uint32_t* sorted;    // cur re-ordered by material bin, misses dropped (scenes with non-Matte materials)
 };
+#define PT_SORT_BINS 256u
+#define PT_SORT_GENERAL0 128u
+#define PT_SORT_COUNT0 16u
+#define PT_SORT_CURSOR0 (16u + 256u)
+#define PT_COUNTS_WORDS (16u + 512u)

@@ -709,7 +709,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_gen(PtScene sc, PtPaths
 extern "C" __global__ void k_prep(PtQueues Q, int mode) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (mode == 0) {            // before SHADE: nee and next start empty
-            Q.counts[1] = 0; Q.counts[2] = 0; Q.counts[3] = 0;
+            Q.counts[1] = 0; Q.counts[2] = 0; Q.counts[3] = 0; Q.counts[4] = 0;
         } else {                    // after SHADE: next becomes cur (host swaps the pointers)
             Q.counts[0] = Q.counts[1]; Q.counts[1] = 0; Q.counts[3] = 0;
         }
@@ -969,6 +969,74 @@ PT_DEV uint32_t sample_discrete(const float* tab, uint32_t n, float u, float* pd
     return idx;
 }
 
+// ============================================================ material-sorted shade queue
+// Scenes with non-Matte materials: after TRACE the shade queue is counting-sorted by the material bin of
+// each path's hit (Matte bins first), misses are dropped.  k_shade then runs over the Matte segment and
+// k_shade_general over the rest with one material per run of lanes, so a wave executes one lobe list.
+PT_DEV uint32_t path_sort_bin(const PtScene& sc, const PtPaths& P, uint32_t p) {
+    int32_t rec = P.hit_rec[p];
+    if (rec < 0) return 0xffffffffu;                                   // miss: nothing to shade
+    uint32_t m1 = sc.tris[rec].flags >> PT_TRI_MATERIAL_SHIFT;         // material index + 1, 0 = none
+    return m1 == 0 ? 0u : sc.materials[m1 - 1].sort_bin;               // material-less surfaces ride with bin 0
+}
+// One atomic per (wave, distinct bin): returns this lane's slot among the lanes of its bin.
+PT_DEV uint32_t wave_bin_reserve(uint32_t* counters, uint32_t bin, bool valid) {
+    uint32_t slot = 0;
+    unsigned long long todo = __ballot(valid);
+    const uint32_t lane = threadIdx.x & 63;
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        uint32_t b0 = (uint32_t)__shfl((int)bin, leader, 64);
+        unsigned long long same = __ballot(valid && bin == b0) & todo;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&counters[b0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (valid && bin == b0) slot = base + (uint32_t)__popcll(same & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+        todo &= ~same;
+    }
+    return slot;
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_count(PtScene sc, PtPaths P, PtQueues Q) {
+    const uint32_t n = Q.counts[0];
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        bool valid = i < n;
+        uint32_t bin = valid ? path_sort_bin(sc, P, Q.cur[i]) : 0xffffffffu;
+        valid = valid && bin != 0xffffffffu;
+        (void)wave_bin_reserve(Q.counts + PT_SORT_COUNT0, valid ? bin : 0u, valid);
+    }
+}
+extern "C" __global__ void k_sort_scan(PtQueues Q) {          // one block of PT_SORT_BINS threads
+    __shared__ uint32_t s[PT_SORT_BINS];
+    const uint32_t t = threadIdx.x;
+    uint32_t c = Q.counts[PT_SORT_COUNT0 + t];
+    s[t] = c;
+    __syncthreads();
+    for (uint32_t d = 1; d < PT_SORT_BINS; d <<= 1) {           // Hillis-Steele inclusive scan
+        uint32_t v = t >= d ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    uint32_t excl = s[t] - c;
+    Q.counts[PT_SORT_CURSOR0 + t] = excl;
+    Q.counts[PT_SORT_COUNT0 + t] = 0;                           // ready for the next bounce
+    if (t == PT_SORT_GENERAL0) Q.counts[5] = excl;
+    if (t == PT_SORT_BINS - 1) Q.counts[6] = s[t];
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc, PtPaths P, PtQueues Q) {
+    const uint32_t n = Q.counts[0];
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        bool valid = i < n;
+        uint32_t p = valid ? Q.cur[i] : 0u;
+        uint32_t bin = valid ? path_sort_bin(sc, P, p) : 0xffffffffu;
+        valid = valid && bin != 0xffffffffu;
+        uint32_t pos = wave_bin_reserve(Q.counts + PT_SORT_CURSOR0, valid ? bin : 0u, valid);
+        if (valid) Q.sorted[pos] = p;
+    }
+}
+
 // ============================================================ K_SHADE
 // One bounce of PathIntegrator::li for every path in Q.cur (path.rs:85-234).
 #ifndef PT_SHADE_WAVES
@@ -977,22 +1045,22 @@ PT_DEV uint32_t sample_discrete(const float* tab, uint32_t n, float u, float* pd
 // GENERAL = false: every material is Matte (at most one diffuse lobe; the RT1M / Cornell fast path).
 // GENERAL = true: BSDFs are the per-material lobe lists of pt_bxdf.h (specular bounces, eta_scale, glass without a BSDF).
 template <bool GENERAL>
-PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt) {
+PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, const uint32_t* list, uint32_t begin, uint32_t end,
+                       uint32_t* ticket) {
     __shared__ unsigned long long s_vert;
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
-    const uint32_t n_cur = Q.counts[0];
     uint32_t n_vert = 0;
     const uint32_t lane = threadIdx.x & 63;
     for (;;) {
-        uint32_t base = wave_ticket(&Q.counts[3]);
-        if (base >= n_cur) break;
+        uint32_t base = begin + wave_ticket(ticket);
+        if (base >= end) break;
         uint32_t item = base + lane;
-        bool active = item < n_cur;
+        bool active = item < end;
         bool cont = false, want_nee = false;
         uint32_t p = 0;
         if (active) {
-            p = Q.cur[item];
+            p = list[item];
             float4 ro4 = P.ray_o[p], rd4 = P.ray_d[p];
             V3 ro = f4_3(ro4), rd = f4_3(rd4);
             int32_t rec = P.hit_rec[p];
@@ -1190,10 +1258,14 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     if (threadIdx.x == 0 && s_vert) atomicAdd(&cnt->vertices, s_vert);
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<false>(sc, P, Q, cnt);
+    shade_body<false>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[0], &Q.counts[3]);
+}
+// the two halves of a material-sorted queue
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade_matte_sorted(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<false>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[5], &Q.counts[3]);
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<true>(sc, P, Q, cnt);
+    shade_body<true>(sc, P, Q, cnt, Q.sorted, Q.counts[5], Q.counts[6], &Q.counts[4]);
 }
 
 // ============================================================ film
@@ -1441,8 +1513,15 @@ hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode) {
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt) {
-    if (sc.general_materials) hipLaunchKernelGGL(k_shade_general, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-    else hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+    if (sc.general_materials) {
+        hipLaunchKernelGGL(k_sort_count, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(PT_SORT_BINS), 0, st, Q);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
+        hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        hipLaunchKernelGGL(k_shade_general, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+    } else {
+        hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+    }
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,
