@@ -996,15 +996,30 @@ PT_DEV uint32_t wave_bin_reserve(uint32_t* counters, uint32_t bin, bool valid) {
     }
     return slot;
 }
+// Block b owns the contiguous chunk [b*chunk, (b+1)*chunk) of the queue.  Bins are counted in LDS first
+// (wave-aggregated), so the device-wide counters see one atomic per (block, bin), not one per item:
+// with a handful of materials, per-item atomics on the same few addresses serialise in L2.
+PT_DEV void sort_chunk(uint32_t n, uint32_t* lo, uint32_t* hi) {
+    uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    chunk = (chunk + 63u) & ~63u;
+    *lo = min(n, blockIdx.x * chunk);
+    *hi = min(n, *lo + chunk);
+}
 extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_count(PtScene sc, PtPaths P, PtQueues Q) {
-    const uint32_t n = Q.counts[0];
-    const uint32_t n_round = (n + 63u) & ~63u;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
-        bool valid = i < n;
+    __shared__ uint32_t s_cnt[PT_SORT_BINS];
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t lo, hi;
+    sort_chunk(Q.counts[0], &lo, &hi);
+    for (uint32_t i = lo + threadIdx.x; i < ((hi + 63u) & ~63u); i += blockDim.x) {
+        bool valid = i < hi;
         uint32_t bin = valid ? path_sort_bin(sc, P, Q.cur[i]) : 0xffffffffu;
         valid = valid && bin != 0xffffffffu;
-        (void)wave_bin_reserve(Q.counts + PT_SORT_COUNT0, valid ? bin : 0u, valid);
+        (void)wave_bin_reserve(s_cnt, valid ? bin : 0u, valid);
     }
+    __syncthreads();
+    uint32_t c = s_cnt[threadIdx.x];
+    if (c) atomicAdd(&Q.counts[PT_SORT_COUNT0 + threadIdx.x], c);
 }
 extern "C" __global__ void k_sort_scan(PtQueues Q) {          // one block of PT_SORT_BINS threads
     __shared__ uint32_t s[PT_SORT_BINS];
@@ -1025,14 +1040,30 @@ extern "C" __global__ void k_sort_scan(PtQueues Q) {          // one block of PT
     if (t == PT_SORT_BINS - 1) Q.counts[6] = s[t];
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc, PtPaths P, PtQueues Q) {
-    const uint32_t n = Q.counts[0];
-    const uint32_t n_round = (n + 63u) & ~63u;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
-        bool valid = i < n;
+    __shared__ uint32_t s_cnt[PT_SORT_BINS];      // phase A: this block's count per bin; phase C: running cursor
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t lo, hi;
+    sort_chunk(Q.counts[0], &lo, &hi);
+    const uint32_t hi_round = (hi + 63u) & ~63u;
+    for (uint32_t i = lo + threadIdx.x; i < hi_round; i += blockDim.x) {
+        bool valid = i < hi;
+        uint32_t bin = valid ? path_sort_bin(sc, P, Q.cur[i]) : 0xffffffffu;
+        valid = valid && bin != 0xffffffffu;
+        (void)wave_bin_reserve(s_cnt, valid ? bin : 0u, valid);
+    }
+    __syncthreads();
+    {   // phase B: reserve this block's range in every bin it uses
+        uint32_t c = s_cnt[threadIdx.x];
+        s_cnt[threadIdx.x] = c ? atomicAdd(&Q.counts[PT_SORT_CURSOR0 + threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi_round; i += blockDim.x) {
+        bool valid = i < hi;
         uint32_t p = valid ? Q.cur[i] : 0u;
         uint32_t bin = valid ? path_sort_bin(sc, P, p) : 0xffffffffu;
         valid = valid && bin != 0xffffffffu;
-        uint32_t pos = wave_bin_reserve(Q.counts + PT_SORT_CURSOR0, valid ? bin : 0u, valid);
+        uint32_t pos = wave_bin_reserve(s_cnt, valid ? bin : 0u, valid);
         if (valid) Q.sorted[pos] = p;
     }
 }

@@ -480,7 +480,7 @@ def cornell_box(res=512, spp=64, max_depth=5, light_strategy="spatial", sampler=
     return b.build()
 
 
-def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequence=1, sampler="sobol"):
+def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequence=1, sampler="sobol", materials="matte"):
     """BASELINE config 2 ("RT1M"): 12-triangle enclosure + light, the rest random matte triangles.
 
     Filler triangle k draws, in order, cx cy cz then v0x..v2z as lerp(uniform_float(), lo, hi)
@@ -506,7 +506,24 @@ def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequ
         c = (one - u[:, 0:3]) * f32(-0.9) + u[:, 0:3] * f32(0.9)                       # lerp(t, lo, hi)
         off = (one - u[:, 3:12]) * f32(-s) + u[:, 3:12] * f32(s)
         verts = (np.repeat(c, 3, axis=0).reshape(n_fill, 9) + off).astype(np.float32).reshape(-1, 3)
-        b.shape_trianglemesh_fast(verts, np.arange(3 * n_fill), twosided=True)
+        if materials == "matte":
+            b.shape_trianglemesh_fast(verts, np.arange(3 * n_fill), twosided=True)
+        else:
+            # "killeroo-class" stand-in for BASELINE config 4: the same geometry cut into six shapes with
+            # matte / plastic / metal / glass / mirror / substrate materials (40/20/15/15/5/5 %)
+            cuts = (np.cumsum([0.0, 0.40, 0.20, 0.15, 0.15, 0.05, 0.05]) * n_fill).astype(np.int64)
+            setters = [lambda: b.material_matte((0.5, 0.5, 0.5)),
+                       lambda: b.material_plastic(Kd=(0.4, 0.2, 0.2), Ks=(0.3, 0.3, 0.3), roughness=0.1),
+                       lambda: b.material_metal(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=0.05),
+                       lambda: b.material_glass(eta=1.5),
+                       lambda: b.material_mirror(),
+                       lambda: b.material_substrate(Kd=(0.2, 0.3, 0.5), Ks=(0.4, 0.4, 0.4))]
+            for g, setm in enumerate(setters):
+                lo, hi = int(cuts[g]), int(cuts[g + 1])
+                if hi > lo:
+                    setm()
+                    b.shape_trianglemesh_fast(verts[3 * lo:3 * hi], np.arange(3 * (hi - lo)), twosided=True)
+            b.material_matte((0.5, 0.5, 0.5))
     b.area_light_source_diffuse(L=(17, 12, 4))
     _quad(b, (0.25, 0.999, -0.25), (0.25, 0.999, 0.25), (-0.25, 0.999, 0.25), (-0.25, 0.999, -0.25))  # faces -y
     return b.build()
