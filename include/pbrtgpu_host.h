@@ -10,7 +10,7 @@
  * for the subset of the format the accelerated path renders: triangle
  * meshes, matte / plastic / mirror / glass / metal (rgb eta, k) / uber / substrate materials with constant
  * parameters (incl. named materials and per-shape overrides), diffuse area lights,
- * perspective camera, box/gaussian/mitchell/triangle filters, Halton (the default) and Sobol' samplers, path integrator,
+ * perspective camera, box/gaussian/mitchell/sinc/triangle filters, Halton (the default) and Sobol' samplers, path integrator,
  * BVH accelerator, the full transform / attribute stack and Include.  Anything else is reported
  * as PT_ERR_UNSUPPORTED with a message naming the directive -- never silently approximated.
  *

@@ -430,6 +430,18 @@ public:
         if (x > 1.0f) return ((-b - 6.0f * c) * x * x * x + (6.0f * b + 30.0f * c) * x * x + (-12.0f * b - 48.0f * c) * x + (8.0f * b + 24.0f * c)) * (1.0f / 6.0f);
         return ((12.0f - 9.0f * b - 6.0f * c) * x * x * x + (-18.0f + 12.0f * b + 6.0f * c) * x * x + (6.0f - 2.0f * b)) * (1.0f / 6.0f);
     }
+    static float sinc1(float x) {                                   // filters/sinc.rs:24-31
+        x = std::fabs(x);
+        if (x < 1e-5f) return 1.0f;
+        const float pi = 3.14159265358979323846f;
+        return std::sin(pi * x) / (pi * x);
+    }
+    static float windowed_sinc(float x, float radius, float tau) {  // filters/sinc.rs:33-41
+        x = std::fabs(x);
+        if (x > radius) return 0.0f;
+        float lanczos = sinc1(x / tau);
+        return sinc1(x) * lanczos;
+    }
     bool make_filter() {
         float rx, ry;
         const ParamSet& fp = filter_params;
@@ -438,7 +450,9 @@ public:
         else if (filter_name == "gaussian") { kind = 1; rx = fp.find_one_float("xwidth", 2.0f); ry = fp.find_one_float("ywidth", 2.0f); }
         else if (filter_name == "mitchell") { kind = 2; rx = fp.find_one_float("xwidth", 2.0f); ry = fp.find_one_float("ywidth", 2.0f); }
         else if (filter_name == "triangle") { kind = 3; rx = fp.find_one_float("xwidth", 2.0f); ry = fp.find_one_float("ywidth", 2.0f); }
+        else if (filter_name == "sinc") { kind = 4; rx = fp.find_one_float("xwidth", 4.0f); ry = fp.find_one_float("ywidth", 4.0f); }
         else { fail("PixelFilter \"" + filter_name + "\" is not supported"); return false; }
+        const float tau = fp.find_one_float("tau", 3.0f);
         float alpha = fp.find_one_float("alpha", 2.0f), B = fp.find_one_float("B", 1.0f / 3.0f), C = fp.find_one_float("C", 1.0f / 3.0f);
         float ex = std::exp(-alpha * rx * rx), ey = std::exp(-alpha * ry * ry);
         desc.filter_radius[0] = rx; desc.filter_radius[1] = ry;
@@ -448,6 +462,7 @@ public:
                 if (kind == 1) v = gaussian1(xx, alpha, ex) * gaussian1(yy, alpha, ey);
                 else if (kind == 2) v = mitchell1(xx * (1.0f / rx), B, C) * mitchell1(yy * (1.0f / ry), B, C);
                 else if (kind == 3) v = std::fmax(0.0f, rx - std::fabs(xx)) * std::fmax(0.0f, ry - std::fabs(yy));
+                else if (kind == 4) v = windowed_sinc(xx, rx, tau) * windowed_sinc(yy, ry, tau);
                 desc.filter_table[y * 16 + x] = v;
             }
         return true;

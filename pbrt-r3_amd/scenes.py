@@ -30,6 +30,14 @@ def _expf(x):
     return f32(_libm.expf(float(x)))
 
 
+_libm.sinf.argtypes = [C.c_float]
+_libm.sinf.restype = C.c_float
+
+
+def _sinf(x):
+    return f32(_libm.sinf(float(x)))
+
+
 # --------------------------------------------------------------------------
 # PCG32 (src/core/rng.rs:8-67), vectorised: the LCG state after k steps is
 # a^k * s0 + c * (a^(k-1) + ... + 1)  (mod 2^64), so all states come from two
@@ -235,6 +243,24 @@ class SceneBuilder:
             return f32(v * f32(f32(1.0) / f32(6.0)))
         irx, iry = f32(1.0) / f32(xwidth), f32(1.0) / f32(ywidth)
         self._filter_table((xwidth, ywidth), lambda x, y: f32(m1(f32(x * irx)) * m1(f32(y * iry))))
+
+    def pixel_filter_sinc(self, xwidth=4.0, ywidth=4.0, tau=3.0):
+        """filters/sinc.rs:15-57 (Lanczos-windowed sinc; sinf through libm, as the reference)."""
+        pi, t = f32(np.pi), f32(tau)
+
+        def sinc(x):
+            x = abs(f32(x))
+            if x < 1e-5:
+                return f32(1.0)
+            return f32(_sinf(f32(pi * x)) / f32(pi * x))
+
+        def wsinc(x, radius):
+            x = abs(f32(x))
+            if x > f32(radius):
+                return f32(0.0)
+            lanczos = sinc(f32(x / t))
+            return f32(sinc(x) * lanczos)
+        self._filter_table((xwidth, ywidth), lambda x, y: f32(wsinc(x, xwidth) * wsinc(y, ywidth)))
 
     def sampler_sobol(self, pixelsamples=16):
         self.spp, self.sampler = int(pixelsamples), capi.PT_SAMPLER_SOBOL

@@ -105,6 +105,8 @@ def scene_camera_film(filt="gaussian"):
         b.pixel_filter_gaussian(2.0, 2.0, 2.0)
     elif filt == "mitchell":
         b.pixel_filter_mitchell(2.0, 1.5)
+    elif filt == "sinc":
+        b.pixel_filter_sinc(3.0, 2.5, 2.0)
     else:
         b.pixel_filter_triangle(1.5, 2.0)
     room(b)

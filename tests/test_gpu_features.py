@@ -53,6 +53,7 @@ def _compare(ctx, osc, exact_film, frac_limit=0.0):
     ("lens_gaussian", lambda: fs.scene_camera_film("gaussian"), False),
     ("lens_mitchell", lambda: fs.scene_camera_film("mitchell"), False),
     ("lens_triangle", lambda: fs.scene_camera_film("triangle"), False),
+    ("lens_sinc", lambda: fs.scene_camera_film("sinc"), False),
     ("accel_middle_1", lambda: fs.scene_accel("middle", 1), True),
     ("accel_equal_8", lambda: fs.scene_accel("equal", 8), True),
     ("accel_sah_2", lambda: fs.scene_accel("sah", 2), True),

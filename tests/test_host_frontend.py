@@ -223,3 +223,23 @@ def test_metal_without_rgb_spectra_is_refused():
     with pytest.raises(capi.PtError) as e:
         capi.ParsedScene(text='Sampler "sobol"\nWorldBegin\nMaterial "metal"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd')
     assert e.value.status == 4 and "copper" in str(e.value)
+
+
+@pytest.mark.parametrize("name,params,build", [
+    ("box", "", lambda b: b.pixel_filter_box()),
+    ("gaussian", '"float xwidth" 2.5 "float alpha" 1.5', lambda b: b.pixel_filter_gaussian(2.5, 2.0, 1.5)),
+    ("mitchell", '"float ywidth" 3 "float B" 0.2 "float C" 0.4', lambda b: b.pixel_filter_mitchell(2.0, 3.0, 0.2, 0.4)),
+    ("triangle", '"float xwidth" 1.5', lambda b: b.pixel_filter_triangle(1.5, 2.0)),
+    ("sinc", '"float xwidth" 3 "float tau" 2', lambda b: b.pixel_filter_sinc(3.0, 4.0, 2.0)),
+])
+def test_filter_tables_match_scene_builder(name, params, build):
+    """Film::new's 16x16 filter table (film.rs:102-120) from the C++ front end == the Python restatement, bit for bit,
+    for every reconstruction filter of src/filters/ (defaults included)."""
+    text = ('Sampler "sobol"\nPixelFilter "%s" %s\nWorldBegin\nAreaLightSource "diffuse"\n'
+            'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd' % (name, params))
+    ps = capi.ParsedScene(text=text)        # keep it alive: desc points into it
+    d = ps.desc
+    b = scenes.SceneBuilder()
+    build(b)
+    assert np.array_equal(bits(list(d.filter_table)), bits(b.filter_table))
+    assert np.array_equal(bits(list(d.filter_radius)), bits(np.array(b.filter_radius, np.float32)))
