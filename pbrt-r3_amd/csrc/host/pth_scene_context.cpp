@@ -237,17 +237,19 @@ public:
     void pbrt_object_end() override {}
     void pbrt_object_instance(const std::string&) override { fail("ObjectInstance: object instancing is outside the accelerated path"); }
 
-    // TextureParams lookup order: shape parameters first, then the material's (texture_params.rs:14-120)
+    // TextureParams (core/param_set/texture_params.rs:36-105): a texture binding is looked up in the shape's
+    // parameters first, but constant float / spectrum VALUES come from the material's parameters first and
+    // from the shape's only when the material does not give them (the reverse of pbrt-v3; reproduced as is).
     bool lookup_rgb(const ParamSet& geom, const ParamSet& mat, const std::string& n, float out[3]) {
         if (geom.textures.count(n) || mat.textures.count(n)) { fail("material parameter \"" + n + "\" bound to a texture: outside the accelerated path"); return false; }
-        if (geom.find_one_rgb(n, out)) return true;
-        return mat.find_one_rgb(n, out);
+        if (mat.find_one_rgb(n, out)) return true;
+        return geom.find_one_rgb(n, out);
     }
-    // TextureParams::get_float_texture(_or_null) for constant values (texture_params.rs:107-124): shape first, then material
+    // TextureParams::get_float_texture(_or_null) for constant values (texture_params.rs:36-54, :107-124): material first, then shape
     bool lookup_float(const ParamSet& geom, const ParamSet& mat, const std::string& n, float* out) {
         if (geom.textures.count(n) || mat.textures.count(n)) { fail("material parameter \"" + n + "\" bound to a texture: outside the accelerated path"); return false; }
-        if (geom.floats.count(n)) { *out = geom.find_one_float(n, *out); return true; }
         if (mat.floats.count(n)) { *out = mat.find_one_float(n, *out); return true; }
+        if (geom.floats.count(n)) { *out = geom.find_one_float(n, *out); return true; }
         return false;
     }
     int material_for_shape(const ParamSet& geom) {

@@ -147,7 +147,8 @@ def test_transform_stack_and_overrides(oracle):
     assert d.n_triangles == 6 and d.n_meshes == 4
     m = [d.meshes[i] for i in range(4)]
     assert m[0].area_light == 0 and m[1].area_light == -1
-    assert d.materials[m[1].material].sigma == 20.0 and abs(d.materials[m[1].material].kd[0] - 0.8) < 1e-6      # shape overrides
+    # texture_params.rs:36-83: the material's Kd wins over the shape's; sigma is only on the shape, so it is used
+    assert d.materials[m[1].material].sigma == 20.0 and abs(d.materials[m[1].material].kd[0] - 0.2) < 1e-6
     assert abs(d.materials[m[2].material].kd[0] - 0.2) < 1e-6
     f2 = m[2].flags
     assert (f2 & capi.PT_MESH_REVERSE_ORIENTATION) and (f2 & capi.PT_MESH_SWAPS_HANDEDNESS) and not (f2 & capi.PT_MESH_TWO_SIDED)
@@ -166,8 +167,9 @@ def test_transform_stack_and_overrides(oracle):
 
 
 def test_materials_from_pbrt_text():
-    """Material / MakeNamedMaterial for every supported type: parameters, defaults (create_*_material) and the
-    shape-parameter-overrides-material rule (TextureParams, core/param_set/texture_params.rs)."""
+    """Material / MakeNamedMaterial for every supported type: parameters, defaults (create_*_material) and
+    TextureParams' precedence (core/param_set/texture_params.rs:36-83: constant values come from the material
+    first, from the shape only when the material has none -- the reverse of pbrt-v3)."""
     tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]'
     text = '''
     Sampler "sobol" "integer pixelsamples" 1
@@ -188,6 +190,8 @@ def test_materials_from_pbrt_text():
       %(tri)s
       Material "metal" "rgb eta" [0.2 0.9 1.1] "rgb k" [3.9 2.4 2.1] "float vroughness" 0.2
       %(tri)s
+      Material "plastic" "rgb Kd" [0.1 0.2 0.3] "float roughness" 0.3
+      %(tri)s "rgb Kd" [0.9 0.9 0.9] "float roughness" 0.7 "rgb Ks" [0.6 0.6 0.6]
       MakeNamedMaterial "u" "string type" "uber" "rgb Kt" [0.1 0.1 0.1] "rgb opacity" [0.5 0.5 0.5] "float roughness" 0.25
       NamedMaterial "u"
       %(tri)s
@@ -204,7 +208,7 @@ def test_materials_from_pbrt_text():
     assert abs(m.roughness - 0.1) < 1e-7 and m.remap_roughness == 1
     m = mats[2]
     assert np.allclose(list(m.kd), [0.1, 0.2, 0.3]) and np.allclose(list(m.ks), [0.4, 0.5, 0.6]) and abs(m.roughness - 0.3) < 1e-7 and m.remap_roughness == 0
-    assert mats[3].type == T.PT_MATERIAL_MIRROR and np.allclose(list(mats[3].kr), [0.5, 0.6, 0.7])       # shape parameter wins
+    assert mats[3].type == T.PT_MATERIAL_MIRROR and np.allclose(list(mats[3].kr), [0.5, 0.6, 0.7])       # the material gives no Kr: the shape's is used
     m = mats[4]
     assert m.type == T.PT_MATERIAL_GLASS and abs(m.eta - 1.33) < 1e-6 and abs(m.uroughness - 0.05) < 1e-7 and m.vroughness == 0.0
     assert list(m.kr) == [1.0] * 3 and list(m.kt) == [1.0] * 3
@@ -212,10 +216,12 @@ def test_materials_from_pbrt_text():
     m = mats[6]
     assert m.type == T.PT_MATERIAL_METAL and np.allclose(list(m.metal_k), [3.9, 2.4, 2.1]) and abs(m.roughness - 0.01) < 1e-8
     assert m.uroughness == T.PT_ROUGHNESS_UNSET and abs(m.vroughness - 0.2) < 1e-7
-    m = mats[7]
+    m = mats[7]        # material values first, shape values only for what the material leaves out
+    assert np.allclose(list(m.kd), [0.1, 0.2, 0.3]) and abs(m.roughness - 0.3) < 1e-7 and np.allclose(list(m.ks), [0.6] * 3)
+    m = mats[8]
     assert m.type == T.PT_MATERIAL_UBER and np.allclose(list(m.opacity), [0.5] * 3) and np.allclose(list(m.kt), [0.1] * 3)
     assert list(m.kr) == [0.0] * 3 and abs(m.roughness - 0.25) < 1e-7 and abs(m.eta - 1.5) < 1e-7
-    m = mats[8]
+    m = mats[9]
     assert m.type == T.PT_MATERIAL_SUBSTRATE and abs(m.uroughness - 0.3) < 1e-7 and abs(m.vroughness - 0.1) < 1e-7 and list(m.kd) == [0.5] * 3
 
 
