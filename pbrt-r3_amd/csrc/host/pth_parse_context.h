@@ -16,7 +16,13 @@ public:
     std::map<std::string, std::vector<int>> ints;
     std::map<std::string, std::vector<bool>> bools;
     std::map<std::string, std::vector<std::string>> strings, textures;
-    std::vector<std::string> unsupported;      // "spectrum"/"blackbody"/"xyz" entries: named, not converted
+    std::vector<std::string> unsupported;      // "blackbody"/"xyz"/inline "spectrum" entries: named ("type name"), not converted
+    std::map<std::string, std::vector<float>> blackbodies;   // "blackbody name" [T scale ...]
+    std::map<std::string, std::string> spectrum_files;   // "spectrum name" "file.spd": path resolved against the including file
+    bool is_unsupported(const std::string& n) const {
+        for (auto& u : unsupported) { size_t k = u.find(' '); if (k != std::string::npos && u.substr(k + 1) == n) return true; }
+        return false;
+    }
 
     float find_one_float(const std::string& n, float d) const { auto i = floats.find(n); return (i != floats.end() && i->second.size() == 1) ? i->second[0] : d; }
     int find_one_int(const std::string& n, int d) const { auto i = ints.find(n); return (i != ints.end() && i->second.size() == 1) ? i->second[0] : d; }

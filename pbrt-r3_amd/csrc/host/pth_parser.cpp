@@ -144,12 +144,20 @@ struct Parser {
             else if (type == "vector" || type == "vector3" || type == "vector2") ps.vectors[name] = nums;
             else if (type == "normal" || type == "normal3") ps.normals[name] = nums;
             else if (type == "rgb" || type == "color") ps.rgbs[name] = nums;
+            else if (type == "spectrum" && !strs.empty() && nums.empty()) {      // parser/common.rs:108-111: spectrum values are file names
+                const std::string& f = strs[0];
+                ps.spectrum_files[name] = (!f.empty() && f[0] == '/') ? f : (cur_dir.empty() ? f : cur_dir + "/" + f);
+            }
+            else if (type == "blackbody" && !nums.empty()) ps.blackbodies[name] = nums;
             else if (type == "spectrum" || type == "blackbody" || type == "xyz") ps.unsupported.push_back(type + " " + name);
             else return fail("unknown parameter type '" + type + "'", t.line);
         }
     }
 
+    std::string cur_dir;        // directory of the text being parsed: base of Include and of .spd file names
     bool parse_text(const std::string& text, const std::string& work_dir) {
+        struct DirScope { std::string& d; std::string saved; ~DirScope() { d = saved; } } scope{cur_dir, cur_dir};
+        cur_dir = work_dir;
         if (++depth > 32) return fail("Include nesting too deep", 0);
         Lexer lx(text);
         for (;;) {

@@ -19,6 +19,7 @@
 #include "../../../include/pbrtgpu_host.h"
 #include "../pt_host_math.h"
 #include "pth_parse_context.h"
+#include "pth_spectrum.h"
 
 namespace pth {
 
@@ -240,10 +241,27 @@ public:
     // TextureParams (core/param_set/texture_params.rs:36-105): a texture binding is looked up in the shape's
     // parameters first, but constant float / spectrum VALUES come from the material's parameters first and
     // from the shape's only when the material does not give them (the reverse of pbrt-v3; reproduced as is).
+    // get_spectrum_from (texture_params.rs:56-73): an rgb value, else a "spectrum" file converted to RGB
+    bool spectrum_from(const ParamSet& ps, const std::string& n, float out[3]) {
+        if (ps.find_one_rgb(n, out)) return true;
+        if (ps.is_unsupported(n)) { fail("parameter \"" + n + "\" given as xyz / inline spectrum: outside the accelerated path"); return false; }
+        auto f = ps.spectrum_files.find(n);
+        auto b = ps.blackbodies.find(n);
+        if (f == ps.spectrum_files.end() && b == ps.blackbodies.end()) return false;
+        std::string err;
+        const SpectrumTables* T = spectrum_tables(&err);
+        if (!T) { fail("spectrum \"" + n + "\": " + err); return false; }
+        if (f != ps.spectrum_files.end()) {
+            if (!rgb_from_spd_file(*T, f->second, out, &err)) { fail("spectrum \"" + n + "\": " + err); return false; }
+        } else {
+            rgb_from_blackbody(*T, b->second, out);
+        }
+        return true;
+    }
     bool lookup_rgb(const ParamSet& geom, const ParamSet& mat, const std::string& n, float out[3]) {
         if (geom.textures.count(n) || mat.textures.count(n)) { fail("material parameter \"" + n + "\" bound to a texture: outside the accelerated path"); return false; }
-        if (mat.find_one_rgb(n, out)) return true;
-        return geom.find_one_rgb(n, out);
+        if (spectrum_from(mat, n, out)) return true;
+        return spectrum_from(geom, n, out);
     }
     // TextureParams::get_float_texture(_or_null) for constant values (texture_params.rs:36-54, :107-124): material first, then shape
     bool lookup_float(const ParamSet& geom, const ParamSet& mat, const std::string& n, float* out) {
@@ -291,10 +309,12 @@ public:
             m.type = PT_MATERIAL_METAL;
             m.roughness = 0.01f;
             bool have_eta = lookup_rgb(geom, mp, "eta", m.metal_eta), have_k = lookup_rgb(geom, mp, "k", m.metal_k);
-            if (!have_eta || !have_k) {
-                fail("Material \"metal\": \"eta\" and \"k\" must be given as rgb -- the default copper spectrum and \"spectrum\" parameters "
-                     "need the SPD -> RGB conversion, which is outside the accelerated path so far");
-                return -1;
+            if (!have_eta || !have_k) {                 // defaults: the measured copper spectrum (metal.rs:87-132)
+                std::string err;
+                const SpectrumTables* T = spectrum_tables(&err);
+                if (!T) { fail("Material \"metal\" defaults: " + err); return -1; }
+                if (!have_eta) rgb_from_sampled(*T, T->cu_lambda, T->cu_n, m.metal_eta);
+                if (!have_k) rgb_from_sampled(*T, T->cu_lambda, T->cu_k, m.metal_k);
             }
             lookup_float(geom, mp, "roughness", &m.roughness);
             lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
@@ -327,8 +347,9 @@ public:
         if (gs.area_light_name.empty()) return -1;
         if (gs.area_light_name != "diffuse" && gs.area_light_name != "area") { fail("AreaLightSource \"" + gs.area_light_name + "\" unknown"); return -1; }
         float L[3] = {1.0f, 1.0f, 1.0f}, sc[3] = {1.0f, 1.0f, 1.0f};
-        gs.area_light_params.find_one_rgb("L", L);
-        gs.area_light_params.find_one_rgb("scale", sc);
+        spectrum_from(gs.area_light_params, "L", L);          // ParamSet::find_one_spectrum: rgb, spectrum file or blackbody
+        spectrum_from(gs.area_light_params, "scale", sc);
+        if (!error.empty()) return -1;
         pt_area_light al;
         al.L[0] = L[0] * sc[0]; al.L[1] = L[1] * sc[1]; al.L[2] = L[2] * sc[2];
         al.two_sided = gs.area_light_params.find_one_bool("twosided", false) ? 1 : 0;

@@ -225,12 +225,6 @@ def test_materials_from_pbrt_text():
     assert m.type == T.PT_MATERIAL_SUBSTRATE and abs(m.uroughness - 0.3) < 1e-7 and abs(m.vroughness - 0.1) < 1e-7 and list(m.kd) == [0.5] * 3
 
 
-def test_metal_without_rgb_spectra_is_refused():
-    with pytest.raises(capi.PtError) as e:
-        capi.ParsedScene(text='Sampler "sobol"\nWorldBegin\nMaterial "metal"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd')
-    assert e.value.status == 4 and "copper" in str(e.value)
-
-
 @pytest.mark.parametrize("name,params,build", [
     ("box", "", lambda b: b.pixel_filter_box()),
     ("gaussian", '"float xwidth" 2.5 "float alpha" 1.5', lambda b: b.pixel_filter_gaussian(2.5, 2.0, 1.5)),
@@ -249,3 +243,83 @@ def test_filter_tables_match_scene_builder(name, params, build):
     build(b)
     assert np.array_equal(bits(list(d.filter_table)), bits(b.filter_table))
     assert np.array_equal(bits(list(d.filter_radius)), bits(np.array(b.filter_radius, np.float32)))
+
+
+# ---- spectra: SPD -> RGB in the front end (pth_spectrum.cpp) against an independent f64 numpy evaluation
+def _cie():
+    raw = open(os.path.join(ROOT, "pbrt-r3_amd", "data", "spectrum_tables.bin"), "rb").read()
+    assert raw[:8] == b"PTSPECT1"
+    n = int(np.frombuffer(raw, np.uint32, 1, 8)[0])
+    a = np.frombuffer(raw, np.float32, 4 * n + 1, 12).astype(np.float64)
+    off = 12 + 4 * (4 * n + 1)
+    m = int(np.frombuffer(raw, np.uint32, 1, off)[0])
+    cu = np.frombuffer(raw, np.float32, 3 * m, off + 4).astype(np.float64)
+    return a[:n], a[n:2 * n], a[2 * n:3 * n], a[3 * n:4 * n], a[4 * n], cu[:m], cu[m:2 * m], cu[2 * m:]
+
+
+_XYZ2RGB = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
+
+
+def _rgb_60bins(lam, val):
+    """SampledSpectrum pipeline in f64: piecewise-linear SPD averaged over 60 bins of [400,700], times the
+    bin-averaged matching functions, scaled by 300 / (Yint * 60)."""
+    X, Y, Z, L, yint, *_ = _cie()
+    order = np.argsort(lam, kind="stable")
+    lam, val = np.asarray(lam, np.float64)[order], np.asarray(val, np.float64)[order]
+
+    def bins(l, v):
+        out = np.empty(60)
+        for i in range(60):
+            w = np.linspace(400 + 5 * i, 405 + 5 * i, 2001)
+            out[i] = np.trapezoid(np.interp(w, l, v), w) / 5.0
+        return out
+    c = bins(lam, val)
+    xyz = np.array([(bins(L, m) * c).sum() for m in (X, Y, Z)]) * (300.0 / (yint * 60))
+    return _XYZ2RGB @ xyz
+
+
+def _scene_with(material_line, light='AreaLightSource "diffuse" "rgb L" [1 1 1]'):
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]'
+    return 'Sampler "sobol"\nWorldBegin\nAttributeBegin\n%s\n%s\nAttributeEnd\n%s\n%s\nWorldEnd' % (light, tri, material_line, tri)
+
+
+def test_metal_defaults_are_the_copper_spectrum():
+    """create_metal_material (metal.rs:127-132): eta / k default to the measured copper SPD through
+    RGBSpectrum::from_sampled (1 nm CIE integration, rgb.rs:124-149)."""
+    ps = capi.ParsedScene(text=_scene_with('Material "metal"'))
+    m = ps.desc.materials[ps.desc.meshes[1].material]
+    X, Y, Z, L, yint, cw, cn, ck = _cie()
+    for got, vals in ((list(m.metal_eta), cn), (list(m.metal_k), ck)):
+        v = np.interp(L, cw, vals)
+        xyz = np.array([(v * X).sum(), (v * Y).sum(), (v * Z).sum()]) * ((L[-1] - L[0]) / (yint * len(L)))
+        assert np.allclose(got, _XYZ2RGB @ xyz, rtol=2e-5)
+    assert np.allclose(list(m.metal_eta), [0.2004, 0.9240, 1.1022], atol=5e-3)     # the familiar copper RGB constants (60-bin route)
+    assert np.allclose(list(m.metal_k), [3.9129, 2.4528, 2.1421], atol=1e-2)
+    assert abs(m.roughness - 0.01) < 1e-9
+
+
+def test_spectrum_files_and_blackbody(tmp_path):
+    """"spectrum" parameters name .spd files (parser/common.rs:108-111, scene_context.rs:733-760): '#' lines are
+    dropped, samples may be unsorted; "blackbody L" [T scale] goes through blackbody_normalized."""
+    spd = tmp_path / "kd.spd"
+    lam = np.array([700, 380, 450, 500, 560, 620, 780], np.float64)
+    val = np.array([0.8, 0.05, 0.1, 0.3, 0.7, 0.9, 0.6], np.float64)
+    spd.write_text("# wavelength value\n" + "\n".join("%g %g" % (l, v) for l, v in zip(lam, val)) + "\n550 0.123 # dropped line\n")
+    text = _scene_with('Material "matte" "spectrum Kd" "kd.spd"', light='AreaLightSource "diffuse" "blackbody L" [6500 2.5]')
+    ps = capi.ParsedScene(text=text, work_dir=str(tmp_path))
+    d = ps.desc
+    kd = list(d.materials[d.meshes[1].material].kd)
+    assert np.allclose(kd, _rgb_60bins(lam, val), rtol=3e-4, atol=1e-5)
+    # blackbody: Planck's law normalised at Wien's peak, times the scale
+    X, Y, Z, L, yint, *_ = _cie()
+    h, c, kb, T = 6.62606957e-34, 299792458.0, 1.3806488e-23, 6500.0
+    planck = lambda nm: (2 * h * c * c) / ((nm * 1e-9) ** 5 * (np.exp((h * c) / (nm * 1e-9 * kb * T)) - 1))
+    le = planck(L) / planck(2.8977721e-3 / T * 1e9) * 2.5
+    want = _rgb_60bins(L, le)
+    got = list(d.area_lights[0].L)
+    assert np.allclose(got, want, rtol=3e-4)
+    assert got[0] > got[2] * 0.8 and all(g > 0.5 for g in got)           # 6500 K is near white
+    # an inline numeric spectrum is refused, not silently defaulted
+    with pytest.raises(capi.PtError) as e:
+        capi.ParsedScene(text=_scene_with('Material "matte" "spectrum Kd" [400 0.5 700 0.5]'))
+    assert e.value.status == 4
