@@ -8,7 +8,7 @@
  *   SceneContext (the ParseContext that builds the scene)
  *                                           src/core/api/scene_context/scene_context.rs:817-1396
  * for the subset of the format the accelerated path renders: triangle
- * meshes, matte / plastic / mirror / glass / metal (rgb eta, k) / uber / substrate materials with constant
+ * meshes ("trianglemesh" and "plymesh": ASCII / binary / gzip PLY), matte / plastic / mirror / glass / metal (rgb eta, k) / uber / substrate materials with constant
  * parameters (incl. named materials and per-shape overrides; colours as rgb, .spd "spectrum" files or
  * "blackbody"; metal defaults to the measured copper spectrum), diffuse area lights,
  * perspective camera, box/gaussian/mitchell/sinc/triangle filters, Halton (the default) and Sobol' samplers, path integrator,

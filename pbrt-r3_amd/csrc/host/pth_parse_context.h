@@ -18,6 +18,7 @@ public:
     std::map<std::string, std::vector<std::string>> strings, textures;
     std::vector<std::string> unsupported;      // "blackbody"/"xyz"/inline "spectrum" entries: named ("type name"), not converted
     std::map<std::string, std::vector<float>> blackbodies;   // "blackbody name" [T scale ...]
+    std::string base_dir;                      // directory of the file the directive came from (relative "filename" parameters)
     std::map<std::string, std::string> spectrum_files;   // "spectrum name" "file.spd": path resolved against the including file
     bool is_unsupported(const std::string& n) const {
         for (auto& u : unsupported) { size_t k = u.find(' '); if (k != std::string::npos && u.substr(k + 1) == n) return true; }

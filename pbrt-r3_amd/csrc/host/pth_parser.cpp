@@ -106,6 +106,7 @@ struct Parser {
 
     // "type name" value | [ values ]   repeated until the next directive
     bool read_params(Lexer& lx, ParamSet& ps) {
+        ps.base_dir = cur_dir;
         for (;;) {
             Tok t = lx.peek();
             if (t.kind != Tok::STRING) return true;

@@ -19,6 +19,7 @@
 #include "../../../include/pbrtgpu_host.h"
 #include "../pt_host_math.h"
 #include "pth_parse_context.h"
+#include "pth_ply.h"
 #include "pth_spectrum.h"
 
 namespace pth {
@@ -369,10 +370,20 @@ public:
 
     void pbrt_shape(const std::string& name, const ParamSet& p) override {
         if (!error.empty()) return;
-        if (name != "trianglemesh") { fail("Shape \"" + name + "\": only trianglemesh is on the accelerated path"); return; }
+        if (name != "trianglemesh" && name != "plymesh") { fail("Shape \"" + name + "\": only trianglemesh and plymesh are on the accelerated path"); return; }
         const TransformSet& ts = transforms.back();
         if (std::memcmp(&ts.t[0].m, &ts.t[1].m, sizeof(M44)) != 0) { fail("animated transforms are outside the accelerated path"); return; }
         if (p.has("alpha") || p.has("shadowalpha")) { fail("alpha-masked shapes are outside the accelerated path"); return; }
+        if (name == "plymesh") {                                    // shapes/plymesh.rs:251-380
+            std::string file = p.find_one_string("filename", "");
+            if (!file.empty() && file[0] != '/' && !p.base_dir.empty()) file = p.base_dir + "/" + file;
+            PlyMesh ply;
+            std::string perr;
+            if (!read_ply(file, &ply, &perr)) { fail("plymesh: " + perr); return; }
+            if (ply.indices.empty() || ply.P.empty()) { warn("Invalid mesh"); return; }
+            emit_mesh(p, ply.indices, ply.P, ply.N.empty() ? nullptr : &ply.N, nullptr, ply.UV);
+            return;
+        }
         const std::vector<int>* vi = p.get_ints("indices");
         const std::vector<float>* ps = p.get_points("P");
         if (!vi || !ps || vi->empty() || ps->empty()) { warn("Invalid mesh"); return; }
@@ -395,12 +406,23 @@ public:
                     if (uv[2 * v] == 0.0f && uv[2 * v + 1] == 0.0f) { uv[2 * v] = tri_uv[j][0]; uv[2 * v + 1] = tri_uv[j][1]; }
                 }
         }
-        if (!uv.empty() && uv.size() / 2 < nv) { fail("trianglemesh uv count does not match P"); return; }
         const std::vector<float>* sv = p.get_points("S");
         if (!sv) sv = p.get_vectors("S");
         const std::vector<float>* nn = p.get_points("N");
         if (!nn) nn = p.get_normals("N");
-        if ((sv && sv->size() / 3 < nv) || (nn && nn->size() / 3 < nv)) { fail("trianglemesh S / N count does not match P"); return; }
+        emit_mesh(p, idx, *ps, nn, sv, uv);
+    }
+
+    // create_triangle_mesh (triangle.rs:696-731) on object-space arrays: pre-transform, flags, material / light, degenerate filter
+    void emit_mesh(const ParamSet& p, const std::vector<uint32_t>& idx, const std::vector<float>& obj_p, const std::vector<float>* nn,
+                   const std::vector<float>* sv, const std::vector<float>& uv) {
+        const TransformSet& ts = transforms.back();
+        const std::vector<float>* ps = &obj_p;
+        size_t nv = obj_p.size() / 3;
+        for (uint32_t i : idx)
+            if (i >= nv) { fail("mesh has out-of-bounds vertex index"); return; }
+        if (!uv.empty() && uv.size() / 2 < nv) { fail("mesh uv count does not match P"); return; }
+        if ((sv && sv->size() / 3 < nv) || (nn && nn->size() / 3 < nv)) { fail("mesh S / N count does not match P"); return; }
 
         const Xf& o2w = ts.t[0];
         std::vector<float> wp(3 * nv), wn, ws;                      // TriangleMesh::new pre-transforms (triangle.rs:49-66)

@@ -323,3 +323,70 @@ def test_spectrum_files_and_blackbody(tmp_path):
     with pytest.raises(capi.PtError) as e:
         capi.ParsedScene(text=_scene_with('Material "matte" "spectrum Kd" [400 0.5 700 0.5]'))
     assert e.value.status == 4
+
+
+def _write_ply(path, fmt, P, N, UV, faces, gz=False):
+    import gzip, struct
+    hdr = ["ply", "format %s 1.0" % fmt, "comment made by the test", "element vertex %d" % len(P),
+           "property float x", "property float y", "property float z"]
+    if N is not None:
+        hdr += ["property float nx", "property float ny", "property float nz"]
+    if UV is not None:
+        hdr += ["property float u", "property float v"]
+    hdr += ["property uchar red", "element face %d" % len(faces), "property list uchar int vertex_indices", "property float quality", "end_header"]
+    data = ("\n".join(hdr) + "\n").encode()
+    e = "<" if fmt == "binary_little_endian" else ">"
+    rows = []
+    for i in range(len(P)):
+        row = list(P[i]) + (list(N[i]) if N is not None else []) + (list(UV[i]) if UV is not None else [])
+        if fmt == "ascii":
+            rows.append((" ".join(repr(float(np.float32(x))) for x in row) + " 200\n").encode())
+        else:
+            rows.append(struct.pack(e + "%df" % len(row), *row) + struct.pack("B", 200))
+    for f in faces:
+        if fmt == "ascii":
+            rows.append(("%d %s 0.5\n" % (len(f), " ".join(str(i) for i in f))).encode())
+        else:
+            rows.append(struct.pack("B", len(f)) + struct.pack(e + "%di" % len(f), *f) + struct.pack(e + "f", 0.5))
+    data += b"".join(rows)
+    (gzip.open if gz else open)(path, "wb").write(data)
+
+
+@pytest.mark.parametrize("fmt,gz", [("ascii", False), ("binary_little_endian", False), ("binary_big_endian", False), ("binary_little_endian", True)])
+def test_plymesh_equals_trianglemesh(tmp_path, fmt, gz):
+    """Shape "plymesh" (shapes/plymesh.rs:251-380): every encoding flattens to the arrays of the equivalent
+    trianglemesh; quads split as (i0,i1,i2),(i3,i0,i2); unknown vertex / face properties are skipped."""
+    rng = np.random.default_rng(3)
+    P = rng.random((9, 3)).astype(np.float32) * 2 - 1
+    N = rng.standard_normal((9, 3)).astype(np.float32)
+    UV = rng.random((9, 2)).astype(np.float32)
+    faces = [(0, 1, 2), (3, 4, 5, 6), (6, 7, 8), (1, 3, 5, 7)]
+    name = "m.ply.gz" if gz else "m.ply"
+    _write_ply(str(tmp_path / name), fmt, P, N, UV, faces, gz)
+    idx = []
+    for f in faces:
+        idx += list(f) if len(f) == 3 else [f[0], f[1], f[2], f[3], f[0], f[2]]
+    arr = lambda a: " ".join(repr(float(x)) for x in np.asarray(a).reshape(-1))
+    head = 'Sampler "sobol"\nWorldBegin\nAttributeBegin\nAreaLightSource "diffuse"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 9 1 0 9 0 1 9]\nAttributeEnd\nTranslate 0.5 0 0\nRotate 30 0 1 0\n'
+    a = capi.ParsedScene(text=head + 'Shape "plymesh" "string filename" "%s"\nWorldEnd' % name, work_dir=str(tmp_path))
+    b = capi.ParsedScene(text=head + 'Shape "trianglemesh" "integer indices" [%s] "point P" [%s] "normal N" [%s] "float uv" [%s]\nWorldEnd'
+                         % (" ".join(map(str, idx)), arr(P), arr(N), arr(UV)))
+    da, db = a.desc, b.desc
+    assert (da.n_vertices, da.n_triangles) == (db.n_vertices, db.n_triangles) == (12, 7)
+    for field, w in (("P", 3), ("N", 3), ("UV", 2)):
+        ga = np.ctypeslib.as_array(getattr(da, field), (da.n_vertices * w,))
+        gb = np.ctypeslib.as_array(getattr(db, field), (db.n_vertices * w,))
+        assert np.array_equal(bits(ga), bits(gb)), field
+    assert np.array_equal(np.ctypeslib.as_array(da.indices, (21,)), np.ctypeslib.as_array(db.indices, (21,)))
+    assert da.meshes[1].flags == db.meshes[1].flags
+
+
+def test_plymesh_errors(tmp_path):
+    (tmp_path / "bad.ply").write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty double x\nproperty double y\nproperty double z\n"
+                                      "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    (tmp_path / "pent.ply").write_text("ply\nformat ascii 1.0\nelement vertex 5\nproperty float x\nproperty float y\nproperty float z\n"
+                                       "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n0 2 0\n5 0 1 2 3 4\n")
+    for f, needle in (("bad.ply", "float"), ("pent.ply", "5 vertices"), ("missing.ply", "open")):
+        with pytest.raises(capi.PtError) as e:
+            capi.ParsedScene(text='Sampler "sobol"\nWorldBegin\nShape "plymesh" "string filename" "%s"\nWorldEnd' % f, work_dir=str(tmp_path))
+        assert needle in str(e.value)
