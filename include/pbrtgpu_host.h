@@ -7,13 +7,17 @@
  *   trait ParseContext                      src/core/api/parse_context.rs:5-66
  *   SceneContext (the ParseContext that builds the scene)
  *                                           src/core/api/scene_context/scene_context.rs:817-1396
- * for the subset of the format the accelerated path renders: triangle
- * meshes ("trianglemesh" and "plymesh": ASCII / binary / gzip PLY), matte / plastic / mirror / glass / metal (rgb eta, k) / uber / substrate materials with constant
- * parameters (incl. named materials and per-shape overrides; colours as rgb, .spd "spectrum" files or
- * "blackbody"; metal defaults to the measured copper spectrum), diffuse area lights,
- * perspective camera, box/gaussian/mitchell/sinc/triangle filters, Halton (the default) and Sobol' samplers, path integrator,
- * BVH accelerator, the full transform / attribute stack and Include.  Anything else is reported
- * as PT_ERR_UNSUPPORTED with a message naming the directive -- never silently approximated.
+ * for the subset of the format the accelerated path renders:
+ *   shapes      "trianglemesh", "plymesh" (ASCII / binary / gzip PLY)
+ *   materials   matte, plastic, mirror, glass, metal, uber, substrate with constant parameters; named
+ *               materials; colours as rgb, .spd "spectrum" files or "blackbody" (metal defaults to the
+ *               measured copper spectrum)
+ *   lights      diffuse area lights
+ *   camera      perspective;  filters box / gaussian / mitchell / sinc / triangle
+ *   samplers    halton (the default), sobol;  integrator path;  accelerator bvh (sah, hlbvh, middle, equal)
+ *   the full transform / attribute stack, named coordinate systems, Include
+ * Anything else is reported as PT_ERR_UNSUPPORTED with a message naming the directive -- never silently
+ * approximated.
  *
  * The C++ class interface (ParseContext with the reference's method names) is in
  * pbrt-r3_amd/csrc/host/pth_parse_context.h; this header is the C ABI over it.
