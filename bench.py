@@ -82,6 +82,11 @@ def main():
     n_gpus = max(args.gpus, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    # BENCH_REHEARSE=gloo: run the N>1 flow (partition, reduce, barrier, max-over-ranks timing) with every rank
+    # on GPU 0 and a host-staged gloo reduce -- a 1-GPU box cannot host two RCCL ranks.  Never a judged number.
+    rehearse = os.environ.get("BENCH_REHEARSE") == "gloo"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_REDUCE") == "1"     # the latter: rehearse the N>1 code path on one GPU
     if use_dist:
@@ -91,7 +96,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def log(msg):
         if rank == 0:
@@ -116,7 +124,12 @@ def main():
             # the one collective of the path: sum the per-rank XYZW films (disjoint tiles)
             ptr, n = ctx.film_device_xyzw()
             t = pkg.dist.wrap_device_floats(ptr, n, local_rank)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if rehearse:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()      # the library's next film_clear runs on its own stream
             ctx.film_commit_xyzw()
 
@@ -125,6 +138,14 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def check_reduced_film():
+        # every camera sample of every rank's tiles must be in the reduced film exactly once (box filter: weight 1 each)
+        x = ctx.film_xyzw()
+        want = float(info.spp) * (info.cropped_bounds[2] - info.cropped_bounds[0]) * (info.cropped_bounds[3] - info.cropped_bounds[1])
+        got = float(x[..., 3].astype(np.float64).sum())
+        log("reduced film: sum of weights %.1f, expected %.1f (%s)" % (got, want, "ok" if abs(got - want) <= 1e-6 * want else "MISMATCH"))
+        return abs(got - want) <= 1e-6 * want
 
     log("scene %d tris uploaded (gen %.1fs, bvh %.0f ms), %d tiles for this rank" % (sd.desc.n_triangles, t_scene, info.bvh_build_ms, len(my_tiles)))
     for i in range(args.warmup):
@@ -140,9 +161,11 @@ def main():
     elapsed = time.time() - t_start
     cnt = ctx.counters()
 
+    if use_dist and (rehearse or os.environ.get("BENCH_CHECK_FILM") == "1"):
+        check_reduced_film()
     stats = torch.tensor([elapsed, cnt["regular_rays"], cnt["shadow_rays"], cnt["nodes_visited"], cnt["tris_tested"],
                           cnt["path_vertices"], cnt["trace_ms"], cnt["trace_launches"], cnt["camera_rays"], cnt["shade_ms"]],
-                         dtype=torch.float64, device="cuda")
+                         dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
