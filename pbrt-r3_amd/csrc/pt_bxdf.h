@@ -215,7 +215,7 @@ PT_DEV V3 tr_sample_wh(float ax, float ay, V3 wo, V2 u) {
 // ---- the lobes
 PT_DEV bool lobe_matches(const PtLobe& l, uint32_t flags) { return (l.type & flags) == l.type; }
 
-PT_DEV V3 globe_f(const PtLobe& l, V3 wo, V3 wi) {
+__device__ __noinline__ V3 globe_f(const PtLobe& l, V3 wo, V3 wi) {
     const V3 zero = mk3(0.0f, 0.0f, 0.0f);
     switch (l.kind) {
         case PT_LOBE_LAMBERT: return ld3(l.r) * PT_INV_PI;
@@ -271,7 +271,7 @@ PT_DEV V3 globe_f(const PtLobe& l, V3 wo, V3 wi) {
     }
 }
 
-PT_DEV float globe_pdf(const PtLobe& l, V3 wo, V3 wi) {
+__device__ __noinline__ float globe_pdf(const PtLobe& l, V3 wo, V3 wi) {
     switch (l.kind) {
         case PT_LOBE_LAMBERT: case PT_LOBE_OREN_NAYAR: return bx_same_hemisphere(wo, wi) ? fabsf(wi.z) * PT_INV_PI : 0.0f;
         case PT_LOBE_MF_REFL: {
@@ -302,7 +302,7 @@ PT_DEV float globe_pdf(const PtLobe& l, V3 wo, V3 wi) {
 }
 
 // BxDF::sample_f; *sampled_type = 0 means "the lobe's own type"
-PT_DEV bool globe_sample_f(const PtLobe& l, V3 wo, V2 u, V3* f, V3* wi_out, float* pdf, uint32_t* sampled_type) {
+__device__ __noinline__ bool globe_sample_f(const PtLobe& l, V3 wo, V2 u, V3* f, V3* wi_out, float* pdf, uint32_t* sampled_type) {
     *sampled_type = 0;
     switch (l.kind) {
         case PT_LOBE_LAMBERT: case PT_LOBE_OREN_NAYAR: {
