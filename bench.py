@@ -71,6 +71,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU sample (0 = auto, about 15 s)")
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  Native libraries (RCCL's version banner and NCCL WARN lines, gloo's
+    # connection notes) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the
+    # JSON line goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -122,16 +128,16 @@ def main():
         ctx.render(my_tiles)
         if use_dist:
             # the one collective of the path: sum the per-rank XYZW films (disjoint tiles)
-            ptr, n = ctx.film_device_xyzw()
-            t = pkg.dist.wrap_device_floats(ptr, n, local_rank)
             if rehearse:
+                ptr, n = ctx.film_device_xyzw()
+                t = pkg.dist.wrap_device_floats(ptr, n, local_rank)
                 h = t.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 t.copy_(h)
+                torch.cuda.synchronize()
+                ctx.film_commit_xyzw()
             else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()      # the library's next film_clear runs on its own stream
-            ctx.film_commit_xyzw()
+                pkg.dist.reduce_film(ctx, local_rank, staged=os.environ.get("BENCH_REDUCE_IN_PLACE") != "1")
 
     def fence():
         torch.cuda.synchronize()
@@ -237,7 +243,8 @@ def main():
                        "scene_gen_s": round(t_scene, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
