@@ -248,3 +248,18 @@ extern "C" void orc_bsdf_sample(const orc_scene* s, uint32_t material, uint32_t 
     }
 }
 extern "C" float orc_roughness_to_alpha(float r) { return TRDist::roughness_to_alpha(r); }
+
+// Diagnostic for tools/sim_wave_sched.py: render one tile single-threaded and return the traversal step stream of
+// every ray the path integrator traced (0 = node visit, k = leaf with k triangle tests, 255 = end of ray).
+extern "C" uint64_t orc_step_log(orc_scene* s, const pt_tile* tile, uint8_t* out, uint64_t cap) {
+    std::vector<uint8_t> log;
+    s->sc.bvh.step_log = &log;
+    int32_t tb[4] = {tile->x0, tile->y0, tile->x1, tile->y1};
+    RayCounters rc;
+    std::vector<float> rad((size_t)(tb[2] - tb[0]) * (tb[3] - tb[1]) * s->sc.spp * 3);
+    render_tile(s->sc, s->ld, tb, nullptr, rad.data(), rc);
+    s->sc.bvh.step_log = nullptr;
+    uint64_t n = std::min<uint64_t>(cap, log.size());
+    std::memcpy(out, log.data(), n);
+    return log.size();
+}

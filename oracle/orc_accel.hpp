@@ -556,6 +556,9 @@ struct QBVH {
     std::vector<QNode> nodes;
     Bounds3 bounds;
     size_t n_interior4 = 0, n_leaves = 0;
+    // tools/sim_wave_sched.py: byte stream of traversal steps (0 = node visit, k = leaf with k triangles, 255 = ray end);
+    // single-threaded diagnostic use only
+    mutable std::vector<uint8_t>* step_log = nullptr;
     // traversal statistics (thread-unsafe; callers keep one copy per thread or ignore)
     struct Stats { uint64_t nodes = 0, tris = 0; };
 
@@ -682,6 +685,7 @@ struct QBVH {
             const QNode& nd = nodes[cur];
             if (nd.is_leaf == 0) {
                 if (st) st->nodes++;
+                if (step_log) step_log->push_back(0);
                 uint32_t hit_mask = test_aabb(nd, org, idir, sign, tmin, tmax);
                 if (hit_mask != 0) {
                     uint32_t node_idx = (uint32_t)((sign[nd.axis_top] << 2) | (sign[nd.axis_left] << 1) | sign[nd.axis_right]);
@@ -694,6 +698,7 @@ struct QBVH {
                 }
             } else {
                 size_t start = nd.children[0], end = start + nd.children[1];
+                if (step_log) step_log->push_back((uint8_t)std::min<size_t>(end - start, 250));
                 bool leaf_hit = false;
                 for (size_t i = start; i < end; i++) {   // intersect_primitives :206-218
                     if (st) st->tris++;
@@ -708,6 +713,7 @@ struct QBVH {
                 if (leaf_hit) { tmax = r.t_max; hit = true; }
             }
         }
+        if (step_log) step_log->push_back(255);
         return hit;
     }
     // intersect_simd_p (qbvh_x86.rs:289-343)
@@ -726,6 +732,7 @@ struct QBVH {
             const QNode& nd = nodes[cur];
             if (nd.is_leaf == 0) {
                 if (st) st->nodes++;
+                if (step_log) step_log->push_back(0);
                 uint32_t hit_mask = test_aabb(nd, org, idir, sign, tmin, tmax);
                 if (hit_mask != 0) {
                     uint32_t node_idx = (uint32_t)((sign[nd.axis_top] << 2) | (sign[nd.axis_left] << 1) | sign[nd.axis_right]);
@@ -740,10 +747,15 @@ struct QBVH {
                 size_t start = nd.children[0], end = start + nd.children[1];
                 for (size_t i = start; i < end; i++) {
                     if (st) st->tris++;
-                    if (TriRef(geom, (uint32_t)prims[i]).intersect_p(r)) return true;
+                    if (TriRef(geom, (uint32_t)prims[i]).intersect_p(r)) {
+                        if (step_log) { step_log->push_back((uint8_t)std::min<size_t>(i - start + 1, 250)); step_log->push_back(255); }
+                        return true;
+                    }
                 }
+                if (step_log) step_log->push_back((uint8_t)std::min<size_t>(end - start, 250));
             }
         }
+        if (step_log) step_log->push_back(255);
         return false;
     }
     // accelerators/exhaustive: brute force over every primitive, used as a cross-check

@@ -77,7 +77,7 @@ struct pt_context {
     size_t pool_paths = 0;
     DevBuf d_pool;          // one slab carved into the SoA arrays of PtPaths
     PtPaths paths;
-    DevBuf d_qa, d_qb, d_qnee, d_qsorted, d_counts, d_pixels;
+    DevBuf d_qa, d_qb, d_qnee, d_qshadow, d_qprobe, d_qsorted, d_counts, d_pixels;
     size_t pixels_cap = 0;
 
     // ---- film
@@ -159,6 +159,8 @@ pt_status ensure_pool(pt_context* ctx, size_t n_paths) {
     PT_HIP(ctx->d_qb.alloc(n_paths * 4));
     PT_HIP(ctx->d_qnee.alloc(n_paths * 4));
     PT_HIP(ctx->d_qsorted.alloc(n_paths * 4));
+    PT_HIP(ctx->d_qshadow.alloc(n_paths * 4));
+    PT_HIP(ctx->d_qprobe.alloc(n_paths * 4));
     ctx->pool_paths = n_paths;
     return PT_OK;
 }
@@ -807,6 +809,8 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     Q.nee = ctx->d_qnee.as<uint32_t>();
     Q.counts = ctx->d_counts.as<uint32_t>();
     Q.sorted = ctx->d_qsorted.as<uint32_t>();
+    Q.shadow = ctx->d_qshadow.as<uint32_t>();
+    Q.probe = ctx->d_qprobe.as<uint32_t>();
     PtCounters* cnt = ctx->d_counters.as<PtCounters>();
     uint32_t* err = ctx->d_err.as<uint32_t>();
     size_t ev_i = 0;
@@ -851,11 +855,11 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 // paths can outlive max_depth+1 iterations only by passing through material-less
                 // surfaces; the last SHADE may also have queued NEE work.  One counter read per pass.
                 for (;;) {
-                    uint32_t counts[4];
-                    PT_HIP(hipMemcpyAsync(counts, Q.counts, 16, hipMemcpyDeviceToHost, ctx->stream));
+                    uint32_t counts[PT_Q_NEE + 1];
+                    PT_HIP(hipMemcpyAsync(counts, Q.counts, sizeof(counts), hipMemcpyDeviceToHost, ctx->stream));
                     PT_HIP(hipStreamSynchronize(ctx->stream));
-                    if (counts[0] == 0 && counts[2] == 0) break;
-                    if (counts[0] == 0) {     // only NEE resolves left
+                    if (counts[PT_Q_CUR] == 0 && counts[PT_Q_NEE] == 0) break;
+                    if (counts[PT_Q_CUR] == 0) {     // only NEE resolves left
                         PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
                         ctx->trace_launches++;
                         PT_HIP(ptk_prep(ctx->stream, Q, 0));
@@ -874,6 +878,16 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
         PT_HIP(hipMemset(err, 0, 4));
         return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow (BVH deeper than the computed bound)");
     }
+#ifdef PT_PROFILE_PHASES
+    {   // diagnostic build (tools/tune_trace.sh "prof:-DPT_PROFILE_PHASES:4"): wave-clock split of k_trace's two phases
+        unsigned long long pr[10];
+        PT_HIP(hipMemcpy(pr, ctx->d_spill.p, sizeof(pr), hipMemcpyDeviceToHost));
+        PT_HIP(hipMemset(ctx->d_spill.p, 0, sizeof(pr)));
+        std::fprintf(stderr, "[phases] node: %.3e clk, %llu steps, %.1f lanes/step | leaf: %.3e clk, %llu steps, %.1f lanes/step | wave total %.3e clk | service+begin %.3e clk, iterations with a retire %llu, with a ray start %llu\n",
+                     (double)pr[0], pr[1], pr[1] ? (double)pr[2] / pr[1] : 0.0, (double)pr[3], pr[4], pr[4] ? (double)pr[5] / pr[4] : 0.0, (double)pr[6],
+                     (double)pr[7], pr[8], pr[9]);
+    }
+#endif
     float ms = 0;
     PT_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
     ctx->render_ms += ms;

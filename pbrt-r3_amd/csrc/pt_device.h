@@ -202,14 +202,24 @@ struct PtPaths {
 struct PtQueues {
     uint32_t* cur;       // path ids to shade / whose continuation ray is traced
     uint32_t* next;
-    uint32_t* nee;       // path ids with a pending NEE resolve
-    uint32_t* counts;    // [0]=n_cur [1]=n_next [2]=n_nee [3]=work ticket; material sort: [4]=ticket of the general
-                         // segment [5]=end of the Matte segment [6]=end of the general segment,
-                         // [PT_SORT_COUNT0, +256) bin counts, [PT_SORT_CURSOR0, +256) bin cursors
+    uint32_t* nee;       // path ids with a pending NEE resolve (k_nee_resolve)
+    uint32_t* shadow;    // path ids whose NEE shadow ray (any hit) is to be traced   (counts[7])
+    uint32_t* probe;     // path ids whose MIS probe ray (closest hit) is to be traced (counts[8])
+    uint32_t* counts;    // counters, PT_Q_* below.  The ones every wave bumps with an atomic sit 128 bytes apart:
+                         // atomics on one line serialise in a single L2 channel (k_shade was bound by exactly that)
     uint32_t* sorted;    // cur re-ordered by material bin, misses dropped (scenes with non-Matte materials)
 };
+#define PT_Q_CUR 0u          // items in cur
+#define PT_Q_MATTE_END 1u    // material sort: end of the Matte segment of sorted
+#define PT_Q_GENERAL_END 2u  // material sort: end of the general segment
+#define PT_Q_NEXT 32u        // items pushed to next
+#define PT_Q_NEE 64u         // paths with a pending NEE resolve
+#define PT_Q_TICKET 96u      // work ticket (k_trace, k_shade Matte segment)
+#define PT_Q_TICKET2 128u    // work ticket of k_shade_general
+#define PT_Q_SHADOW 160u     // shadow rays queued
+#define PT_Q_PROBE 192u      // probe rays queued
 #define PT_SORT_BINS 256u
 #define PT_SORT_GENERAL0 128u
-#define PT_SORT_COUNT0 16u
-#define PT_SORT_CURSOR0 (16u + 256u)
-#define PT_COUNTS_WORDS (16u + 512u)
+#define PT_SORT_COUNT0 256u                       // [+256) bin counts
+#define PT_SORT_CURSOR0 (256u + 256u)             // [+256) bin cursors
+#define PT_COUNTS_WORDS (256u + 512u)

@@ -502,10 +502,10 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 }
 
 // ============================================================ K_TRACE (wavefront)
-// Items [0, n_cur) are continuation rays (closest hit -> hit_t / hit_rec).
-// Items [n_cur, n_cur + n_nee) resolve the previous bounce's next-event estimate:
-// shadow ray (any hit), MIS probe ray (closest hit, accepted only if it lands on the
-// sampled light's triangle), then L += beta * ((A + B) / pdf_light)   (path.rs:122-136).
+// Items [0, n_cur) are continuation rays (closest hit -> hit_t / hit_rec), then the previous bounce's
+// next-event rays as independent items: n_shadow shadow rays (any hit -> occluded flag) and n_probe MIS probe
+// rays (closest hit -> probe_rec).  k_nee_resolve, launched right behind, turns the two results into
+// L += beta * ((A + B) / pdf_light)   (path.rs:122-136).
 //
 // Persistent lanes: ray lengths are heavy-tailed (a wave of 64 fresh rays would idle most of
 // its lanes waiting for the slowest one), so every lane runs a small state machine and a wave
@@ -533,68 +533,58 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(P
     c.spill = spill + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     c.spill_depth = spill_depth;
     c.n_nodes = 0; c.n_tris = 0; c.overflow = 0;
-    const uint32_t n_cur = Q.counts[0], n_nee = Q.counts[2];
-    const uint32_t total = n_cur + n_nee;
+    const uint32_t n_cur = Q.counts[PT_Q_CUR], n_sh = Q.counts[PT_Q_SHADOW], n_pr = Q.counts[PT_Q_PROBE];
+    const uint32_t total = n_cur + n_sh + n_pr;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     unsigned long long regular = 0, shadow = 0;
 
-    // lane job: 0 idle, 1 continuation (closest), 2 shadow (any), 3 MIS probe (closest)
+    // lane job: 0 idle, 1 continuation (closest), 2 shadow (any), 3 MIS probe (closest).  The three kinds are
+    // independent work items; a finished ray only stores its result (hit record / occlusion flag / probe record),
+    // k_nee_resolve combines the two NEE results afterwards, so retiring never waits on a load.
     int kind = 0;
-    uint32_t p = 0, nee = 0;
-    V3 ld = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t p = 0;
     LaneRay r;
     r.sp = 0;
     r.top = PT_EMPTY_REF;
     bool more = total > 0;
+#ifdef PT_PROFILE_PHASES
+    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0-2 node clk/steps/lanes, 3-5 leaf, 6 total, 7 service+begin clk, 8 retire events, 9 begin events
+    long long prof_t0 = __builtin_readcyclecounter();
+#endif
     for (;;) {
+#ifdef PT_PROFILE_PHASES
+        long long pt_iter = __builtin_readcyclecounter();
+#endif
         // ---- which ray does this lane start next (at most one ray_begin site: it is long)
         int start = 0;                               // 0 none, else the kind to start
         unsigned long long idle = __ballot(kind == 0);
         int n_idle = __popcll(idle);
         if (more && (n_idle >= PT_REFILL_MIN || n_idle == 64)) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&Q.counts[3], (uint32_t)n_idle);
+            if (lane == 0) base = atomicAdd(&Q.counts[PT_Q_TICKET], (uint32_t)n_idle);
             base = __shfl(base, 0, 64);
             if (base + (uint32_t)n_idle >= total) more = false;
             uint32_t item = base + (uint32_t)__popcll(idle & below);
             if (kind == 0 && item < total) {
-                if (item < n_cur) {
-                    p = Q.cur[item];
-                    start = 1;
-                } else {
-                    p = Q.nee[item - n_cur];
-                    nee = P.nee[p];
-                    ld = mk3(0.0f, 0.0f, 0.0f);
-                    start = (nee & PT_NEE_SHADOW) ? 2 : 3;
-                }
+                if (item < n_cur) { p = Q.cur[item]; start = 1; }
+                else if (item < n_cur + n_sh) { p = Q.shadow[item - n_cur]; start = 2; }
+                else { p = Q.probe[item - n_cur - n_sh]; start = 3; }
             }
         }
-        // ---- retire finished rays (rare, divergent)
+        // ---- retire finished rays: stores only
+#ifdef PT_PROFILE_PHASES
+        if (__ballot(kind != 0 && ray_done(r)) != 0ull) prof[8] += 1;
+#endif
         if (kind != 0 && ray_done(r)) {
-            if (kind == 1) {                         // continuation ray finished
-                P.hit_t[p] = r.ray_tmax;
-                P.hit_rec[p] = r.best;
-                kind = 0;
-            } else {
-                if (kind == 2) {                     // shadow ray: unoccluded => light term A
-                    if (r.best < 0) { float4 A = P.pendA[p]; ld = ld + mk3(A.x, A.y, A.z); }
-                    if (nee & PT_NEE_PROBE) start = 3;
-                } else {                             // probe: counts only on the sampled light's triangle
-                    if (r.best >= 0 && (uint32_t)r.best == sc.lights[nee >> 8].tri_rec) { float4 B = P.pendB[p]; ld = ld + mk3(B.x, B.y, B.z); }
-                }
-                if (start == 0) {
-                    float pdf_sel = P.pendA[p].w;
-                    V3 ldn = ld / pdf_sel;
-                    float4 pb = P.pbeta[p];
-                    float4 L = P.L[p];
-                    V3 add = mk3(pb.x, pb.y, pb.z) * ldn;
-                    L.x += add.x; L.y += add.y; L.z += add.z;
-                    P.L[p] = L;
-                }
-                kind = 0;
-            }
+            if (kind == 1) { P.hit_t[p] = r.ray_tmax; P.hit_rec[p] = r.best; }
+            else if (kind == 2) P.occluded[p] = r.best >= 0 ? 1 : 0;
+            else P.probe_rec[p] = r.best;
+            kind = 0;
         }
+#ifdef PT_PROFILE_PHASES
+        if (__ballot(start != 0) != 0ull) prof[9] += 1;
+#endif
         if (start != 0) {
             const float4* so = start == 1 ? P.ray_o : (start == 2 ? P.sh_o : P.pr_o);
             const float4* sd = start == 1 ? P.ray_d : (start == 2 ? P.sh_d : P.pr_d);
@@ -615,12 +605,26 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(P
         bool w_tri = kind != 0 && ray_wants_tri(r);
         bool w_node = kind != 0 && ray_wants_node(r);
         unsigned long long m_tri = __ballot(w_tri), m_node = __ballot(w_node);
+#ifdef PT_PROFILE_PHASES
+        long long pt0 = __builtin_readcyclecounter();
+        prof[7] += (unsigned long long)(pt0 - pt_iter);
+#endif
         if (m_node != 0 && __popcll(m_tri) < PT_LEAF_MIN) {
             if (w_node) ray_step_node(sc, r, c);
+#ifdef PT_PROFILE_PHASES
+            prof[0] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[1] += 1; prof[2] += (unsigned long long)__popcll(m_node);
+#endif
         } else {
             if (w_tri) ray_step_tri(sc, r, kind == 2, c);
+#ifdef PT_PROFILE_PHASES
+            prof[3] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[4] += 1; prof[5] += (unsigned long long)__popcll(m_tri);
+#endif
         }
     }
+#ifdef PT_PROFILE_PHASES
+    prof[6] = (unsigned long long)(__builtin_readcyclecounter() - prof_t0);
+    if (lane == 0) for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(spill) + i, prof[i]);   // diagnostic build only: clobbers spill[0..19]
+#endif
     if (c.overflow) atomicOr(err, 1u);
     flush_counters(cnt, s_cnt, regular, shadow, c.n_nodes, c.n_tris);
 }
@@ -700,7 +704,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_gen(PtScene sc, PtPaths
         Q.cur[i] = i;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        Q.counts[0] = n; Q.counts[1] = 0; Q.counts[2] = 0; Q.counts[3] = 0;
+        Q.counts[PT_Q_CUR] = n; Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_NEE] = 0; Q.counts[PT_Q_TICKET] = 0; Q.counts[PT_Q_SHADOW] = 0; Q.counts[PT_Q_PROBE] = 0;
         atomicAdd(&cnt->camera_rays, (unsigned long long)n);
     }
 }
@@ -709,9 +713,9 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_gen(PtScene sc, PtPaths
 extern "C" __global__ void k_prep(PtQueues Q, int mode) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (mode == 0) {            // before SHADE: nee and next start empty
-            Q.counts[1] = 0; Q.counts[2] = 0; Q.counts[3] = 0; Q.counts[4] = 0;
+            Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_NEE] = 0; Q.counts[PT_Q_TICKET] = 0; Q.counts[PT_Q_TICKET2] = 0; Q.counts[PT_Q_SHADOW] = 0; Q.counts[PT_Q_PROBE] = 0;
         } else {                    // after SHADE: next becomes cur (host swaps the pointers)
-            Q.counts[0] = Q.counts[1]; Q.counts[1] = 0; Q.counts[3] = 0;
+            Q.counts[PT_Q_CUR] = Q.counts[PT_Q_NEXT]; Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_TICKET] = 0;
         }
     }
 }
@@ -969,6 +973,31 @@ PT_DEV uint32_t sample_discrete(const float* tab, uint32_t n, float u, float* pd
     return idx;
 }
 
+// ============================================================ NEE resolve
+// After TRACE: L += beta * ((A + B) / pdf_light) for every path with a pending next-event estimate, where the
+// light-sample term A counts if its shadow ray was unoccluded and the BSDF-sample term B if its probe ray's
+// closest hit is the sampled light's own triangle (sample_lights.rs:372-385, :419-447; path.rs:122-136).
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_nee_resolve(PtScene sc, PtPaths P, PtQueues Q) {
+    const uint32_t n = Q.counts[PT_Q_NEE];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = Q.nee[i];
+        const uint32_t nee = P.nee[p];
+        const float4 A = P.pendA[p];
+        V3 ld = mk3(0.0f, 0.0f, 0.0f);
+        if ((nee & PT_NEE_SHADOW) && P.occluded[p] == 0) ld = ld + mk3(A.x, A.y, A.z);
+        if (nee & PT_NEE_PROBE) {
+            const int32_t best = P.probe_rec[p];
+            if (best >= 0 && (uint32_t)best == sc.lights[nee >> 8].tri_rec) { float4 B = P.pendB[p]; ld = ld + mk3(B.x, B.y, B.z); }
+        }
+        V3 ldn = ld / A.w;
+        float4 pb = P.pbeta[p];
+        float4 L = P.L[p];
+        V3 add = mk3(pb.x, pb.y, pb.z) * ldn;
+        L.x += add.x; L.y += add.y; L.z += add.z;
+        P.L[p] = L;
+    }
+}
+
 // ============================================================ material-sorted shade queue
 // Scenes with non-Matte materials: after TRACE the shade queue is counting-sorted by the material bin of
 // each path's hit (Matte bins first), misses are dropped.  k_shade then runs over the Matte segment and
@@ -1010,7 +1039,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_count(PtScene sc, 
     s_cnt[threadIdx.x] = 0;
     __syncthreads();
     uint32_t lo, hi;
-    sort_chunk(Q.counts[0], &lo, &hi);
+    sort_chunk(Q.counts[PT_Q_CUR], &lo, &hi);
     for (uint32_t i = lo + threadIdx.x; i < ((hi + 63u) & ~63u); i += blockDim.x) {
         bool valid = i < hi;
         uint32_t bin = valid ? path_sort_bin(sc, P, Q.cur[i]) : 0xffffffffu;
@@ -1036,15 +1065,15 @@ extern "C" __global__ void k_sort_scan(PtQueues Q) {          // one block of PT
     uint32_t excl = s[t] - c;
     Q.counts[PT_SORT_CURSOR0 + t] = excl;
     Q.counts[PT_SORT_COUNT0 + t] = 0;                           // ready for the next bounce
-    if (t == PT_SORT_GENERAL0) Q.counts[5] = excl;
-    if (t == PT_SORT_BINS - 1) Q.counts[6] = s[t];
+    if (t == PT_SORT_GENERAL0) Q.counts[PT_Q_MATTE_END] = excl;
+    if (t == PT_SORT_BINS - 1) Q.counts[PT_Q_GENERAL_END] = s[t];
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc, PtPaths P, PtQueues Q) {
     __shared__ uint32_t s_cnt[PT_SORT_BINS];      // phase A: this block's count per bin; phase C: running cursor
     s_cnt[threadIdx.x] = 0;
     __syncthreads();
     uint32_t lo, hi;
-    sort_chunk(Q.counts[0], &lo, &hi);
+    sort_chunk(Q.counts[PT_Q_CUR], &lo, &hi);
     const uint32_t hi_round = (hi + 63u) & ~63u;
     for (uint32_t i = lo + threadIdx.x; i < hi_round; i += blockDim.x) {
         bool valid = i < hi;
@@ -1083,12 +1112,20 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     __syncthreads();
     uint32_t n_vert = 0;
     const uint32_t lane = threadIdx.x & 63;
+    uint32_t chunk_left = 0, next_base = 0;
     for (;;) {
-        uint32_t base = begin + wave_ticket(ticket);
+        if (chunk_left == 0) {                 // one ticket atomic per 4 x 64 items
+            uint32_t t0 = 0;
+            if (lane == 0) t0 = atomicAdd(ticket, 256u);
+            next_base = begin + (uint32_t)__shfl((int)t0, 0, 64);
+            chunk_left = 4;
+        }
+        uint32_t base = next_base;
+        next_base += 64u; chunk_left--;
         if (base >= end) break;
         uint32_t item = base + lane;
         bool active = item < end;
-        bool cont = false, want_nee = false;
+        bool cont = false, want_nee = false, want_sh = false, want_pr = false;
         uint32_t p = 0;
         if (active) {
             p = list[item];
@@ -1237,6 +1274,8 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                 P.pbeta[p] = make_float4(beta.x, beta.y, beta.z, 0.0f);
                                 P.nee[p] = nee;
                                 want_nee = true;
+                                want_sh = (nee & PT_NEE_SHADOW) != 0;
+                                want_pr = (nee & PT_NEE_PROBE) != 0;
                             }
                         }
                     }
@@ -1273,30 +1312,34 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             }
         }
         // ---- order-preserving wave compaction into the next / nee queues
-        unsigned long long mc = __ballot(cont), mn = __ballot(want_nee);
-        uint32_t bc = 0, bn = 0;
+        unsigned long long mc = __ballot(cont), mn = __ballot(want_nee), ms = __ballot(want_sh), mp = __ballot(want_pr);
+        uint32_t bc = 0, bn = 0, bs = 0, bp = 0;
         if (lane == 0) {
-            if (mc) bc = atomicAdd(&Q.counts[1], (uint32_t)__popcll(mc));
-            if (mn) bn = atomicAdd(&Q.counts[2], (uint32_t)__popcll(mn));
+            if (mc) bc = atomicAdd(&Q.counts[PT_Q_NEXT], (uint32_t)__popcll(mc));
+            if (mn) bn = atomicAdd(&Q.counts[PT_Q_NEE], (uint32_t)__popcll(mn));
+            if (ms) bs = atomicAdd(&Q.counts[PT_Q_SHADOW], (uint32_t)__popcll(ms));
+            if (mp) bp = atomicAdd(&Q.counts[PT_Q_PROBE], (uint32_t)__popcll(mp));
         }
-        bc = __shfl(bc, 0, 64); bn = __shfl(bn, 0, 64);
+        bc = __shfl(bc, 0, 64); bn = __shfl(bn, 0, 64); bs = __shfl(bs, 0, 64); bp = __shfl(bp, 0, 64);
         unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         if (cont) Q.next[bc + (uint32_t)__popcll(mc & below)] = p;
         if (want_nee) Q.nee[bn + (uint32_t)__popcll(mn & below)] = p;
+        if (want_sh) Q.shadow[bs + (uint32_t)__popcll(ms & below)] = p;
+        if (want_pr) Q.probe[bp + (uint32_t)__popcll(mp & below)] = p;
     }
     if (n_vert) atomicAdd(&s_vert, (unsigned long long)n_vert);
     __syncthreads();
     if (threadIdx.x == 0 && s_vert) atomicAdd(&cnt->vertices, s_vert);
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<false>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[0], &Q.counts[3]);
+    shade_body<false>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[PT_Q_CUR], &Q.counts[PT_Q_TICKET]);
 }
 // the two halves of a material-sorted queue
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade_matte_sorted(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<false>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[5], &Q.counts[3]);
+    shade_body<false>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], &Q.counts[PT_Q_TICKET]);
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<true>(sc, P, Q, cnt, Q.sorted, Q.counts[5], Q.counts[6], &Q.counts[4]);
+    shade_body<true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
 }
 
 // ============================================================ film
@@ -1527,6 +1570,7 @@ extern "C" __global__ void k_bsdf_sample(PtScene sc, uint32_t material, uint32_t
 hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err) {
     hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out,
