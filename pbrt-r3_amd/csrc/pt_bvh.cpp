@@ -348,12 +348,16 @@ void morton_sort(std::vector<Item>& items, std::vector<Item>& scratch, std::vect
     }
 }
 
+inline uint32_t leaf_reference(uint32_t first, uint32_t count) {
+    return PT_LEAF_BIT | ((std::min(count, 8u) - 1u) << PT_LEAF_COUNT_SHIFT) | first;
+}
+
 struct Collapser {
     const std::vector<BNode>& b;
     Result& out;
     uint32_t max_depth4 = 0;
 
-    uint32_t leaf_ref(const BNode& n) const { return PT_LEAF_BIT | n.first; }
+    uint32_t leaf_ref(const BNode& n) const { return leaf_reference(n.first, n.count); }
 
     // One 4-wide node from a binary node and its two children (a leaf child fills slot 0/2 and
     // leaves slot 1/3 empty, exactly like flatten_qbvh_tree).  Returns the node index.
@@ -393,6 +397,7 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
     out->nodes.clear(); out->tris.clear(); out->rec_of_prim.clear();
     out->n_leaves = 0; out->max_stack = 1;
     if (n_tris == 0) { out->root_ref = PT_EMPTY_REF; return true; }
+    if (n_tris >= PT_LEAF_FIRST_MASK - 16u) return false;      // a leaf reference keeps 28 bits for the first record
     std::vector<Item> items(n_tris), scratch(n_tris);
     const float eps = std::numeric_limits<float>::epsilon() * 2.0f;   // BOUND_EPS (build/node.rs:13)
     for (uint32_t t = 0; t < n_tris; t++) {
@@ -459,10 +464,11 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
         out->tris.push_back(pad);
     }
     out->n_leaves = 0;
+    out->max_leaf = 0;
     for (const BNode& n : tree)
-        if (n.count > 0) { out->tris[n.first + n.count - 1].flags |= PT_TRI_LAST; out->n_leaves++; }
+        if (n.count > 0) { out->tris[n.first + n.count - 1].flags |= PT_TRI_LAST; out->n_leaves++; out->max_leaf = std::max(out->max_leaf, n.count); }
     if (tree[root].count > 0) {           // the whole scene is one leaf
-        out->root_ref = PT_LEAF_BIT | tree[root].first;
+        out->root_ref = leaf_reference(tree[root].first, tree[root].count);
         out->max_stack = 1;
         return true;
     }

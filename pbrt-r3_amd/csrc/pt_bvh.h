@@ -13,6 +13,7 @@ struct Result {
     std::vector<PtTri> tris;            // triangle records in leaf order + one zero pad record
     std::vector<uint32_t> rec_of_prim;  // caller's triangle index -> record index
     uint32_t root_ref = PT_EMPTY_REF;
+    uint32_t max_leaf = 0;             // most triangles in one leaf
     uint32_t n_leaves = 0;
     uint32_t max_stack = 1;             // upper bound on traversal stack entries
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};

@@ -496,7 +496,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     ptbvh::Result bvh;
     if (!ptbvh::build(d->P, d->indices, tri_flags.data(), d->n_triangles, d->split_method, d->max_node_prims > 0 ? d->max_node_prims : 4, &bvh))
-        return ctx->fail(PT_ERR_INVALID_ARGUMENT, "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)");
+        return ctx->fail(PT_ERR_INVALID_ARGUMENT, d->n_triangles >= PT_LEAF_FIRST_MASK - 16u ? "more than 2^28 triangles" : "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)");
     double t1 = now_ms();
     ctx->max_stack = bvh.max_stack;
 
@@ -573,6 +573,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     sc.UV = d->UV ? ctx->d_UV.as<float>() : nullptr;
     sc.materials = ctx->d_materials.as<PtMaterial>();
     sc.general_materials = general_materials ? 1u : 0u;
+    sc.dist_leaves = (bvh.max_leaf <= 8 && !std::getenv("PBRTGPU_SEQ_LEAVES")) ? 1u : 0u;
     ctx->n_materials = d->n_materials;
     sc.lights = ctx->d_lights.as<PtLight>();
     sc.n_lights = (uint32_t)lights.size();

@@ -11,6 +11,8 @@
 #endif
 #define PT_EMPTY_REF 0xffffffffu
 #define PT_LEAF_BIT 0x80000000u
+#define PT_LEAF_COUNT_SHIFT 28          // bits 28..30 of a leaf reference: min(triangles in the leaf, 8) - 1
+#define PT_LEAF_FIRST_MASK 0x0fffffffu   // bits 0..27: first triangle record
 
 // One 4-wide BVH node = one 128-byte line.  Replaces the reference's 144-byte
 // SIMDBVHNode + separate leaf nodes (qbvh_x86.rs:15-24, :93-176): a child that is
@@ -153,6 +155,7 @@ struct PtCounters {
 };
 
 struct PtScene {
+    uint32_t dist_leaves;        // 1: no leaf holds more than 8 triangles, k_trace spreads leaf tests over the wave
     uint32_t general_materials;  // 1 when any material is not Matte: k_shade_general runs instead of k_shade
     const PtNode* nodes;
     const PtTri* tris;

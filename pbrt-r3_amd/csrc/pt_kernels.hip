@@ -215,7 +215,12 @@ struct TriHit { float t, b0, b1, b2; };
 // the reference's early-outs, so branching on them only adds SALU work; the values computed are
 // the reference's, the early-outs become terms of one boolean.  Only the f64 re-evaluation of
 // the edge functions (needed when one is exactly zero) stays behind a branch.
-PT_DEV bool tri_test(const RayPre& r, V3 p0, V3 p1, V3 p2, uint32_t flags, float t_max, TriHit& h) {
+// tri_core evaluates everything that does not depend on the ray's current t_max; tri_accept is the one
+// comparison that does (t_scaled against t_max * det, triangle.rs:297-303).  Sequential leaf loops call
+// them back to back (= tri_test); the distributed leaf phase runs tri_core for all triangles of a leaf in
+// parallel and applies tri_accept in leaf order with the t_max each triangle would have seen.
+struct TriCore { float t_scaled, det, t, b0, b1, b2; };
+PT_DEV bool tri_core(const RayPre& r, V3 p0, V3 p1, V3 p2, uint32_t flags, TriCore& h) {
     bool ok = true;
     if (flags & PT_TRI_ONE_SIDED) {
         V3 n = cross(p0 - p2, p1 - p2);
@@ -247,10 +252,6 @@ PT_DEV bool tri_test(const RayPre& r, V3 p0, V3 p1, V3 p2, uint32_t flags, float
     ok &= !(det == 0.0f);
     p0z *= r.sz; p1z *= r.sz; p2z *= r.sz;
     float t_scaled = e0 * p0z + e1 * p1z + e2 * p2z;
-    float tmd = t_max * det;
-    bool rej_neg = (det < 0.0f) & ((t_scaled >= 0.0f) | (t_scaled < tmd));
-    bool rej_pos = (det > 0.0f) & ((t_scaled <= 0.0f) | (t_scaled > tmd));
-    ok &= !(rej_neg | rej_pos);
     float inv_det = 1.0f / det;
     float t = t_scaled * inv_det;
     float max_zt = max3(fabsf(p0z), fabsf(p1z), fabsf(p2z));
@@ -263,7 +264,21 @@ PT_DEV bool tri_test(const RayPre& r, V3 p0, V3 p1, V3 p2, uint32_t flags, float
     float max_e = max3(fabsf(e0), fabsf(e1), fabsf(e2));
     float delta_t = 3.0f * (PT_GAMMA(3.0f) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
     ok &= !(t <= delta_t);
-    h.t = t; h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;
+    h.t_scaled = t_scaled; h.det = det; h.t = t;
+    h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;
+    return ok;
+}
+PT_DEV bool tri_accept(float t_scaled, float det, float t_max) {
+    float tmd = t_max * det;
+    bool rej_neg = (det < 0.0f) & ((t_scaled >= 0.0f) | (t_scaled < tmd));
+    bool rej_pos = (det > 0.0f) & ((t_scaled <= 0.0f) | (t_scaled > tmd));
+    return !(rej_neg | rej_pos);
+}
+PT_DEV bool tri_test(const RayPre& r, V3 p0, V3 p1, V3 p2, uint32_t flags, float t_max, TriHit& h) {
+    TriCore c;
+    bool ok = tri_core(r, p0, p1, p2, flags, c);
+    ok &= tri_accept(c.t_scaled, c.det, t_max);
+    h.t = c.t; h.b0 = c.b0; h.b1 = c.b1; h.b2 = c.b2;
     return ok;
 }
 
@@ -432,7 +447,7 @@ PT_DEV void ray_step_node(const PtScene& sc, LaneRay& r, TravCtx& c) {
 // fetched two per round trip and tested in order.  any_hit: stop at the first accepted triangle
 // (sets best, empties the stack).
 PT_DEV void ray_step_tri(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
-    uint32_t rec = stk_pop(c, r.top, r.sp) & ~PT_LEAF_BIT;
+    uint32_t rec = stk_pop(c, r.top, r.sp) & PT_LEAF_FIRST_MASK;
     bool leaf_hit = false;
     for (;;) {
         TriVerts t0 = load_tri(sc.tris, rec), t1 = load_tri(sc.tris, rec + 1);   // array is padded by one record
@@ -523,10 +538,17 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #define PT_TRACE_WAVES 4        // waves per SIMD the register allocator must leave room for
 #endif
 
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
-                                                              uint32_t spill_depth, uint32_t* err) {
+#ifndef PT_LEAF_TRIS_MIN
+#define PT_LEAF_TRIS_MIN 64          // distributed leaf phase: run it once this many triangle tests are parked
+#endif
+// DIST: every leaf holds at most 8 triangles and its reference carries the count, so a leaf phase can pool the
+// triangles of all parked lanes and hand one (ray, triangle) test to each lane of the wave.
+template <bool DIST>
+PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
     __shared__ uint32_t s_stack[PT_LDS_STACK * PT_BLOCK];
     __shared__ unsigned long long s_cnt[4];
+    __shared__ float4 s_res[DIST ? PT_BLOCK : 1];          // per wave: 64 test results (ok, t_scaled, det, t)
+    __shared__ unsigned char s_map[DIST ? PT_BLOCK : 1];   // per wave: work item -> owner lane
     TravCtx c;
     c.lds = &s_stack[threadIdx.x];
     c.spill_stride = gridDim.x * PT_BLOCK;
@@ -609,6 +631,74 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(P
         long long pt0 = __builtin_readcyclecounter();
         prof[7] += (unsigned long long)(pt0 - pt_iter);
 #endif
+        if constexpr (DIST) {
+            // triangles parked: the count rides in bits 28..30 of the leaf reference
+            const uint32_t tcnt = w_tri ? ((r.top >> PT_LEAF_COUNT_SHIFT) & 7u) + 1u : 0u;
+            const unsigned long long c0 = __ballot((tcnt & 1u) != 0), c1 = __ballot((tcnt & 2u) != 0), c2 = __ballot((tcnt & 4u) != 0),
+                                     c3 = __ballot((tcnt & 8u) != 0);
+            const uint32_t n_parked = (uint32_t)(__popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2) + 8 * __popcll(c3));
+            if (m_node != 0 && n_parked < PT_LEAF_TRIS_MIN) {
+                if (w_node) ray_step_node(sc, r, c);
+#ifdef PT_PROFILE_PHASES
+                prof[0] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[1] += 1; prof[2] += (unsigned long long)__popcll(m_node);
+#endif
+            } else if (m_tri != 0) {
+                // ---- distributed leaf phase: one round of up to 64 (ray, triangle) tests.  Owners are served in lane
+                // order while their whole leaf fits; the others stay parked for the next round.
+                const uint32_t wbase = threadIdx.x & ~63u;
+                const uint32_t pre = (uint32_t)(__popcll(c0 & below) + 2 * __popcll(c1 & below) + 4 * __popcll(c2 & below) + 8 * __popcll(c3 & below));
+                const bool served = w_tri && pre + tcnt <= 64u;
+                const unsigned long long m_served = __ballot(served);
+                const int last = 63 - __clzll(m_served);                      // m_served != 0: the first parked lane always fits
+                const uint32_t n_items = (uint32_t)__shfl((int)(pre + tcnt), last, 64);
+                if (served)
+                    for (uint32_t k = 0; k < tcnt; k++) s_map[wbase + pre + k] = (unsigned char)lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {   // helper side: lane w tests triangle k of owner o
+                    const bool valid = lane < n_items;
+                    const int o = valid ? (int)s_map[wbase + lane] : 0;
+                    const uint32_t k = lane - (uint32_t)__shfl((int)pre, o, 64);
+                    const uint32_t first = (uint32_t)__shfl((int)(r.top & PT_LEAF_FIRST_MASK), o, 64);
+                    RayPre rp;
+                    rp.o = mk3(__shfl(r.rp.o.x, o, 64), __shfl(r.rp.o.y, o, 64), __shfl(r.rp.o.z, o, 64));
+                    rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));
+                    const int kk = __shfl(r.rp.kx | (r.rp.ky << 2) | (r.rp.kz << 4), o, 64);
+                    rp.kx = kk & 3; rp.ky = (kk >> 2) & 3; rp.kz = (kk >> 4) & 3;
+                    rp.sx = __shfl(r.rp.sx, o, 64); rp.sy = __shfl(r.rp.sy, o, 64); rp.sz = __shfl(r.rp.sz, o, 64);
+                    rp.dperm = rp.d;        // not read by tri_core
+                    if (valid) {
+                        TriVerts tv = load_tri(sc.tris, first + k);
+                        TriCore tc;
+                        bool ok = tri_core(rp, tv.p0, tv.p1, tv.p2, tv.flags, tc);
+                        s_res[wbase + lane] = make_float4(ok ? 1.0f : 0.0f, tc.t_scaled, tc.det, tc.t);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (served) {   // owner side: the leaf's triangles in order, each against the t_max it would have seen
+                    const uint32_t rec0 = stk_pop(c, r.top, r.sp) & PT_LEAF_FIRST_MASK;
+                    const bool any_hit = kind == 2;
+                    bool leaf_hit = false;
+                    uint32_t tested = tcnt;
+                    for (uint32_t k = 0; k < tcnt; k++) {
+                        const float4 v = s_res[wbase + pre + k];
+                        if (v.x != 0.0f && tri_accept(v.y, v.z, r.ray_tmax)) {
+                            r.best = (int32_t)(rec0 + k); leaf_hit = true;
+                            if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; tested = k + 1; break; }
+                            r.ray_tmax = v.w;
+                        }
+                    }
+                    c.n_tris += tested;
+                    if (leaf_hit && !any_hit) r.tmax = r.ray_tmax;
+                }
+#ifdef PT_PROFILE_PHASES
+                prof[3] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[4] += 1; prof[5] += (unsigned long long)n_items;
+#endif
+            }
+        } else {
         if (m_node != 0 && __popcll(m_tri) < PT_LEAF_MIN) {
             if (w_node) ray_step_node(sc, r, c);
 #ifdef PT_PROFILE_PHASES
@@ -620,6 +710,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(P
             prof[3] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[4] += 1; prof[5] += (unsigned long long)__popcll(m_tri);
 #endif
         }
+        }
     }
 #ifdef PT_PROFILE_PHASES
     prof[6] = (unsigned long long)(__builtin_readcyclecounter() - prof_t0);
@@ -627,6 +718,15 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(P
 #endif
     if (c.overflow) atomicOr(err, 1u);
     flush_counters(cnt, s_cnt, regular, shadow, c.n_nodes, c.n_tris);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+                                                              uint32_t spill_depth, uint32_t* err) {
+    trace_body<true>(sc, P, Q, cnt, spill, spill_depth, err);
+}
+// leaves of more than 8 triangles ("maxnodeprims" > 8): every lane walks its own leaf
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace_seq(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+                                                                  uint32_t spill_depth, uint32_t* err) {
+    trace_body<false>(sc, P, Q, cnt, spill, spill_depth, err);
 }
 
 // ============================================================ hooks: plain ray batches
@@ -1569,7 +1669,8 @@ extern "C" __global__ void k_bsdf_sample(PtScene sc, uint32_t material, uint32_t
 
 hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err) {
-    hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    if (sc.dist_leaves) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    else hipLaunchKernelGGL(k_trace_seq, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
     return PT_LAUNCH_CHECK();
 }
