@@ -57,6 +57,7 @@ def _compare(ctx, osc, exact_film, frac_limit=0.0):
     ("accel_middle_1", lambda: fs.scene_accel("middle", 1), True),
     ("accel_equal_8", lambda: fs.scene_accel("equal", 8), True),
     ("accel_sah_2", lambda: fs.scene_accel("sah", 2), True),
+    ("accel_middle_16", lambda: fs.scene_accel("middle", 16), True),     # leaves of more than 8 triangles: k_trace_seq
     ("accel_hlbvh_4", lambda: fs.scene_accel("hlbvh", 4), True),
     ("accel_hlbvh_1", lambda: fs.scene_accel("hlbvh", 1), True),
 ])
