@@ -843,6 +843,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                     }
                     PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
                     if (timed) PT_HIP(hipEventRecord(b, ctx->stream));
+                    PT_HIP(ptk_nee_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q));
                     ctx->trace_launches++;
                     PT_HIP(ptk_prep(ctx->stream, Q, 0));
                     PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, cnt));
@@ -862,6 +863,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                     if (counts[PT_Q_CUR] == 0 && counts[PT_Q_NEE] == 0) break;
                     if (counts[PT_Q_CUR] == 0) {     // only NEE resolves left
                         PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                        PT_HIP(ptk_nee_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q));
                         ctx->trace_launches++;
                         PT_HIP(ptk_prep(ctx->stream, Q, 0));
                     } else if ((st = bounce()) != PT_OK) return st;

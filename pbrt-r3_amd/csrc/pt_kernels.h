@@ -10,6 +10,7 @@ hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t
                            uint8_t* occ, int any_hit, uint32_t* ticket, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err);
 hipError_t ptk_gen(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const uint32_t* pixels, uint32_t n_pix,
                    uint32_t s0, uint32_t n_samples, PtCounters* cnt);
+hipError_t ptk_nee_resolve(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q);
 hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode);
 hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt);
 hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,

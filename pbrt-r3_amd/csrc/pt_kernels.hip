@@ -1671,6 +1671,9 @@ hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths&
                      uint32_t spill_depth, uint32_t* err) {
     if (sc.dist_leaves) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else hipLaunchKernelGGL(k_trace_seq, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_nee_resolve(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q) {
     hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
     return PT_LAUNCH_CHECK();
 }
