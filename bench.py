@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--max-depth", type=int, default=8)
     ap.add_argument("--materials", default="matte", choices=["matte", "mixed"],
                     help="matte = BASELINE config 2 (the headline); mixed = killeroo-class stand-in for config 4 (secondary number)")
+    ap.add_argument("--sampler", default="sobol", choices=["sobol", "halton"], help="sobol = the headline; halton = the reference's default sampler (secondary number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU sample (0 = auto, about 15 s)")
     args = ap.parse_args()
@@ -114,7 +115,7 @@ def main():
     t_prog = time.time()
     pkg = importlib.import_module("pbrt-r3_amd")
     t0 = time.time()
-    sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, materials=args.materials)
+    sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, materials=args.materials, sampler=args.sampler)
     t_scene = time.time() - t0
     ctx = pkg.Context(local_rank)
     info = ctx.upload(sd)
@@ -234,9 +235,9 @@ def main():
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "RT1M: %d random %s triangles, %dx%d, Sobol %d spp, path maxdepth %d, BVH sah/4, spatial lights"
+            "config": {"workload": "RT1M: %d random %s triangles, %dx%d, %s %d spp, path maxdepth %d, BVH sah/4, spatial lights"
                                    % (sd.desc.n_triangles, "matte" if args.materials == "matte" else "mixed-material (matte/plastic/metal/glass/mirror/substrate)",
-                                      args.res, args.res, info.spp, args.max_depth),
+                                      args.res, args.res, "Sobol" if args.sampler == "sobol" else "Halton", info.spp, args.max_depth),
                        "partition": "16x16 film tiles round-robin over %d rank(s), RCCL all-reduce of the XYZW film" % world,
                        "rays_per_step": int(rays / max(1, args.steps)), "camera_samples_per_step": int(tot[8] / max(1, args.steps)),
                        "bvh_build_ms": round(info.bvh_build_ms, 1), "upload_ms": round(info.upload_ms, 1),
