@@ -794,10 +794,24 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     if (pixels.empty()) return PT_OK;
     const uint32_t spp = sc.sobol.spp;
 
-    size_t pool_target = (size_t)4 << 20;       // paths in flight per pass
+    // Paths in flight per pass.  Every k_trace launch ends with a drain tail (ray lengths are heavy-tailed and a
+    // lane sees only a handful of rays per launch), so big launches pay: 4 M paths -> 662 Mrays/s, 64 M -> 850 on
+    // RT1M.  64 M slots are ~14.4 GB of path state + 1.5 GB of queues -- HBM3E is 288 GB.
+    size_t pool_target = (size_t)64 << 20;
     if (const char* e = std::getenv("PBRTGPU_POOL_PATHS")) pool_target = std::max<size_t>(65536, std::strtoull(e, nullptr, 10));
+    {   // never more than half of what the device has free
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ctx->pool_paths < pool_target) {
+            const size_t per_path = 11 * 16 + 8 + 8 + 6 * 4 + 4 + 6 * 4;
+            pool_target = std::min(pool_target, std::max<size_t>(ctx->pool_paths, std::max<size_t>(1u << 20, (free_b / 2) / per_path)));
+        }
+    }
     size_t chunk_pix = std::min(pixels.size(), pool_target);
     uint32_t S = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, pool_target / chunk_pix));
+    {   // equal passes: 256 spp at 63 spp per pass would leave a 4-spp runt
+        const uint32_t passes = (spp + S - 1) / S;
+        S = (spp + passes - 1) / passes;
+    }
     pt_status st;
     if ((st = ensure_pool(ctx, chunk_pix * S)) != PT_OK) return st;
     if (ctx->pixels_cap < pixels.size()) {
