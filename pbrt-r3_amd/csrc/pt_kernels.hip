@@ -539,7 +539,7 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #endif
 
 #ifndef PT_LEAF_TRIS_MIN
-#define PT_LEAF_TRIS_MIN 44          // distributed leaf phase: run it once this many triangle tests are parked
+#define PT_LEAF_TRIS_MIN 56          // distributed leaf phase: run it once this many triangle tests are parked
 #endif
 // DIST: every leaf holds at most 8 triangles and its reference carries the count, so a leaf phase can pool the
 // triangles of all parked lanes and hand one (ray, triangle) test to each lane of the wave.
