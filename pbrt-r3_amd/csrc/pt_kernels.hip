@@ -529,7 +529,7 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 // leaf (48-byte triangle records, fetched two at a time).  The order of pops, tests and t_max
 // updates per ray is exactly the reference's, whatever the interleaving across lanes.
 #ifndef PT_REFILL_MIN
-#define PT_REFILL_MIN 20
+#define PT_REFILL_MIN 16
 #endif
 #ifndef PT_LEAF_MIN
 #define PT_LEAF_MIN 24
@@ -570,6 +570,10 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     r.sp = 0;
     r.top = PT_EMPTY_REF;
     bool more = total > 0;
+    // prefetch reservation (see the loop): stage, ticket result (lane 0), rays reserved / handed out, one ray per lane
+    int pf_stage = 0, pf_kind = 0;
+    uint32_t pf_raw = 0, pf_count = 0, pf_used = 0, pf_p = 0;
+    float4 pf_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf_d = pf_o;
 #ifdef PT_PROFILE_PHASES
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0-2 node clk/steps/lanes, 3-5 leaf, 6 total, 7 service+begin clk, 8 retire events, 9 begin events
     long long prof_t0 = __builtin_readcyclecounter();
@@ -578,45 +582,71 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #ifdef PT_PROFILE_PHASES
         long long pt_iter = __builtin_readcyclecounter();
 #endif
-        // ---- which ray does this lane start next (at most one ray_begin site: it is long)
-        int start = 0;                               // 0 none, else the kind to start
-        unsigned long long idle = __ballot(kind == 0);
-        int n_idle = __popcll(idle);
-        if (more && (n_idle >= PT_REFILL_MIN || n_idle == 64)) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&Q.counts[PT_Q_TICKET], (uint32_t)n_idle);
-            base = __shfl(base, 0, 64);
-            if (base + (uint32_t)n_idle >= total) more = false;
-            uint32_t item = base + (uint32_t)__popcll(idle & below);
-            if (kind == 0 && item < total) {
-                if (item < n_cur) { p = Q.cur[item]; start = 1; }
-                else if (item < n_cur + n_sh) { p = Q.shadow[item - n_cur]; start = 2; }
-                else { p = Q.probe[item - n_cur - n_sh]; start = 3; }
+        // ---- ray prefetch pipeline.  A refill used to be three dependent round trips (ticket atomic, path id, ray
+        // record) with the whole wave waiting; now the wave keeps the next 64 rays in registers, one per lane, and
+        // fetches them one stage per iteration so that every wait is covered by a traversal step:
+        //   0 -> 1  reserve 64 items (atomic)        1 -> 2  load the path ids        2 -> 3  load origin / direction
+        // Idle lanes then take their ray from the reservation lane by ds_bpermute, so refills are cheap enough to
+        // happen as soon as PT_REFILL_MIN lanes are free.
+        if (pf_stage == 0) {
+            if (more) {
+                if (lane == 0) pf_raw = atomicAdd(&Q.counts[PT_Q_TICKET], 64u);
+                pf_stage = 1;
             }
+        } else if (pf_stage == 1) {
+            const uint32_t base = (uint32_t)__shfl((int)pf_raw, 0, 64);
+            if (base >= total) { more = false; pf_stage = 0; }
+            else {
+                pf_count = min(64u, total - base);
+                if (base + 64u >= total) more = false;
+                pf_used = 0;
+                const uint32_t item = base + lane;
+                if (lane < pf_count) {
+                    if (item < n_cur) { pf_p = Q.cur[item]; pf_kind = 1; }
+                    else if (item < n_cur + n_sh) { pf_p = Q.shadow[item - n_cur]; pf_kind = 2; }
+                    else { pf_p = Q.probe[item - n_cur - n_sh]; pf_kind = 3; }
+                }
+                pf_stage = 2;
+            }
+        } else if (pf_stage == 2) {
+            if (lane < pf_count) {
+                const float4* so = pf_kind == 1 ? P.ray_o : (pf_kind == 2 ? P.sh_o : P.pr_o);
+                const float4* sd = pf_kind == 1 ? P.ray_d : (pf_kind == 2 ? P.sh_d : P.pr_d);
+                pf_o = so[pf_p]; pf_d = sd[pf_p];
+            }
+            pf_stage = 3;
         }
         // ---- retire finished rays: stores only
-#ifdef PT_PROFILE_PHASES
-        if (__ballot(kind != 0 && ray_done(r)) != 0ull) prof[8] += 1;
-#endif
         if (kind != 0 && ray_done(r)) {
             if (kind == 1) { P.hit_t[p] = r.ray_tmax; P.hit_rec[p] = r.best; }
             else if (kind == 2) P.occluded[p] = r.best >= 0 ? 1 : 0;
             else P.probe_rec[p] = r.best;
             kind = 0;
         }
-#ifdef PT_PROFILE_PHASES
-        if (__ballot(start != 0) != 0ull) prof[9] += 1;
-#endif
-        if (start != 0) {
-            const float4* so = start == 1 ? P.ray_o : (start == 2 ? P.sh_o : P.pr_o);
-            const float4* sd = start == 1 ? P.ray_d : (start == 2 ? P.sh_d : P.pr_d);
-            float4 ro = so[p], rd = sd[p];
-            kind = start;
-            if (start == 2) shadow++; else regular++;
-            ray_begin(sc, r, f4_3(ro), f4_3(rd), ro.w);
+        // ---- hand prefetched rays to idle lanes (one ray_begin site: it is long)
+        {
+            const unsigned long long idle = __ballot(kind == 0);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (pf_stage == 3 && (n_idle >= PT_REFILL_MIN || idle == ~0ull || (!more && n_idle != 0))) {
+                const uint32_t take = min(n_idle, pf_count - pf_used);
+                const uint32_t rank = (uint32_t)__popcll(idle & below);
+                const int src = (int)((pf_used + rank) & 63u);
+                const uint32_t np = (uint32_t)__shfl((int)pf_p, src, 64);
+                const int nk = __shfl(pf_kind, src, 64);
+                float4 ro, rd;
+                ro.x = __shfl(pf_o.x, src, 64); ro.y = __shfl(pf_o.y, src, 64); ro.z = __shfl(pf_o.z, src, 64); ro.w = __shfl(pf_o.w, src, 64);
+                rd.x = __shfl(pf_d.x, src, 64); rd.y = __shfl(pf_d.y, src, 64); rd.z = __shfl(pf_d.z, src, 64);
+                if (kind == 0 && rank < take) {
+                    p = np; kind = nk;
+                    if (nk == 2) shadow++; else regular++;
+                    ray_begin(sc, r, f4_3(ro), mk3(rd.x, rd.y, rd.z), ro.w);
+                }
+                pf_used += take;
+                if (pf_used == pf_count) pf_stage = 0;
+            }
         }
         if (__ballot(kind != 0) == 0) {
-            if (!more) break;
+            if (!more && pf_stage == 0) break;
             continue;
         }
         // ---- one traversal phase for the whole wave.  A node visit (one 128-byte line, 4 slab tests)
