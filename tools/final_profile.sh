@@ -14,7 +14,7 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$out/prof" --output-forma
 find "$out/prof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$out/kernel_stats.csv"
 head -8 "$out/kernel_stats.csv"
 echo "== PMC traffic"
-tools/pmc_traffic.sh "$tag" 2>&1 | tail -3
+SPP=52 tools/pmc_traffic.sh "$tag" 2>&1 | tail -3
 cp "gpurun_out/pmc_$tag/traffic.json" "$out/traffic.json"
 cp "gpurun_out/pmc_$tag/summary.txt" "$out/pmc_summary.txt"
 echo "== mixed-material workload"
