@@ -268,3 +268,27 @@ def test_pbrt_text_with_ply_spectra_and_materials(gpu_ctx, oracle, tmp_path):
     ox, _, _ = osc.render(threads=8)
     assert rel_l2(gpu_ctx.film_rgb(), osc.resolve_rgb(ox)) <= 1e-3
     osc.close()
+
+
+def test_pass_structure_does_not_change_the_film(gpu_ctx):
+    """The pool size only decides how the samples are cut into passes / pixel chunks (render_tiles): a film rendered
+    in 1 pass, in 3 unequal-looking passes (7 spp -> 3,2,2) and in pixel chunks must agree -- bit for bit where a
+    sample's footprint is its own pixel (sample-ordered sums), to float-atomic order elsewhere."""
+    sd = scenes.rt1m(3000, res=300, spp=3, max_depth=4, sampler="halton")        # 302 x 302 = 91 204 sample pixels
+    gpu_ctx.upload(sd)
+    films = []
+    try:
+        for pool in ("67108864", "200000", "65536"):        # one pass | 2 spp per pass -> passes of 2 and 1 | two pixel chunks x 1 spp
+            os.environ["PBRTGPU_POOL_PATHS"] = pool
+            gpu_ctx.film_clear(); gpu_ctx.reset_counters(); gpu_ctx.render()
+            films.append((gpu_ctx.film_xyzw().copy(), gpu_ctx.counters()))
+    finally:
+        os.environ.pop("PBRTGPU_POOL_PATHS", None)
+    (a, ca), (b, cb), (c, cc) = films
+    for k in ("camera_rays", "regular_rays", "shadow_rays", "nodes_visited", "tris_tested", "path_vertices"):
+        assert ca[k] == cb[k] == cc[k], k
+    assert cb["trace_launches"] > ca["trace_launches"]
+    for other in (b, c):
+        assert np.array_equal(bits(a[..., 3]), bits(other[..., 3]))
+        same = np.all(bits(a) == bits(other), axis=-1)
+        assert same.mean() > 0.9 and rel_l2(other, a) < 1e-6
