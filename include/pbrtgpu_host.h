@@ -11,7 +11,7 @@
  *   shapes      "trianglemesh", "plymesh" (ASCII / binary / gzip PLY)
  *   materials   matte, plastic, mirror, glass, metal, uber, substrate with constant parameters; named
  *               materials; colours as rgb, .spd "spectrum" files or "blackbody" (metal defaults to the
- *               measured copper spectrum)
+ *               measured copper spectrum); Texture "constant" / "scale" / "mix" of constants (folded)
  *   lights      diffuse area lights
  *   camera      perspective;  filters box / gaussian / mitchell / sinc / triangle
  *   samplers    halton (the default), sobol;  integrator path;  accelerator bvh (sah, hlbvh, middle, equal)

@@ -9,6 +9,7 @@
 //   diffuse area lights                                        lights/diffuse.rs:165-194
 // All arithmetic that reaches the renderer (CTM products, vertex transforms, filter tables) is f32 in
 // the reference's operation order.  Unsupported directives set an error naming them.
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -119,6 +120,9 @@ public:
     std::vector<uint32_t> indices, tri_mesh;
     std::vector<pt_mesh> meshes;
     std::vector<pt_material> materials;
+    std::map<std::string, float> float_textures;                        // constant-folded named textures (global, see pbrt_texture)
+    std::map<std::string, std::array<float, 3>> spectrum_textures;
+    std::map<std::string, std::string> unsupported_textures;          // name -> class of textures that do not fold
     std::vector<pt_area_light> area_lights;
     bool any_n = false, any_s = false, any_uv = false;
     pt_scene_desc desc;
@@ -205,8 +209,47 @@ public:
         if (transforms.size() <= 1) { warn("Unmatched TransformEnd"); return; }
         transforms.pop_back(); bits.pop_back();
     }
-    void pbrt_texture(const std::string& name, const std::string&, const std::string& tex_name, const ParamSet&) override {
-        fail("Texture \"" + name + "\" (" + tex_name + "): textures other than implicit constants are outside the accelerated path");
+    // Texture directive (scene_context.rs:1077-1114).  Only textures whose value does not depend on the surface point
+    // are on the accelerated path: "constant", and "scale" / "mix" of such (textures/{constant,scale,mix}.rs).  They
+    // fold to a value here.  As in the reference the texture tables are NOT scoped by AttributeBegin/End
+    // (pbrt_texture writes through the shared map without the copy-on-write that named materials get).
+    void pbrt_texture(const std::string& name, const std::string& type, const std::string& tex_class, const ParamSet& p) override {
+        if (!error.empty()) return;
+        const bool is_float = type == "float", is_spec = type == "color" || type == "rgb" || type == "spectrum";
+        if (!is_float && !is_spec) { warn("Texture type \"" + type + "\" unknown."); return; }
+        if (tex_class != "constant" && tex_class != "scale" && tex_class != "mix") {
+            unsupported_textures[name] = tex_class;       // fails only if something uses it
+            float_textures.erase(name); spectrum_textures.erase(name);
+            return;
+        }
+        if (is_float) {
+            float v = 1.0f;
+            if (tex_class == "constant") v = p.find_one_float("value", 1.0f);
+            else {
+                float t1 = 1.0f, t2 = 1.0f, amt = 0.5f;
+                lookup_float(p, p, "tex1", &t1); lookup_float(p, p, "tex2", &t2);
+                if (tex_class == "scale") v = t1 * t2;
+                else { lookup_float(p, p, "amount", &amt); v = t1 * (1.0f - amt) + t2 * amt; }
+            }
+            if (!error.empty()) return;
+            float_textures[name] = v;
+            unsupported_textures.erase(name);
+        } else {
+            std::array<float, 3> v = {1.0f, 1.0f, 1.0f};
+            if (tex_class == "constant") { float c[3] = {1.0f, 1.0f, 1.0f}; spectrum_from(p, "value", c); v = {c[0], c[1], c[2]}; }
+            else {
+                float t1[3] = {1.0f, 1.0f, 1.0f}, t2[3] = {1.0f, 1.0f, 1.0f}, amt = 0.5f;
+                lookup_rgb(p, p, "tex1", t1); lookup_rgb(p, p, "tex2", t2);
+                if (tex_class == "scale") v = {t1[0] * t2[0], t1[1] * t2[1], t1[2] * t2[2]};
+                else {
+                    lookup_float(p, p, "amount", &amt);
+                    for (int i = 0; i < 3; i++) v[i] = t1[i] * (1.0f - amt) + t2[i] * amt;
+                }
+            }
+            if (!error.empty()) return;
+            spectrum_textures[name] = v;
+            unsupported_textures.erase(name);
+        }
     }
     void pbrt_material(const std::string& name, const ParamSet& p) override {
         MaterialInstance mi;
@@ -259,14 +302,42 @@ public:
         }
         return true;
     }
+    // get_texture (texture_params.rs:85-105): the texture NAME bound to a parameter, shape first
+    static const std::string* bound_texture(const ParamSet& geom, const ParamSet& mat, const std::string& n) {
+        auto g = geom.textures.find(n);
+        if (g != geom.textures.end() && !g->second.empty()) return &g->second[0];
+        auto m = mat.textures.find(n);
+        if (m != mat.textures.end() && !m->second.empty()) return &m->second[0];
+        return nullptr;
+    }
+    // get_spectrum_texture_or_null (texture_params.rs:126-139) for textures that fold to a constant
     bool lookup_rgb(const ParamSet& geom, const ParamSet& mat, const std::string& n, float out[3]) {
-        if (geom.textures.count(n) || mat.textures.count(n)) { fail("material parameter \"" + n + "\" bound to a texture: outside the accelerated path"); return false; }
+        if (const std::string* tex = bound_texture(geom, mat, n)) {
+            auto it = spectrum_textures.find(*tex);
+            if (it == spectrum_textures.end()) {
+                if (float_textures.count(*tex)) warn("Couldn't find spectrum texture named \"" + *tex + "\" for parameter \"" + n + "\"");
+                else if (unsupported_textures.count(*tex)) fail("parameter \"" + n + "\" uses texture \"" + *tex + "\" (" + unsupported_textures[*tex] + "): only textures that fold to a constant are on the accelerated path");
+                else warn("Couldn't find spectrum texture named \"" + *tex + "\" for parameter \"" + n + "\"");
+                return false;
+            }
+            out[0] = it->second[0]; out[1] = it->second[1]; out[2] = it->second[2];
+            return true;
+        }
         if (spectrum_from(mat, n, out)) return true;
         return spectrum_from(geom, n, out);
     }
     // TextureParams::get_float_texture(_or_null) for constant values (texture_params.rs:36-54, :107-124): material first, then shape
     bool lookup_float(const ParamSet& geom, const ParamSet& mat, const std::string& n, float* out) {
-        if (geom.textures.count(n) || mat.textures.count(n)) { fail("material parameter \"" + n + "\" bound to a texture: outside the accelerated path"); return false; }
+        if (const std::string* tex = bound_texture(geom, mat, n)) {
+            auto it = float_textures.find(*tex);
+            if (it == float_textures.end()) {
+                if (unsupported_textures.count(*tex)) fail("parameter \"" + n + "\" uses texture \"" + *tex + "\" (" + unsupported_textures[*tex] + "): only textures that fold to a constant are on the accelerated path");
+                else warn("Couldn't find float texture named \"" + *tex + "\" for parameter \"" + n + "\"");
+                return false;
+            }
+            *out = it->second;
+            return true;
+        }
         if (mat.floats.count(n)) { *out = mat.find_one_float(n, *out); return true; }
         if (geom.floats.count(n)) { *out = geom.find_one_float(n, *out); return true; }
         return false;

@@ -390,3 +390,41 @@ def test_plymesh_errors(tmp_path):
         with pytest.raises(capi.PtError) as e:
             capi.ParsedScene(text='Sampler "sobol"\nWorldBegin\nShape "plymesh" "string filename" "%s"\nWorldEnd' % f, work_dir=str(tmp_path))
         assert needle in str(e.value)
+
+
+def test_constant_folding_textures():
+    """Texture "constant" / "scale" / "mix" (textures/{constant,scale,mix}.rs) fold to values; a texture binding wins
+    over constant values (texture_params.rs:107-139); texture tables are global, not attribute-scoped (pbrt_texture
+    writes through the shared map, scene_context.rs:1093-1110); position-dependent textures fail only when used."""
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]'
+    text = '''
+    Sampler "sobol" "integer pixelsamples" 1
+    WorldBegin
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [1 1 1]
+        %(tri)s
+        Texture "red" "spectrum" "constant" "rgb value" [0.8 0.1 0.1]
+        Texture "half" "float" "constant" "float value" 0.5
+      AttributeEnd
+      Texture "dim" "spectrum" "scale" "texture tex1" "red" "rgb tex2" [0.5 0.5 0.5]
+      Texture "blend" "color" "mix" "texture tex1" "red" "rgb tex2" [0 0 1] "float amount" 0.25
+      Texture "rough" "float" "mix" "float tex1" 0.1 "float tex2" 0.3 "texture amount" "half"
+      Texture "chk" "spectrum" "checkerboard"
+      Material "plastic" "texture Kd" "dim" "rgb Ks" [0.2 0.2 0.2] "texture roughness" "rough"
+      %(tri)s
+      Material "matte" "rgb Kd" [0.3 0.3 0.3]
+      %(tri)s "texture Kd" "blend"
+    WorldEnd
+    ''' % {"tri": tri}
+    ps = capi.ParsedScene(text=text)
+    d = ps.desc
+    f = np.float32
+    m1 = d.materials[d.meshes[1].material]
+    assert np.array_equal(bits(list(m1.kd)), bits([f(0.8) * f(0.5), f(0.1) * f(0.5), f(0.1) * f(0.5)]))
+    assert bits([m1.roughness])[0] == bits([f(f(0.1) * f(f(1.0) - f(0.5))) + f(f(0.3) * f(0.5))])[0]
+    m2 = d.materials[d.meshes[2].material]          # the shape's texture binding beats the material's constant Kd
+    want = [f(f(f(c1) * f(f(1.0) - f(0.25))) + f(f(c2) * f(0.25))) for c1, c2 in zip((0.8, 0.1, 0.1), (0.0, 0.0, 1.0))]
+    assert np.array_equal(bits(list(m2.kd)), bits(want))
+    with pytest.raises(capi.PtError) as e:
+        capi.ParsedScene(text=text.replace('"texture Kd" "blend"', '"texture Kd" "chk"'))
+    assert e.value.status == 4 and "checkerboard" in str(e.value)
