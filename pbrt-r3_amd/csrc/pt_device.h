@@ -225,4 +225,5 @@ struct PtQueues {
 #define PT_SORT_GENERAL0 128u
 #define PT_SORT_COUNT0 256u                       // [+256) bin counts
 #define PT_SORT_CURSOR0 (256u + 256u)             // [+256) bin cursors
-#define PT_COUNTS_WORDS (256u + 512u)
+#define PT_Q_SEG_TICKET0 768u                     // k_trace: one ticket per queue segment (8 segments, 128 B apart)
+#define PT_COUNTS_WORDS (768u + 8u * 32u)

@@ -573,6 +573,8 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     // prefetch reservation (see the loop): stage, ticket result (lane 0), rays reserved / handed out, one ray per lane
     int pf_stage = 0, pf_kind = 0;
     uint32_t pf_raw = 0, pf_count = 0, pf_used = 0, pf_p = 0;
+    uint32_t seg = blockIdx.x & 7u, seg_dry = 0;
+    const uint32_t seg_len = (((total + 7u) >> 3) + 63u) & ~63u;
     float4 pf_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf_d = pf_o;
 #ifdef PT_PROFILE_PHASES
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0-2 node clk/steps/lanes, 3-5 leaf, 6 total, 7 service+begin clk, 8 retire events, 9 begin events
@@ -590,15 +592,22 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         // happen as soon as PT_REFILL_MIN lanes are free.
         if (pf_stage == 0) {
             if (more) {
-                if (lane == 0) pf_raw = atomicAdd(&Q.counts[PT_Q_TICKET], 64u);
+                if (lane == 0) pf_raw = atomicAdd(&Q.counts[PT_Q_SEG_TICKET0 + 32u * seg], 64u);
                 pf_stage = 1;
             }
         } else if (pf_stage == 1) {
-            const uint32_t base = (uint32_t)__shfl((int)pf_raw, 0, 64);
-            if (base >= total) { more = false; pf_stage = 0; }
-            else {
-                pf_count = min(64u, total - base);
-                if (base + 64u >= total) more = false;
+            // The queue is cut into 8 segments and a wave starts on the segment of its XCD (workgroups are dealt to
+            // the XCDs round-robin), so each L2 sees one contiguous, pixel-ordered slice of the rays; a wave whose
+            // segment has run dry moves on to the next one.
+            const uint32_t seg_lo = seg * seg_len, seg_hi = min(total, seg_lo + seg_len);
+            const uint32_t base = seg_lo + (uint32_t)__shfl((int)pf_raw, 0, 64);
+            if (seg_lo >= total || base >= seg_hi) {
+                seg = (seg + 1u) & 7u;
+                if (++seg_dry == 8u) more = false;
+                pf_stage = 0;
+            } else {
+                seg_dry = 0;
+                pf_count = min(64u, seg_hi - base);
                 pf_used = 0;
                 const uint32_t item = base + lane;
                 if (lane < pf_count) {
@@ -835,6 +844,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_gen(PtScene sc, PtPaths
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         Q.counts[PT_Q_CUR] = n; Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_NEE] = 0; Q.counts[PT_Q_TICKET] = 0; Q.counts[PT_Q_SHADOW] = 0; Q.counts[PT_Q_PROBE] = 0;
+        for (uint32_t k = 0; k < 8u; k++) Q.counts[PT_Q_SEG_TICKET0 + 32u * k] = 0;
         atomicAdd(&cnt->camera_rays, (unsigned long long)n);
     }
 }
@@ -844,8 +854,10 @@ extern "C" __global__ void k_prep(PtQueues Q, int mode) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (mode == 0) {            // before SHADE: nee and next start empty
             Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_NEE] = 0; Q.counts[PT_Q_TICKET] = 0; Q.counts[PT_Q_TICKET2] = 0; Q.counts[PT_Q_SHADOW] = 0; Q.counts[PT_Q_PROBE] = 0;
+            for (uint32_t k = 0; k < 8u; k++) Q.counts[PT_Q_SEG_TICKET0 + 32u * k] = 0;
         } else {                    // after SHADE: next becomes cur (host swaps the pointers)
             Q.counts[PT_Q_CUR] = Q.counts[PT_Q_NEXT]; Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_TICKET] = 0;
+            for (uint32_t k = 0; k < 8u; k++) Q.counts[PT_Q_SEG_TICKET0 + 32u * k] = 0;
         }
     }
 }
