@@ -210,7 +210,7 @@ def main():
                     "note": "achieved counts ALGORITHMIC bytes (128 B per node visit, 48 B per triangle test, ray records); the upper BVH "
                             "levels are re-read from L2 / Infinity Cache, so it can exceed the HBM peak -- traffic is the measured HBM side"}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only (rank 0 would keep the other ranks waiting)
             import oracle_lib
             osc = oracle_lib.load().scene(sd)
             cores = min(effective_cores(), 16)      # a 1-GPU box grants 16 host CPUs; BENCH_CPU_THREADS overrides the probe
