@@ -524,15 +524,16 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 //
 // Persistent lanes: ray lengths are heavy-tailed (a wave of 64 fresh rays would idle most of
 // its lanes waiting for the slowest one), so every lane runs a small state machine and a wave
-// re-fills its idle lanes from the device-wide ticket as soon as PT_REFILL_MIN of them are free.
-// Each traversal step pops one reference: a 128-byte node (4 slab tests, ordered pushes) or a
-// leaf (48-byte triangle records, fetched two at a time).  The order of pops, tests and t_max
-// updates per ray is exactly the reference's, whatever the interleaving across lanes.
+// re-fills its idle lanes from a register-resident reservation of prefetched rays as soon as
+// PT_REFILL_MIN of them are free.  Each traversal step handles one reference per ray: a 128-byte
+// node (4 slab tests, ordered pushes) or a leaf, whose triangle tests are pooled over the wave
+// (DIST) or walked by the owning lane (leaves of more than 8 triangles).  The order of pops,
+// tests and t_max updates per ray is exactly the reference's, whatever the interleaving across lanes.
 #ifndef PT_REFILL_MIN
 #define PT_REFILL_MIN 16
 #endif
 #ifndef PT_LEAF_MIN
-#define PT_LEAF_MIN 24
+#define PT_LEAF_MIN 24          // k_trace_seq: leaf phase once this many lanes are parked on a leaf
 #endif
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 4        // waves per SIMD the register allocator must leave room for
