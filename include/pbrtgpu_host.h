@@ -36,6 +36,16 @@ typedef struct pth_scene pth_scene;
 /* Parse a .pbrt file (Include resolved relative to the including file).  On failure *out is NULL
  * and err (if non-NULL) receives a message. */
 pt_status pth_parse_file(const char* filename, pth_scene** out, char* err, size_t err_cap);
+/* Command-line options of the reference that act while the scene is being assembled (src/bin/pbrt.rs:360-366,
+ * :234-238): --quick (pixelsamples 1, a quarter of the film resolution per axis), --quick_full_resolution,
+ * --pixelsamples (0 = keep the scene's). */
+typedef struct {
+    int32_t quick;
+    int32_t quick_full_resolution;
+    int32_t pixelsamples;
+    int32_t reserved;
+} pth_options;
+pt_status pth_parse_file_opts(const char* filename, const pth_options* opts, pth_scene** out, char* err, size_t err_cap);
 /* Parse scene text; work_dir is the base for Include (may be NULL). */
 pt_status pth_parse_string(const char* text, const char* work_dir, pth_scene** out, char* err, size_t err_cap);
 /* The flattened scene; pointers stay valid until pth_scene_free. */

@@ -155,7 +155,7 @@ def tiles_array(tiles):
     return arr
 
 
-HOST_SYMBOLS = ["pth_parse_file", "pth_parse_string", "pth_scene_get_desc", "pth_scene_output_filename",
+HOST_SYMBOLS = ["pth_parse_file", "pth_parse_file_opts", "pth_parse_string", "pth_scene_get_desc", "pth_scene_output_filename",
                 "pth_scene_set_pixelsamples", "pth_scene_warnings", "pth_scene_free", "pth_write_pfm", "pth_parse_to_log"]
 
 

@@ -1,6 +1,7 @@
 // pbrt_gpu -- command-line front end mirroring `pbrt-r3 -i scene.pbrt` (src/bin/pbrt.rs:44-132,
 // :263-356): parse the scene description, hand the flattened scene to the MI355X library, write
 // the image.  Options follow the reference's names where they exist.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -12,21 +13,37 @@
 
 static void usage() {
     std::fprintf(stderr,
-                 "usage: pbrt_gpu [-i] scene.pbrt [--outfile out.pfm] [--pixelsamples N] [--device D] [--quiet]\n"
+                 "usage: pbrt_gpu [-i] scene.pbrt [options]\n"
                  "  Renders the scene with the wavefront path tracer on a HIP device (no CPU fallback) and writes a\n"
-                 "  linear-RGB PFM.  Film \"filename\" is used when --outfile is absent (extension replaced by .pfm).\n");
+                 "  linear-RGB PFM.  Film \"filename\" is used when --outfile is absent (extension replaced by .pfm).\n"
+                 "  -o, --outfile <file>      image file to write\n"
+                 "  -s, --pixelsamples <n>    override the sampler's pixelsamples\n"
+                 "      --quick               pixelsamples 1 and a quarter of the film resolution per axis\n"
+                 "      --quick_full_resolution   --quick at the full resolution\n"
+                 "  -c, --cat                 print the parsed directives, do not render\n"
+                 "      --stats               print the ray counters\n"
+                 "      --quiet               only error messages\n"
+                 "  -j, --nthreads <n>        accepted for compatibility (the device schedules itself)\n"
+                 "      --device <d>          HIP device index\n");
 }
 
 int main(int argc, char** argv) {
     std::string input, outfile;
     int spp = 0, device = 0;
-    bool quiet = false;
+    bool quiet = false, cat = false, stats = false;
+    pth_options opts;
+    std::memset(&opts, 0, sizeof(opts));
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](const char* name) -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", name); std::exit(2); } return argv[++i]; };
         if (a == "-i" || a == "--infile") input = need("-i");
         else if (a == "-o" || a == "--outfile") outfile = need("--outfile");
-        else if (a == "--pixelsamples") spp = std::atoi(need("--pixelsamples"));
+        else if (a == "--pixelsamples" || a == "-s") spp = std::max(1, std::atoi(need("--pixelsamples")));
+        else if (a == "--quick") opts.quick = 1;
+        else if (a == "--quick_full_resolution" || a == "--quick-full-resolution") opts.quick_full_resolution = 1;
+        else if (a == "--cat" || a == "-c") cat = true;
+        else if (a == "--stats") stats = true;
+        else if (a == "--nthreads" || a == "-j") (void)need("--nthreads");
         else if (a == "--device") device = std::atoi(need("--device"));
         else if (a == "--quiet") quiet = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -34,12 +51,26 @@ int main(int argc, char** argv) {
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 2; }
     }
     if (input.empty()) { usage(); return 2; }
+    if (cat) {                                    // --cat (bin/pbrt.rs:211-224): the directives as parsed
+        FILE* f = std::fopen(input.c_str(), "rb");
+        if (!f) { std::fprintf(stderr, "pbrt_gpu: cannot open %s\n", input.c_str()); return 1; }
+        std::string text;
+        char buf[65536];
+        size_t n;
+        while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, n);
+        std::fclose(f);
+        std::string dir = input.find_last_of('/') == std::string::npos ? std::string(".") : input.substr(0, input.find_last_of('/'));
+        std::vector<char> out(text.size() * 8 + (1u << 20));
+        pt_status cs = pth_parse_to_log(text.c_str(), dir.c_str(), out.data(), out.size());
+        std::fputs(out.data(), cs == PT_OK ? stdout : stderr);
+        return cs == PT_OK ? 0 : 1;
+    }
+    opts.pixelsamples = spp;
     char err[1024] = {0};
     pth_scene* scene = nullptr;
-    pt_status st = pth_parse_file(input.c_str(), &scene, err, sizeof(err));
+    pt_status st = pth_parse_file_opts(input.c_str(), &opts, &scene, err, sizeof(err));
     if (st != PT_OK) { std::fprintf(stderr, "pbrt_gpu: %s\n", err); return 1; }
     if (!quiet && pth_scene_warnings(scene)[0]) std::fprintf(stderr, "%s", pth_scene_warnings(scene));
-    if (spp > 0) pth_scene_set_pixelsamples(scene, spp);
     if (outfile.empty()) {
         outfile = pth_scene_output_filename(scene);
         size_t dot = outfile.find_last_of('.');
@@ -64,6 +95,9 @@ int main(int argc, char** argv) {
     if (!quiet)
         std::fprintf(stderr, "pbrt_gpu: %s  %dx%d, %d spp, %u lights, BVH %u nodes (%.0f ms)  rendered in %.3f s  %.1f Mrays/s  -> %s\n", input.c_str(), w, h,
                      info.spp, info.n_lights, info.n_nodes, info.bvh_build_ms, secs, (double)(c.regular_rays + c.shadow_rays) / secs / 1e6, outfile.c_str());
+    if (stats)                                    // the counters behind "Intersections/..." (core/scene/scene.rs:11-12)
+        std::fprintf(stderr, "  Regular ray intersection tests %llu\n  Shadow ray intersection tests  %llu\n  Camera rays %llu, path vertices %llu\n",
+                     (unsigned long long)c.regular_rays, (unsigned long long)c.shadow_rays, (unsigned long long)c.camera_rays, (unsigned long long)c.path_vertices);
     pt_context_destroy(ctx);
     pth_scene_free(scene);
     return 0;

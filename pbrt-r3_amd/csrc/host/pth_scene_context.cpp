@@ -119,6 +119,7 @@ public:
     std::vector<float> P, N, S, UV;
     std::vector<uint32_t> indices, tri_mesh;
     std::vector<pt_mesh> meshes;
+    bool quick_render = false, quick_full_resolution = false;          // PbrtOptions (--quick, --quick_full_resolution)
     std::vector<pt_material> materials;
     std::map<std::string, float> float_textures;                        // constant-folded named textures (global, see pbrt_texture)
     std::map<std::string, std::array<float, 3>> spectrum_textures;
@@ -592,6 +593,10 @@ public:
         if (film_name != "image") warn("Film \"" + film_name + "\" treated as \"image\"");
         desc.xres = film_params.find_one_int("xresolution", 1280);
         desc.yres = film_params.find_one_int("yresolution", 720);
+        if (quick_render && !quick_full_resolution) {               // create_film (film.rs:548-554)
+            desc.xres = std::max(1, desc.xres / 4);
+            desc.yres = std::max(1, desc.yres / 4);
+        }
         desc.crop_window[0] = 0.0f; desc.crop_window[1] = 1.0f; desc.crop_window[2] = 0.0f; desc.crop_window[3] = 1.0f;
         if (const std::vector<float>* cw = film_params.get_floats("cropwindow")) {
             if (cw->size() != 4) { fail("\"cropwindow\" expects 4 values"); return; }
@@ -637,6 +642,7 @@ public:
             return;
         }
         desc.spp = sampler_params.find_one_int("pixelsamples", 16);
+        if (quick_render) desc.spp = 1;                              // create_halton_sampler / create_sobol_sampler
         // integrator (integrators/path.rs:252-271)
         if (integrator_name != "path") { fail("Integrator \"" + integrator_name + "\": only path is on the accelerated path"); return; }
         desc.max_depth = integrator_params.find_one_int("maxdepth", 5);
@@ -700,11 +706,20 @@ static pt_status finish(pth_scene* s, bool parsed, const std::string& perr, pth_
 extern "C" {
 
 pt_status pth_parse_file(const char* filename, pth_scene** out, char* err, size_t err_cap) {
+    return pth_parse_file_opts(filename, nullptr, out, err, err_cap);
+}
+pt_status pth_parse_file_opts(const char* filename, const pth_options* opts, pth_scene** out, char* err, size_t err_cap) {
     if (!filename || !out) return PT_ERR_INVALID_ARGUMENT;
     pth_scene* s = new pth_scene;
+    if (opts) {
+        s->ctx.quick_render = opts->quick != 0 || opts->quick_full_resolution != 0;     // bin/pbrt.rs:360-366
+        s->ctx.quick_full_resolution = opts->quick_full_resolution != 0;
+    }
     std::string perr;
     bool ok = pth::pbrt_parse_file(filename, s->ctx, &perr);
-    return finish(s, ok, perr, out, err, err_cap);
+    pt_status st = finish(s, ok, perr, out, err, err_cap);
+    if (st == PT_OK && opts && opts->pixelsamples > 0) (*out)->ctx.desc.spp = opts->pixelsamples;   // bin/pbrt.rs:234-238
+    return st;
 }
 pt_status pth_parse_string(const char* text, const char* work_dir, pth_scene** out, char* err, size_t err_cap) {
     if (!text || !out) return PT_ERR_INVALID_ARGUMENT;

@@ -428,3 +428,31 @@ def test_constant_folding_textures():
     with pytest.raises(capi.PtError) as e:
         capi.ParsedScene(text=text.replace('"texture Kd" "blend"', '"texture Kd" "chk"'))
     assert e.value.status == 4 and "checkerboard" in str(e.value)
+
+
+def test_parse_options_quick_and_pixelsamples():
+    """--quick (bin/pbrt.rs:360-366): pixelsamples 1 and resolution / 4 (create_film, film.rs:548-554; the camera's
+    frame aspect follows the reduced resolution); --quick_full_resolution keeps the resolution; --pixelsamples
+    overrides afterwards (bin/pbrt.rs:234-238)."""
+    import ctypes as C
+
+    class Opts(C.Structure):
+        _fields_ = [("quick", C.c_int32), ("quick_full_resolution", C.c_int32), ("pixelsamples", C.c_int32), ("reserved", C.c_int32)]
+    lib = capi.load_library()
+    lib.pth_parse_file_opts.argtypes = [C.c_char_p, C.POINTER(Opts), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    lib.pth_scene_get_desc.restype = C.POINTER(capi.pt_scene_desc)
+    lib.pth_scene_get_desc.argtypes = [C.c_void_p]
+    lib.pth_scene_free.argtypes = [C.c_void_p]
+    scene = os.path.join(ROOT, "tests", "scenes", "cornell.pbrt").encode()
+
+    def parse(**kw):
+        h, err = C.c_void_p(), C.create_string_buffer(512)
+        assert lib.pth_parse_file_opts(scene, C.byref(Opts(**kw)), C.byref(h), err, 512) == 0, err.value
+        d = lib.pth_scene_get_desc(h).contents
+        out = (d.xres, d.yres, d.spp)
+        lib.pth_scene_free(h)
+        return out
+    assert parse() == (64, 64, 16)
+    assert parse(quick=1) == (16, 16, 1)
+    assert parse(quick_full_resolution=1) == (64, 64, 1)
+    assert parse(quick=1, pixelsamples=5) == (16, 16, 5)
