@@ -65,6 +65,11 @@ pt_status pth_parse_to_log(const char* text, const char* work_dir, char* out, si
 /* Linear-RGB float image as PFM (the smallest float format the reference can also write,
  * src/core/imageio/write_image.rs:59-76). */
 pt_status pth_write_pfm(const char* path, const float* rgb, int width, int height);
+/* Film::write_image (film.rs:440-484 -> imageio/write_image.rs:59-76) by file extension: ".exr" (32-bit float scanline
+ * OpenEXR, uncompressed; data window = the cropped pixel bounds at (x0, y0) inside a full_w x full_h display window),
+ * ".png" (8-bit, to_byte = clamp(255 * gamma_correct(v)) as write_image.rs:16-18), ".pfm".  Anything else:
+ * PT_ERR_UNSUPPORTED. */
+pt_status pth_write_image(const char* path, const float* rgb, int width, int height, int x0, int y0, int full_w, int full_h);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,8 @@ static void usage() {
     std::fprintf(stderr,
                  "usage: pbrt_gpu [-i] scene.pbrt [options]\n"
                  "  Renders the scene with the wavefront path tracer on a HIP device (no CPU fallback) and writes a\n"
-                 "  linear-RGB PFM.  Film \"filename\" is used when --outfile is absent (extension replaced by .pfm).\n"
+                 "  the image: .exr (float, uncompressed), .png (8-bit sRGB) or .pfm by extension.  Film \"filename\" is used when\n"
+                 "  --outfile is absent.\n"
                  "  -o, --outfile <file>      image file to write\n"
                  "  -s, --pixelsamples <n>    override the sampler's pixelsamples\n"
                  "      --quick               pixelsamples 1 and a quarter of the film resolution per axis\n"
@@ -74,7 +75,8 @@ int main(int argc, char** argv) {
     if (outfile.empty()) {
         outfile = pth_scene_output_filename(scene);
         size_t dot = outfile.find_last_of('.');
-        outfile = (dot == std::string::npos ? outfile : outfile.substr(0, dot)) + ".pfm";
+        std::string ext = dot == std::string::npos ? std::string() : outfile.substr(dot);
+        if (ext != ".exr" && ext != ".png" && ext != ".pfm") outfile = (dot == std::string::npos ? outfile : outfile.substr(0, dot)) + ".pfm";
     }
     pt_context* ctx = nullptr;
     st = pt_context_create(device, &ctx);
@@ -91,7 +93,8 @@ int main(int argc, char** argv) {
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     pt_counters c;
     pt_get_counters(ctx, &c);
-    if (pth_write_pfm(outfile.c_str(), rgb.data(), w, h) != PT_OK) { std::fprintf(stderr, "pbrt_gpu: cannot write %s\n", outfile.c_str()); return 1; }
+    const pt_scene_desc* dsc = pth_scene_get_desc(scene);
+    if (pth_write_image(outfile.c_str(), rgb.data(), w, h, info.cropped_bounds[0], info.cropped_bounds[1], dsc->xres, dsc->yres) != PT_OK) { std::fprintf(stderr, "pbrt_gpu: cannot write %s\n", outfile.c_str()); return 1; }
     if (!quiet)
         std::fprintf(stderr, "pbrt_gpu: %s  %dx%d, %d spp, %u lights, BVH %u nodes (%.0f ms)  rendered in %.3f s  %.1f Mrays/s  -> %s\n", input.c_str(), w, h,
                      info.spp, info.n_lights, info.n_nodes, info.bvh_build_ms, secs, (double)(c.regular_rays + c.shadow_rays) / secs / 1e6, outfile.c_str());

@@ -734,14 +734,4 @@ void pth_scene_set_pixelsamples(pth_scene* s, int spp) { if (s && spp > 0) s->ct
 const char* pth_scene_warnings(const pth_scene* s) { return s ? s->ctx.warnings.c_str() : ""; }
 void pth_scene_free(pth_scene* s) { delete s; }
 
-pt_status pth_write_pfm(const char* path, const float* rgb, int w, int h) {
-    if (!path || !rgb || w <= 0 || h <= 0) return PT_ERR_INVALID_ARGUMENT;
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return PT_ERR_INVALID_ARGUMENT;
-    std::fprintf(f, "PF\n%d %d\n-1.0\n", w, h);                  // little-endian, bottom row first
-    for (int y = h - 1; y >= 0; y--) std::fwrite(rgb + (size_t)y * w * 3, sizeof(float), (size_t)w * 3, f);
-    std::fclose(f);
-    return PT_OK;
-}
-
 }  // extern "C"

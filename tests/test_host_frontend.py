@@ -456,3 +456,67 @@ def test_parse_options_quick_and_pixelsamples():
     assert parse(quick=1) == (16, 16, 1)
     assert parse(quick_full_resolution=1) == (64, 64, 1)
     assert parse(quick=1, pixelsamples=5) == (16, 16, 5)
+
+
+def test_image_writers(tmp_path):
+    """pth_write_image: EXR (uncompressed float scanlines, data window inside the display window), PNG with the
+    reference's to_byte (write_image.rs:16-18) and PFM, decoded here independently."""
+    import ctypes as C, struct, zlib
+    lib = capi.load_library()
+    lib.pth_write_image.argtypes = [C.c_char_p, C.c_void_p] + [C.c_int] * 6
+    rng = np.random.default_rng(4)
+    w, h = 7, 5
+    img = (rng.random((h, w, 3), dtype=np.float32) * 1.4 - 0.1).astype(np.float32)
+    img[0, 0] = (0.0, 0.002, 1.0)
+    ptr = img.ctypes.data_as(C.c_void_p)
+    # ---- PNG
+    p = str(tmp_path / "a.png")
+    assert lib.pth_write_image(p.encode(), ptr, w, h, 0, 0, w, h) == 0
+    raw = open(p, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat = 8, b""
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+        if typ == b"IHDR":
+            assert struct.unpack(">IIBBBBB", body) == (w, h, 8, 2, 0, 0, 0)
+        if typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert (rows[:, 0] == 0).all()
+    f = np.float32
+    with np.errstate(invalid="ignore"):
+        g = np.where(img <= f(0.0031308), f(12.92) * img, f(1.055) * np.power(img, f(1.0 / 2.4), dtype=np.float32) - f(0.055)).astype(np.float32)
+    want = np.clip(np.nan_to_num(f(255.0) * g, nan=0.0), 0, 255).astype(np.uint8)
+    got = rows[:, 1:].reshape(h, w, 3)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1 and (got == want).mean() > 0.97      # numpy's powf may differ in the last ulp
+    # ---- EXR: 4 x 3 crop at (2, 1) of a 10 x 8 frame
+    p = str(tmp_path / "a.exr")
+    assert lib.pth_write_image(p.encode(), ptr, w, h, 2, 1, 10, 8) == 0
+    raw = open(p, "rb").read()
+    assert struct.unpack("<II", raw[:8]) == (20000630, 2)
+    pos, attrs = 8, {}
+    while raw[pos] != 0:
+        e = raw.index(b"\0", pos); name = raw[pos:e].decode(); pos = e + 1
+        e = raw.index(b"\0", pos); typ = raw[pos:e].decode(); pos = e + 1
+        n = struct.unpack("<I", raw[pos:pos + 4])[0]
+        attrs[name] = (typ, raw[pos + 4:pos + 4 + n]); pos += 4 + n
+    pos += 1
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (2, 1, 2 + w - 1, 1 + h - 1)
+    assert struct.unpack("<4i", attrs["displayWindow"][1]) == (0, 0, 9, 7) and attrs["compression"][1] == b"\0"
+    offs = struct.unpack("<%dQ" % h, raw[pos:pos + 8 * h])
+    back = np.empty((h, w, 3), np.float32)
+    for y in range(h):
+        yy, n = struct.unpack("<ii", raw[offs[y]:offs[y] + 8])
+        assert yy == 1 + y and n == 12 * w
+        line = np.frombuffer(raw, np.float32, 3 * w, offs[y] + 8).reshape(3, w)       # B, G, R planes
+        back[y, :, 2], back[y, :, 1], back[y, :, 0] = line[0], line[1], line[2]
+    assert np.array_equal(bits(back), bits(img))
+    # ---- PFM and an unknown extension
+    p = str(tmp_path / "a.pfm")
+    assert lib.pth_write_image(p.encode(), ptr, w, h, 0, 0, w, h) == 0
+    body = open(p, "rb").read().split(b"\n", 3)[3]
+    assert np.array_equal(bits(np.frombuffer(body, "<f4").reshape(h, w, 3)[::-1]), bits(img))
+    assert lib.pth_write_image(str(tmp_path / "a.tga").encode(), ptr, w, h, 0, 0, w, h) == 4
