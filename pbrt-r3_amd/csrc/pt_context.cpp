@@ -573,6 +573,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     sc.UV = d->UV ? ctx->d_UV.as<float>() : nullptr;
     sc.materials = ctx->d_materials.as<PtMaterial>();
     sc.general_materials = general_materials ? 1u : 0u;
+    sc.any_one_sided = 0;
+    for (uint32_t f : tri_flags) if (f & PT_TRI_ONE_SIDED) { sc.any_one_sided = 1; break; }
     sc.dist_leaves = (bvh.max_leaf <= 8 && !std::getenv("PBRTGPU_SEQ_LEAVES")) ? 1u : 0u;
     ctx->n_materials = d->n_materials;
     sc.lights = ctx->d_lights.as<PtLight>();

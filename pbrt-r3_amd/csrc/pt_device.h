@@ -156,6 +156,7 @@ struct PtCounters {
 
 struct PtScene {
     uint32_t dist_leaves;        // 1: no leaf holds more than 8 triangles, k_trace spreads leaf tests over the wave
+    uint32_t any_one_sided;      // 1: some triangle is one-sided ("twosided" false): leaf rounds also need the ray direction
     uint32_t general_materials;  // 1 when any material is not Matte: k_shade_general runs instead of k_shade
     const PtNode* nodes;
     const PtTri* tris;

@@ -703,7 +703,8 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     const uint32_t first = (uint32_t)__shfl((int)(r.top & PT_LEAF_FIRST_MASK), o, 64);
                     RayPre rp;
                     rp.o = mk3(__shfl(r.rp.o.x, o, 64), __shfl(r.rp.o.y, o, 64), __shfl(r.rp.o.z, o, 64));
-                    rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));
+                    rp.d = mk3(0.0f, 0.0f, 0.0f);        // only the one-sided test reads the direction
+                    if (sc.any_one_sided) rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));
                     const int kk = __shfl(r.rp.kx | (r.rp.ky << 2) | (r.rp.kz << 4), o, 64);
                     rp.kx = kk & 3; rp.ky = (kk >> 2) & 3; rp.kz = (kk >> 4) & 3;
                     rp.sx = __shfl(r.rp.sx, o, 64); rp.sy = __shfl(r.rp.sy, o, 64); rp.sz = __shfl(r.rp.sz, o, 64);
