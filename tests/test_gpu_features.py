@@ -140,6 +140,19 @@ def test_golden_fixtures(gpu_ctx):
     gpu_ctx.film_clear(); gpu_ctx.render()
     want = np.load(os.path.join(G, "rt2k_32x32_4spp_xyzw.npy"))
     assert rel_l2(gpu_ctx.film_xyzw()[..., :3], want[..., :3]) <= 1e-3
+    # material lobes + Halton + HLBVH
+    sd3 = fs.scene_materials_render(["plastic", "mirror", "glass"], spp=6, sampler="halton")
+    sd3.desc.split_method = 1
+    gpu_ctx.upload(sd3)
+    gpu_ctx.film_clear(); gpu_ctx.render()
+    want = np.load(os.path.join(G, "materials_halton_40x40_6spp_xyzw.npy"))
+    got = gpu_ctx.film_xyzw()
+    assert np.array_equal(bits(got[..., 3]), bits(want[..., 3]))
+    assert rel_l2(got[..., :3], want[..., :3]) <= 1e-3
+    gpu_ctx.upload(fs.scene_materials_render(["metal", "uber", "substrate"], spp=8))
+    sb = list(gpu_ctx.info.sample_bounds)
+    rad = gpu_ctx.radiance_samples((sb[0] + 14, sb[1] + 14, sb[0] + 26, sb[1] + 26))
+    assert np.array_equal(bits(rad), bits(np.load(os.path.join(G, "materials_sobol_40x40_8spp_samples.npy"))))
 
 
 def test_baseline_size_properties(gpu_ctx, oracle):

@@ -242,6 +242,19 @@ def test_oracle_matches_committed_golden(oracle):
     x2, _, _ = sc2.render(threads=4)
     assert np.array_equal(bits(x2), bits(np.load(os.path.join(GOLD, "rt2k_32x32_4spp_xyzw.npy"))))
     sc2.close()
+    # material lobes + Halton + HLBVH
+    import feature_scenes as fs
+    sd3 = fs.scene_materials_render(["plastic", "mirror", "glass"], spp=6, sampler="halton")
+    sd3.desc.split_method = 1
+    sc3 = oracle.scene(sd3)
+    x3, _, _ = sc3.render(threads=4)
+    assert np.array_equal(bits(x3), bits(np.load(os.path.join(GOLD, "materials_halton_40x40_6spp_xyzw.npy"))))
+    sc3.close()
+    sc4 = oracle.scene(fs.scene_materials_render(["metal", "uber", "substrate"], spp=8))
+    sb = list(sc4.info.sample_bounds)
+    rad = sc4.radiance_samples((sb[0] + 14, sb[1] + 14, sb[0] + 26, sb[1] + 26))
+    assert np.array_equal(bits(rad), bits(np.load(os.path.join(GOLD, "materials_sobol_40x40_8spp_samples.npy"))))
+    sc4.close()
 
 
 def test_cornell_energy_sanity(oracle):

@@ -5,6 +5,8 @@ against accidental change and give the GPU tests a committed target:
   tests/golden/cornell_32x32_8spp_xyzw.npy   film {X,Y,Z,weight}
   tests/golden/cornell_32x32_8spp_rays.npz   camera rays + closest hits for sample 0
   tests/golden/rt2k_32x32_4spp_xyzw.npy
+  tests/golden/materials_halton_40x40_6spp_xyzw.npy   plastic sphere + mirror + glass slabs, Halton, HLBVH
+  tests/golden/materials_sobol_40x40_8spp_samples.npy per-sample radiance of a 12x12 tile: metal / uber / substrate
 """
 import importlib, os, sys
 import numpy as np
@@ -30,4 +32,14 @@ sd2 = pkg.scenes.rt1m(2000, res=32, spp=4)
 sc2 = orc.scene(sd2)
 xyzw2, _, _ = sc2.render(threads=1)
 np.save(os.path.join(G, "rt2k_32x32_4spp_xyzw.npy"), xyzw2)
+import feature_scenes as fs
+sd3 = fs.scene_materials_render(["plastic", "mirror", "glass"], spp=6, sampler="halton")
+sd3.desc.split_method = 1
+sc3 = orc.scene(sd3)
+xyzw3, _, _ = sc3.render(threads=1)
+np.save(os.path.join(G, "materials_halton_40x40_6spp_xyzw.npy"), xyzw3)
+sd4 = fs.scene_materials_render(["metal", "uber", "substrate"], spp=8)
+sc4 = orc.scene(sd4)
+sb4 = list(sc4.info.sample_bounds)
+np.save(os.path.join(G, "materials_sobol_40x40_8spp_samples.npy"), sc4.radiance_samples((sb4[0] + 14, sb4[1] + 14, sb4[0] + 26, sb4[1] + 26)))
 print("golden written:", os.listdir(G))
