@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 typedef enum {
     PT_OK = 0,
@@ -115,6 +115,25 @@ typedef struct {
     uint32_t reserved;
 } pt_mesh;
 
+/* Sphere (src/shapes/sphere.rs:7-41, create_sphere_shape :401-420).  The only analytic shape on the
+ * path: pbrt-v3's killeroo-simple lights its scene with two of them.  It lives in the same BVH as
+ * the triangles (one primitive), is tested with the reference's EFloat interval arithmetic
+ * (core/efloat/efloat.rs) in object space, and carries its own material / area light. */
+#define PT_SPHERE_REVERSE_ORIENTATION 1u
+typedef struct {
+    float object_to_world[16];  /* row-major Transform.m of the CTM at the Shape directive */
+    float world_to_object[16];  /* Transform.m_inv (the reference keeps both; it never re-inverts) */
+    float radius;               /* "radius", default 1 */
+    float zmin, zmax;           /* "zmin" / "zmax", defaults -radius / radius; clamped as Sphere::new does */
+    float phimax;               /* "phimax" in degrees, default 360 */
+    uint32_t flags;             /* PT_SPHERE_REVERSE_ORIENTATION */
+    int32_t material;           /* index into materials[], or -1 */
+    int32_t area_light;         /* index into area_lights[], or -1: one DiffuseAreaLight for the sphere */
+    uint32_t before_triangle;   /* position in the primitive list: the sphere precedes triangle number
+                                 * `before_triangle` (n_triangles = after the last one).  Non-decreasing
+                                 * over spheres[]; equal values keep array order. */
+} pt_sphere;
+
 typedef enum { PT_SPLIT_SAH = 0, PT_SPLIT_HLBVH = 1, PT_SPLIT_MIDDLE = 2, PT_SPLIT_EQUAL_COUNTS = 3 } pt_split_method;
 typedef enum {
     PT_SAMPLER_SOBOL = 0,   /* samplers/sobol.rs */
@@ -166,7 +185,14 @@ typedef struct {
     float rr_threshold;         /* default 1 */
     int32_t light_strategy;     /* pt_light_strategy, default spatial */
     int32_t halton_sample_at_center;  /* Halton "samplepixelcenter", default 0 */
-    int32_t reserved[3];
+
+    /* ---- analytic shapes (ABI 3).  The scene's primitive list is the triangles in order with the
+     * spheres spliced in at `before_triangle`; BVH builders, light order (one light per emissive
+     * primitive, scene_context.rs:1218-1231) and pt_hit.prim all use that merged numbering, which is
+     * the plain triangle index when n_spheres == 0. */
+    uint32_t n_spheres;
+    const pt_sphere* spheres;
+    int32_t reserved[2];
 } pt_scene_desc;
 
 /* Axis-aligned block of film *sample* pixels, half-open: the unit the reference
@@ -175,8 +201,9 @@ typedef struct { int32_t x0, y0, x1, y1; } pt_tile;
 
 typedef struct {
     float t;                /* hit distance (undefined when prim < 0) */
-    int32_t prim;           /* index into the caller's triangle list, -1 = miss */
-    float b0, b1;           /* barycentrics of v0, v1 (triangle.rs:321-323) */
+    int32_t prim;           /* index into the scene's primitive list (= the caller's triangle index
+                             * when the scene has no spheres), -1 = miss */
+    float b0, b1;           /* barycentrics of v0, v1 (triangle.rs:321-323); 0 for a sphere */
 } pt_hit;
 
 typedef struct {
@@ -263,10 +290,10 @@ pt_status pt_bsdf_sample(pt_context* ctx, uint32_t material, uint32_t n, const f
 pt_status pt_radiance_samples(pt_context* ctx, const pt_tile* tile, float* out_rgb);
 
 /* Host-only utility (no device, no context): builds the BVH exactly as pt_scene_upload
- * does and returns the leaf order (order_out[k] = caller's triangle index stored k-th),
+ * does and returns the leaf order (order_out[k] = primitive index stored k-th),
  * the 4-wide node / leaf counts and the traversal stack bound.  Lets a host check the
  * tree against the reference's ordered_prims (build/node.rs:138-151) without a GPU. */
-pt_status pt_bvh_leaf_order(const pt_scene_desc* desc, uint32_t* order_out /* n_triangles */,
+pt_status pt_bvh_leaf_order(const pt_scene_desc* desc, uint32_t* order_out /* n_triangles + n_spheres */,
                             uint32_t* n_nodes, uint32_t* n_leaves, uint32_t* max_stack);
 
 pt_status pt_get_counters(pt_context* ctx, pt_counters* out);

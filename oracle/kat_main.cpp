@@ -5,6 +5,8 @@
 //   tests/shapes.rs:156-196  triangle_reintersect (+ helper :369-414)
 //   tests/shapes.rs:200-278  triangle_solid_angle
 //   tests/shapes.rs:480-504  triangle_badcases
+//   tests/shapes.rs:280-329  sphere_solid_angle (+ Shape::solid_angle, shape.rs:56-73)
+//   tests/shapes.rs:416-457  full_sphere_reintersect, partial_sphere_reintersect
 // Usage: orc_kat [name ...]   (no argument = all); exit code = number of failures.
 #include "orc_render.hpp"
 #include <cstdlib>
@@ -228,12 +230,122 @@ static bool triangle_badcases() {
     return true;
 }
 
+// ---- spheres
+static bool sph_hits(const Sphere& s, const Ray& r) { Ray r2 = r; Float t; SurfHit si; return s.intersect(r2, &t, &si); }
+static bool sphere_reintersect_convex(const Sphere& sp, RNG& rng, int* n_found) {   // tests/shapes.rs:369-414
+    V3 o(0, 0, 0);
+    o.x = p_exp(rng, 8.0f); o.y = p_exp(rng, 8.0f); o.z = p_exp(rng, 8.0f);
+    Bounds3 bbox = sp.world_bound();
+    V3 t(0, 0, 0);
+    t.x = rng.uniform_float(); t.y = rng.uniform_float(); t.z = rng.uniform_float();
+    V3 p2 = bbox.lerp(t);
+    Ray r(o, p2 - o, kInfinity);
+    if (rng.uniform_float() < 0.5f) r.d = normalize(r.d);
+    Float th; SurfHit isect;
+    if (sp.intersect(r, &th, &isect)) {
+        (*n_found)++;
+        for (int j = 0; j < 10000; j++) {
+            V2 u = rand2(rng);
+            V3 w = face_forward(uniform_sample_sphere(u), isect.n);
+            Ray r_out = spawn_ray(isect, w);
+            CHECK(!sp.intersect_p(r_out), "sphere spawn_ray intersect_p j=%d", j);
+            CHECK(!sph_hits(sp, r_out), "sphere spawn_ray intersect j=%d", j);
+            V3 q(0, 0, 0);
+            q.x = p_exp(rng, 8.0f); q.y = p_exp(rng, 8.0f); q.z = p_exp(rng, 8.0f);
+            V3 ww = face_forward(q - isect.p, isect.n);
+            Ray r_out2 = spawn_ray_to_point(isect, isect.p + ww);
+            CHECK(!sp.intersect_p(r_out2), "sphere spawn_ray_to intersect_p j=%d", j);
+            CHECK(!sph_hits(sp, r_out2), "sphere spawn_ray_to intersect j=%d", j);
+        }
+    }
+    return true;
+}
+static bool full_sphere_reintersect() {
+    int n_found = 0;
+    for (uint64_t i = 0; i < 100; i++) {
+        RNG rng(i);
+        Mat4 id = Mat4::identity();
+        Float radius = p_exp(rng, 4.0f);
+        Sphere sp;
+        sp.init(id.m, id.m, false, radius, -radius, radius, 360.0f);
+        if (!sphere_reintersect_convex(sp, rng, &n_found)) { std::printf("  (sphere %llu)\n", (unsigned long long)i); return false; }
+    }
+    CHECK(n_found > 20, "only %d of 100 rays found their sphere", n_found);
+    return true;
+}
+static bool partial_sphere_reintersect() {
+    int n_found = 0;
+    for (uint64_t i = 0; i < 100; i++) {
+        RNG rng(i);
+        Mat4 id = Mat4::identity();
+        Float radius = p_exp(rng, 4.0f);
+        Float zmin, zmax, phi_max;
+        if (rng.uniform_float() < 0.5f) zmin = -radius; else zmin = lerpf(rng.uniform_float(), -radius, radius);
+        if (rng.uniform_float() < 0.5f) zmax = radius; else zmax = lerpf(rng.uniform_float(), -radius, radius);
+        if (zmin > zmax) std::swap(zmin, zmax);
+        if (rng.uniform_float() < 0.5f) phi_max = 360.0f; else phi_max = rng.uniform_float() * 360.0f;
+        Sphere sp;
+        sp.init(id.m, id.m, false, radius, zmin, zmax, phi_max);
+        if (!sphere_reintersect_convex(sp, rng, &n_found)) { std::printf("  (sphere %llu)\n", (unsigned long long)i); return false; }
+    }
+    CHECK(n_found > 10, "only %d of 100 rays found their sphere", n_found);
+    return true;
+}
+static Float mc_solid_angle(V3 p, const Sphere& sp, int n_samples) {   // tests/shapes.rs:282-293
+    int n_hits = 0;
+    for (int i = 0; i < n_samples; i++) {
+        V2 u(radical_inverse(0, (uint64_t)i), radical_inverse(1, (uint64_t)i));
+        Ray ray(p, uniform_sample_sphere(u), kInfinity);
+        if (sp.intersect_p(ray)) n_hits++;
+    }
+    const Float inv4pi = kInvPi * 0.25f;
+    return (Float)n_hits / (inv4pi * (Float)n_samples);
+}
+static Float shape_solid_angle(V3 p, const Sphere& sp, int n_samples) {   // Shape::solid_angle (shape.rs:56-73)
+    Float solid_angle = 0.0f;
+    for (int i = 0; i < n_samples; i++) {
+        V2 u(radical_inverse(0, (uint64_t)i), radical_inverse(1, (uint64_t)i));
+        V3 ps, ns, pe; Float pdf;
+        if (sp.sample_from(p, V3(0, 0, 0), V3(0, 0, 0), u, &ps, &ns, &pe, &pdf)) {
+            Ray r(p, ps - p, 0.999f);
+            if (!sp.intersect_p(r)) solid_angle += 1.0f / pdf;
+        }
+    }
+    return solid_angle / (Float)n_samples;
+}
+static bool sphere_solid_angle() {
+    // Transform::translate(1, .5, -.8) * Transform::rotate_x(30) and its inverse (transform.rs:33-50, :276-281)
+    Float sn = std::sin(radians(30.0f)), cs = std::cos(radians(30.0f));
+    Mat4 rot = Mat4::identity();
+    rot.m[5] = cs; rot.m[6] = -sn; rot.m[9] = sn; rot.m[10] = cs;
+    Mat4 rot_inv = Mat4::identity();
+    rot_inv.m[5] = cs; rot_inv.m[6] = sn; rot_inv.m[9] = -sn; rot_inv.m[10] = cs;
+    Mat4 m = Mat4::translate(1.0f, 0.5f, -0.8f) * rot;
+    Mat4 minv = rot_inv * Mat4::translate(-1.0f, -0.5f, 0.8f);
+    Sphere sp;
+    sp.init(m.m, minv.m, false, 1.0f, -1.0f, 1.0f, 360.0f);
+    const int n_samples = 128 * 1024;
+    V3 p_inside(1.0f, 0.9f, -0.8f);
+    Float sa_mc = mc_solid_angle(p_inside, sp, n_samples);
+    CHECK(std::fabs(sa_mc - 4.0f * kPi) < 0.01f, "solid_angle_mc %g", sa_mc);
+    Float sa = shape_solid_angle(p_inside, sp, n_samples);
+    CHECK(std::fabs(sa - 4.0f * kPi) < 0.01f, "solid_angle %g", sa);
+    V3 p_outside(-0.25f, -1.0f, 0.8f);
+    Float mc_sa = mc_solid_angle(p_outside, sp, n_samples);
+    Float sphere_sa = shape_solid_angle(p_outside, sp, n_samples);
+    CHECK(std::fabs(mc_sa - sphere_sa) < 0.001f, "mc_sa %g sphere_sa %g", mc_sa, sphere_sa);
+    return true;
+}
+
 int main(int argc, char** argv) {
     struct T { const char* name; bool (*fn)(); } tests[] = {
         {"triangle_badcases", triangle_badcases},
         {"triangle_watertight", triangle_watertight},
         {"triangle_reintersect", triangle_reintersect},
         {"triangle_solid_angle", triangle_solid_angle},
+        {"sphere_solid_angle", sphere_solid_angle},
+        {"full_sphere_reintersect", full_sphere_reintersect},
+        {"partial_sphere_reintersect", partial_sphere_reintersect},
     };
     for (auto& t : tests) {
         bool run = argc == 1;

@@ -32,17 +32,6 @@ struct MeshFlags {
     bool has_n = false, has_s = false, has_uv = false;
 };
 
-// Flattened scene geometry: one record per triangle (the reference's
-// Triangle{mesh, v[3]} + TriangleMesh SoA, triangle.rs:10-22, :92-96).
-struct Geometry {
-    std::vector<V3> P, N, S;
-    std::vector<V2> UV;
-    std::vector<uint32_t> idx;        // 3 per triangle
-    std::vector<uint32_t> tri_mesh;   // mesh id per triangle
-    std::vector<MeshFlags> mesh;
-    size_t n_tris() const { return idx.size() / 3; }
-};
-
 // What SurfaceInteraction carries for the path (surface_interaction.rs:25-57).
 struct SurfHit {
     V3 p, p_error, n, wo;
@@ -50,7 +39,29 @@ struct SurfHit {
     V3 dpdu, dpdv;
     V3 sh_n, sh_dpdu, sh_dpdv;
     Float b0 = 0, b1 = 0, b2 = 0;
-    int32_t prim = -1;
+    int32_t prim = -1;          // index into the scene's primitive list (Geometry::prim_ref)
+};
+
+}  // namespace orc
+#include "orc_sphere.hpp"
+namespace orc {
+
+// Flattened scene geometry: one record per triangle (the reference's
+// Triangle{mesh, v[3]} + TriangleMesh SoA, triangle.rs:10-22, :92-96) plus the spheres.
+// prim_ref lists the scene's primitives in creation order (render_options.primitives,
+// scene_context.rs:1301-1316): a triangle index, or PRIM_SPHERE | sphere index.
+static const uint32_t PRIM_SPHERE = 0x80000000u;
+struct Geometry {
+    std::vector<V3> P, N, S;
+    std::vector<V2> UV;
+    std::vector<uint32_t> idx;        // 3 per triangle
+    std::vector<uint32_t> tri_mesh;   // mesh id per triangle
+    std::vector<MeshFlags> mesh;
+    std::vector<Sphere> spheres;
+    std::vector<uint32_t> prim_ref;   // empty = triangles only, prim == triangle index
+    size_t n_tris() const { return idx.size() / 3; }
+    size_t n_prims() const { return prim_ref.empty() ? n_tris() : prim_ref.size(); }
+    uint32_t ref(size_t prim) const { return prim_ref.empty() ? (uint32_t)prim : prim_ref[prim]; }
 };
 
 struct TriRef {
@@ -255,6 +266,22 @@ struct TriRef {
         return pdf;
     }
 };
+
+// Primitive dispatch (the reference's Arc<dyn Primitive> -> GeometricPrimitive -> dyn Shape chain).
+inline bool prim_intersect(const Geometry* g, size_t prim, const Ray& r, Float* t, SurfHit* si) {
+    uint32_t ref = g->ref(prim);
+    bool hit = (ref & PRIM_SPHERE) ? g->spheres[ref & ~PRIM_SPHERE].intersect(r, t, si) : TriRef(g, ref).intersect(r, t, si);
+    if (hit) si->prim = (int32_t)prim;
+    return hit;
+}
+inline bool prim_intersect_p(const Geometry* g, size_t prim, const Ray& r) {
+    uint32_t ref = g->ref(prim);
+    return (ref & PRIM_SPHERE) ? g->spheres[ref & ~PRIM_SPHERE].intersect_p(r) : TriRef(g, ref).intersect_p(r);
+}
+inline Bounds3 prim_world_bound(const Geometry* g, size_t prim) {
+    uint32_t ref = g->ref(prim);
+    return (ref & PRIM_SPHERE) ? g->spheres[ref & ~PRIM_SPHERE].world_bound() : TriRef(g, ref).world_bound();
+}
 
 // ---------------------------------------------------------------- BVH build
 enum SplitMethod { SPLIT_SAH = 0, SPLIT_HLBVH = 1, SPLIT_MIDDLE = 2, SPLIT_EQUAL = 3 };
@@ -610,11 +637,11 @@ struct QBVH {
     // QBVHAccel::new (qbvh_x86.rs:352-370) + create_bvh_node (build/node.rs:107-151)
     bool build(const Geometry* g, size_t max_prims_in_node, SplitMethod method) {
         geom = g;
-        size_t n = g->n_tris();
+        size_t n = g->n_prims();
         const Float eps = std::numeric_limits<Float>::epsilon() * 2.0f;  // BOUND_EPS node.rs:13
         std::vector<PrimInfo> info(n);
         for (size_t i = 0; i < n; i++) {
-            Bounds3 b = TriRef(g, (uint32_t)i).world_bound();
+            Bounds3 b = prim_world_bound(g, i);
             V3 mn = b.min, mx = b.max;
             mn.x -= eps; mn.y -= eps; mn.z -= eps;
             mx.x += eps; mx.y += eps; mx.z += eps;
@@ -704,7 +731,7 @@ struct QBVH {
                     if (st) st->tris++;
                     Float t;
                     SurfHit si;
-                    if (TriRef(geom, (uint32_t)prims[i]).intersect(r, &t, &si)) {
+                    if (prim_intersect(geom, prims[i], r, &t, &si)) {
                         r.t_max = t;                      // GeometricPrimitive::intersect :41-58
                         *out = si;
                         leaf_hit = true;
@@ -747,7 +774,7 @@ struct QBVH {
                 size_t start = nd.children[0], end = start + nd.children[1];
                 for (size_t i = start; i < end; i++) {
                     if (st) st->tris++;
-                    if (TriRef(geom, (uint32_t)prims[i]).intersect_p(r)) {
+                    if (prim_intersect_p(geom, prims[i], r)) {
                         if (step_log) { step_log->push_back((uint8_t)std::min<size_t>(i - start + 1, 250)); step_log->push_back(255); }
                         return true;
                     }
@@ -761,10 +788,10 @@ struct QBVH {
     // accelerators/exhaustive: brute force over every primitive, used as a cross-check
     bool intersect_exhaustive(const Ray& r, SurfHit* out) const {
         bool hit = false;
-        for (size_t i = 0; i < geom->n_tris(); i++) {
+        for (size_t i = 0; i < geom->n_prims(); i++) {
             Float t;
             SurfHit si;
-            if (TriRef(geom, (uint32_t)i).intersect(r, &t, &si)) { r.t_max = t; *out = si; hit = true; }
+            if (prim_intersect(geom, i, r, &t, &si)) { r.t_max = t; *out = si; hit = true; }
         }
         return hit;
     }

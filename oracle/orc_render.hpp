@@ -109,7 +109,7 @@ struct BSDF {
 };
 
 struct AreaLight {          // lights/diffuse.rs:5-11
-    uint32_t tri;
+    uint32_t shape;         // Geometry::ref encoding: triangle index, or PRIM_SPHERE | sphere index
     RGB lemit;
     bool two_sided;
     Float area;
@@ -120,7 +120,12 @@ struct Scene {
     QBVH bvh;
     std::vector<pt_material> materials;
     std::vector<int32_t> mesh_material, mesh_light_params;
-    std::vector<int32_t> tri_light;     // light index per triangle or -1
+    std::vector<int32_t> sphere_material;
+    std::vector<int32_t> prim_light;    // light index per primitive or -1
+    int32_t prim_material(int32_t prim) const {
+        uint32_t ref = geom.ref((size_t)prim);
+        return (ref & PRIM_SPHERE) ? sphere_material[ref & ~PRIM_SPHERE] : mesh_material[geom.tri_mesh[ref]];
+    }
     std::vector<AreaLight> lights;
     Bounds3 world_bound;
 
@@ -154,9 +159,12 @@ inline RGB light_L(const AreaLight& l, V3 n, V3 w) { return (l.two_sided || dot(
 
 // DiffuseAreaLight::sample_li (diffuse.rs:70-87).  Outputs wi, pdf, the sampled
 // point (p, p_error, n) for the visibility tester.
-inline bool light_sample_li(const Scene& sc, const AreaLight& l, V3 ref_p, V2 u, RGB* li, V3* wi, Float* pdf, V3* lp, V3* lperr, V3* ln) {
-    TriRef tri(&sc.geom, l.tri);
-    if (!tri.sample_from(ref_p, u, lp, ln, lperr, pdf)) return false;
+inline bool light_sample_li(const Scene& sc, const AreaLight& l, V3 ref_p, V3 ref_p_error, V3 ref_n, V2 u, RGB* li, V3* wi, Float* pdf, V3* lp, V3* lperr, V3* ln) {
+    if (l.shape & PRIM_SPHERE) {
+        if (!sc.geom.spheres[l.shape & ~PRIM_SPHERE].sample_from(ref_p, ref_p_error, ref_n, u, lp, ln, lperr, pdf)) return false;
+    } else {
+        if (!TriRef(&sc.geom, l.shape).sample_from(ref_p, u, lp, ln, lperr, pdf)) return false;
+    }
     if (*pdf <= 0.0f || length_squared(*lp - ref_p) <= 0.0f) return false;
     *wi = normalize(*lp - ref_p);
     *li = light_L(l, *ln, -*wi);
@@ -224,7 +232,7 @@ struct LightDistribution {
             V2 u(radical_inverse(3, i), radical_inverse(4, i));
             for (size_t j = 0; j < lsz; j++) {
                 RGB li; V3 wi, lp, le, ln; Float pdf;
-                if (light_sample_li(*sc, sc->lights[j], po, u, &li, &wi, &pdf, &lp, &le, &ln))
+                if (light_sample_li(*sc, sc->lights[j], po, V3(0.0f, 0.0f, 0.0f), V3(0.0f, 0.0f, 0.0f), u, &li, &wi, &pdf, &lp, &le, &ln))
                     if (pdf > 0.0f) contrib[j] += li.y() / pdf;
             }
         }
@@ -403,14 +411,14 @@ inline bool make_bsdf_from_material(const pt_material& m, const SurfHit& si, BSD
     return false;
 }
 inline bool make_bsdf(const Scene& sc, const SurfHit& si, BSDF* b) {
-    int32_t mid = sc.mesh_material[sc.geom.tri_mesh[si.prim]];
+    int32_t mid = sc.prim_material(si.prim);
     if (mid < 0) return false;
     return make_bsdf_from_material(sc.materials[mid], si, b);
 }
 
 // SurfaceInteraction::le (surface_interaction.rs:297-306)
 inline RGB surf_le(const Scene& sc, const SurfHit& si, V3 w) {
-    int32_t li = sc.tri_light[si.prim];
+    int32_t li = sc.prim_light[si.prim];
     if (li < 0) return RGB();
     return light_L(sc.lights[li], si.n, w);
 }
@@ -432,7 +440,7 @@ inline RGB uniform_sample_one_light(const Scene& sc, const SurfHit& it, const BS
     // -- sample the light
     {
         RGB li; V3 wi, lp, lperr, ln; Float lpdf;
-        if (light_sample_li(sc, light, it.p, u_light, &li, &wi, &lpdf, &lp, &lperr, &ln)) {
+        if (light_sample_li(sc, light, it.p, it.p_error, it.n, u_light, &li, &wi, &lpdf, &lp, &lperr, &ln)) {
             if (lpdf > 0.0f && !li.is_black()) {
                 RGB f = bsdf.f(it.wo, wi, bsdf_flags) * abs_dot(wi, it.sh_n);
                 Float scattering_pdf = bsdf.pdf(it.wo, wi, bsdf_flags);
@@ -469,7 +477,8 @@ inline RGB uniform_sample_one_light(const Scene& sc, const SurfHit& it, const BS
             Float weight = 1.0f;
             bool skip = false;
             if (!sampled_specular) {
-                Float lpdf = TriRef(&sc.geom, light.tri).pdf_from(it.p, it.p_error, it.n, wi);   // pdf_li, diffuse.rs:89-94
+                Float lpdf = (light.shape & PRIM_SPHERE) ? sc.geom.spheres[light.shape & ~PRIM_SPHERE].pdf_from(it.p, it.p_error, it.n, wi)
+                                                         : TriRef(&sc.geom, light.shape).pdf_from(it.p, it.p_error, it.n, wi);   // pdf_li, diffuse.rs:89-94
                 if (lpdf == 0.0f) skip = true;     // `return ld`
                 else weight = power_heuristic(1, scattering_pdf, 1, lpdf);
             }
@@ -482,7 +491,7 @@ inline RGB uniform_sample_one_light(const Scene& sc, const SurfHit& it, const BS
                 rc.nodes += st.nodes; rc.tris += st.tris;
                 RGB li;
                 if (found) {
-                    if (sc.tri_light[lh.prim] == (int32_t)light_num) li = surf_le(sc, lh, -wi);
+                    if (sc.prim_light[lh.prim] == (int32_t)light_num) li = surf_le(sc, lh, -wi);
                 }   // else light.le(ray): zero for area lights (light.rs:33-35)
                 if (!li.is_black()) ld += f * li * (weight / scattering_pdf);
             }
@@ -737,17 +746,37 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
         mesh_light_params[i] = d.meshes[i].area_light;
     }
     materials.assign(d.materials, d.materials + d.n_materials);
-    // one DiffuseAreaLight per emissive triangle, in primitive order (scene_context.rs:1218-1231)
-    tri_light.assign(d.n_triangles, -1);
-    for (uint32_t t = 0; t < d.n_triangles; t++) {
-        int32_t lp = mesh_light_params[geom.tri_mesh[t]];
+    // spheres, spliced into the primitive list at before_triangle
+    if (d.n_spheres > 0) {
+        geom.spheres.resize(d.n_spheres);
+        sphere_material.resize(d.n_spheres);
+        uint32_t s = 0;
+        for (uint32_t t = 0; t <= d.n_triangles; t++) {
+            while (s < d.n_spheres && d.spheres[s].before_triangle <= t) {
+                if (d.spheres[s].before_triangle < t) { if (err) *err = "spheres[] must be ordered by before_triangle"; return false; }
+                const pt_sphere& ps = d.spheres[s];
+                geom.spheres[s].init(ps.object_to_world, ps.world_to_object, (ps.flags & PT_SPHERE_REVERSE_ORIENTATION) != 0, ps.radius, ps.zmin,
+                                     ps.zmax, ps.phimax);
+                sphere_material[s] = ps.material;
+                geom.prim_ref.push_back(PRIM_SPHERE | s);
+                s++;
+            }
+            if (t < d.n_triangles) geom.prim_ref.push_back(t);
+        }
+        if (s != d.n_spheres) { if (err) *err = "sphere before_triangle exceeds n_triangles"; return false; }
+    }
+    // one DiffuseAreaLight per emissive primitive, in primitive order (scene_context.rs:1218-1231)
+    prim_light.assign(geom.n_prims(), -1);
+    for (size_t p = 0; p < geom.n_prims(); p++) {
+        uint32_t ref = geom.ref(p);
+        int32_t lp = (ref & PRIM_SPHERE) ? d.spheres[ref & ~PRIM_SPHERE].area_light : mesh_light_params[geom.tri_mesh[ref]];
         if (lp >= 0) {
             AreaLight al;
-            al.tri = t;
+            al.shape = ref;
             al.lemit = RGB(d.area_lights[lp].L[0], d.area_lights[lp].L[1], d.area_lights[lp].L[2]);
             al.two_sided = d.area_lights[lp].two_sided != 0;
-            al.area = TriRef(&geom, t).area();
-            tri_light[t] = (int32_t)lights.size();
+            al.area = (ref & PRIM_SPHERE) ? geom.spheres[ref & ~PRIM_SPHERE].area() : TriRef(&geom, ref).area();
+            prim_light[p] = (int32_t)lights.size();
             lights.push_back(al);
         }
     }

@@ -45,6 +45,16 @@ class pt_mesh(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("material", C.c_int32), ("area_light", C.c_int32), ("reserved", C.c_uint32)]
 
 
+class pt_sphere(C.Structure):
+    _fields_ = [("object_to_world", C.c_float * 16), ("world_to_object", C.c_float * 16),
+                ("radius", C.c_float), ("zmin", C.c_float), ("zmax", C.c_float), ("phimax", C.c_float),
+                ("flags", C.c_uint32), ("material", C.c_int32), ("area_light", C.c_int32),
+                ("before_triangle", C.c_uint32)]
+
+
+PT_SPHERE_REVERSE_ORIENTATION = 1
+
+
 class pt_scene_desc(C.Structure):
     _fields_ = [
         ("n_vertices", C.c_uint32), ("P", C.POINTER(C.c_float)), ("N", C.POINTER(C.c_float)),
@@ -62,7 +72,8 @@ class pt_scene_desc(C.Structure):
         ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
         ("sampler", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
         ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
-        ("halton_sample_at_center", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("halton_sample_at_center", C.c_int32),
+        ("n_spheres", C.c_uint32), ("spheres", C.POINTER(pt_sphere)), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -223,7 +234,7 @@ def parse_to_log(text, lib=None):
 def bvh_leaf_order(scene, lib=None):
     """Host-only BVH build (no GPU): returns (order, n_nodes, n_leaves, max_stack)."""
     lib = lib or load_library()
-    order = np.empty(scene.desc.n_triangles, np.uint32)
+    order = np.empty(scene.desc.n_triangles + scene.desc.n_spheres, np.uint32)
     nn, nl, ms = C.c_uint32(), C.c_uint32(), C.c_uint32()
     st = lib.pt_bvh_leaf_order(C.byref(scene.desc), _ptr(order), C.byref(nn), C.byref(nl), C.byref(ms))
     if st != 0:

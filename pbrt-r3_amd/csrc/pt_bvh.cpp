@@ -392,19 +392,36 @@ struct Collapser {
 
 }  // namespace
 
-bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, int split_method, int max_node_prims,
-           Result* out) {
+bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, const SpherePrim* spheres, uint32_t n_spheres,
+           int split_method, int max_node_prims, Result* out) {
     out->nodes.clear(); out->tris.clear(); out->rec_of_prim.clear();
     out->n_leaves = 0; out->max_stack = 1;
-    if (n_tris == 0) { out->root_ref = PT_EMPTY_REF; return true; }
-    if (n_tris >= PT_LEAF_FIRST_MASK - 16u) return false;      // a leaf reference keeps 28 bits for the first record
-    std::vector<Item> items(n_tris), scratch(n_tris);
+    const uint64_t n_prims64 = (uint64_t)n_tris + n_spheres;
+    if (n_prims64 == 0) { out->root_ref = PT_EMPTY_REF; return true; }
+    if (n_prims64 >= PT_LEAF_FIRST_MASK - 16u) return false;      // a leaf reference keeps 28 bits for the first record
+    const uint32_t n_prims = (uint32_t)n_prims64;
+    std::vector<Item> items(n_prims), scratch(n_prims);
+    // primitive -> triangle index, or 0x80000000 | sphere index
+    std::vector<uint32_t> ref(n_spheres ? n_prims : 0);
     const float eps = std::numeric_limits<float>::epsilon() * 2.0f;   // BOUND_EPS (build/node.rs:13)
-    for (uint32_t t = 0; t < n_tris; t++) {
+    uint32_t si = 0, pi = 0;
+    for (uint32_t t = 0; t <= n_tris; t++) {
+        while (si < n_spheres && spheres[si].before_triangle <= t) {
+            if (spheres[si].before_triangle < t) return false;        // not ordered
+            Item& it = items[pi];
+            for (int i = 0; i < 3; i++) {
+                it.lo[i] = spheres[si].lo[i] - eps;
+                it.hi[i] = spheres[si].hi[i] + eps;
+                it.c[i] = (it.lo[i] + it.hi[i]) * 0.5f;
+            }
+            it.prim = pi;
+            ref[pi++] = 0x80000000u | si++;
+        }
+        if (t == n_tris) break;
         const float* p0 = P + 3 * (size_t)indices[3 * (size_t)t];
         const float* p1 = P + 3 * (size_t)indices[3 * (size_t)t + 1];
         const float* p2 = P + 3 * (size_t)indices[3 * (size_t)t + 2];
-        Item& it = items[t];
+        Item& it = items[pi];
         for (int i = 0; i < 3; i++) {
             float lo = std::fmin(std::fmin(p0[i], p1[i]), p2[i]);   // union3 (triangle.rs:189-200)
             float hi = std::fmax(std::fmax(p0[i], p1[i]), p2[i]);
@@ -412,8 +429,12 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
             it.hi[i] = hi + eps;
             it.c[i] = (it.lo[i] + it.hi[i]) * 0.5f;
         }
-        it.prim = t;
+        it.prim = pi;
+        if (n_spheres) ref[pi] = t;
+        pi++;
     }
+    if (si != n_spheres) return false;                                // before_triangle > n_tris
+    const uint32_t n_items = n_prims;
     Builder bld;
     bld.items = items.data();
     bld.scratch = scratch.data();
@@ -421,7 +442,7 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
     bld.method = split_method;
     bld.par_threshold = 32768;
     std::vector<BNode> tree;
-    tree.reserve((size_t)n_tris);
+    tree.reserve((size_t)n_items);
     int32_t root = 0;
     if (split_method == PT_SPLIT_HLBVH) {
         std::vector<uint32_t> code;
@@ -429,8 +450,8 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
         Hlbvh h{items.data(), code.data(), bld.max_prims, tree};
         std::vector<int32_t> treelets;
         const uint32_t top12 = 0x3ffc0000u;
-        for (size_t start = 0, end = 1; end <= n_tris; end++) {
-            if (end == n_tris || (code[start] & top12) != (code[end] & top12)) {
+        for (size_t start = 0, end = 1; end <= n_items; end++) {
+            if (end == n_items || (code[start] & top12) != (code[end] & top12)) {
                 treelets.push_back(h.emit(start, end, 29 - 12));
                 start = end;
             }
@@ -438,24 +459,34 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
         root = h.upper(treelets);
         if (h.failed || root < 0) return false;
     } else {
-        bld.build(tree, 0, n_tris, 0);
+        bld.build(tree, 0, n_items, 0);
     }
 
     std::memcpy(out->root_lo, tree[root].lo, 12);
     std::memcpy(out->root_hi, tree[root].hi, 12);
     // triangle records in final item order; PT_TRI_LAST closes each leaf
-    out->tris.resize(n_tris);
-    out->rec_of_prim.resize(n_tris);
-    for (uint32_t r = 0; r < n_tris; r++) {
-        uint32_t t = items[r].prim;
+    out->tris.resize(n_items);
+    out->rec_of_prim.resize(n_items);
+    for (uint32_t r = 0; r < n_items; r++) {
+        const uint32_t prim = items[r].prim;
+        uint32_t t = n_spheres ? ref[prim] : prim;
         PtTri& tr = out->tris[r];
+        if (t & 0x80000000u) {                 // sphere: the record carries its index instead of vertices
+            const uint32_t sidx = t & 0x7fffffffu;
+            std::memset(&tr, 0, sizeof(tr));
+            std::memcpy(&tr.p0[0], &sidx, 4);
+            tr.prim = prim;
+            tr.flags = (spheres[sidx].flags | PT_TRI_SPHERE) & ~PT_TRI_LAST;
+            out->rec_of_prim[prim] = r;
+            continue;
+        }
         std::memcpy(tr.p0, P + 3 * (size_t)indices[3 * (size_t)t], 12);
         std::memcpy(tr.p1, P + 3 * (size_t)indices[3 * (size_t)t + 1], 12);
         std::memcpy(tr.p2, P + 3 * (size_t)indices[3 * (size_t)t + 2], 12);
-        tr.prim = t;
-        tr.flags = tri_flags[t] & ~PT_TRI_LAST;
+        tr.prim = prim;
+        tr.flags = tri_flags[t] & ~(PT_TRI_LAST | PT_TRI_SPHERE);
         tr.light1 = 0;            // filled by the caller once lights are numbered
-        out->rec_of_prim[t] = r;
+        out->rec_of_prim[prim] = r;
     }
     {   // one zero pad record: the kernels fetch triangle records two at a time
         PtTri pad;

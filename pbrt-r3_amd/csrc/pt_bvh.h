@@ -11,7 +11,7 @@ namespace ptbvh {
 struct Result {
     std::vector<PtNode> nodes;          // 4-wide interior nodes, root first
     std::vector<PtTri> tris;            // triangle records in leaf order + one zero pad record
-    std::vector<uint32_t> rec_of_prim;  // caller's triangle index -> record index
+    std::vector<uint32_t> rec_of_prim;  // primitive index -> record index
     uint32_t root_ref = PT_EMPTY_REF;
     uint32_t max_leaf = 0;             // most triangles in one leaf
     uint32_t n_leaves = 0;
@@ -21,7 +21,11 @@ struct Result {
 
 // tri_flags[t]: PT_TRI_ONE_SIDED / PT_TRI_FLIP / PT_TRI_HAS_ATTR bits and the material field of triangle t.  Returns false for an
 // unsupported split method.
-bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, int split_method, int max_node_prims,
-           Result* out);
+// spheres[]: analytic primitives spliced into the primitive list before triangle `before_triangle` (non-decreasing); lo / hi is
+// Sphere::world_bound, flags the record flags (PT_TRI_SPHERE | material field).  Primitive numbering (PtTri::prim, rec_of_prim) is the
+// merged list; with no spheres it is the triangle index.
+struct SpherePrim { float lo[3], hi[3]; uint32_t flags; uint32_t before_triangle; };
+bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, const SpherePrim* spheres, uint32_t n_spheres,
+           int split_method, int max_node_prims, Result* out);
 
 }  // namespace ptbvh

@@ -60,7 +60,7 @@ struct pt_context {
     bool have_scene = false;
     PtScene sc;
     pt_scene_info info;
-    DevBuf d_nodes, d_tris, d_tri_info, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab, d_hdims, d_hperms;
+    DevBuf d_nodes, d_tris, d_tri_info, d_spheres, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab, d_hdims, d_hperms;
     std::vector<uint32_t> sobol_m32;
     std::vector<uint64_t> sobol_vdc, sobol_inv;
     uint32_t sobol_n_vdc = 0, sobol_n_inv = 0, sobol_msize = 52;
@@ -455,6 +455,44 @@ pt_status setup_halton(pt_context* ctx, PtSobol& sb, int32_t res_x, int32_t res_
     sb.h_mul[1] = (uint32_t)((stride / scale[1]) * (int32_t)mod_inverse(scale[0], scale[1]));
     return PT_OK;
 }
+// Sphere::new + world_bound (sphere.rs:18-59, transform.rs:134-182): device records and BVH build items
+static void build_spheres(const pt_scene_desc* d, std::vector<PtSphere>& sph, std::vector<ptbvh::SpherePrim>& sprims) {
+    sph.assign(d->n_spheres, PtSphere());
+    sprims.assign(d->n_spheres, ptbvh::SpherePrim());
+    for (uint32_t i = 0; i < d->n_spheres; i++) {
+        const pt_sphere& in = d->spheres[i];
+        PtSphere& s = sph[i];
+        std::memset(&s, 0, sizeof(s));
+        std::memcpy(s.o2w, in.object_to_world, 48);
+        std::memcpy(s.w2o, in.world_to_object, 48);
+        const float* m = in.object_to_world;
+        const float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+        const bool swaps = det < 0.0f, reverse = (in.flags & PT_SPHERE_REVERSE_ORIENTATION) != 0;
+        auto clampf = [](float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); };
+        s.radius = in.radius;
+        s.z_min = clampf(std::fmin(in.zmin, in.zmax), -in.radius, in.radius);
+        s.z_max = clampf(std::fmax(s.z_min, in.zmax), -in.radius, in.radius);        // as written (sphere.rs:28)
+        s.theta_min = std::acos(clampf(s.z_min / in.radius, -1.0f, 1.0f));
+        s.theta_max = std::acos(clampf(s.z_max / in.radius, -1.0f, 1.0f));
+        s.phi_max = clampf(in.phimax, 0.0f, 360.0f) * (3.14159265358979323846f / 180.0f);
+        s.area = s.phi_max * s.radius * (s.z_max - s.z_min);
+        s.flags = (reverse ? PT_SPH_REVERSE : 0u) | ((reverse ^ swaps) ? PT_SPH_FLIP : 0u);
+        const float r = s.radius * 1.001f, diff = r - s.radius;
+        const float lo[3] = {-r, -r, s.z_min - diff}, hi[3] = {r, r, s.z_max + diff};
+        ptbvh::SpherePrim& sp = sprims[i];
+        for (int c = 0; c < 8; c++) {
+            const float x = (c & 4) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 1) ? hi[2] : lo[2];
+            const float q[3] = {m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]};
+            for (int k = 0; k < 3; k++) {
+                sp.lo[k] = c == 0 ? q[k] : std::fmin(sp.lo[k], q[k]);
+                sp.hi[k] = c == 0 ? q[k] : std::fmax(sp.hi[k], q[k]);
+            }
+        }
+        sp.before_triangle = in.before_triangle;
+        sp.flags = PT_TRI_SPHERE;
+        if (in.material >= 0 && d->materials && d->materials[in.material].type != PT_MATERIAL_NONE) sp.flags |= (uint32_t)(in.material + 1) << PT_TRI_MATERIAL_SHIFT;
+    }
+}
 }  // namespace
 
 pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
@@ -462,7 +500,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     (void)hipSetDevice(ctx->device);
     ctx->have_scene = false;
     // ---- validation (the kernels index these arrays unchecked)
-    if (d->n_triangles == 0 || !d->P || !d->indices || !d->tri_mesh || !d->meshes) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no triangles");
+    if (d->n_triangles == 0 && d->n_spheres == 0) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no primitives");
+    if (d->n_triangles > 0 && (!d->P || !d->indices || !d->tri_mesh || !d->meshes)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "triangle arrays missing");
+    if (d->n_spheres > 0 && !d->spheres) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "spheres array missing");
     if (d->xres <= 0 || d->yres <= 0 || d->spp <= 0 || d->max_depth < 0 || d->max_depth > 250) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "bad film / sampler / integrator parameters");
     if (d->sampler != PT_SAMPLER_SOBOL && d->sampler != PT_SAMPLER_HALTON)
         return ctx->fail(PT_ERR_UNSUPPORTED, "sampler not on the accelerated path: only the index-addressed samplers (sobol, halton) are reproducible on a wavefront");
@@ -480,6 +520,21 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (mi >= 0 && (d->materials[mi].type < PT_MATERIAL_NONE || d->materials[mi].type > PT_MATERIAL_SUBSTRATE))
             return ctx->fail(PT_ERR_UNSUPPORTED, "material type not on the accelerated path");
     }
+    for (uint32_t i = 0; i < d->n_spheres; i++) {
+        const pt_sphere& sp = d->spheres[i];
+        if (sp.material >= (int32_t)d->n_materials || sp.material >= 65535) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "sphere material index out of range");
+        if (sp.area_light >= (int32_t)d->n_area_lights) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "sphere area light index out of range");
+        if (sp.material >= 0 && (d->materials[sp.material].type < PT_MATERIAL_NONE || d->materials[sp.material].type > PT_MATERIAL_SUBSTRATE))
+            return ctx->fail(PT_ERR_UNSUPPORTED, "material type not on the accelerated path");
+        if (sp.before_triangle > d->n_triangles || (i > 0 && sp.before_triangle < d->spheres[i - 1].before_triangle))
+            return ctx->fail(PT_ERR_INVALID_ARGUMENT, "spheres[] must be ordered by before_triangle <= n_triangles");
+        if (!(sp.radius > 0.0f)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "sphere radius must be positive");
+        for (int k = 0; k < 2; k++) {
+            const float* m = k ? sp.world_to_object : sp.object_to_world;
+            if (m[12] != 0.0f || m[13] != 0.0f || m[14] != 0.0f || m[15] != 1.0f)
+                return ctx->fail(PT_ERR_UNSUPPORTED, "sphere under a projective transform (last matrix row must be 0 0 0 1)");
+        }
+    }
     if (ctx->sobol_m32.empty() && !load_sobol(ctx)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "cannot read sobol_tables.bin from data dir '" + ctx->data_dir + "'");
 
     double t0 = now_ms();
@@ -494,18 +549,45 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (mat >= 0 && d->materials[mat].type != PT_MATERIAL_NONE) f |= (uint32_t)(mat + 1) << PT_TRI_MATERIAL_SHIFT;
         tri_flags[t] = f;
     }
+    std::vector<PtSphere> sph;
+    std::vector<ptbvh::SpherePrim> sprims;
+    build_spheres(d, sph, sprims);
     ptbvh::Result bvh;
-    if (!ptbvh::build(d->P, d->indices, tri_flags.data(), d->n_triangles, d->split_method, d->max_node_prims > 0 ? d->max_node_prims : 4, &bvh))
-        return ctx->fail(PT_ERR_INVALID_ARGUMENT, d->n_triangles >= PT_LEAF_FIRST_MASK - 16u ? "more than 2^28 triangles" : "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)");
+    if (!ptbvh::build(d->P, d->indices, tri_flags.data(), d->n_triangles, sprims.data(), d->n_spheres, d->split_method,
+                      d->max_node_prims > 0 ? d->max_node_prims : 4, &bvh))
+        return ctx->fail(PT_ERR_INVALID_ARGUMENT, (uint64_t)d->n_triangles + d->n_spheres >= PT_LEAF_FIRST_MASK - 16u ? "more than 2^28 primitives" : "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)");
     double t1 = now_ms();
     ctx->max_stack = bvh.max_stack;
 
     // ---- shading records ----------------------------------------------------
-    std::vector<PtTriInfo> tinfo(d->n_triangles);
+    const uint32_t n_prims = d->n_triangles + d->n_spheres;
+    std::vector<PtTriInfo> tinfo(n_prims);      // indexed by primitive (sphere entries unused)
     std::vector<PtLight> lights;
-    for (uint32_t t = 0; t < d->n_triangles; t++) {
+    for (uint32_t prim = 0, t = 0, si = 0; prim < n_prims; prim++) {
+        if (si < d->n_spheres && d->spheres[si].before_triangle <= t) {       // a sphere sits here in the primitive list
+            const pt_sphere& in = d->spheres[si];
+            std::memset(&tinfo[prim], 0, sizeof(PtTriInfo));
+            tinfo[prim].light = -1; tinfo[prim].material = in.material;
+            if (in.area_light >= 0) {       // one DiffuseAreaLight for the sphere (scene_context.rs:1218-1231)
+                const pt_area_light& al = d->area_lights[in.area_light];
+                PtLight L;
+                std::memset(&L, 0, sizeof(L));
+                std::memcpy(&L.p0[0], &si, 4);
+                L.area = sph[si].area;
+                L.mesh_flags = PT_LIGHT_SPHERE;
+                L.two_sided = al.two_sided;
+                std::memcpy(L.L, al.L, 12);
+                L.tri_rec = bvh.rec_of_prim[prim];
+                L.prim = prim;
+                tinfo[prim].light = (int32_t)lights.size();
+                bvh.tris[bvh.rec_of_prim[prim]].light1 = (uint32_t)lights.size() + 1u;
+                lights.push_back(L);
+            }
+            si++;
+            continue;
+        }
         const pt_mesh& m = d->meshes[d->tri_mesh[t]];
-        PtTriInfo& ti = tinfo[t];
+        PtTriInfo& ti = tinfo[prim];
         ti.v[0] = d->indices[3 * (size_t)t]; ti.v[1] = d->indices[3 * (size_t)t + 1]; ti.v[2] = d->indices[3 * (size_t)t + 2];
         ti.mesh = d->tri_mesh[t];
         ti.material = m.material;
@@ -530,17 +612,18 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             L.mesh_flags = mf;
             L.two_sided = al.two_sided;
             std::memcpy(L.L, al.L, 12);
-            L.tri_rec = bvh.rec_of_prim[t];
-            L.prim = t;
+            L.tri_rec = bvh.rec_of_prim[prim];
+            L.prim = prim;
             if (mf & PT_MESH_HAS_N) {
                 std::memcpy(L.n0, d->N + 3 * (size_t)ti.v[0], 12); std::memcpy(L.n1, d->N + 3 * (size_t)ti.v[1], 12); std::memcpy(L.n2, d->N + 3 * (size_t)ti.v[2], 12);
             }
             ti.light = (int32_t)lights.size();
-            bvh.tris[bvh.rec_of_prim[t]].light1 = (uint32_t)lights.size() + 1u;
+            bvh.tris[bvh.rec_of_prim[prim]].light1 = (uint32_t)lights.size() + 1u;
             lights.push_back(L);
         }
+        t++;
     }
-    if (lights.size() >= (1u << 24)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^24 emissive triangles");
+    if (lights.size() >= (1u << 24)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^24 emissive primitives");
     std::vector<PtMaterial> mats(std::max<uint32_t>(d->n_materials, 1));
     std::memset(mats.data(), 0, mats.size() * sizeof(PtMaterial));
     bool general_materials = false;
@@ -562,6 +645,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if ((st = upload(ctx, ctx->d_tri_info, tinfo.data(), tinfo.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_materials, mats.data(), mats.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_lights, lights.data(), lights.size())) != PT_OK) return st;
+    if (d->n_spheres) { if ((st = upload(ctx, ctx->d_spheres, sph.data(), sph.size())) != PT_OK) return st; } else ctx->d_spheres.release();
     if (d->N) { if ((st = upload(ctx, ctx->d_N, d->N, 3 * (size_t)d->n_vertices)) != PT_OK) return st; } else ctx->d_N.release();
     if (d->S) { if ((st = upload(ctx, ctx->d_S, d->S, 3 * (size_t)d->n_vertices)) != PT_OK) return st; } else ctx->d_S.release();
     if (d->UV) { if ((st = upload(ctx, ctx->d_UV, d->UV, 2 * (size_t)d->n_vertices)) != PT_OK) return st; } else ctx->d_UV.release();
@@ -579,6 +663,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     ctx->n_materials = d->n_materials;
     sc.lights = ctx->d_lights.as<PtLight>();
     sc.n_lights = (uint32_t)lights.size();
+    sc.spheres = d->n_spheres ? ctx->d_spheres.as<PtSphere>() : nullptr;
+    sc.n_spheres = d->n_spheres;
+    if (d->n_spheres) { sc.dist_leaves = 0; sc.general_materials = 1; }     // sphere scenes run the sphere-capable kernel instantiations
     sc.root_ref = bvh.root_ref;
     std::memcpy(sc.wb_min, bvh.root_lo, 12);
     std::memcpy(sc.wb_max, bvh.root_hi, 12);
@@ -1113,12 +1200,19 @@ pt_status pt_radiance_samples(pt_context* ctx, const pt_tile* tile, float* out_r
 }
 
 pt_status pt_bvh_leaf_order(const pt_scene_desc* d, uint32_t* order_out, uint32_t* n_nodes, uint32_t* n_leaves, uint32_t* max_stack) {
-    if (!d || !order_out || !d->P || !d->indices || !d->tri_mesh || !d->meshes || d->n_triangles == 0) return PT_ERR_INVALID_ARGUMENT;
+    if (!d || !order_out || (d->n_triangles == 0 && d->n_spheres == 0)) return PT_ERR_INVALID_ARGUMENT;
+    if (d->n_triangles > 0 && (!d->P || !d->indices || !d->tri_mesh || !d->meshes)) return PT_ERR_INVALID_ARGUMENT;
+    if (d->n_spheres > 0 && !d->spheres) return PT_ERR_INVALID_ARGUMENT;
     std::vector<uint32_t> tri_flags(d->n_triangles, 0);
+    std::vector<PtSphere> sph;
+    std::vector<ptbvh::SpherePrim> sprims;
+    build_spheres(d, sph, sprims);
+    for (ptbvh::SpherePrim& sp : sprims) sp.flags = PT_TRI_SPHERE;
     ptbvh::Result bvh;
-    if (!ptbvh::build(d->P, d->indices, tri_flags.data(), d->n_triangles, d->split_method, d->max_node_prims > 0 ? d->max_node_prims : 4, &bvh))
+    if (!ptbvh::build(d->P, d->indices, tri_flags.data(), d->n_triangles, sprims.data(), d->n_spheres, d->split_method,
+                      d->max_node_prims > 0 ? d->max_node_prims : 4, &bvh))
         return PT_ERR_UNSUPPORTED;
-    for (uint32_t r = 0; r < d->n_triangles; r++) order_out[r] = bvh.tris[r].prim;
+    for (uint32_t r = 0; r < d->n_triangles + d->n_spheres; r++) order_out[r] = bvh.tris[r].prim;
     if (n_nodes) *n_nodes = (uint32_t)bvh.nodes.size();
     if (n_leaves) *n_leaves = bvh.n_leaves;
     if (max_stack) *max_stack = bvh.max_stack;

@@ -32,6 +32,7 @@ struct PtNode {
 #define PT_TRI_ONE_SIDED 2u      // !two_sided: cull when dot(n, d) >= 0 (triangle.rs:247-251)
 #define PT_TRI_FLIP 4u           // reverse_orientation ^ swaps_handedness
 #define PT_TRI_HAS_ATTR 8u       // mesh carries N / S / UV: shading must also read PtTriInfo
+#define PT_TRI_SPHERE 16u        // the record stands for a sphere: p0[0] holds its index into PtScene::spheres (as bits)
 #define PT_TRI_MATERIAL_SHIFT 16 // bits 16..31: material index + 1 (0 = no material)
 struct PtTri {
     float p0[3];
@@ -95,6 +96,19 @@ struct PtLight {
     float n1[3]; uint32_t pad0;
     float n2[3]; uint32_t pad1;
 };
+
+// Sphere (shapes/sphere.rs:7-41), affine transforms only.
+#define PT_SPH_REVERSE 1u        // reverse_orientation: flips sampled normals (sphere.rs:293-295, :380-382)
+#define PT_SPH_FLIP 2u           // reverse_orientation ^ transform_swaps_handedness: flips the intersection normal
+struct PtSphere {                // 144 bytes
+    float o2w[12];               // rows 0..2 of object_to_world.m
+    float w2o[12];               // rows 0..2 of object_to_world.m_inv
+    float radius, z_min, z_max, phi_max;
+    float theta_min, theta_max, area;
+    uint32_t flags;
+    uint32_t pad[4];
+};
+#define PT_LIGHT_SPHERE 0x80000000u   // PtLight::mesh_flags: the light's shape is sphere number bits(p0[0])
 
 struct PtCamera {
     float raster_to_camera[16];
@@ -164,6 +178,8 @@ struct PtScene {
     const float* N; const float* S; const float* UV;     // per-vertex attributes or null
     const PtMaterial* materials;
     const PtLight* lights;
+    const PtSphere* spheres;
+    uint32_t n_spheres;          // > 0: the sphere-capable kernel instantiations run
     uint32_t n_lights;
     uint32_t root_ref;           // node 0, or a leaf reference when the whole scene is one leaf
     float wb_min[3], wb_max[3];  // BVH root bounds (Scene::world_bound)

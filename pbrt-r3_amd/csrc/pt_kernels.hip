@@ -19,6 +19,7 @@
 #include "pt_device.h"
 #include "pt_device_math.h"
 #include "pt_bxdf.h"
+#include "pt_sphere.h"
 #include "pt_kernels.h"
 #include "../../include/pbrtgpu.h"
 
@@ -415,6 +416,7 @@ PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t
 // a node visit or a leaf visit.
 struct LaneRay {
     V3 o, idir;
+    V3 d;                        // read by the sphere test only: dead in the triangle-only kernels
     RayPre rp;
     float tmin, tmax, ray_tmax;
     uint32_t sbits;              // bits 0-2: direction signs, bit 3: needs the EXACT slab form
@@ -423,6 +425,7 @@ struct LaneRay {
 };
 PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max) {
     r.o = o;
+    r.d = d;
     r.idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     r.sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
     if (!(fabsf(r.idir.x) < PT_INF) || !(fabsf(r.idir.y) < PT_INF) || !(fabsf(r.idir.z) < PT_INF)) r.sbits |= 8u;
@@ -446,6 +449,21 @@ PT_DEV void ray_step_node(const PtScene& sc, LaneRay& r, TravCtx& c) {
 // One leaf (entering it from the top of the stack): its 1..max_node_prims triangle records are
 // fetched two per round trip and tested in order.  any_hit: stop at the first accepted triangle
 // (sets best, empties the stack).
+// A leaf record that stands for a sphere (SPH kernels only): Sphere::intersect / intersect_p, t from its EFloat root.
+PT_DEV bool sphere_rec_test(const PtScene& sc, const TriVerts& tv, const LaneRay& r, bool any_hit, float* t) {
+    SphHit sh;
+    if (!sph_hit_test(sc.spheres[__float_as_uint(tv.p0.x)], r.o, r.d, r.ray_tmax, any_hit ? 2.0f * PT_PI : PT_PI, &sh)) return false;
+    *t = sh.t;
+    return true;
+}
+template <bool SPH>
+PT_DEV bool prim_test(const PtScene& sc, const TriVerts& tv, const LaneRay& r, bool any_hit, TriHit& h) {
+    if constexpr (SPH) {
+        if (tv.flags & PT_TRI_SPHERE) return sphere_rec_test(sc, tv, r, any_hit, &h.t);
+    }
+    return tri_test(r.rp, tv.p0, tv.p1, tv.p2, tv.flags, r.ray_tmax, h);
+}
+template <bool SPH>
 PT_DEV void ray_step_tri(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
     uint32_t rec = stk_pop(c, r.top, r.sp) & PT_LEAF_FIRST_MASK;
     bool leaf_hit = false;
@@ -453,14 +471,14 @@ PT_DEV void ray_step_tri(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c
         TriVerts t0 = load_tri(sc.tris, rec), t1 = load_tri(sc.tris, rec + 1);   // array is padded by one record
         TriHit h;
         c.n_tris++;
-        if (tri_test(r.rp, t0.p0, t0.p1, t0.p2, t0.flags, r.ray_tmax, h)) {
+        if (prim_test<SPH>(sc, t0, r, any_hit, h)) {
             r.best = (int32_t)rec; leaf_hit = true;
             if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; return; }
             r.ray_tmax = h.t;                           // GeometricPrimitive::intersect: r.t_max = t_hit
         }
         if (t0.flags & PT_TRI_LAST) break;
         c.n_tris++;
-        if (tri_test(r.rp, t1.p0, t1.p1, t1.p2, t1.flags, r.ray_tmax, h)) {
+        if (prim_test<SPH>(sc, t1, r, any_hit, h)) {
             r.best = (int32_t)(rec + 1); leaf_hit = true;
             if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; return; }
             r.ray_tmax = h.t;
@@ -470,24 +488,27 @@ PT_DEV void ray_step_tri(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c
     }
     if (leaf_hit) r.tmax = r.ray_tmax;                  // intersect_simd: tmax shrinks after the whole leaf
 }
+template <bool SPH>
 PT_DEV void ray_step(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
-    if (ray_wants_tri(r)) ray_step_tri(sc, r, any_hit, c);
+    if (ray_wants_tri(r)) ray_step_tri<SPH>(sc, r, any_hit, c);
     else ray_step_node(sc, r, c);
 }
 
 // intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
+template <bool SPH>
 PT_DEV int32_t trace_closest(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c, float* t_out) {
     LaneRay r;
     ray_begin(sc, r, o, d, t_max);
-    while (!ray_done(r)) ray_step(sc, r, false, c);
+    while (!ray_done(r)) ray_step<SPH>(sc, r, false, c);
     *t_out = r.ray_tmax;
     return r.best;
 }
 // intersect_simd_p (qbvh_x86.rs:289-343): any hit
+template <bool SPH>
 PT_DEV bool trace_any(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c) {
     LaneRay r;
     ray_begin(sc, r, o, d, t_max);
-    while (!ray_done(r)) ray_step(sc, r, true, c);
+    while (!ray_done(r)) ray_step<SPH>(sc, r, true, c);
     return r.best >= 0;
 }
 
@@ -544,7 +565,7 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #endif
 // DIST: every leaf holds at most 8 triangles and its reference carries the count, so a leaf phase can pool the
 // triangles of all parked lanes and hand one (ray, triangle) test to each lane of the wave.
-template <bool DIST>
+template <bool DIST, bool SPH>
 PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
     __shared__ uint32_t s_stack[PT_LDS_STACK * PT_BLOCK];
     __shared__ unsigned long long s_cnt[4];
@@ -746,7 +767,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             prof[0] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[1] += 1; prof[2] += (unsigned long long)__popcll(m_node);
 #endif
         } else {
-            if (w_tri) ray_step_tri(sc, r, kind == 2, c);
+            if (w_tri) ray_step_tri<SPH>(sc, r, kind == 2, c);
 #ifdef PT_PROFILE_PHASES
             prof[3] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[4] += 1; prof[5] += (unsigned long long)__popcll(m_tri);
 #endif
@@ -762,18 +783,23 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                               uint32_t spill_depth, uint32_t* err) {
-    trace_body<true>(sc, P, Q, cnt, spill, spill_depth, err);
+    trace_body<true, false>(sc, P, Q, cnt, spill, spill_depth, err);
 }
 // leaves of more than 8 triangles ("maxnodeprims" > 8): every lane walks its own leaf
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace_seq(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                                   uint32_t spill_depth, uint32_t* err) {
-    trace_body<false>(sc, P, Q, cnt, spill, spill_depth, err);
+    trace_body<false, false>(sc, P, Q, cnt, spill, spill_depth, err);
+}
+// scenes with spheres: sequential leaves, a leaf record may stand for a sphere
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, 2) k_trace_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+                                                                      uint32_t spill_depth, uint32_t* err) {
+    trace_body<false, true>(sc, P, Q, cnt, spill, spill_depth, err);
 }
 
 // ============================================================ hooks: plain ray batches
-extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace_batch(PtScene sc, uint32_t n, const float* o, const float* d, const float* tmax,
-                                                                    pt_hit* out, uint8_t* occ_out, int any_hit, uint32_t* ticket, PtCounters* cnt,
-                                                                    uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
+template <bool SPH>
+PT_DEV void trace_batch_body(const PtScene& sc, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out, uint8_t* occ_out, int any_hit,
+                             uint32_t* ticket, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
     __shared__ uint32_t s_stack[PT_LDS_STACK * PT_BLOCK];
     __shared__ unsigned long long s_cnt[4];
     TravCtx c;
@@ -791,26 +817,39 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace_batch(PtScene sc,
         V3 ro = ld3(o + 3 * (size_t)i), rd = ld3(d + 3 * (size_t)i);
         if (any_hit) {
             shadow++;
-            occ_out[i] = trace_any(sc, ro, rd, tmax[i], c) ? 1 : 0;
+            occ_out[i] = trace_any<SPH>(sc, ro, rd, tmax[i], c) ? 1 : 0;
         } else {
             regular++;
             float t;
-            int32_t rec = trace_closest(sc, ro, rd, tmax[i], c, &t);
+            int32_t rec = trace_closest<SPH>(sc, ro, rd, tmax[i], c, &t);
             pt_hit h;
             h.t = 0.0f; h.prim = -1; h.b0 = 0.0f; h.b1 = 0.0f;
             if (rec >= 0) {
                 TriVerts tv = load_tri(sc.tris, (uint32_t)rec);
-                RayPre rp;
-                ray_precompute(rp, ro, rd);
-                TriHit th;
-                tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, PT_INF, th);   // same arithmetic => same t, b
-                h.t = t; h.prim = (int32_t)tv.prim; h.b0 = th.b0; h.b1 = th.b1;
+                h.t = t; h.prim = (int32_t)tv.prim;
+                if (!(SPH && (tv.flags & PT_TRI_SPHERE))) {
+                    RayPre rp;
+                    ray_precompute(rp, ro, rd);
+                    TriHit th;
+                    tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, PT_INF, th);   // same arithmetic => same t, b
+                    h.b0 = th.b0; h.b1 = th.b1;
+                }
             }
             out[i] = h;
         }
     }
     if (c.overflow) atomicOr(err, 1u);
     flush_counters(cnt, s_cnt, regular, shadow, c.n_nodes, c.n_tris);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace_batch(PtScene sc, uint32_t n, const float* o, const float* d, const float* tmax,
+                                                                    pt_hit* out, uint8_t* occ_out, int any_hit, uint32_t* ticket, PtCounters* cnt,
+                                                                    uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
+    trace_batch_body<false>(sc, n, o, d, tmax, out, occ_out, any_hit, ticket, cnt, spill, spill_depth, err);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace_batch_sph(PtScene sc, uint32_t n, const float* o, const float* d, const float* tmax,
+                                                                        pt_hit* out, uint8_t* occ_out, int any_hit, uint32_t* ticket, PtCounters* cnt,
+                                                                        uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
+    trace_batch_body<true>(sc, n, o, d, tmax, out, occ_out, any_hit, ticket, cnt, spill, spill_depth, err);
 }
 
 // ============================================================ K_GEN: camera samples
@@ -959,6 +998,29 @@ PT_DEV bool make_surf(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, fl
     return make_surf_tv(sc, ro, rd, tv, __float_as_uint(c.w), s, t_out);
 }
 
+// A record of a sphere-capable scene: Sphere::intersect again on the same ray (deterministic, and t_max only ever
+// rejected candidates, so the unbounded re-test finds the hit the traversal found) and its world-space interaction.
+template <bool SPH>
+PT_DEV bool make_surf_any(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, float* t_out) {
+    if constexpr (SPH) {
+        const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)rec * 3;
+        const float4 a = q[0], b = q[1];
+        const uint32_t flags = __float_as_uint(b.w);
+        if (flags & PT_TRI_SPHERE) {
+            SphHit sh;
+            const PtSphere& sp = sc.spheres[__float_as_uint(a.x)];
+            if (!sph_hit_test(sp, ro, rd, PT_INF, PT_PI, &sh)) return false;
+            sph_interaction(sp, sh, &s.p, &s.p_error, &s.n, &s.wo, &s.sh_n, &s.sh_dpdu);
+            s.prim = __float_as_uint(a.w);
+            s.material = (int32_t)(flags >> PT_TRI_MATERIAL_SHIFT) - 1;
+            s.light = (int32_t)__float_as_uint(q[2].w) - 1;
+            *t_out = sh.t;
+            return true;
+        }
+    }
+    return make_surf(sc, ro, rd, rec, s, t_out);
+}
+
 // ---- BSDF with at most one diffuse-reflection lobe (Matte: Lambertian or OrenNayar)
 struct Bsdf {
     V3 ns, ng, ss, ts;
@@ -1058,6 +1120,26 @@ PT_DEV bool light_sample_li(const PtLight& l, V3 ref_p, V2 u, V3* li, V3* wi, fl
     *li = light_L(l, n, -*wi);
     *pdf = pd; *lp = p; *ln = n;
     return true;
+}
+
+// DiffuseAreaLight::sample_li over either shape.  The reference interaction's p_error and n only matter to
+// Sphere::sample_from (its inside test starts from the offset origin, sphere.rs:309-315).
+template <bool SPH>
+PT_DEV bool light_sample_any(const PtScene& sc, const PtLight& l, V3 ref_p, V3 ref_pe, V3 ref_n, V2 u, V3* li, V3* wi, float* pdf, V3* lp, V3* lperr,
+                             V3* ln) {
+    if constexpr (SPH) {
+        if (l.mesh_flags & PT_LIGHT_SPHERE) {
+            V3 p, n, pe;
+            float pd;
+            if (!sph_sample_from(sc.spheres[__float_as_uint(l.p0[0])], ref_p, ref_pe, ref_n, u, &p, &n, &pe, &pd)) return false;
+            if (pd <= 0.0f || length_squared(p - ref_p) <= 0.0f) return false;      // diffuse.rs:79-81
+            *wi = normalize(p - ref_p);
+            *li = light_L(l, n, -*wi);
+            *pdf = pd; *lp = p; *lperr = pe; *ln = n;
+            return true;
+        }
+    }
+    return light_sample_li(l, ref_p, u, li, wi, pdf, lp, lperr, ln);
 }
 
 // ---- light distribution lookup (spatial.rs:84-111 + distribution.rs:12-31, :88-106)
@@ -1248,7 +1330,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 #endif
 // GENERAL = false: every material is Matte (at most one diffuse lobe; the RT1M / Cornell fast path).
 // GENERAL = true: BSDFs are the per-material lobe lists of pt_bxdf.h (specular bounces, eta_scale, glass without a BSDF).
-template <bool GENERAL>
+template <bool GENERAL, bool SPH>
 PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, const uint32_t* list, uint32_t begin, uint32_t end,
                        uint32_t* ticket) {
     __shared__ unsigned long long s_vert;
@@ -1283,7 +1365,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             float eta_scale = beta4.w;
             Surf s;
             float thit;
-            bool found = rec >= 0 && make_surf(sc, ro, rd, (uint32_t)rec, s, &thit);
+            bool found = rec >= 0 && make_surf_any<SPH>(sc, ro, rd, (uint32_t)rec, s, &thit);
             // emitted radiance at the first vertex / after a specular bounce (path.rs:87-98)
             if (found && (bounces == 0 || (flags & PT_ST_SPECULAR))) {
                 int32_t li = s.light;
@@ -1358,7 +1440,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                             V3 A = mk3(0.0f, 0.0f, 0.0f), B = mk3(0.0f, 0.0f, 0.0f);
                             V3 li, wi, lp, lperr, ln;
                             float lpdf;
-                            if (light_sample_li(lt, s.p, u_light, &li, &wi, &lpdf, &lp, &lperr, &ln)) {
+                            if (light_sample_any<SPH>(sc, lt, s.p, s.p_error, s.n, u_light, &li, &wi, &lpdf, &lp, &lperr, &ln)) {
                                 if (lpdf > 0.0f && !is_black(li)) {
                                     V3 f = eval_f(s.wo, wi) * abs_dot(wi, s.sh_n);
                                     float spdf = eval_pdf(s.wo, wi);
@@ -1387,8 +1469,8 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                     Surf ls;
                                     float lt_t;
                                     bool lhit;
-                                    if (lt.mesh_flags & (PT_MESH_HAS_N | PT_MESH_HAS_S | PT_MESH_HAS_UV)) {
-                                        lhit = make_surf(sc, po, wi2, lt.tri_rec, ls, &lt_t);
+                                    if (lt.mesh_flags & (PT_MESH_HAS_N | PT_MESH_HAS_S | PT_MESH_HAS_UV | PT_LIGHT_SPHERE)) {
+                                        lhit = make_surf_any<SPH>(sc, po, wi2, lt.tri_rec, ls, &lt_t);
                                     } else {           // the light record already holds the triangle
                                         TriVerts ltv;
                                         ltv.p0 = ld3(lt.p0); ltv.p1 = ld3(lt.p1); ltv.p2 = ld3(lt.p2);
@@ -1428,11 +1510,12 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     V3 f, wi;
                     float pdf;
                     uint32_t stype;
-                    if (sample_bsdf(s.wo, u, PT_BSDF_ALL, &f, &wi, &pdf, &stype) && !(is_black(f) || pdf == 0.0f)) {
+                    const V3 wo_ray = -rd;        // path.rs:140 samples with -ray.d; isect.wo differs from it on a sphere (renormalised)
+                    if (sample_bsdf(wo_ray, u, PT_BSDF_ALL, &f, &wi, &pdf, &stype) && !(is_black(f) || pdf == 0.0f)) {
                         beta = beta * (f * (abs_dot(wi, s.sh_n) / pdf));
                         if (stype & PT_BSDF_SPECULAR) flags |= PT_ST_SPECULAR; else flags &= ~PT_ST_SPECULAR;
                         if ((stype & PT_BSDF_SPECULAR) && (stype & PT_BSDF_TRANSMISSION))     // path.rs:157-168
-                            eta_scale *= dot(s.wo, s.n) > 0.0f ? bsdf_eta * bsdf_eta : 1.0f / (bsdf_eta * bsdf_eta);
+                            eta_scale *= dot(wo_ray, s.n) > 0.0f ? bsdf_eta * bsdf_eta : 1.0f / (bsdf_eta * bsdf_eta);
                         V3 no = offset_ray_origin(s.p, s.p_error, s.n, wi);
                         bool alive = true;
                         V3 rr = beta * eta_scale;
@@ -1476,14 +1559,21 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     if (threadIdx.x == 0 && s_vert) atomicAdd(&cnt->vertices, s_vert);
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<false>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[PT_Q_CUR], &Q.counts[PT_Q_TICKET]);
+    shade_body<false, false>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[PT_Q_CUR], &Q.counts[PT_Q_TICKET]);
 }
 // the two halves of a material-sorted queue
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade_matte_sorted(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<false>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], &Q.counts[PT_Q_TICKET]);
+    shade_body<false, false>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], &Q.counts[PT_Q_TICKET]);
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
+    shade_body<true, false>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
+}
+// scenes with spheres: hits and lights may be spheres
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_matte_sorted_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<false, true>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], &Q.counts[PT_Q_TICKET]);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
 }
 
 // ============================================================ film
@@ -1608,7 +1698,8 @@ PT_DEV float radical_inverse_dev(uint32_t base_index, uint64_t a) {   // radical
     }
     return fminf((float)rev * inv_base_n, PT_ONE_MINUS_EPS);
 }
-extern "C" __global__ void k_light_grid(PtScene sc, float* data, uint32_t n_vox) {
+template <bool SPH>
+PT_DEV void light_grid_body(const PtScene& sc, float* data, uint32_t n_vox) {
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_vox; v += gridDim.x * blockDim.x) {
         const PtLightGrid& g = sc.grid;
         uint32_t pi0 = v % g.voxels[0], pi1 = (v / g.voxels[0]) % g.voxels[1], pi2 = v / (g.voxels[0] * g.voxels[1]);
@@ -1630,7 +1721,8 @@ extern "C" __global__ void k_light_grid(PtScene sc, float* data, uint32_t n_vox)
             for (uint32_t j = 0; j < nl; j++) {
                 V3 li, wi, lp, le, ln;
                 float pdf;
-                if (light_sample_li(sc.lights[j], po, u, &li, &wi, &pdf, &lp, &le, &ln))
+                // the reference point is a bare Interaction: zero normal and error (spatial.rs:152-159)
+                if (light_sample_any<SPH>(sc, sc.lights[j], po, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 0.0f), u, &li, &wi, &pdf, &lp, &le, &ln))
                     if (pdf > 0.0f) func[j] += lum_y(li) / pdf;
             }
         }
@@ -1647,6 +1739,8 @@ extern "C" __global__ void k_light_grid(PtScene sc, float* data, uint32_t n_vox)
         cdf[nl + 1] = func_int;
     }
 }
+extern "C" __global__ void k_light_grid(PtScene sc, float* data, uint32_t n_vox) { light_grid_body<false>(sc, data, n_vox); }
+extern "C" __global__ void k_light_grid_sph(PtScene sc, float* data, uint32_t n_vox) { light_grid_body<true>(sc, data, n_vox); }
 
 // ============================================================ hooks: sampler / camera
 extern "C" __global__ void k_camera_rays(PtScene sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* out_o, float* out_d,
@@ -1713,7 +1807,8 @@ extern "C" __global__ void k_bsdf_sample(PtScene sc, uint32_t material, uint32_t
 
 hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err) {
-    if (sc.dist_leaves) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    if (sc.n_spheres) hipLaunchKernelGGL(k_trace_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    else if (sc.dist_leaves) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else hipLaunchKernelGGL(k_trace_seq, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     return PT_LAUNCH_CHECK();
 }
@@ -1723,7 +1818,8 @@ hipError_t ptk_nee_resolve(hipStream_t st, int grid, const PtScene& sc, const Pt
 }
 hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out,
                            uint8_t* occ, int any_hit, uint32_t* ticket, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
-    hipLaunchKernelGGL(k_trace_batch, dim3(grid), dim3(PT_BLOCK), 0, st, sc, n, o, d, tmax, out, occ, any_hit, ticket, cnt, spill, spill_depth, err);
+    if (sc.n_spheres) hipLaunchKernelGGL(k_trace_batch_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, n, o, d, tmax, out, occ, any_hit, ticket, cnt, spill, spill_depth, err);
+    else hipLaunchKernelGGL(k_trace_batch, dim3(grid), dim3(PT_BLOCK), 0, st, sc, n, o, d, tmax, out, occ, any_hit, ticket, cnt, spill, spill_depth, err);
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_gen(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const uint32_t* pixels, uint32_t n_pix,
@@ -1740,8 +1836,13 @@ hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths&
         hipLaunchKernelGGL(k_sort_count, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(PT_SORT_BINS), 0, st, Q);
         hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
-        hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-        hipLaunchKernelGGL(k_shade_general, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        if (sc.n_spheres) {
+            hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            hipLaunchKernelGGL(k_shade_general_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        } else {
+            hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            hipLaunchKernelGGL(k_shade_general, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        }
     } else {
         hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
     }
@@ -1761,7 +1862,8 @@ hipError_t ptk_film_rgb(hipStream_t st, const float4* xyzw, float* rgb, uint32_t
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32_t n_vox) {
-    hipLaunchKernelGGL(k_light_grid, dim3((n_vox + 63) / 64), dim3(64), 0, st, sc, data, n_vox);
+    if (sc.n_spheres) hipLaunchKernelGGL(k_light_grid_sph, dim3((n_vox + 63) / 64), dim3(64), 0, st, sc, data, n_vox);
+    else hipLaunchKernelGGL(k_light_grid, dim3((n_vox + 63) / 64), dim3(64), 0, st, sc, data, n_vox);
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_camera_rays(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* o, float* d,

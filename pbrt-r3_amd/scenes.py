@@ -38,6 +38,14 @@ def _sinf(x):
     return f32(_libm.sinf(float(x)))
 
 
+_libm.cosf.argtypes = [C.c_float]
+_libm.cosf.restype = C.c_float
+
+
+def _cosf(x):
+    return f32(_libm.cosf(float(x)))
+
+
 # --------------------------------------------------------------------------
 # PCG32 (src/core/rng.rs:8-67), vectorised: the LCG state after k steps is
 # a^k * s0 + c * (a^(k-1) + ... + 1)  (mod 2^64), so all states come from two
@@ -128,6 +136,49 @@ def _transform_points(m, P):
     return out
 
 
+def transform_translate(x, y, z):
+    """Transform::translate (transform.rs:33-37): (m, m_inv) row-major."""
+    m, mi = np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)
+    m[:3, 3] = [x, y, z]
+    mi[:3, 3] = [-x, -y, -z]
+    return m.reshape(-1), mi.reshape(-1)
+
+
+def transform_scale(x, y, z):
+    """Transform::scale (transform.rs:39-43)."""
+    m, mi = np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)
+    m[0, 0], m[1, 1], m[2, 2] = x, y, z
+    mi[0, 0], mi[1, 1], mi[2, 2] = f32(1.0) / f32(x), f32(1.0) / f32(y), f32(1.0) / f32(z)
+    return m.reshape(-1), mi.reshape(-1)
+
+
+def transform_rotate_x(theta_deg):
+    """Transform::rotate_x (transform.rs:45-49, matrix4x4.rs:67-75); sin/cos through the libm port above."""
+    r = f32(theta_deg) * (f32(np.pi) / f32(180.0))
+    sn, cs = _sinf(r), _cosf(r)
+    m = np.eye(4, dtype=np.float32)
+    m[1, 1], m[1, 2], m[2, 1], m[2, 2] = cs, -sn, sn, cs
+    return m.reshape(-1), m.T.copy().reshape(-1)
+
+
+def _mul4(a, b):
+    """Matrix4x4 * Matrix4x4 (matrix4x4.rs:320-348): row . column, left to right, f32."""
+    a, b = np.asarray(a, np.float32).reshape(4, 4), np.asarray(b, np.float32).reshape(4, 4)
+    out = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            acc = a[i, 0] * b[0, j]
+            for k in range(1, 4):
+                acc = f32(acc + a[i, k] * b[k, j])
+            out[i, j] = acc
+    return out.reshape(-1)
+
+
+def transform_mul(t1, t2):
+    """Transform * Transform (transform.rs:276-281): m = m1*m2, m_inv = m2_inv*m1_inv."""
+    return _mul4(t1[0], t2[0]), _mul4(t2[1], t1[1])
+
+
 def _swaps_handedness(m):
     m = np.asarray(m, np.float32)
     det = (m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8])) + m[2] * (m[4] * m[9] - m[5] * m[8])
@@ -173,6 +224,7 @@ class SceneBuilder:
         self.P, self.N, self.S, self.UV = [], [], [], []
         self.idx, self.tri_mesh = [], []
         self.meshes, self.materials, self.area_lights = [], [], []
+        self.spheres = []
         self.n_vertices = 0
         self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, (0.5, 0.5, 0.5), 0.0)   # default matte
         self.cur_area_light = -1
@@ -400,6 +452,28 @@ class SceneBuilder:
         self.n_vertices += nv
         return mid
 
+    def shape_sphere(self, radius=1.0, zmin=None, zmax=None, phimax=360.0, object_to_world=None, world_to_object=None):
+        """Shape "sphere" (shapes/sphere.rs:401-420) under the given CTM (m and m_inv, row-major; identity by
+        default).  A translate/scale/rotate product and its inverse are built by `transform_*` below."""
+        sp = capi.pt_sphere()
+        m = np.eye(4, dtype=np.float32).reshape(-1) if object_to_world is None else np.asarray(object_to_world, np.float32).reshape(-1)
+        if world_to_object is None:
+            assert object_to_world is None, "pass the inverse too: the reference never re-inverts a CTM"
+            mi = m.copy()
+        else:
+            mi = np.asarray(world_to_object, np.float32).reshape(-1)
+        sp.object_to_world[:] = [float(v) for v in m]
+        sp.world_to_object[:] = [float(v) for v in mi]
+        sp.radius = radius
+        sp.zmin = -radius if zmin is None else zmin
+        sp.zmax = radius if zmax is None else zmax
+        sp.phimax = phimax
+        sp.flags = capi.PT_SPHERE_REVERSE_ORIENTATION if self.reverse_orientation else 0
+        sp.material, sp.area_light = self.cur_material, self.cur_area_light
+        sp.before_triangle = sum(len(i) for i in self.idx)
+        self.spheres.append(sp)
+        return len(self.spheres) - 1
+
     def shape_trianglemesh_fast(self, P, indices, twosided=True):
         """Bulk path for meshes whose triangles do not share vertices (indices == arange):
         identical result to shape_trianglemesh (uv fill = (0,0),(1,0),(1,1) per triangle)."""
@@ -438,6 +512,10 @@ class SceneBuilder:
         d.n_meshes, d.meshes = len(self.meshes), meshes
         d.n_materials, d.materials = len(self.materials), mats
         d.n_area_lights, d.area_lights = len(self.area_lights), als
+        if self.spheres:
+            sph = (capi.pt_sphere * len(self.spheres))(*self.spheres)
+            sd.buffers["spheres"] = sph
+            d.n_spheres, d.spheres = len(self.spheres), sph
         d.split_method, d.max_node_prims = self.split_method, self.max_node_prims
         d.camera_to_world[:] = [float(v) for v in self.camera_to_world]
         d.fov = self.fov

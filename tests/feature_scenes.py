@@ -192,3 +192,43 @@ def scene_materials_render(kinds, res=40, spp=8, depth=6, sampler="sobol"):
     apply_material(b, kinds[2 % len(kinds)])
     b.shape_trianglemesh([(-1.9, 0.0, 1.2), (-0.5, 0.0, 1.6), (-0.5, 1.4, 1.6), (-1.9, 1.4, 1.2)], [0, 1, 2, 0, 2, 3])
     return b.build()
+
+
+def scene_spheres(strategy="spatial", split="sah", res=40, spp=8, depth=6, sampler="sobol", lights_only=False):
+    """Analytic spheres in the triangle BVH (shapes/sphere.rs): two sphere lights (one rotated and non-uniformly scaled, one
+    two-sided and reversed), and as scene objects a matte full sphere, a glass sphere, a mirror sphere clipped in z and phi and a
+    plastic sphere under a handedness-swapping transform.  The room's own quad light stays, so light sampling mixes shapes."""
+    b = base(res=res, spp=spp, depth=depth)
+    if sampler == "halton":
+        b.sampler_halton(spp)
+    b.integrator_path(maxdepth=depth, lightsamplestrategy=strategy)
+    b.accelerator_bvh(splitmethod=split)
+    T = scenes
+    # a sphere light ahead of every triangle in the primitive list
+    b.area_light_source_diffuse(L=(30, 26, 20))
+    t = T.transform_mul(T.transform_translate(-1.2, 1.3, 0.4), T.transform_mul(T.transform_rotate_x(30.0), T.transform_scale(0.25, 0.15, 0.2)))
+    b.shape_sphere(radius=1.0, object_to_world=t[0], world_to_object=t[1])
+    b.no_area_light()
+    room(b, light_L=(4, 4, 4))
+    if not lights_only:
+        b.material_matte((0.3, 0.4, 0.8), sigma=20.0)
+        t = T.transform_translate(-0.9, -1.4, 0.6)
+        b.shape_sphere(radius=0.6, object_to_world=t[0], world_to_object=t[1])
+        b.material_glass()
+        t = T.transform_translate(0.9, -1.3, -0.3)
+        b.shape_sphere(radius=0.7, object_to_world=t[0], world_to_object=t[1])
+        b.material_mirror()
+        t = T.transform_mul(T.transform_translate(0.2, 0.1, 1.1), T.transform_rotate_x(-70.0))
+        b.shape_sphere(radius=0.55, zmin=-0.3, zmax=0.45, phimax=250.0, object_to_world=t[0], world_to_object=t[1])
+        b.material_plastic()
+        t = T.transform_mul(T.transform_translate(-0.2, -0.6, -0.9), T.transform_scale(0.4, -0.4, 0.4))
+        b.shape_sphere(radius=1.0, object_to_world=t[0], world_to_object=t[1])
+    # a two-sided light sphere with reversed orientation, after the triangles
+    b.material_matte((0.5, 0.5, 0.5))
+    b.area_light_source_diffuse(L=(6, 8, 12), twosided=True)
+    b.reverse_orientation = True
+    t = T.transform_translate(1.3, 0.9, 0.8)
+    b.shape_sphere(radius=0.2, object_to_world=t[0], world_to_object=t[1])
+    b.reverse_orientation = False
+    b.no_area_light()
+    return b.build()

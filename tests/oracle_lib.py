@@ -116,7 +116,7 @@ class OracleScene:
         return (cb[3] - cb[1], cb[2] - cb[0])
 
     def ordered_prims(self):
-        n = self.sd.desc.n_triangles
+        n = self.sd.desc.n_triangles + self.sd.desc.n_spheres
         out = np.empty(n, np.uint32)
         m = self.lib.orc_bvh_ordered_prims(self.h, _p(out), n)
         return out[:m]

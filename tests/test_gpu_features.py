@@ -60,6 +60,11 @@ def _compare(ctx, osc, exact_film, frac_limit=0.0):
     ("accel_middle_16", lambda: fs.scene_accel("middle", 16), True),     # leaves of more than 8 triangles: k_trace_seq
     ("accel_hlbvh_4", lambda: fs.scene_accel("hlbvh", 4), True),
     ("accel_hlbvh_1", lambda: fs.scene_accel("hlbvh", 1), True),
+    # analytic spheres (shapes/sphere.rs) as objects and as lights, next to triangles
+    ("spheres_spatial", lambda: fs.scene_spheres("spatial"), True),
+    ("spheres_power_hlbvh", lambda: fs.scene_spheres("power", split="hlbvh"), True),
+    ("spheres_uniform_halton", lambda: fs.scene_spheres("uniform", split="middle", sampler="halton"), True),
+    ("sphere_lights_only", lambda: fs.scene_spheres("spatial", lights_only=True), True),
 ])
 def test_feature_scene(gpu_ctx, oracle, name, make, exact):
     sd = make()
