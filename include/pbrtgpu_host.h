@@ -8,7 +8,8 @@
  *   SceneContext (the ParseContext that builds the scene)
  *                                           src/core/api/scene_context/scene_context.rs:817-1396
  * for the subset of the format the accelerated path renders:
- *   shapes      "trianglemesh", "plymesh" (ASCII / binary / gzip PLY)
+ *   shapes      "trianglemesh", "plymesh" (ASCII / binary / gzip PLY), "sphere" (full or clipped by zmin / zmax /
+ *               phimax, under any affine CTM; as a scene object or as an area light)
  *   materials   matte, plastic, mirror, glass, metal, uber, substrate with constant parameters; named
  *               materials; colours as rgb, .spd "spectrum" files or "blackbody" (metal defaults to the
  *               measured copper spectrum); Texture "constant" / "scale" / "mix" of constants (folded)

@@ -1,6 +1,9 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README.md): CPU restatement of the reference's Sphere shape.
-// Follows src/shapes/sphere.rs, src/core/efloat/efloat.rs, src/core/transform/transform.rs:122-323
-// and the Shape trait defaults in src/core/shape/shape.rs:19-74.  Included by orc_accel.hpp after
+// ORACLE -- test infrastructure only (see orc_math.hpp).
+// orc_sphere.hpp: the Sphere shape with its EFloat running-error intervals.
+//   follows src/shapes/sphere.rs, src/core/efloat/efloat.rs, src/core/transform/transform.rs:122-323,
+//           the Shape trait defaults in src/core/shape/shape.rs:19-74
+// Pinned by the reference's sphere_solid_angle / full_sphere_reintersect / partial_sphere_reintersect
+// (tests/shapes.rs:280-329, :416-457), restated in kat_main.cpp.  Included by orc_accel.hpp after
 // Ray / SurfHit / Bounds3 / Mat4 are defined.
 #pragma once
 
@@ -215,7 +218,7 @@ struct Sphere {
         Float z = 1.0f - 2.0f * u.x;                               // uniform_sample_sphere (sampling.rs:97-102)
         Float rr = std::sqrt(fmax_(0.0f, 1.0f - z * z));
         Float phi = 2.0f * kPi * u.y;
-        V3 p_obj = radius * V3(rr * std::cos(phi), rr * std::sin(phi), z);
+        V3 p_obj = V3(0.0f, 0.0f, 0.0f) + radius * V3(rr * std::cos(phi), rr * std::sin(phi), z);
         V3 nn = normalize(normal_to_world(p_obj));
         if (reverse_orientation) nn = nn * -1.0f;
         p_obj = p_obj * (radius / length(p_obj));

@@ -119,6 +119,7 @@ public:
     std::vector<float> P, N, S, UV;
     std::vector<uint32_t> indices, tri_mesh;
     std::vector<pt_mesh> meshes;
+    std::vector<pt_sphere> spheres;                                     // Shape "sphere", spliced into the primitive order by before_triangle
     bool quick_render = false, quick_full_resolution = false;          // PbrtOptions (--quick, --quick_full_resolution)
     std::vector<pt_material> materials;
     std::map<std::string, float> float_textures;                        // constant-folded named textures (global, see pbrt_texture)
@@ -442,10 +443,30 @@ public:
 
     void pbrt_shape(const std::string& name, const ParamSet& p) override {
         if (!error.empty()) return;
-        if (name != "trianglemesh" && name != "plymesh") { fail("Shape \"" + name + "\": only trianglemesh and plymesh are on the accelerated path"); return; }
+        if (name != "trianglemesh" && name != "plymesh" && name != "sphere") { fail("Shape \"" + name + "\": only trianglemesh, plymesh and sphere are on the accelerated path"); return; }
         const TransformSet& ts = transforms.back();
         if (std::memcmp(&ts.t[0].m, &ts.t[1].m, sizeof(M44)) != 0) { fail("animated transforms are outside the accelerated path"); return; }
         if (p.has("alpha") || p.has("shadowalpha")) { fail("alpha-masked shapes are outside the accelerated path"); return; }
+        if (name == "sphere") {                                     // create_sphere_shape (shapes/sphere.rs:401-420)
+            const Xf& o2w = ts.t[0];
+            if (o2w.m.a[12] != 0.0f || o2w.m.a[13] != 0.0f || o2w.m.a[14] != 0.0f || o2w.m.a[15] != 1.0f) { fail("sphere under a projective transform is outside the accelerated path"); return; }
+            pt_sphere sp;
+            std::memset(&sp, 0, sizeof(sp));
+            std::memcpy(sp.object_to_world, o2w.m.a, 64);
+            std::memcpy(sp.world_to_object, o2w.inv.a, 64);       // create_shapes passes object2world.inverse(): the stored m_inv, not a re-inversion
+            sp.radius = p.find_one_float("radius", 1.0f);
+            sp.zmin = p.find_one_float("zmin", -sp.radius);
+            sp.zmax = p.find_one_float("zmax", sp.radius);
+            sp.phimax = p.find_one_float("phimax", 360.0f);
+            if (!(sp.radius > 0.0f)) { fail("sphere radius must be positive"); return; }
+            sp.flags = gstates.back().reverse_orientation ? PT_SPHERE_REVERSE_ORIENTATION : 0u;
+            sp.material = material_for_shape(p);
+            sp.area_light = area_light_for_shape();
+            if (!error.empty()) return;
+            sp.before_triangle = (uint32_t)tri_mesh.size();
+            spheres.push_back(sp);
+            return;
+        }
         if (name == "plymesh") {                                    // shapes/plymesh.rs:251-380
             std::string file = p.find_one_string("filename", "");
             if (!file.empty() && file[0] != '/' && !p.base_dir.empty()) file = p.base_dir + "/" + file;
@@ -588,7 +609,7 @@ public:
     void pbrt_world_end() override {
         world_ended = true;
         if (!error.empty()) return;
-        if (indices.empty()) { fail("scene has no triangles"); return; }
+        if (indices.empty() && spheres.empty()) { fail("scene has no primitives on the accelerated path"); return; }
         // film (film.rs:520-580)
         if (film_name != "image") warn("Film \"" + film_name + "\" treated as \"image\"");
         desc.xres = film_params.find_one_int("xresolution", 1280);
@@ -665,6 +686,8 @@ public:
         desc.tri_mesh = tri_mesh.data();
         desc.n_meshes = (uint32_t)meshes.size();
         desc.meshes = meshes.data();
+        desc.n_spheres = (uint32_t)spheres.size();
+        desc.spheres = spheres.empty() ? nullptr : spheres.data();
         desc.n_materials = (uint32_t)materials.size();
         desc.materials = materials.data();
         desc.n_area_lights = (uint32_t)area_lights.size();

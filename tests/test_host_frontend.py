@@ -78,7 +78,7 @@ def test_syntax_errors_are_reported():
 
 
 @pytest.mark.parametrize("text,needle", [
-    ('Sampler "sobol"\nWorldBegin\nShape "sphere" "float radius" 1\nWorldEnd', "sphere"),
+    ('Sampler "sobol"\nWorldBegin\nShape "cylinder" "float radius" 1\nWorldEnd', "cylinder"),
     ('Sampler "stratified"\nWorldBegin\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "stratified"),
     ('Sampler "sobol"\nWorldBegin\nLightSource "point"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "LightSource"),
     ('Sampler "sobol"\nWorldBegin\nMaterial "disney"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd', "disney"),
@@ -164,6 +164,78 @@ def test_transform_stack_and_overrides(oracle):
     sc2 = oracle.scene(ps)
     assert sc2.info.spp == 8
     sc.close(); sc2.close()
+
+
+def test_sphere_shape_from_pbrt_text(oracle):
+    """Shape "sphere" (shapes/sphere.rs:401-420): CTM and its stored inverse, parameters, ReverseOrientation, material and
+    area light per sphere, and its place in the primitive order -- against the programmatic scene, bit for bit."""
+    text = '''
+    LookAt 0 0 -6.5  0 0 0  0 1 0
+    Camera "perspective" "float fov" 40
+    Film "image" "integer xresolution" 24 "integer yresolution" 24
+    Sampler "sobol" "integer pixelsamples" 4
+    Integrator "path" "integer maxdepth" 4
+    WorldBegin
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [30 26 20]
+        Translate -1.2 1.3 0.4
+        Rotate 30 1 0 0
+        Scale 0.25 0.15 0.2
+        Shape "sphere"
+      AttributeEnd
+      Material "matte" "rgb Kd" [0.7 0.7 0.7]
+      Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [2 -2 -2  -2 -2 -2  -2 -2 2  2 -2 2]
+      AttributeBegin
+        Material "mirror"
+        Translate 0.2 0.1 1.1
+        Shape "sphere" "float radius" 0.55 "float zmin" -0.3 "float zmax" 0.45 "float phimax" 250
+      AttributeEnd
+      Shape "trianglemesh" "integer indices" [0 1 2] "point P" [2 -2 2  -2 -2 2  0 2 2]
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [6 8 12] "bool twosided" "true"
+        ReverseOrientation
+        Translate 1.3 0.9 0.8
+        Shape "sphere" "float radius" 0.2
+      AttributeEnd
+    WorldEnd
+    '''
+    ps = capi.ParsedScene(text=text)
+    d = ps.desc
+    assert (d.n_triangles, d.n_spheres) == (3, 3)
+    sp = [d.spheres[i] for i in range(3)]
+    assert [s.before_triangle for s in sp] == [0, 2, 3]
+    assert [s.flags for s in sp] == [0, 0, capi.PT_SPHERE_REVERSE_ORIENTATION]
+    assert (sp[0].radius, sp[0].zmin, sp[0].zmax, sp[0].phimax) == (1.0, -1.0, 1.0, 360.0)
+    assert abs(sp[1].zmin + 0.3) < 1e-7 and sp[1].phimax == 250.0
+    assert sp[0].area_light == 0 and sp[1].area_light == -1 and sp[2].area_light == 1
+    assert d.materials[sp[1].material].type == capi.PT_MATERIAL_MIRROR
+    T = scenes
+    t0 = T.transform_mul(T.transform_mul(T.transform_translate(-1.2, 1.3, 0.4), T.transform_rotate_x(30.0)), T.transform_scale(0.25, 0.15, 0.2))
+    assert np.array_equal(bits(list(sp[0].object_to_world)), bits(t0[0]))
+    assert np.array_equal(bits(list(sp[0].world_to_object)), bits(t0[1]))
+    b = scenes.SceneBuilder()
+    b.look_at((0, 0, -6.5), (0, 0, 0), (0, 1, 0)); b.camera_perspective(fov=40.0); b.film(xresolution=24, yresolution=24)
+    b.pixel_filter_box(); b.sampler_sobol(4); b.integrator_path(maxdepth=4)
+    b.area_light_source_diffuse(L=(30, 26, 20))
+    b.shape_sphere(object_to_world=t0[0], world_to_object=t0[1])
+    b.no_area_light()
+    b.material_matte((0.7, 0.7, 0.7))
+    b.shape_trianglemesh([(2, -2, -2), (-2, -2, -2), (-2, -2, 2), (2, -2, 2)], [0, 1, 2, 0, 2, 3])
+    b.material_mirror()
+    t1 = T.transform_translate(0.2, 0.1, 1.1)
+    b.shape_sphere(radius=0.55, zmin=-0.3, zmax=0.45, phimax=250.0, object_to_world=t1[0], world_to_object=t1[1])
+    b.material_matte((0.7, 0.7, 0.7))
+    b.shape_trianglemesh([(2, -2, 2), (-2, -2, 2), (0, 2, 2)], [0, 1, 2])
+    b.area_light_source_diffuse(L=(6, 8, 12), twosided=True)
+    b.reverse_orientation = True
+    t2 = T.transform_translate(1.3, 0.9, 0.8)
+    b.shape_sphere(radius=0.2, object_to_world=t2[0], world_to_object=t2[1])
+    ref = b.build()
+    a, r = oracle.scene(ps), oracle.scene(ref)
+    xa, ca, _ = a.render(threads=2)
+    xr, cr, _ = r.render(threads=2)
+    assert np.array_equal(bits(xa), bits(xr)) and ca == cr and xa[..., :3].max() > 0
+    a.close(); r.close()
 
 
 def test_materials_from_pbrt_text():
