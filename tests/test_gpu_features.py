@@ -288,6 +288,75 @@ def test_pbrt_text_with_ply_spectra_and_materials(gpu_ctx, oracle, tmp_path):
     osc.close()
 
 
+def test_killeroo_simple_shaped_scene(gpu_ctx, oracle, tmp_path):
+    """BASELINE config 4 names pbrt-v3's killeroo-simple.pbrt, which is not in this tree; this scene has its
+    shape: Halton sampler, a black-matte *sphere* area light far above two large uv-mapped quads,
+    two instances of an Included mesh with vertex normals under Scale / Rotate / Translate, plastic materials given as
+    "color" parameters, default integrator depth.  Front end -> device must equal front end -> oracle per sample."""
+    (tmp_path / "geometry").mkdir()
+    P, N, UV, idx = fs.uv_sphere((0, 0, 0), 60.0, nt=10, nphi=14)
+    P[:, 2] *= 1.6                                     # an elongated blob standing in for the killeroo mesh
+    with open(tmp_path / "geometry" / "killeroo.pbrt", "w") as f:
+        f.write('Shape "trianglemesh" "integer indices" [%s]\n "point P" [%s]\n "normal N" [%s]\n' % (
+            " ".join(map(str, idx)), " ".join("%.9g" % v for v in P.reshape(-1)), " ".join("%.9g" % v for v in N.reshape(-1))))
+    text = '''
+    LookAt 400 20 30   0 63 -110   0 0 1
+    Rotate -5 0 0 1
+    Camera "perspective" "float fov" [39]
+    Film "image" "integer xresolution" [56] "integer yresolution" [56] "string filename" "killeroo-simple.exr"
+    Sampler "halton" "integer pixelsamples" [8]
+    Integrator "path"
+    WorldBegin
+    AttributeBegin
+      Material "matte" "color Kd" [0 0 0]
+      Translate 150 0 20
+      Translate 0 120 0
+      AreaLightSource "area" "color L" [2000 2000 2000] "integer nsamples" [8]
+      Shape "sphere" "float radius" [3]
+    AttributeEnd
+    AttributeBegin
+      Material "matte" "color Kd" [.5 .5 .8]
+      Translate 0 0 -140
+      Shape "trianglemesh" "point P" [ -1000 -1000 0 1000 -1000 0 1000 1000 0 -1000 1000 0 ]
+          "float uv" [ 0 0 5 0 5 5 0 5 ] "integer indices" [ 0 1 2 2 3 0]
+      Shape "trianglemesh" "point P" [ -400 -1000 -1000   -400 1000 -1000   -400 1000 1000 -400 -1000 1000 ]
+          "float uv" [ 0 0 5 0 5 5 0 5 ] "integer indices" [ 0 1 2 2 3 0]
+    AttributeEnd
+    AttributeBegin
+      Scale .5 .5 .5
+      Rotate -60 0 0 1
+      Material "plastic" "color Kd" [.4 .2 .2] "color Ks" [.5 .5 .5] "float roughness" [.025]
+      Translate 100 200 -140
+      Include "geometry/killeroo.pbrt"
+      Material "plastic" "color Ks" [.3 .3 .3] "color Kd" [.4 .5 .4] "float roughness" [.15]
+      Translate -200 0 0
+      Include "geometry/killeroo.pbrt"
+    AttributeEnd
+    WorldEnd
+    '''
+    ps = pkg.capi.ParsedScene(text=text, work_dir=str(tmp_path))
+    d = ps.desc
+    assert d.sampler == pkg.capi.PT_SAMPLER_HALTON and d.spp == 8 and d.max_depth == 5
+    assert d.n_spheres == 1 and d.spheres[0].before_triangle == 0 and d.spheres[0].area_light == 0
+    assert d.n_triangles > 400 and ps.output_filename == "killeroo-simple.exr"
+    osc = oracle.scene(ps)
+    gpu_ctx.upload(ps)
+    assert gpu_ctx.info.n_lights == 1
+    sb = list(gpu_ctx.info.sample_bounds)
+    tile = (sb[0] + 12, sb[1] + 12, sb[0] + 44, sb[1] + 44)
+    g, r = gpu_ctx.radiance_samples(tile), osc.radiance_samples(tile)
+    assert r.sum() > 0
+    same = np.all(bits(g) == bits(r), axis=-1)
+    assert same.all(), float(1 - same.mean())
+    gpu_ctx.film_clear(); gpu_ctx.reset_counters(); gpu_ctx.render()
+    ox, oc, _ = osc.render(threads=8)
+    gc = gpu_ctx.counters()
+    assert rel_l2(gpu_ctx.film_rgb(), osc.resolve_rgb(ox)) <= 1e-3
+    for k in ("regular_rays", "shadow_rays", "path_vertices", "nodes_visited", "tris_tested"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    osc.close()
+
+
 def test_pass_structure_does_not_change_the_film(gpu_ctx):
     """The pool size only decides how the samples are cut into passes / pixel chunks (render_tiles): a film rendered
     in 1 pass, in 3 unequal-looking passes (7 spp -> 3,2,2) and in pixel chunks must agree -- bit for bit where a
