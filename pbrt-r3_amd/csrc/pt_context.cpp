@@ -166,7 +166,7 @@ pt_status ensure_pool(pt_context* ctx, size_t n_paths) {
 }
 
 pt_status ensure_traversal_scratch(pt_context* ctx) {
-    uint32_t need = ctx->max_stack > PT_LDS_STACK ? ctx->max_stack - PT_LDS_STACK : 0;
+    uint32_t need = ctx->max_stack + 1 > PT_LDS_STACK ? ctx->max_stack + 1 - PT_LDS_STACK : 0;     // +1: the top entry is stored too
     size_t threads = (size_t)std::max(ctx->grid_trace, 2048) * PT_BLOCK;
     if (!ctx->d_spill.p || ctx->spill_depth < need) {
         PT_HIP(ctx->d_spill.alloc((size_t)std::max(need, 1u) * threads * 4));

@@ -307,35 +307,32 @@ struct TravCtx {
     uint32_t n_nodes, n_tris;
     uint32_t overflow;
 };
-// The top of the stack lives in a register (`top`, PT_EMPTY_REF = empty); LDS/HBM hold the rest.
-// The child pushed last is popped next, so most pushes/pops never touch LDS.
-PT_DEV void stk_store(TravCtx& c, uint32_t& sp, uint32_t v) {
+// The stack lives in LDS (entries 0..PT_LDS_STACK-1, then the HBM spill area); `sp` is its depth and `top` a register
+// copy of entry sp-1 (PT_EMPTY_REF when empty), so a pop has its reference at once and the read that refreshes `top`
+// overlaps the node fetch.  The root is never written: nothing can lie above it when it is popped.
+PT_DEV void stk_push(TravCtx& c, uint32_t& top, uint32_t& sp, uint32_t v) {
     if (sp < PT_LDS_STACK) c.lds[sp * PT_BLOCK] = v;
     else if (sp - PT_LDS_STACK < c.spill_depth) c.spill[(size_t)(sp - PT_LDS_STACK) * c.spill_stride] = v;
     else { c.overflow = 1; return; }
     sp++;
-}
-PT_DEV void stk_push(TravCtx& c, uint32_t& top, uint32_t& sp, uint32_t v) {
-    if (top != PT_EMPTY_REF) stk_store(c, sp, top);
     top = v;
 }
-// Same effect as `if (en) stk_push(...)` while sp stays inside the LDS part, without branches:
-// the old top is always written to the slot above the stack and sp advances only if it counted.
+// Same effect as `if (en) stk_push(...)` while sp stays inside the LDS part, without branches: the value is always
+// written to the slot above the stack and only counts if enabled (5 VALU instructions per push; k_trace is VALU-bound).
 PT_DEV void stk_push_lds(TravCtx& c, uint32_t& top, uint32_t& sp, uint32_t v, bool en) {
-    c.lds[sp * PT_BLOCK] = top;
-    sp += (en && top != PT_EMPTY_REF) ? 1u : 0u;
+    c.lds[sp * PT_BLOCK] = v;
+    sp += en ? 1u : 0u;
     top = en ? v : top;
 }
-PT_DEV uint32_t stk_pop(TravCtx& c, uint32_t& top, uint32_t& sp) {
+PT_DEV uint32_t stk_pop(TravCtx& c, uint32_t& top, uint32_t& sp) {      // precondition: top != PT_EMPTY_REF (sp >= 1)
     uint32_t v = top;
-    if (sp > PT_LDS_STACK) {                       // rare: entry lives in the HBM spill area
-        sp--;
-        top = c.spill[(size_t)(sp - PT_LDS_STACK) * c.spill_stride];
+    sp--;
+    if (sp > PT_LDS_STACK) {                       // rare: the new top lives in the HBM spill area
+        top = c.spill[(size_t)(sp - 1u - PT_LDS_STACK) * c.spill_stride];
     } else {
         uint32_t below = sp > 0 ? sp - 1 : 0;
         uint32_t e = c.lds[below * PT_BLOCK];
         top = sp > 0 ? e : PT_EMPTY_REF;
-        sp = below;
     }
     return v;
 }
@@ -434,7 +431,7 @@ PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max) {
     r.sp = 0;
     r.top = PT_EMPTY_REF;
     ray_precompute(r.rp, o, d);
-    if (root_test(sc, o, r.idir, r.sbits, t_max, r.tmin, r.tmax)) r.top = sc.root_ref;
+    if (root_test(sc, o, r.idir, r.sbits, t_max, r.tmin, r.tmax)) { r.top = sc.root_ref; r.sp = 1; }
 }
 PT_DEV bool ray_done(const LaneRay& r) { return r.top == PT_EMPTY_REF; }
 PT_DEV bool ray_wants_tri(const LaneRay& r) { return r.top != PT_EMPTY_REF && (r.top & PT_LEAF_BIT) != 0; }
