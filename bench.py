@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--materials", default="matte", choices=["matte", "mixed"],
                     help="matte = BASELINE config 2 (the headline); mixed = killeroo-class stand-in for config 4 (secondary number)")
     ap.add_argument("--sampler", default="sobol", choices=["sobol", "halton"], help="sobol = the headline; halton = the reference's default sampler (secondary number)")
+    ap.add_argument("--light", default="quad", choices=["quad", "sphere"], help="quad = the headline; sphere = an analytic sphere light instead (secondary number: k_trace_sph / k_shade_*_sph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU sample (0 = auto, about 15 s)")
     args = ap.parse_args()
@@ -115,7 +116,7 @@ def main():
     t_prog = time.time()
     pkg = importlib.import_module("pbrt-r3_amd")
     t0 = time.time()
-    sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, materials=args.materials, sampler=args.sampler)
+    sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, materials=args.materials, sampler=args.sampler, light=args.light)
     t_scene = time.time() - t0
     ctx = pkg.Context(local_rank)
     info = ctx.upload(sd)
@@ -195,12 +196,12 @@ def main():
         peak = 8000.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and args.materials == "matte" and args.light == "quad":      # measured on the headline workload only
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "k_trace_sph" if args.light == "sphere" else "k_trace", "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
                     "frac": round(achieved / peak, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1),
                     "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
@@ -237,9 +238,9 @@ def main():
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "RT1M: %d random %s triangles, %dx%d, %s %d spp, path maxdepth %d, BVH sah/4, spatial lights"
+            "config": {"workload": "RT1M: %d random %s triangles%s, %dx%d, %s %d spp, path maxdepth %d, BVH sah/4, spatial lights"
                                    % (sd.desc.n_triangles, "matte" if args.materials == "matte" else "mixed-material (matte/plastic/metal/glass/mirror/substrate)",
-                                      args.res, args.res, "Sobol" if args.sampler == "sobol" else "Halton", info.spp, args.max_depth),
+                                      " + a sphere area light" if args.light == "sphere" else "", args.res, args.res, "Sobol" if args.sampler == "sobol" else "Halton", info.spp, args.max_depth),
                        "partition": "16x16 film tiles round-robin over %d rank(s), RCCL all-reduce of the XYZW film" % world,
                        "rays_per_step": int(rays / max(1, args.steps)), "camera_samples_per_step": int(tot[8] / max(1, args.steps)),
                        "bvh_build_ms": round(info.bvh_build_ms, 1), "upload_ms": round(info.upload_ms, 1),

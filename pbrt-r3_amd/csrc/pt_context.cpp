@@ -665,7 +665,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     sc.n_lights = (uint32_t)lights.size();
     sc.spheres = d->n_spheres ? ctx->d_spheres.as<PtSphere>() : nullptr;
     sc.n_spheres = d->n_spheres;
-    if (d->n_spheres) { sc.dist_leaves = 0; sc.general_materials = 1; }     // sphere scenes run the sphere-capable kernel instantiations
+    if (d->n_spheres) sc.general_materials = 1;     // sphere scenes run the sphere-capable kernel instantiations (sorted shade queue)
     sc.root_ref = bvh.root_ref;
     std::memcpy(sc.wb_min, bvh.root_lo, 12);
     std::memcpy(sc.wb_max, bvh.root_hi, 12);

@@ -721,17 +721,26 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     const uint32_t first = (uint32_t)__shfl((int)(r.top & PT_LEAF_FIRST_MASK), o, 64);
                     RayPre rp;
                     rp.o = mk3(__shfl(r.rp.o.x, o, 64), __shfl(r.rp.o.y, o, 64), __shfl(r.rp.o.z, o, 64));
-                    rp.d = mk3(0.0f, 0.0f, 0.0f);        // only the one-sided test reads the direction
-                    if (sc.any_one_sided) rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));
-                    const int kk = __shfl(r.rp.kx | (r.rp.ky << 2) | (r.rp.kz << 4), o, 64);
+                    rp.d = mk3(0.0f, 0.0f, 0.0f);        // only the one-sided test (and a sphere) reads the direction
+                    if (SPH || sc.any_one_sided) rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));
+                    const int kk = __shfl(r.rp.kx | (r.rp.ky << 2) | (r.rp.kz << 4) | ((kind == 2 ? 1 : 0) << 6), o, 64);
                     rp.kx = kk & 3; rp.ky = (kk >> 2) & 3; rp.kz = (kk >> 4) & 3;
                     rp.sx = __shfl(r.rp.sx, o, 64); rp.sy = __shfl(r.rp.sy, o, 64); rp.sz = __shfl(r.rp.sz, o, 64);
                     rp.dperm = rp.d;        // not read by tri_core
                     if (valid) {
                         TriVerts tv = load_tri(sc.tris, first + k);
-                        TriCore tc;
-                        bool ok = tri_core(rp, tv.p0, tv.p1, tv.p2, tv.flags, tc);
-                        s_res[wbase + lane] = make_float4(ok ? 1.0f : 0.0f, tc.t_scaled, tc.det, tc.t);
+                        bool sphere_rec = false;
+                        if constexpr (SPH) sphere_rec = (tv.flags & PT_TRI_SPHERE) != 0;
+                        if (sphere_rec) {       // Sphere::intersect(_p) against t_max = +inf; the owner applies the t_max tests
+                            SphHit sh;
+                            sh.t = 0.0f; sh.a_hi = 0.0f; sh.b_hi = 0.0f;
+                            bool ok = sph_hit_test(sc.spheres[__float_as_uint(tv.p0.x)], rp.o, rp.d, PT_INF, (kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
+                            s_res[wbase + lane] = make_float4(ok ? 2.0f : 0.0f, sh.a_hi, sh.b_hi, sh.t);
+                        } else {
+                            TriCore tc;
+                            bool ok = tri_core(rp, tv.p0, tv.p1, tv.p2, tv.flags, tc);
+                            s_res[wbase + lane] = make_float4(ok ? 1.0f : 0.0f, tc.t_scaled, tc.det, tc.t);
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -744,7 +753,10 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     uint32_t tested = tcnt;
                     for (uint32_t k = 0; k < tcnt; k++) {
                         const float4 v = s_res[wbase + pre + k];
-                        if (v.x != 0.0f && tri_accept(v.y, v.z, r.ray_tmax)) {
+                        bool acc;
+                        if (SPH && v.x == 2.0f) acc = !(v.y > r.ray_tmax) && !(v.z > r.ray_tmax);
+                        else acc = v.x != 0.0f && tri_accept(v.y, v.z, r.ray_tmax);
+                        if (acc) {
                             r.best = (int32_t)(rec0 + k); leaf_hit = true;
                             if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; tested = k + 1; break; }
                             r.ray_tmax = v.w;
@@ -787,7 +799,11 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace_s
                                                                   uint32_t spill_depth, uint32_t* err) {
     trace_body<false, false>(sc, P, Q, cnt, spill, spill_depth, err);
 }
-// scenes with spheres: sequential leaves, a leaf record may stand for a sphere
+// scenes with spheres: a leaf record may stand for a sphere
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace_sph_dist(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+                                                                           uint32_t spill_depth, uint32_t* err) {
+    trace_body<true, true>(sc, P, Q, cnt, spill, spill_depth, err);
+}
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 2) k_trace_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                                       uint32_t spill_depth, uint32_t* err) {
     trace_body<false, true>(sc, P, Q, cnt, spill, spill_depth, err);
@@ -1804,7 +1820,8 @@ extern "C" __global__ void k_bsdf_sample(PtScene sc, uint32_t material, uint32_t
 
 hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err) {
-    if (sc.n_spheres) hipLaunchKernelGGL(k_trace_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    if (sc.n_spheres && sc.dist_leaves) hipLaunchKernelGGL(k_trace_sph_dist, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    else if (sc.n_spheres) hipLaunchKernelGGL(k_trace_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else if (sc.dist_leaves) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else hipLaunchKernelGGL(k_trace_seq, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     return PT_LAUNCH_CHECK();

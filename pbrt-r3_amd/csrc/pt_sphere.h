@@ -70,7 +70,10 @@ PT_DEV V3 sph_point_abs_error(const float* m, V3 p, V3 pe) {
     return e;
 }
 
-struct SphHit { V3 o, d, p_hit; float t, phi; };      // object-space ray, refined hit point
+// Object-space ray and refined hit point, plus the two interval ends the t_max tests compared against: the hit stands for a
+// given t_max iff !(a_hi > t_max) && !(b_hi > t_max)  (sphere.rs:87-95, :110-113: t0's upper bound always, t1's when t1 is
+// the root taken).  A caller that passes t_max = +inf and applies that test later gets the decision of any finite t_max.
+struct SphHit { V3 o, d, p_hit; float t, phi, a_hi, b_hi; };
 
 PT_DEV bool sph_clipped(const PtSphere& s, V3 p_hit, float phi) {
     return (s.z_min > -s.radius && p_hit.z < s.z_min) || (s.z_max < s.radius && p_hit.z > s.z_max) || (phi > s.phi_max);
@@ -127,6 +130,8 @@ __device__ __noinline__ bool sph_hit_test(const PtSphere& s, V3 ro, V3 rd, float
         if (sph_clipped(s, p_hit, phi)) return false;
     }
     h->o = o; h->d = d; h->p_hit = p_hit; h->t = th.v; h->phi = phi;
+    h->a_hi = t0.hi;
+    h->b_hi = ef_eq(th, t0) ? -PT_INF : t1.hi;
     return true;
 }
 // World-space interaction of a hit (sphere.rs:130-198 + transform_surface_interaction, transform.rs:299-323).

@@ -584,7 +584,7 @@ def cornell_box(res=512, spp=64, max_depth=5, light_strategy="spatial", sampler=
     return b.build()
 
 
-def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequence=1, sampler="sobol", materials="matte"):
+def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequence=1, sampler="sobol", materials="matte", light="quad"):
     """BASELINE config 2 ("RT1M"): 12-triangle enclosure + light, the rest random matte triangles.
 
     Filler triangle k draws, in order, cx cy cz then v0x..v2z as lerp(uniform_float(), lo, hi)
@@ -629,7 +629,11 @@ def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequ
                     b.shape_trianglemesh_fast(verts[3 * lo:3 * hi], np.arange(3 * (hi - lo)), twosided=True)
             b.material_matte((0.5, 0.5, 0.5))
     b.area_light_source_diffuse(L=(17, 12, 4))
-    _quad(b, (0.25, 0.999, -0.25), (0.25, 0.999, 0.25), (-0.25, 0.999, 0.25), (-0.25, 0.999, -0.25))  # faces -y
+    if light == "sphere":       # secondary workload: an analytic sphere light (the sphere-capable kernel instantiations run)
+        t = transform_translate(0.0, 0.85, 0.0)
+        b.shape_sphere(radius=0.1, object_to_world=t[0], world_to_object=t[1])
+    else:
+        _quad(b, (0.25, 0.999, -0.25), (0.25, 0.999, 0.25), (-0.25, 0.999, 0.25), (-0.25, 0.999, -0.25))  # faces -y
     return b.build()
 
 
