@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 typedef enum {
     PT_OK = 0,
@@ -58,8 +58,39 @@ typedef struct pt_context pt_context;
 
 /* ---- flattened scene description ------------------------------------- */
 
-/* Material::compute_scattering_functions variants (src/materials/).  All parameter textures are
- * constant (core/texture/constant.rs); bump maps are outside the accelerated path. */
+/* Procedural textures (src/textures/, src/core/texture/mapping2d.rs, mapping3d.rs).  A texture evaluates to an RGB triple;
+ * a float texture is one whose three channels are equal (consumers read channel 0), so scale / mix / checkerboard are the
+ * same arithmetic per channel as the reference's generic Texture<T>.  textures[] is in definition order: a child index is
+ * always smaller than the index of the texture that uses it.  Image maps (imagemap.rs, mipmap.rs) and the noise textures
+ * are not on the accelerated path yet. */
+typedef enum {
+    PT_TEX_CONSTANT = 0,         /* core/texture/constant.rs: value[0] */
+    PT_TEX_SCALE = 1,            /* textures/scale.rs: tex1 * tex2 */
+    PT_TEX_MIX = 2,              /* textures/mix.rs: tex1 * (1 - amount) + tex2 * amount; child 2 = "amount" */
+    PT_TEX_CHECKERBOARD_2D = 3,  /* textures/checkerboard.rs:13-84: point-sampled or closed-form box-filtered */
+    PT_TEX_CHECKERBOARD_3D = 4,  /* textures/checkerboard.rs:86-122 over the identity 3-D mapping */
+    PT_TEX_UV = 5,               /* textures/uv.rs: (frac s, frac t, 0) */
+    PT_TEX_BILERP = 6            /* textures/bilerp.rs: value[0..3] = v00 v01 v10 v11 */
+} pt_texture_type;
+typedef enum {
+    PT_MAPPING_UV = 0,           /* UVMapping2D: su sv du dv */
+    PT_MAPPING_SPHERICAL = 1,    /* SphericalMapping2D: world_to_texture */
+    PT_MAPPING_CYLINDRICAL = 2,  /* CylindricalMapping2D: world_to_texture */
+    PT_MAPPING_PLANAR = 3        /* PlanarMapping2D: v1 v2, du dv as ds dt */
+} pt_mapping_type;
+typedef struct {
+    int32_t type;               /* pt_texture_type */
+    int32_t tex[3];             /* children "tex1", "tex2", "amount": index into textures[] (< own index), or -1 = value[i] */
+    float value[4][3];          /* constants: see the type; a float is replicated over the three channels */
+    int32_t mapping;            /* pt_mapping_type, 2-D textures ("mapping", default "uv") */
+    int32_t aa_none;            /* checkerboard "aamode" "none" (default "closedform") */
+    float su, sv, du, dv;       /* "uscale" "vscale" "udelta" "vdelta" (defaults 1 1 0 0) */
+    float v1[3], v2[3];         /* planar "v1" (1 0 0), "v2" (0 1 0) */
+    float world_to_texture[16]; /* inverse of the CTM at the Texture directive: spherical / cylindrical / 3-D mappings */
+} pt_texture;
+
+/* Material::compute_scattering_functions variants (src/materials/).  Colour parameters and Matte's sigma may be
+ * textures (tex_* below); roughness and eta textures must fold to constants, bump maps are outside the accelerated path. */
 typedef enum {
     PT_MATERIAL_NONE = 0,      /* GeometricPrimitive.material == None: ray passes through (path.rs:108-111) */
     PT_MATERIAL_MATTE = 1,     /* materials/matte.rs:25-53      Kd, sigma */
@@ -74,7 +105,7 @@ typedef enum {
 #define PT_ROUGHNESS_UNSET (-1.0f)   /* "uroughness"/"vroughness" not given: Metal and Uber fall back to "roughness" */
 
 /* Field defaults are the reference's create_*_material defaults; a field a material type does not
- * read is ignored.  128 bytes. */
+ * read is ignored.  160 bytes. */
 typedef struct {
     int32_t type;           /* pt_material_type */
     float kd[3];            /* "Kd": matte 0.5, plastic/uber 0.25, substrate 0.5 */
@@ -90,6 +121,9 @@ typedef struct {
     int32_t remap_roughness;/* "remaproughness", default true */
     float metal_eta[3];     /* metal "eta" as RGB (the reference's default is the copper SPD) */
     float metal_k[3];       /* metal "k" as RGB */
+    /* ABI 4: index + 1 of the texture that drives the parameter at each hit (Texture::evaluate(si)), 0 = the constant
+     * above.  Zero-initialised materials are therefore constant. */
+    uint32_t tex_kd, tex_ks, tex_kr, tex_kt, tex_opacity, tex_sigma, tex_metal_eta, tex_metal_k;
     float reserved[3];
 } pt_material;
 
@@ -192,6 +226,10 @@ typedef struct {
      * the plain triangle index when n_spheres == 0. */
     uint32_t n_spheres;
     const pt_sphere* spheres;
+
+    /* ---- procedural textures (ABI 4), referenced by pt_material.tex_* */
+    uint32_t n_textures;
+    const pt_texture* textures;
     int32_t reserved[2];
 } pt_scene_desc;
 

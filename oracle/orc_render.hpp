@@ -108,6 +108,10 @@ struct BSDF {
     }
 };
 
+}  // namespace orc
+#include "orc_texture.hpp"
+namespace orc {
+
 struct AreaLight {          // lights/diffuse.rs:5-11
     uint32_t shape;         // Geometry::ref encoding: triangle index, or PRIM_SPHERE | sphere index
     RGB lemit;
@@ -119,6 +123,7 @@ struct Scene {
     Geometry geom;
     QBVH bvh;
     std::vector<pt_material> materials;
+    std::vector<pt_texture> textures;
     std::vector<int32_t> mesh_material, mesh_light_params;
     std::vector<int32_t> sphere_material;
     std::vector<int32_t> prim_light;    // light index per primitive or -1
@@ -282,7 +287,8 @@ inline void transform_ray(const Mat4& m, V3* o, V3* d) {   // transform.rs:216-2
     *d = dd;
 }
 struct CameraSample { V2 p_film, p_lens; Float time; };
-inline Ray generate_ray(const Scene& sc, const CameraSample& s) {
+inline Ray generate_ray(const Scene& sc, const CameraSample& s, RayDiff* rdiff = nullptr);
+inline Ray generate_ray_main(const Scene& sc, const CameraSample& s) {
     V3 p_camera = sc.raster_to_camera.transform_point(V3(s.p_film.x, s.p_film.y, 0.0f));
     V3 o(0.0f, 0.0f, 0.0f);
     V3 d = normalize(p_camera);
@@ -295,6 +301,47 @@ inline Ray generate_ray(const Scene& sc, const CameraSample& s) {
     }
     transform_ray(sc.camera_to_world, &o, &d);
     return Ray(o, d, kInfinity);
+}
+// PerspectiveCamera::generate_ray_differential (perspective.rs:121-183) + the 1/sqrt(spp) scaling of render_tile
+// (sampler.rs:218,233; ray_differential.rs:26-35)
+inline Ray generate_ray(const Scene& sc, const CameraSample& s, RayDiff* rdiff) {
+    Ray ray = generate_ray_main(sc, s);
+    if (!rdiff) return ray;
+    V3 p_camera = sc.raster_to_camera.transform_point(V3(s.p_film.x, s.p_film.y, 0.0f));
+    V3 dx_camera = sc.raster_to_camera.transform_point(V3(1.0f, 0.0f, 0.0f)) - sc.raster_to_camera.transform_point(V3(0.0f, 0.0f, 0.0f));
+    V3 dy_camera = sc.raster_to_camera.transform_point(V3(0.0f, 1.0f, 0.0f)) - sc.raster_to_camera.transform_point(V3(0.0f, 0.0f, 0.0f));
+    V3 rxo, ryo, rxd, ryd;
+    if (sc.lens_radius > 0.0f) {
+        V2 p_lens = concentric_sample_disk(s.p_lens) * sc.lens_radius;
+        {
+            V3 dx = normalize(p_camera + dx_camera);
+            Float ft = sc.focal_distance / dx.z;
+            V3 p_focus = V3(0.0f, 0.0f, 0.0f) + (ft * dx);
+            rxo = V3(p_lens.x, p_lens.y, 0.0f);
+            rxd = normalize(p_focus - rxo);
+        }
+        {
+            V3 dy = normalize(p_camera + dy_camera);
+            Float ft = sc.focal_distance / dy.z;
+            V3 p_focus = V3(0.0f, 0.0f, 0.0f) + (ft * dy);
+            ryo = V3(p_lens.x, p_lens.y, 0.0f);
+            ryd = normalize(p_focus - ryo);
+        }
+    } else {
+        rxo = V3(0.0f, 0.0f, 0.0f); ryo = rxo;          // = ray.o before the lens / camera transform
+        rxd = normalize(p_camera + dx_camera);
+        ryd = normalize(p_camera + dy_camera);
+    }
+    // transform_ray_differential (transform.rs:284-297): plain point / vector transforms for the offset rays
+    rxo = sc.camera_to_world.transform_point(rxo); ryo = sc.camera_to_world.transform_point(ryo);
+    rxd = sc.camera_to_world.transform_vector(rxd); ryd = sc.camera_to_world.transform_vector(ryd);
+    Float scale = std::sqrt(1.0f / (Float)sc.spp);
+    rdiff->has = true;
+    rdiff->rx_o = ray.o + (rxo - ray.o) * scale;
+    rdiff->ry_o = ray.o + (ryo - ray.o) * scale;
+    rdiff->rx_d = ray.d + (rxd - ray.d) * scale;
+    rdiff->ry_d = ray.d + (ryd - ray.d) * scale;
+    return ray;
 }
 
 struct RayCounters { uint64_t camera = 0, regular = 0, shadow = 0, nodes = 0, tris = 0, vertices = 0; };
@@ -410,10 +457,25 @@ inline bool make_bsdf_from_material(const pt_material& m, const SurfHit& si, BSD
     }
     return false;
 }
-inline bool make_bsdf(const Scene& sc, const SurfHit& si, BSDF* b) {
+// Parameter textures are evaluated at the hit (TextureParams::get_spectrum_texture / get_float_texture bound at material
+// creation; Texture::evaluate(si) inside each compute_scattering_functions), then the constant-parameter code runs.
+inline bool make_bsdf(const Scene& sc, const SurfHit& si, BSDF* b, const RayDiff& rd = RayDiff()) {
     int32_t mid = sc.prim_material(si.prim);
     if (mid < 0) return false;
-    return make_bsdf_from_material(sc.materials[mid], si, b);
+    const pt_material& m0 = sc.materials[mid];
+    if (!(m0.tex_kd | m0.tex_ks | m0.tex_kr | m0.tex_kt | m0.tex_opacity | m0.tex_sigma | m0.tex_metal_eta | m0.tex_metal_k))
+        return make_bsdf_from_material(m0, si, b);
+    pt_material m = m0;
+    TexHit th = compute_differentials(si, rd);                  // SurfaceInteraction::compute_scattering_functions :284-295
+    auto spec = [&](uint32_t t, float* out) {
+        if (!t) return;
+        RGB v = texture_eval(sc.textures.data(), (int32_t)t - 1, th);
+        out[0] = v.c[0]; out[1] = v.c[1]; out[2] = v.c[2];
+    };
+    spec(m.tex_kd, m.kd); spec(m.tex_ks, m.ks); spec(m.tex_kr, m.kr); spec(m.tex_kt, m.kt); spec(m.tex_opacity, m.opacity);
+    spec(m.tex_metal_eta, m.metal_eta); spec(m.tex_metal_k, m.metal_k);
+    if (m.tex_sigma) m.sigma = texture_eval(sc.textures.data(), (int32_t)m.tex_sigma - 1, th).c[0];
+    return make_bsdf_from_material(m, si, b);
 }
 
 // SurfaceInteraction::le (surface_interaction.rs:297-306)
@@ -501,7 +563,7 @@ inline RGB uniform_sample_one_light(const Scene& sc, const SurfHit& it, const BS
 }
 
 // PathIntegrator::li (integrators/path.rs:61-241)
-inline RGB path_li(const Scene& sc, LightDistribution& ldist, Ray ray, SobolSampler& sampler, RayCounters& rc) {
+inline RGB path_li(const Scene& sc, LightDistribution& ldist, Ray ray, SobolSampler& sampler, RayCounters& rc, RayDiff rdiff = RayDiff()) {
     // no lights => create_light_sample_distribution fails => li returns zero (path.rs:71-74)
     if (sc.lights.empty()) return RGB();
     RGB l, beta(1.0f);
@@ -519,7 +581,9 @@ inline RGB path_li(const Scene& sc, LightDistribution& ldist, Ray ray, SobolSamp
         }
         if (!found || bounces >= sc.max_depth) break;
         BSDF bsdf;
-        if (!make_bsdf(sc, isect, &bsdf)) {
+        bool has_bsdf = make_bsdf(sc, isect, &bsdf, rdiff);
+        rdiff.has = false;                 // every later ray is a plain Ray (`.into()`, path.rs:109,:209)
+        if (!has_bsdf) {
             ray = Ray(offset_ray_origin(isect.p, isect.p_error, isect.n, ray.d), ray.d, kInfinity);
             continue;
         }
@@ -676,9 +740,10 @@ inline void render_tile(const Scene& sc, LightDistribution& ldist, const int32_t
                 cs.p_film = V2((Float)xx, (Float)yy) + sampler.get_2d();
                 cs.p_lens = sampler.get_2d();
                 cs.time = sampler.get_1d();
-                Ray ray = generate_ray(sc, cs);
+                RayDiff rdiff;
+                Ray ray = generate_ray(sc, cs, &rdiff);
                 rc.camera++;
-                RGB l = validate_radiance(path_li(sc, ldist, ray, sampler, rc));
+                RGB l = validate_radiance(path_li(sc, ldist, ray, sampler, rc, rdiff));
                 if (radiance_out) { radiance_out[3 * k] = l.c[0]; radiance_out[3 * k + 1] = l.c[1]; radiance_out[3 * k + 2] = l.c[2]; k++; }
                 tile.add_sample(cs.p_film, l, 1.0f);
             } while (sampler.start_next_sample());
@@ -746,6 +811,14 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
         mesh_light_params[i] = d.meshes[i].area_light;
     }
     materials.assign(d.materials, d.materials + d.n_materials);
+    if (d.n_textures) textures.assign(d.textures, d.textures + d.n_textures);
+    for (uint32_t i = 0; i < d.n_textures; i++)
+        for (int k = 0; k < 3; k++)
+            if (textures[i].tex[k] >= (int32_t)i) { if (err) *err = "texture child index must be smaller than the texture's own"; return false; }
+    for (const pt_material& m : materials) {
+        const uint32_t refs[8] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k};
+        for (uint32_t r : refs) if (r > d.n_textures) { if (err) *err = "material texture index out of range"; return false; }
+    }
     // spheres, spliced into the primitive list at before_triangle
     if (d.n_spheres > 0) {
         geom.spheres.resize(d.n_spheres);

@@ -34,7 +34,20 @@ class pt_material(C.Structure):
     _fields_ = [("type", C.c_int32), ("kd", C.c_float * 3), ("sigma", C.c_float), ("ks", C.c_float * 3), ("kr", C.c_float * 3),
                 ("kt", C.c_float * 3), ("opacity", C.c_float * 3), ("eta", C.c_float), ("roughness", C.c_float),
                 ("uroughness", C.c_float), ("vroughness", C.c_float), ("remap_roughness", C.c_int32),
-                ("metal_eta", C.c_float * 3), ("metal_k", C.c_float * 3), ("reserved", C.c_float * 3)]
+                ("metal_eta", C.c_float * 3), ("metal_k", C.c_float * 3),
+                ("tex_kd", C.c_uint32), ("tex_ks", C.c_uint32), ("tex_kr", C.c_uint32), ("tex_kt", C.c_uint32),
+                ("tex_opacity", C.c_uint32), ("tex_sigma", C.c_uint32), ("tex_metal_eta", C.c_uint32), ("tex_metal_k", C.c_uint32),
+                ("reserved", C.c_float * 3)]
+
+
+class pt_texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("tex", C.c_int32 * 3), ("value", (C.c_float * 3) * 4), ("mapping", C.c_int32),
+                ("aa_none", C.c_int32), ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float),
+                ("v1", C.c_float * 3), ("v2", C.c_float * 3), ("world_to_texture", C.c_float * 16)]
+
+
+PT_TEX_CONSTANT, PT_TEX_SCALE, PT_TEX_MIX, PT_TEX_CHECKERBOARD_2D, PT_TEX_CHECKERBOARD_3D, PT_TEX_UV, PT_TEX_BILERP = range(7)
+PT_MAPPING_UV, PT_MAPPING_SPHERICAL, PT_MAPPING_CYLINDRICAL, PT_MAPPING_PLANAR = range(4)
 
 
 class pt_area_light(C.Structure):
@@ -73,7 +86,8 @@ class pt_scene_desc(C.Structure):
         ("sampler", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
         ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
         ("halton_sample_at_center", C.c_int32),
-        ("n_spheres", C.c_uint32), ("spheres", C.POINTER(pt_sphere)), ("reserved", C.c_int32 * 2),
+        ("n_spheres", C.c_uint32), ("spheres", C.POINTER(pt_sphere)),
+        ("n_textures", C.c_uint32), ("textures", C.POINTER(pt_texture)), ("reserved", C.c_int32 * 2),
     ]
 
 

@@ -520,6 +520,14 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (mi >= 0 && (d->materials[mi].type < PT_MATERIAL_NONE || d->materials[mi].type > PT_MATERIAL_SUBSTRATE))
             return ctx->fail(PT_ERR_UNSUPPORTED, "material type not on the accelerated path");
     }
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const pt_material& m = d->materials[i];
+        const uint32_t refs[8] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k};
+        for (uint32_t r : refs) {
+            if (r > d->n_textures) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "material texture index out of range");
+            if (r) return ctx->fail(PT_ERR_UNSUPPORTED, "textured material parameters: device evaluation not built yet");
+        }
+    }
     for (uint32_t i = 0; i < d->n_spheres; i++) {
         const pt_sphere& sp = d->spheres[i];
         if (sp.material >= (int32_t)d->n_materials || sp.material >= 65535) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "sphere material index out of range");

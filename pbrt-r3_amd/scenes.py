@@ -219,12 +219,19 @@ class SceneDesc:
         setattr(self.desc, name, arr.ctypes.data_as(C.POINTER(ctype)) if arr is not None and arr.size else None)
 
 
+class Tex:
+    """Handle of a texture added to a SceneBuilder."""
+    def __init__(self, index):
+        self.index = index
+
+
 class SceneBuilder:
     def __init__(self):
         self.P, self.N, self.S, self.UV = [], [], [], []
         self.idx, self.tri_mesh = [], []
         self.meshes, self.materials, self.area_lights = [], [], []
         self.spheres = []
+        self.textures = []
         self.n_vertices = 0
         self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, (0.5, 0.5, 0.5), 0.0)   # default matte
         self.cur_area_light = -1
@@ -331,20 +338,74 @@ class SceneBuilder:
 
     # ---- graphics state
     def _add_material(self, typ, kd=(0.0, 0.0, 0.0), sigma=0.0, **kw):
+        """Colour parameters (and Matte's sigma) may be a Tex handle from the texture_* methods: the parameter is then
+        Texture::evaluate(si) at each hit (the reference's get_spectrum_texture / get_float_texture binding)."""
         m = capi.pt_material()
         m.type = typ
-        m.kd[:] = [float(k) for k in kd]
-        m.sigma = float(sigma)
         m.opacity[:] = [1.0, 1.0, 1.0]
         m.eta, m.remap_roughness = 1.5, 1
         m.uroughness = m.vroughness = capi.PT_ROUGHNESS_UNSET
+        kw = dict(kw, kd=kd, sigma=sigma)
         for k, v in kw.items():
-            if isinstance(v, (tuple, list)):
+            if isinstance(v, Tex):
+                setattr(m, "tex_" + k, v.index + 1)
+            elif isinstance(v, (tuple, list)):
                 getattr(m, k)[:] = [float(x) for x in v]
             else:
                 setattr(m, k, v)
         self.materials.append(m)
         return len(self.materials) - 1
+
+    # ---- textures (src/textures/): each returns a Tex handle usable as a material parameter or as a child texture.
+    # `to_world` = (m, m_inv) of the CTM at the Texture directive (spherical / cylindrical / 3-D mappings use its inverse).
+    def _texture(self, typ, children=(), values=(), mapping="uv", uscale=1.0, vscale=1.0, udelta=0.0, vdelta=0.0, v1=(1, 0, 0), v2=(0, 1, 0),
+                 to_world=None, aamode="closedform"):
+        t = capi.pt_texture()
+        t.type = typ
+        for i in range(3):
+            t.tex[i] = -1
+        for i, c in enumerate(children):
+            if isinstance(c, Tex):
+                assert c.index < len(self.textures)
+                t.tex[i] = c.index
+            else:
+                t.value[i][:] = [float(x) for x in (c if isinstance(c, (tuple, list)) else (c, c, c))]
+        for i, v in enumerate(values):
+            t.value[i][:] = [float(x) for x in (v if isinstance(v, (tuple, list)) else (v, v, v))]
+        t.mapping = {"uv": capi.PT_MAPPING_UV, "spherical": capi.PT_MAPPING_SPHERICAL, "cylindrical": capi.PT_MAPPING_CYLINDRICAL,
+                     "planar": capi.PT_MAPPING_PLANAR}[mapping]
+        t.aa_none = 1 if aamode == "none" else 0
+        t.su, t.sv, t.du, t.dv = uscale, vscale, udelta, vdelta
+        t.v1[:] = [float(x) for x in v1]
+        t.v2[:] = [float(x) for x in v2]
+        w2t = np.eye(4, dtype=np.float32).reshape(-1) if to_world is None else np.asarray(to_world[1], np.float32).reshape(-1)
+        t.world_to_texture[:] = [float(x) for x in w2t]
+        self.textures.append(t)
+        return Tex(len(self.textures) - 1)
+
+    def texture_constant(self, value):
+        return self._texture(capi.PT_TEX_CONSTANT, values=[value])
+
+    def texture_scale(self, tex1=1.0, tex2=1.0):
+        return self._texture(capi.PT_TEX_SCALE, children=[tex1, tex2])
+
+    def texture_mix(self, tex1=1.0, tex2=1.0, amount=0.5):
+        return self._texture(capi.PT_TEX_MIX, children=[tex1, tex2, amount])
+
+    def texture_checkerboard(self, tex1=1.0, tex2=0.0, dimension=2, **kw):
+        if dimension == 3:      # IdentityMapping3D is handed tex2world itself, not its inverse (checkerboard.rs:159, mapping3d.rs:19-24)
+            tw = kw.pop("to_world", None)
+            t = self._texture(capi.PT_TEX_CHECKERBOARD_3D, children=[tex1, tex2], **kw)
+            if tw is not None:
+                self.textures[t.index].world_to_texture[:] = [float(x) for x in np.asarray(tw[0], np.float32).reshape(-1)]
+            return t
+        return self._texture(capi.PT_TEX_CHECKERBOARD_2D, children=[tex1, tex2], **kw)
+
+    def texture_uv(self, **kw):
+        return self._texture(capi.PT_TEX_UV, **kw)
+
+    def texture_bilerp(self, v00=0.0, v01=1.0, v10=0.0, v11=1.0, **kw):
+        return self._texture(capi.PT_TEX_BILERP, values=[v00, v01, v10, v11], **kw)
 
     def material_matte(self, Kd=(0.5, 0.5, 0.5), sigma=0.0):
         self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, Kd, sigma)
@@ -512,6 +573,10 @@ class SceneBuilder:
         d.n_meshes, d.meshes = len(self.meshes), meshes
         d.n_materials, d.materials = len(self.materials), mats
         d.n_area_lights, d.area_lights = len(self.area_lights), als
+        if self.textures:
+            tex = (capi.pt_texture * len(self.textures))(*self.textures)
+            sd.buffers["textures"] = tex
+            d.n_textures, d.textures = len(self.textures), tex
         if self.spheres:
             sph = (capi.pt_sphere * len(self.spheres))(*self.spheres)
             sd.buffers["spheres"] = sph

@@ -232,3 +232,50 @@ def scene_spheres(strategy="spatial", split="sah", res=40, spp=8, depth=6, sampl
     b.reverse_orientation = False
     b.no_area_light()
     return b.build()
+
+
+def scene_textures(res=48, spp=8, depth=5, sampler="sobol", aamode="closedform"):
+    """Procedural textures (src/textures/) driving material parameters: a closed-form filtered checkerboard floor (uv mapping
+    with scale / offset) whose checks are themselves a mix and a uv texture, a 3-D checkerboard under a transform on a matte
+    sphere mesh with Oren-Nayar sigma from a bilerp float texture, a planar-mapped checkerboard on plastic Kd with a scale
+    texture on Ks, spherical / cylindrical mappings on two analytic spheres (uber Kd / opacity, metal eta)."""
+    b = base(res=res, spp=spp, depth=depth)
+    if sampler == "halton":
+        b.sampler_halton(spp)
+    T = scenes
+    s = 2.0
+    uvt = b.texture_uv(uscale=3.0, vscale=2.0)
+    mixt = b.texture_mix((0.8, 0.2, 0.1), (0.1, 0.3, 0.8), amount=b.texture_bilerp(0.1, 0.9, 0.6, 0.3))
+    floor = b.texture_checkerboard(mixt, uvt, uscale=6.0, vscale=6.0, udelta=0.25, vdelta=0.1, aamode=aamode)
+    b.material_matte(floor)
+    scenes._quad(b, (s, -s, -s), (-s, -s, -s), (-s, -s, s), (s, -s, s))
+    b.material_matte((0.7, 0.7, 0.7))
+    scenes._quad(b, (s, s, -s), (s, s, s), (-s, s, s), (-s, s, -s))
+    planar = b.texture_checkerboard((0.9, 0.9, 0.2), (0.2, 0.2, 0.2), mapping="planar", v1=(1.5, 0.0, 0.0), v2=(0.0, 1.5, 0.3), udelta=0.2, vdelta=0.4)
+    b.material_plastic(Kd=planar, Ks=b.texture_scale((0.5, 0.5, 0.5), b.texture_checkerboard(1.0, 0.2, uscale=10.0, vscale=10.0)), roughness=0.05)
+    scenes._quad(b, (s, -s, s), (-s, -s, s), (-s, s, s), (s, s, s))
+    b.material_matte((0.2, 0.6, 0.3))
+    scenes._quad(b, (-s, -s, s), (-s, -s, -s), (-s, s, -s), (-s, s, s))
+    b.material_matte((0.7, 0.2, 0.2))
+    scenes._quad(b, (s, -s, -s), (s, -s, s), (s, s, s), (s, s, -s))
+    b.material_matte((0.5, 0.5, 0.5))
+    b.area_light_source_diffuse(L=(10, 9, 8))
+    h = 0.999 * s
+    scenes._quad(b, (0.5, h, -0.5), (0.5, h, 0.5), (-0.5, h, 0.5), (-0.5, h, -0.5))
+    b.no_area_light()
+    # 3-D checkerboard under a rotation + scale, sigma from a float texture
+    t3 = T.transform_mul(T.transform_rotate_x(25.0), T.transform_scale(3.0, 3.0, 3.0))
+    c3 = b.texture_checkerboard((0.9, 0.5, 0.1), (0.1, 0.1, 0.4), dimension=3, to_world=t3)
+    b.material_matte(c3, sigma=b.texture_bilerp(0.0, 40.0, 10.0, 60.0))
+    P, N, UV, idx = uv_sphere((-1.0, -1.2, 0.4), 0.7)
+    b.shape_trianglemesh(P, idx, N=N, uv=UV)
+    # analytic spheres with spherical / cylindrical mappings (their own world_to_texture)
+    ts = T.transform_translate(0.9, -1.3, -0.2)
+    sph_tex = b.texture_checkerboard((0.8, 0.8, 0.8), (0.15, 0.3, 0.15), mapping="spherical", uscale=1.0, to_world=ts, aamode=aamode)
+    b.material_uber(Kd=b.texture_scale(sph_tex, (8.0, 8.0, 8.0)) if False else sph_tex, Ks=(0.2, 0.2, 0.2),
+                    opacity=b.texture_checkerboard((1.0, 1.0, 1.0), (0.3, 0.3, 0.3), mapping="cylindrical", to_world=ts))
+    b.shape_sphere(radius=0.65, object_to_world=ts[0], world_to_object=ts[1])
+    tm = T.transform_translate(0.1, 0.2, 1.2)
+    b.material_metal(eta=b.texture_checkerboard((0.2, 0.92, 1.1), (1.5, 0.9, 0.4), uscale=4.0, vscale=8.0), k=(3.9, 2.45, 2.14), roughness=0.1)
+    b.shape_sphere(radius=0.5, object_to_world=tm[0], world_to_object=tm[1])
+    return b.build()
