@@ -25,6 +25,7 @@
 #include "pt_device.h"
 #include "pt_host_math.h"
 #include "pt_kernels.h"
+#include "pt_lobes.h"
 
 namespace {
 
@@ -60,7 +61,7 @@ struct pt_context {
     bool have_scene = false;
     PtScene sc;
     pt_scene_info info;
-    DevBuf d_nodes, d_tris, d_tri_info, d_spheres, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab, d_hdims, d_hperms;
+    DevBuf d_nodes, d_tris, d_tri_info, d_spheres, d_textures, d_tex_prog, d_mat_params, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab, d_hdims, d_hperms;
     std::vector<uint32_t> sobol_m32;
     std::vector<uint64_t> sobol_vdc, sobol_inv;
     uint32_t sobol_n_vdc = 0, sobol_n_inv = 0, sobol_msize = 52;
@@ -243,143 +244,22 @@ pt_status pt_set_data_dir(pt_context* ctx, const char* dir) {
 }
 
 namespace {
-// ---- Material::compute_scattering_functions for constant parameter textures (src/materials/*.rs), evaluated
-// once per material: the list of BxDFs the BSDF receives, in the order the material adds them.
-const uint32_t kRefl = 1, kTrans = 2, kDiffuse = 4, kGlossy = 8, kSpecular = 16;    // bxdf.rs:8-14
-float clamp_zero(float v) { return v < 0.0f ? 0.0f : v; }                            // Spectrum::clamp_zero per channel
-bool black(const float* c) { return c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f; }
-float roughness_to_alpha(float roughness) {                                           // trowbridge_reitz.rs:104-113
+// trowbridge_reitz.rs:104-113 (host only: logf)
+float roughness_to_alpha(float roughness) {
     roughness = roughness > 1e-3f ? roughness : 1e-3f;
     float x = std::log(roughness);
     return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
 }
-PtLobe* push_lobe(PtMaterial& m, uint32_t kind, uint32_t type, const float* r) {
-    PtLobe* l = &m.lobes[m.n_lobes++];
-    l->kind = kind; l->type = type;
-    l->r[0] = r[0]; l->r[1] = r[1]; l->r[2] = r[2];
-    l->eta_a = l->eta_b = l->fr_eta_i = l->fr_eta_t = 1.0f;
-    l->ax = l->ay = 0.001f;
-    return l;
-}
-void set_distribution(PtLobe* l, float ax, float ay) {                               // TrowbridgeReitzDistribution::new
-    l->ax = 0.001f > ax ? 0.001f : ax;     // f32::max: a NaN roughness becomes 0.001
-    l->ay = 0.001f > ay ? 0.001f : ay;
-    if (ax != ax) l->ax = 0.001f;
-    if (ay != ay) l->ay = 0.001f;
+// The three roughness parameters after the optional remap (plastic.rs:55-58, glass.rs:76-81, metal.rs:58-69, uber.rs:96-104, substrate.rs:49-54)
+void material_alphas(const pt_material& in, float* a_r, float* a_u, float* a_v) {
+    auto remap = [&](float r) { return in.remap_roughness ? roughness_to_alpha(r) : r; };
+    *a_r = remap(in.roughness); *a_u = remap(in.uroughness); *a_v = remap(in.vroughness);
 }
 void build_lobes(const pt_material& in, PtMaterial& m) {
     std::memset(&m, 0, sizeof(m));
-    m.type = in.type;
-    std::memcpy(m.kd, in.kd, 12);
-    m.sigma = in.sigma;
-    m.bsdf_eta = 1.0f;
-    m.has_bsdf = in.type != PT_MATERIAL_NONE;
-    auto pick = [](float specific, float general) { return specific == PT_ROUGHNESS_UNSET ? general : specific; };
-    auto remap = [&](float r) { return in.remap_roughness ? roughness_to_alpha(r) : r; };
-    auto cz = [](const float* c, float* out) { for (int i = 0; i < 3; i++) out[i] = clamp_zero(c[i]); };
-    auto mul = [](const float* a, const float* b, float* out) { for (int i = 0; i < 3; i++) out[i] = a[i] * b[i]; };
-    switch (in.type) {
-        case PT_MATERIAL_MATTE: {                       // matte.rs:25-53 (Kd is not clamped here)
-            float sig = in.sigma < 0.0f ? 0.0f : (in.sigma > 90.0f ? 90.0f : in.sigma);
-            const float pi = 3.14159265358979323846f;
-            float sigma = sig * (pi / 180.0f);
-            float sigma2 = sigma * sigma;
-            m.oren_a = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
-            m.oren_b = 0.45f * sigma2 / (sigma2 + 0.09f);
-            if (!black(in.kd)) {
-                PtLobe* l = push_lobe(m, sig == 0.0f ? PT_LOBE_LAMBERT : PT_LOBE_OREN_NAYAR, kRefl | kDiffuse, in.kd);
-                l->oa = m.oren_a; l->ob = m.oren_b;
-            }
-            break;
-        }
-        case PT_MATERIAL_PLASTIC: {                     // plastic.rs:31-71
-            float kd[3], ks[3];
-            cz(in.kd, kd); cz(in.ks, ks);
-            if (!black(kd)) push_lobe(m, PT_LOBE_LAMBERT, kRefl | kDiffuse, kd);
-            if (!black(ks)) {
-                float rough = remap(in.roughness);
-                PtLobe* l = push_lobe(m, PT_LOBE_MF_REFL, kRefl | kGlossy, ks);
-                set_distribution(l, rough, rough);
-                l->fresnel = PT_FR_DIELECTRIC; l->fr_eta_i = 1.5f; l->fr_eta_t = 1.0f;
-            }
-            break;
-        }
-        case PT_MATERIAL_MIRROR: {                      // mirror.rs:19-41
-            float kr[3];
-            cz(in.kr, kr);
-            if (!black(kr)) push_lobe(m, PT_LOBE_SPEC_REFL, kRefl | kSpecular, kr)->fresnel = PT_FR_NOOP;
-            break;
-        }
-        case PT_MATERIAL_GLASS: {                       // glass.rs:46-110 (Kr, Kt unclamped; allow_multiple_lobes = true)
-            if (black(in.kr) && black(in.kt)) { m.has_bsdf = 0; break; }
-            m.bsdf_eta = in.eta;
-            if (in.uroughness == 0.0f && in.vroughness == 0.0f) {
-                PtLobe* l = push_lobe(m, PT_LOBE_FRESNEL_SPEC, kRefl | kTrans | kSpecular, in.kr);
-                std::memcpy(l->t, in.kt, 12);
-                l->eta_a = 1.0f; l->eta_b = in.eta;
-            } else {
-                float ur = remap(in.uroughness), vr = remap(in.vroughness);
-                if (!black(in.kr)) {
-                    PtLobe* l = push_lobe(m, PT_LOBE_MF_REFL, kRefl | kGlossy, in.kr);
-                    set_distribution(l, ur, vr);
-                    l->fresnel = PT_FR_DIELECTRIC; l->fr_eta_i = 1.0f; l->fr_eta_t = in.eta;
-                }
-                if (!black(in.kt)) {
-                    PtLobe* l = push_lobe(m, PT_LOBE_MF_TRANS, kTrans | kGlossy, in.kt);
-                    set_distribution(l, ur, vr);
-                    l->eta_a = 1.0f; l->eta_b = in.eta;
-                }
-            }
-            break;
-        }
-        case PT_MATERIAL_METAL: {                       // metal.rs:51-85
-            const float one[3] = {1.0f, 1.0f, 1.0f};
-            PtLobe* l = push_lobe(m, PT_LOBE_MF_REFL, kRefl | kGlossy, one);
-            set_distribution(l, remap(pick(in.uroughness, in.roughness)), remap(pick(in.vroughness, in.roughness)));
-            l->fresnel = PT_FR_CONDUCTOR;
-            std::memcpy(l->t, in.metal_eta, 12);
-            std::memcpy(l->k, in.metal_k, 12);
-            break;
-        }
-        case PT_MATERIAL_UBER: {                        // uber.rs:63-127
-            float t[3], c[3], tmp[3];
-            for (int i = 0; i < 3; i++) t[i] = clamp_zero(1.0f - in.opacity[i]);
-            m.bsdf_eta = !black(t) ? 1.0f : in.eta;
-            if (!black(t)) push_lobe(m, PT_LOBE_SPEC_TRANS, kTrans | kSpecular, t);       // eta_a = eta_b = 1
-            cz(in.kd, tmp); mul(in.opacity, tmp, c);
-            if (!black(c)) push_lobe(m, PT_LOBE_LAMBERT, kRefl | kDiffuse, c);
-            cz(in.ks, tmp); mul(in.opacity, tmp, c);
-            if (!black(c)) {
-                PtLobe* l = push_lobe(m, PT_LOBE_MF_REFL, kRefl | kGlossy, c);
-                set_distribution(l, remap(pick(in.uroughness, in.roughness)), remap(pick(in.vroughness, in.roughness)));
-                l->fresnel = PT_FR_DIELECTRIC; l->fr_eta_i = 1.0f; l->fr_eta_t = in.eta;
-            }
-            cz(in.kr, tmp); mul(in.opacity, tmp, c);
-            if (!black(c)) {
-                PtLobe* l = push_lobe(m, PT_LOBE_SPEC_REFL, kRefl | kSpecular, c);
-                l->fresnel = PT_FR_DIELECTRIC; l->fr_eta_i = 1.0f; l->fr_eta_t = in.eta;
-            }
-            cz(in.kt, tmp); mul(in.opacity, tmp, c);
-            if (!black(c)) {
-                PtLobe* l = push_lobe(m, PT_LOBE_SPEC_TRANS, kTrans | kSpecular, c);
-                l->eta_a = 1.0f; l->eta_b = in.eta;
-            }
-            break;
-        }
-        case PT_MATERIAL_SUBSTRATE: {                   // substrate.rs:34-68
-            float d[3], s[3];
-            cz(in.kd, d); cz(in.ks, s);
-            if (!black(d) && !black(s)) {
-                PtLobe* l = push_lobe(m, PT_LOBE_FRESNEL_BLEND, kRefl | kGlossy, d);
-                std::memcpy(l->t, s, 12);
-                set_distribution(l, remap(in.uroughness), remap(in.vroughness));
-            }
-            break;
-        }
-        default: break;
-    }
-    for (uint32_t i = 0; i < m.n_lobes; i++)
-        if (!(m.lobes[i].type & kSpecular)) m.nonspecular++;
+    float a_r, a_u, a_v;
+    material_alphas(in, &a_r, &a_u, &a_v);
+    ::build_lobes(in, a_r, a_u, a_v, m);
 }
 
 // PCG32 with the reference's default state (core/rng.rs:8-67) -- only the bounded draw that
@@ -523,10 +403,15 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const pt_material& m = d->materials[i];
         const uint32_t refs[8] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k};
-        for (uint32_t r : refs) {
-            if (r > d->n_textures) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "material texture index out of range");
-            if (r) return ctx->fail(PT_ERR_UNSUPPORTED, "textured material parameters: device evaluation not built yet");
-        }
+        for (uint32_t r : refs)
+            if (r > d->n_textures || (r && !d->textures)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "material texture index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const pt_texture& t = d->textures[i];
+        if (t.type < PT_TEX_CONSTANT || t.type > PT_TEX_BILERP) return ctx->fail(PT_ERR_UNSUPPORTED, "texture class not on the accelerated path");
+        if (t.mapping < PT_MAPPING_UV || t.mapping > PT_MAPPING_PLANAR) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown texture mapping");
+        for (int k = 0; k < 3; k++)
+            if (t.tex[k] >= (int32_t)i) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "texture child index must be smaller than the texture's own (definition order)");
     }
     for (uint32_t i = 0; i < d->n_spheres; i++) {
         const pt_sphere& sp = d->spheres[i];
@@ -636,9 +521,55 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     std::memset(mats.data(), 0, mats.size() * sizeof(PtMaterial));
     bool general_materials = false;
     uint32_t n_matte_bins = 0, n_general_bins = 0;
+    // textured materials: parameter block + one evaluation program per texture-driven parameter (pt_texture.h)
+    std::vector<PtMatParams> mparams(mats.size());
+    std::memset(mparams.data(), 0, mparams.size() * sizeof(PtMatParams));
+    std::vector<uint32_t> tex_prog(1, 0u);          // offset 0 = "constant"
+    bool any_textured = false;
+    auto add_program = [&](uint32_t root) -> uint32_t {        // post-order over the nodes the root needs; 0 on overflow
+        std::vector<uint32_t> order;
+        std::vector<int32_t> pos(d->n_textures, -1);
+        std::vector<std::pair<uint32_t, int>> stack{{root, 0}};
+        while (!stack.empty()) {
+            auto& top = stack.back();
+            const pt_texture& t = d->textures[top.first];
+            const int n_children = t.type == PT_TEX_MIX ? 3 : ((t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD_2D || t.type == PT_TEX_CHECKERBOARD_3D) ? 2 : 0);
+            if (top.second < n_children) {
+                int32_t c = t.tex[top.second++];
+                if (c >= 0 && pos[c] < 0) stack.push_back({(uint32_t)c, 0});
+                continue;
+            }
+            if (pos[top.first] < 0) { pos[top.first] = (int32_t)order.size(); order.push_back(top.first); }
+            stack.pop_back();
+        }
+        if (order.size() > PT_TEX_PROG_MAX || d->n_textures > 0xffffu) return 0u;
+        const uint32_t off = (uint32_t)tex_prog.size();
+        tex_prog.push_back((uint32_t)order.size());
+        for (uint32_t node : order) {
+            const pt_texture& t = d->textures[node];
+            uint32_t e = node;
+            for (int k = 0; k < 3; k++) e |= (t.tex[k] >= 0 ? (uint32_t)pos[t.tex[k]] : PT_TEX_CHILD_CONST) << (16 + 4 * k);
+            tex_prog.push_back(e);
+        }
+        return off;
+    };
     for (uint32_t i = 0; i < d->n_materials; i++) {
         build_lobes(d->materials[i], mats[i]);
-        const bool general = d->materials[i].type != PT_MATERIAL_NONE && d->materials[i].type != PT_MATERIAL_MATTE;
+        {
+            const pt_material& in = d->materials[i];
+            const uint32_t refs[8] = {in.tex_kd, in.tex_ks, in.tex_kr, in.tex_kt, in.tex_opacity, in.tex_sigma, in.tex_metal_eta, in.tex_metal_k};
+            PtMatParams& mp = mparams[i];
+            mp.m = in;
+            material_alphas(in, &mp.a_r, &mp.a_u, &mp.a_v);
+            for (int k = 0; k < 8; k++) {
+                if (!refs[k] || in.type == PT_MATERIAL_NONE) continue;
+                mp.prog[k] = add_program(refs[k] - 1);
+                if (!mp.prog[k]) return ctx->fail(PT_ERR_UNSUPPORTED, "a material parameter's texture graph needs more than 12 nodes");
+                mats[i].textured = 1;
+                any_textured = true;
+            }
+        }
+        const bool general = d->materials[i].type != PT_MATERIAL_NONE && (d->materials[i].type != PT_MATERIAL_MATTE || mats[i].textured);
         if (general) general_materials = true;
         // shade-queue bin: one per material while they last, the remainder of a class shares its last bin
         mats[i].sort_bin = general ? PT_SORT_GENERAL0 + std::min(n_general_bins++, PT_SORT_BINS - PT_SORT_GENERAL0 - 1u)
@@ -654,6 +585,11 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if ((st = upload(ctx, ctx->d_materials, mats.data(), mats.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_lights, lights.data(), lights.size())) != PT_OK) return st;
     if (d->n_spheres) { if ((st = upload(ctx, ctx->d_spheres, sph.data(), sph.size())) != PT_OK) return st; } else ctx->d_spheres.release();
+    if (any_textured) {
+        if ((st = upload(ctx, ctx->d_textures, d->textures, d->n_textures)) != PT_OK) return st;
+        if ((st = upload(ctx, ctx->d_tex_prog, tex_prog.data(), tex_prog.size())) != PT_OK) return st;
+        if ((st = upload(ctx, ctx->d_mat_params, mparams.data(), mparams.size())) != PT_OK) return st;
+    } else { ctx->d_textures.release(); ctx->d_tex_prog.release(); ctx->d_mat_params.release(); }
     if (d->N) { if ((st = upload(ctx, ctx->d_N, d->N, 3 * (size_t)d->n_vertices)) != PT_OK) return st; } else ctx->d_N.release();
     if (d->S) { if ((st = upload(ctx, ctx->d_S, d->S, 3 * (size_t)d->n_vertices)) != PT_OK) return st; } else ctx->d_S.release();
     if (d->UV) { if ((st = upload(ctx, ctx->d_UV, d->UV, 2 * (size_t)d->n_vertices)) != PT_OK) return st; } else ctx->d_UV.release();
@@ -671,6 +607,10 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     ctx->n_materials = d->n_materials;
     sc.lights = ctx->d_lights.as<PtLight>();
     sc.n_lights = (uint32_t)lights.size();
+    sc.textured = any_textured ? 1u : 0u;
+    sc.textures = any_textured ? ctx->d_textures.as<pt_texture>() : nullptr;
+    sc.tex_prog = any_textured ? ctx->d_tex_prog.as<uint32_t>() : nullptr;
+    sc.mat_params = any_textured ? ctx->d_mat_params.as<PtMatParams>() : nullptr;
     sc.spheres = d->n_spheres ? ctx->d_spheres.as<PtSphere>() : nullptr;
     sc.n_spheres = d->n_spheres;
     if (d->n_spheres) sc.general_materials = 1;     // sphere scenes run the sphere-capable kernel instantiations (sorted shade queue)

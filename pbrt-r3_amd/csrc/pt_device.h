@@ -3,6 +3,7 @@
 // HBM; layouts are chosen for 16-byte lane loads and 128-byte node fetches.
 #pragma once
 #include <stdint.h>
+#include "../../include/pbrtgpu.h"
 
 #define PT_WAVE 64
 #define PT_BLOCK 256
@@ -83,7 +84,20 @@ struct PtMaterial {
     uint32_t nonspecular;        // num_components(BSDF_ALL & !BSDF_SPECULAR)
     float bsdf_eta;              // BSDF::eta
     uint32_t sort_bin;           // shade-queue bin: [0,128) Matte materials, [128,256) the others
+    uint32_t textured;           // 1: parameters come from textures at each hit (PtMatParams), the lobes below are unused
+    uint32_t pad[3];
     PtLobe lobes[PT_MAX_LOBES];
+};
+#define PT_TEX_PROG_MAX 12          // nodes one parameter's texture graph may need
+#define PT_TEX_CHILD_CONST 15u      // texture program entry, child slot: the node's own constant (pt_texture.h)
+// A material with texture-driven parameters: the caller's parameter block, the roughness values after the optional
+// roughness_to_alpha remap (host-side: logf), and per parameter the offset of its texture program in PtScene::tex_prog
+// (0 = constant).  Parameter order: Kd Ks Kr Kt opacity sigma metal-eta metal-k.
+struct PtMatParams {
+    pt_material m;
+    float a_r, a_u, a_v;
+    uint32_t prog[8];
+    uint32_t pad;
 };
 
 // One DiffuseAreaLight (one emissive triangle).
@@ -179,6 +193,10 @@ struct PtScene {
     const PtMaterial* materials;
     const PtLight* lights;
     const PtSphere* spheres;
+    const pt_texture* textures;  // pt_scene_desc.textures as given
+    const uint32_t* tex_prog;    // texture programs (pt_texture.h)
+    const PtMatParams* mat_params;   // per material; read for textured materials only
+    uint32_t textured;           // 1: some material is textured (k_shade_general_full runs)
     uint32_t n_spheres;          // > 0: the sphere-capable kernel instantiations run
     uint32_t n_lights;
     uint32_t root_ref;           // node 0, or a leaf reference when the whole scene is one leaf
@@ -216,6 +234,7 @@ struct PtPaths {
 };
 
 #define PT_ST_SPECULAR 1u
+#define PT_ST_CAMERA 2u         // the ray is still the camera ray: it has differentials (textures filter with them)
 #define PT_NEE_SHADOW 1u
 #define PT_NEE_PROBE 2u
 

@@ -20,6 +20,8 @@
 #include "pt_device_math.h"
 #include "pt_bxdf.h"
 #include "pt_sphere.h"
+#include "pt_texture.h"
+#include "pt_lobes.h"
 #include "pt_kernels.h"
 #include "../../include/pbrtgpu.h"
 
@@ -188,6 +190,43 @@ PT_DEV void generate_camera_ray(const PtScene& sc, V2 p_film, V2 u_lens, V3* o_o
     }
     *o_out = op;
     *d_out = dd;
+}
+
+// The camera ray's offset rays (PerspectiveCamera::generate_ray_differential, perspective.rs:146-171, transformed as
+// transform_ray_differential does, transform.rs:284-297) after render_tile's scale_differentials(1 / sqrt(spp))
+// (sampler.rs:218,233; ray_differential.rs:26-35).  ro / rd: the main ray as k_gen made it.
+PT_DEV void camera_differentials(const PtScene& sc, V2 p_film, V2 u_lens, V3 ro, V3 rd, RayDiffs& out) {
+    const float* r2c = sc.cam.raster_to_camera;
+    V3 p_camera = xform_point(r2c, mk3(p_film.x, p_film.y, 0.0f));
+    V3 c0 = xform_point(r2c, mk3(0.0f, 0.0f, 0.0f));
+    V3 dx_camera = xform_point(r2c, mk3(1.0f, 0.0f, 0.0f)) - c0;
+    V3 dy_camera = xform_point(r2c, mk3(0.0f, 1.0f, 0.0f)) - c0;
+    V3 rxo = mk3(0.0f, 0.0f, 0.0f), ryo = rxo, rxd, ryd;
+    if (sc.cam.lens_radius > 0.0f) {
+        V2 dl = concentric_sample_disk(u_lens);
+        V2 p_lens = mk2(dl.x * sc.cam.lens_radius, dl.y * sc.cam.lens_radius);
+        V3 dx = normalize(p_camera + dx_camera);
+        float ftx = sc.cam.focal_distance / dx.z;
+        V3 pfx = mk3(0.0f, 0.0f, 0.0f) + (ftx * dx);
+        rxo = mk3(p_lens.x, p_lens.y, 0.0f);
+        rxd = normalize(pfx - rxo);
+        V3 dy = normalize(p_camera + dy_camera);
+        float fty = sc.cam.focal_distance / dy.z;
+        V3 pfy = mk3(0.0f, 0.0f, 0.0f) + (fty * dy);
+        ryo = mk3(p_lens.x, p_lens.y, 0.0f);
+        ryd = normalize(pfy - ryo);
+    } else {
+        rxd = normalize(p_camera + dx_camera);
+        ryd = normalize(p_camera + dy_camera);
+    }
+    const float* m = sc.cam.camera_to_world;
+    rxo = xform_point(m, rxo); ryo = xform_point(m, ryo);
+    rxd = xform_vector(m, rxd); ryd = xform_vector(m, ryd);
+    const float scale = sqrtf(1.0f / (float)sc.sobol.spp);
+    out.rx_o = ro + (rxo - ro) * scale;
+    out.ry_o = ro + (ryo - ro) * scale;
+    out.rx_d = rd + (rxd - rd) * scale;
+    out.ry_d = rd + (ryd - rd) * scale;
 }
 
 // ============================================================ ray / triangle
@@ -892,7 +931,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_gen(PtScene sc, PtPaths
         P.p_film[i] = make_float2(p_film.x, p_film.y);
         P.sobol_index[i] = sm.index;
         P.pixel[i] = pk;
-        P.state[i] = sm.dim;          // dim = 5, bounces = 0, flags = 0
+        P.state[i] = sm.dim | (PT_ST_CAMERA << 24);          // dim = 5, bounces = 0, flags = camera ray
         P.nee[i] = 0;
         Q.cur[i] = i;
     }
@@ -922,16 +961,19 @@ struct Surf {            // what SurfaceInteraction carries for this path (surfa
     V3 sh_n, sh_dpdu;
     uint32_t prim;
     int32_t material, light;     // from the triangle record (-1 = none)
+    V2 uv;                       // read by textures only (dead in the kernels without them)
+    V3 dpdu, dpdv;               // geometric partials (compute_differentials)
 };
 
 // Triangle::get_dpdu_dpdv (triangle.rs:132-186)
-PT_DEV void tri_dpdu(const PtScene& sc, bool has_attr, const PtTriInfo& ti, V3 p0, V3 p1, V3 p2, V3* dpdu, V3* dpdv) {
+PT_DEV void tri_dpdu(const PtScene& sc, bool has_attr, const PtTriInfo& ti, V3 p0, V3 p1, V3 p2, V3* dpdu, V3* dpdv, V2* uvs) {
     V2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);
     if (has_attr && (ti.mesh_flags & PT_MESH_HAS_UV) && sc.UV) {
         uv0 = mk2(sc.UV[2 * ti.v[0]], sc.UV[2 * ti.v[0] + 1]);
         uv1 = mk2(sc.UV[2 * ti.v[1]], sc.UV[2 * ti.v[1] + 1]);
         uv2 = mk2(sc.UV[2 * ti.v[2]], sc.UV[2 * ti.v[2] + 1]);
     }
+    uvs[0] = uv0; uvs[1] = uv1; uvs[2] = uv2;
     float du02x = uv0.x - uv2.x, du02y = uv0.y - uv2.y, du12x = uv1.x - uv2.x, du12y = uv1.y - uv2.y;
     V3 dp02 = p0 - p2, dp12 = p1 - p2;
     float determinant = du02x * du12y - du02y * du12x;
@@ -961,7 +1003,10 @@ PT_DEV bool make_surf_tv(const PtScene& sc, V3 ro, V3 rd, const TriVerts& tv, ui
     if (tv.flags & PT_TRI_FLIP) n = n * -1.0f;
     n = normalize(n);
     V3 dpdu, dpdv;
-    tri_dpdu(sc, has_attr, ti, tv.p0, tv.p1, tv.p2, &dpdu, &dpdv);
+    V2 uvs[3];
+    tri_dpdu(sc, has_attr, ti, tv.p0, tv.p1, tv.p2, &dpdu, &dpdv, uvs);
+    s.uv = mk2(h.b0 * uvs[0].x + h.b1 * uvs[1].x + h.b2 * uvs[2].x, h.b0 * uvs[0].y + h.b1 * uvs[1].y + h.b2 * uvs[2].y);   // triangle.rs:352
+    s.dpdu = dpdu; s.dpdv = dpdv;
     float xa = fabsf(h.b0 * tv.p0.x) + fabsf(h.b1 * tv.p1.x) + fabsf(h.b2 * tv.p2.x);
     float ya = fabsf(h.b0 * tv.p0.y) + fabsf(h.b1 * tv.p1.y) + fabsf(h.b2 * tv.p2.y);
     float za = fabsf(h.b0 * tv.p0.z) + fabsf(h.b1 * tv.p1.z) + fabsf(h.b2 * tv.p2.z);
@@ -1023,7 +1068,8 @@ PT_DEV bool make_surf_any(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s
             SphHit sh;
             const PtSphere& sp = sc.spheres[__float_as_uint(a.x)];
             if (!sph_hit_test(sp, ro, rd, PT_INF, PT_PI, &sh)) return false;
-            sph_interaction(sp, sh, &s.p, &s.p_error, &s.n, &s.wo, &s.sh_n, &s.sh_dpdu);
+            sph_interaction(sp, sh, &s.p, &s.p_error, &s.n, &s.wo, &s.sh_n, &s.sh_dpdu, &s.dpdv, &s.uv);
+            s.dpdu = s.sh_dpdu;
             s.prim = __float_as_uint(a.w);
             s.material = (int32_t)(flags >> PT_TRI_MATERIAL_SHIFT) - 1;
             s.light = (int32_t)__float_as_uint(q[2].w) - 1;
@@ -1343,7 +1389,23 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 #endif
 // GENERAL = false: every material is Matte (at most one diffuse lobe; the RT1M / Cornell fast path).
 // GENERAL = true: BSDFs are the per-material lobe lists of pt_bxdf.h (specular bounces, eta_scale, glass without a BSDF).
-template <bool GENERAL, bool SPH>
+// Textured material at a hit: evaluate the parameter textures (Texture::evaluate(si) inside each
+// compute_scattering_functions) into a copy of the parameter block, then build the BxDF list the host builds for constant
+// materials (pt_lobes.h).
+__device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material, const TexHit& th, PtMaterial* out) {
+    PtMatParams mp = sc.mat_params[material];
+    float* dst[8] = {mp.m.kd, mp.m.ks, mp.m.kr, mp.m.kt, mp.m.opacity, nullptr, mp.m.metal_eta, mp.m.metal_k};
+    for (int k = 0; k < 8; k++) {
+        if (!mp.prog[k]) continue;
+        V3 v = tex_eval(sc.textures, sc.tex_prog + mp.prog[k], th);
+        if (k == 5) mp.m.sigma = v.x;
+        else { dst[k][0] = v.x; dst[k][1] = v.y; dst[k][2] = v.z; }
+    }
+    unsigned char* z = reinterpret_cast<unsigned char*>(out);
+    for (uint32_t i = 0; i < sizeof(PtMaterial); i++) z[i] = 0;
+    build_lobes(mp.m, mp.a_r, mp.a_u, mp.a_v, *out);
+}
+template <bool GENERAL, bool SPH, bool TEX = false>
 PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, const uint32_t* list, uint32_t begin, uint32_t end,
                        uint32_t* ticket) {
     __shared__ unsigned long long s_vert;
@@ -1392,7 +1454,33 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             }
             if (found && (int32_t)bounces < sc.max_depth) {
                 bool no_bsdf = s.material < 0;
-                if constexpr (GENERAL) { if (!no_bsdf) no_bsdf = sc.materials[s.material].has_bsdf == 0; }
+                PtMaterial tm;                     // TEX: this hit's lobes
+                bool use_tm = false;
+                if constexpr (TEX) {
+                    if (!no_bsdf && sc.materials[s.material].textured) {
+                        TexHit th;
+                        th.p = s.p; th.uv = s.uv;
+                        RayDiffs rdf;
+                        const bool has_diff = (flags & PT_ST_CAMERA) != 0;
+                        if (has_diff) {             // rebuild the camera ray's offset rays from its camera sample
+                            Sampler sl;
+                            sl.index = P.sobol_index[p];
+                            sl.dim = 2;             // get_camera_sample: film (0,1), lens (2,3), time (4)
+                            uint32_t pk2 = P.pixel[p];
+                            sl.px = (int32_t)(pk2 & 0xffffu) + sc.film.sample_bounds[0];
+                            sl.py = (int32_t)(pk2 >> 16) + sc.film.sample_bounds[1];
+                            V2 u_lens = mk2(0.0f, 0.0f);
+                            if (sc.cam.lens_radius > 0.0f) u_lens = sl.get_2d(sc);
+                            float2 pf = P.p_film[p];
+                            camera_differentials(sc, mk2(pf.x, pf.y), u_lens, ro, rd, rdf);
+                        }
+                        compute_differentials(th, s.p, s.n, s.dpdu, s.dpdv, has_diff, rdf);
+                        textured_lobes(sc, s.material, th, &tm);
+                        use_tm = true;
+                        no_bsdf = tm.has_bsdf == 0;
+                    }
+                }
+                if constexpr (GENERAL) { if (!no_bsdf && !use_tm) no_bsdf = sc.materials[s.material].has_bsdf == 0; }
                 if (no_bsdf) {
                     // no BSDF: continue through the surface, same bounce count (path.rs:108-111)
                     V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
@@ -1405,7 +1493,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     bool nonspecular;
                     float bsdf_eta = 1.0f;
                     if constexpr (GENERAL) {
-                        const PtMaterial& m = sc.materials[s.material];
+                        const PtMaterial& m = use_tm ? tm : sc.materials[s.material];
                         gb.ns = s.sh_n; gb.ng = s.n;
                         gb.ss = normalize(s.sh_dpdu);
                         gb.ts = normalize(cross(gb.ns, gb.ss));
@@ -1548,7 +1636,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     }
                     dim = sm.dim;
                 }
-                if (cont) P.state[p] = (dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+                if (cont) P.state[p] = (dim & 0xffffu) | ((bounces & 0xffu) << 16) | ((flags & ~PT_ST_CAMERA) << 24);     // later rays are plain Rays
             }
         }
         // ---- order-preserving wave compaction into the next / nee queues
@@ -1587,6 +1675,10 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_matte_sorted_s
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
+}
+// scenes with textured materials (and possibly spheres): lobes are built per hit for the textured ones
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
 }
 
 // ============================================================ film
@@ -1850,7 +1942,11 @@ hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths&
         hipLaunchKernelGGL(k_sort_count, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(PT_SORT_BINS), 0, st, Q);
         hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
-        if (sc.n_spheres) {
+        if (sc.textured) {
+            if (sc.n_spheres) hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            else hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            hipLaunchKernelGGL(k_shade_general_tex, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        } else if (sc.n_spheres) {
             hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
             hipLaunchKernelGGL(k_shade_general_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
         } else {

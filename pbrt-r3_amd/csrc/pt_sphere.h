@@ -136,7 +136,7 @@ __device__ __noinline__ bool sph_hit_test(const PtSphere& s, V3 ro, V3 rd, float
 }
 // World-space interaction of a hit (sphere.rs:130-198 + transform_surface_interaction, transform.rs:299-323).
 // Only what the path consumes: p, p_error, n, wo, shading n and dpdu (u, v, dndu, dndv feed textures).
-PT_DEV void sph_interaction(const PtSphere& s, const SphHit& h, V3* p, V3* p_error, V3* n, V3* wo, V3* sh_n, V3* dpdu_w) {
+PT_DEV void sph_interaction(const PtSphere& s, const SphHit& h, V3* p, V3* p_error, V3* n, V3* wo, V3* sh_n, V3* dpdu_w, V3* dpdv_w, V2* uv) {
     V3 ph = h.p_hit;
     float dtheta = s.theta_max - s.theta_min;
     float theta = pt_acosf(clampf(ph.z / s.radius, -1.0f, 1.0f));
@@ -157,6 +157,8 @@ PT_DEV void sph_interaction(const PtSphere& s, const SphHit& h, V3* p, V3* p_err
     *wo = normalize(sph_vector(s.o2w, -h.d));
     *sh_n = face_forward(nw, nw);                                // shading.n = n before the transform
     *dpdu_w = sph_vector(s.o2w, dpdu);
+    *dpdv_w = sph_vector(s.o2w, dpdv);
+    *uv = mk2(h.phi / s.phi_max, (theta - s.theta_min) / dtheta);      // sphere.rs:136-140 (read by textures only)
 }
 // Sphere::sample (sphere.rs:286-304)
 PT_DEV void sph_sample(const PtSphere& s, V2 u, V3* p, V3* n, V3* p_error) {

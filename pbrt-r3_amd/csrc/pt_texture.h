@@ -1,0 +1,163 @@
+// pt_texture.h -- procedural textures at a hit (src/textures/, src/core/texture/mapping2d.rs, mapping3d.rs) and the ray
+// differentials they filter with (surface_interaction.rs:221-282).  Only a camera ray carries differentials in the path
+// integrator (path.rs replaces the ray by a plain Ray after the first vertex), so they are rebuilt from the camera sample
+// in the shade kernel instead of travelling with the path.
+//
+// A texture graph is evaluated bottom-up from a small program the host writes per (material, parameter): the nodes the
+// parameter's root needs, children before parents (pt_scene_desc.textures is in definition order, so that is index order).
+#pragma once
+#include "pt_device.h"
+#include "pt_device_math.h"
+#include "../../include/pbrtgpu.h"
+
+
+struct TexHit {                     // what SurfaceInteraction offers a texture
+    V3 p, dpdx, dpdy;
+    V2 uv;
+    float dudx, dvdx, dudy, dvdy;
+};
+struct RayDiffs { V3 rx_o, ry_o, rx_d, ry_d; };
+
+PT_DEV bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float* x0, float* x1) {   // matrix4x4.rs:9-20
+    float det = a00 * a11 - a01 * a10;
+    if (fabsf(det) < 1e-10f) return false;
+    float r0 = (a11 * b0 - a01 * b1) / det;
+    float r1 = (a00 * b1 - a10 * b0) / det;
+    if (r0 != r0 || r1 != r1) return false;
+    *x0 = r0; *x1 = r1;
+    return true;
+}
+// SurfaceInteraction::compute_differentials (surface_interaction.rs:221-282); has == false: everything zero
+PT_DEV void compute_differentials(TexHit& t, V3 p, V3 n, V3 dpdu, V3 dpdv, bool has, const RayDiffs& rd) {
+    t.dpdx = mk3(0.0f, 0.0f, 0.0f); t.dpdy = t.dpdx;
+    t.dudx = t.dvdx = t.dudy = t.dvdy = 0.0f;
+    if (!has) return;
+    float d = dot(n, p);
+    float tx = -(dot(n, rd.rx_o) - d) / dot(n, rd.rx_d);
+    if (!isfinite(tx)) return;
+    V3 px = rd.rx_o + tx * rd.rx_d;
+    float ty = -(dot(n, rd.ry_o) - d) / dot(n, rd.ry_d);
+    if (!isfinite(ty)) return;
+    V3 py = rd.ry_o + ty * rd.ry_d;
+    t.dpdx = px - p;
+    t.dpdy = py - p;
+    int d0, d1;
+    if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) { d0 = 1; d1 = 2; }
+    else if (fabsf(n.y) > fabsf(n.z)) { d0 = 0; d1 = 2; }
+    else { d0 = 0; d1 = 1; }
+    float a00 = comp(dpdu, d0), a01 = comp(dpdv, d0), a10 = comp(dpdu, d1), a11 = comp(dpdv, d1);
+    float bx0 = comp(px, d0) - comp(p, d0), bx1 = comp(px, d1) - comp(p, d1);
+    float by0 = comp(py, d0) - comp(p, d0), by1 = comp(py, d1) - comp(p, d1);
+    if (!solve_2x2(a00, a01, a10, a11, bx0, bx1, &t.dudx, &t.dvdx)) { t.dudx = 0.0f; t.dvdx = 0.0f; }
+    if (!solve_2x2(a00, a01, a10, a11, by0, by1, &t.dudy, &t.dvdy)) { t.dudy = 0.0f; t.dvdy = 0.0f; }
+}
+
+// matrix4x4.rs:284-297 with the homogeneous divide (texture transforms may be anything the CTM was)
+PT_DEV V3 tex_point(const float* m, V3 p) {
+    float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    float wp = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (wp == 1.0f) return mk3(xp, yp, zp);
+    return mk3(xp / wp, yp / wp, zp / wp);
+}
+PT_DEV V2 sphere_st(const float* w2t, V3 p) {               // SphericalMapping2D::sphere (mapping2d.rs:66-72)
+    V3 vec = normalize(tex_point(w2t, p) - mk3(0.0f, 0.0f, 0.0f));
+    float theta = pt_acosf(clampf(vec.z, -1.0f, 1.0f));
+    float ph = pt_atan2f(vec.y, vec.x);
+    float phi = ph < 0.0f ? ph + 2.0f * PT_PI : ph;
+    return mk2(theta * PT_INV_PI, phi * (PT_INV_PI * 0.5f));
+}
+PT_DEV V2 cylinder_st(const float* w2t, V3 p) {             // CylindricalMapping2D::cylinder (mapping2d.rs:116-120)
+    V3 vec = normalize(tex_point(w2t, p) - mk3(0.0f, 0.0f, 0.0f));
+    return mk2((PT_PI + pt_atan2f(vec.y, vec.x)) * (PT_INV_PI * 0.5f), vec.z);
+}
+PT_DEV float fix_wrap(float d) { return d > 0.5f ? 1.0f - d : (d < -0.5f ? -(d + 1.0f) : d); }
+PT_DEV void map2d(const pt_texture& t, const TexHit& si, V2* st, V2* dstdx, V2* dstdy) {
+    if (t.mapping == PT_MAPPING_SPHERICAL || t.mapping == PT_MAPPING_CYLINDRICAL) {
+        const bool sph = t.mapping == PT_MAPPING_SPHERICAL;
+        const float delta = 0.1f;
+        V3 p0 = si.p, p1 = si.p + delta * si.dpdx, p2 = si.p + delta * si.dpdy;
+        V2 s0 = sph ? sphere_st(t.world_to_texture, p0) : cylinder_st(t.world_to_texture, p0);
+        V2 sx = sph ? sphere_st(t.world_to_texture, p1) : cylinder_st(t.world_to_texture, p1);
+        V2 sy = sph ? sphere_st(t.world_to_texture, p2) : cylinder_st(t.world_to_texture, p2);
+        V2 dx = mk2((sx.x - s0.x) * (1.0f / delta), (sx.y - s0.y) * (1.0f / delta));
+        V2 dy = mk2((sy.x - s0.x) * (1.0f / delta), (sy.y - s0.y) * (1.0f / delta));
+        dx.y = fix_wrap(dx.y); dy.y = fix_wrap(dy.y);
+        *st = s0; *dstdx = dx; *dstdy = dy;
+    } else if (t.mapping == PT_MAPPING_PLANAR) {
+        V3 vs = ld3(t.v1), vt = ld3(t.v2);
+        *st = mk2(t.du + dot(si.p, vs), t.dv + dot(si.p, vt));
+        *dstdx = mk2(dot(si.dpdx, vs), dot(si.dpdx, vt));
+        *dstdy = mk2(dot(si.dpdy, vs), dot(si.dpdy, vt));
+    } else {
+        *dstdx = mk2(t.su * si.dudx, t.sv * si.dvdx);
+        *dstdy = mk2(t.su * si.dudy, t.sv * si.dvdy);
+        *st = mk2(t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv);
+    }
+}
+PT_DEV float bump_int(float x) { return floorf(x / 2.0f) + 2.0f * fmaxf(x / 2.0f - floorf(x / 2.0f) - 0.5f, 0.0f); }
+PT_DEV int32_t f2i_sat(float f) {           // Rust `as i32`: saturating, NaN -> 0
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 0x7fffffff;
+    if (f <= -2147483648.0f) return (int32_t)0x80000000u;
+    return (int32_t)f;
+}
+PT_DEV bool even_sum(int32_t a, int32_t b) { return ((int32_t)((uint32_t)a + (uint32_t)b) % 2) == 0; }
+
+// One node, its children already evaluated (c0, c1, c2 = tex1, tex2, amount).
+PT_DEV V3 tex_node(const pt_texture& t, const TexHit& si, V3 c0, V3 c1, V3 c2) {
+    switch (t.type) {
+        case PT_TEX_SCALE: return c0 * c1;
+        case PT_TEX_MIX: { float amt = c2.x; return c0 * (1.0f - amt) + c1 * amt; }
+        case PT_TEX_CHECKERBOARD_2D: {
+            V2 st, dx, dy;
+            map2d(t, si, &st, &dx, &dy);
+            const bool first = even_sum(f2i_sat(floorf(st.x)), f2i_sat(floorf(st.y)));
+            if (t.aa_none) return first ? c0 : c1;
+            float ds = fmaxf(fabsf(dx.x), fabsf(dy.x)), dt = fmaxf(fabsf(dx.y), fabsf(dy.y));
+            float s0 = st.x - ds, s1 = st.x + ds, t0 = st.y - dt, t1 = st.y + dt;
+            if (floorf(s0) == floorf(s1) && floorf(t0) == floorf(t1)) return first ? c0 : c1;
+            float sint = (bump_int(s1) - bump_int(s0)) / (2.0f * ds);
+            float tint = (bump_int(t1) - bump_int(t0)) / (2.0f * dt);
+            float area2 = sint + tint - 2.0f * sint * tint;
+            if (ds > 1.0f || dt > 1.0f) area2 = 0.5f;
+            return c0 * (1.0f - area2) + c1 * area2;
+        }
+        case PT_TEX_CHECKERBOARD_3D: {
+            V3 p = tex_point(t.world_to_texture, si.p);          // IdentityMapping3D: the matrix is tex2world (checkerboard.rs:159)
+            int32_t s = (int32_t)((uint32_t)f2i_sat(floorf(p.x)) + (uint32_t)f2i_sat(floorf(p.y)) + (uint32_t)f2i_sat(floorf(p.z)));
+            return (s % 2) == 0 ? c0 : c1;
+        }
+        case PT_TEX_UV: {
+            V2 st, dx, dy;
+            map2d(t, si, &st, &dx, &dy);
+            return mk3(st.x - floorf(st.x), st.y - floorf(st.y), 0.0f);
+        }
+        case PT_TEX_BILERP: {
+            V2 st, dx, dy;
+            map2d(t, si, &st, &dx, &dy);
+            float a = (1.0f - st.x) * (1.0f - st.y), b = (1.0f - st.x) * st.y, c = st.x * (1.0f - st.y), d = st.x * st.y;
+            return ld3(t.value[0]) * a + ld3(t.value[1]) * b + ld3(t.value[2]) * c + ld3(t.value[3]) * d;
+        }
+        default: return ld3(t.value[0]);
+    }
+}
+// prog[0] = n; prog[1..n]: node index | child slots (positions in this list, or PT_TEX_CHILD_CONST) << 16 / 20 / 24
+__device__ __noinline__ V3 tex_eval(const pt_texture* textures, const uint32_t* prog, const TexHit& si) {
+    V3 val[PT_TEX_PROG_MAX];
+    const uint32_t n = prog[0];
+    V3 last = mk3(0.0f, 0.0f, 0.0f);
+    for (uint32_t i = 0; i < n && i < PT_TEX_PROG_MAX; i++) {
+        const uint32_t e = prog[1 + i];
+        const pt_texture& t = textures[e & 0xffffu];
+        V3 c[3];
+        for (int k = 0; k < 3; k++) {
+            const uint32_t slot = (e >> (16 + 4 * k)) & 15u;
+            c[k] = slot == PT_TEX_CHILD_CONST ? ld3(t.value[k]) : val[slot];
+        }
+        last = tex_node(t, si, c[0], c[1], c[2]);
+        val[i] = last;
+    }
+    return last;
+}

@@ -234,7 +234,7 @@ def scene_spheres(strategy="spatial", split="sah", res=40, spp=8, depth=6, sampl
     return b.build()
 
 
-def scene_textures(res=48, spp=8, depth=5, sampler="sobol", aamode="closedform"):
+def scene_textures(res=48, spp=8, depth=5, sampler="sobol", aamode="closedform", lens=False):
     """Procedural textures (src/textures/) driving material parameters: a closed-form filtered checkerboard floor (uv mapping
     with scale / offset) whose checks are themselves a mix and a uv texture, a 3-D checkerboard under a transform on a matte
     sphere mesh with Oren-Nayar sigma from a bilerp float texture, a planar-mapped checkerboard on plastic Kd with a scale
@@ -242,6 +242,8 @@ def scene_textures(res=48, spp=8, depth=5, sampler="sobol", aamode="closedform")
     b = base(res=res, spp=spp, depth=depth)
     if sampler == "halton":
         b.sampler_halton(spp)
+    if lens:        # thin lens: the offset rays start at the lens sample (perspective.rs:146-165)
+        b.camera_perspective(fov=40.0, lensradius=0.08, focaldistance=6.0)
     T = scenes
     s = 2.0
     uvt = b.texture_uv(uscale=3.0, vscale=2.0)

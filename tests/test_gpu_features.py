@@ -65,6 +65,10 @@ def _compare(ctx, osc, exact_film, frac_limit=0.0):
     ("spheres_power_hlbvh", lambda: fs.scene_spheres("power", split="hlbvh"), True),
     ("spheres_uniform_halton", lambda: fs.scene_spheres("uniform", split="middle", sampler="halton"), True),
     ("sphere_lights_only", lambda: fs.scene_spheres("spatial", lights_only=True), True),
+    # procedural textures on material parameters, filtered with the camera ray's differentials
+    ("textures_closedform", lambda: fs.scene_textures(), True),
+    ("textures_point_halton", lambda: fs.scene_textures(sampler="halton", aamode="none"), True),
+    ("textures_thin_lens", lambda: fs.scene_textures(lens=True), True),
 ])
 def test_feature_scene(gpu_ctx, oracle, name, make, exact):
     sd = make()
