@@ -124,7 +124,9 @@ public:
     std::vector<pt_material> materials;
     std::map<std::string, float> float_textures;                        // constant-folded named textures (global, see pbrt_texture)
     std::map<std::string, std::array<float, 3>> spectrum_textures;
-    std::map<std::string, std::string> unsupported_textures;          // name -> class of textures that do not fold
+    std::map<std::string, std::string> unsupported_textures;          // name -> class of textures that are not on the path
+    std::vector<pt_texture> textures;                                   // textures that depend on the hit: evaluated on the device
+    std::map<std::string, uint32_t> node_float_textures, node_spectrum_textures;   // name -> index into textures
     std::vector<pt_area_light> area_lights;
     bool any_n = false, any_s = false, any_uv = false;
     pt_scene_desc desc;
@@ -211,46 +213,124 @@ public:
         if (transforms.size() <= 1) { warn("Unmatched TransformEnd"); return; }
         transforms.pop_back(); bits.pop_back();
     }
-    // Texture directive (scene_context.rs:1077-1114).  Only textures whose value does not depend on the surface point
-    // are on the accelerated path: "constant", and "scale" / "mix" of such (textures/{constant,scale,mix}.rs).  They
-    // fold to a value here.  As in the reference the texture tables are NOT scoped by AttributeBegin/End
-    // (pbrt_texture writes through the shared map without the copy-on-write that named materials get).
+    // Texture directive (scene_context.rs:1077-1114).  "constant", and "scale" / "mix" of constants, fold to a value here;
+    // "checkerboard" (2-D with any mapping, 3-D), "uv", "bilerp", and scale / mix over those, become pt_texture nodes that
+    // the device evaluates at each hit; image maps and the noise textures are reported when something uses them.  As in
+    // the reference the texture tables are NOT scoped by AttributeBegin/End (pbrt_texture writes through the shared map
+    // without the copy-on-write that named materials get).
+    struct Child { bool is_node = false; uint32_t node = 0; float v[3] = {0, 0, 0}; };
+    Child child_float(const ParamSet& p, const char* n, float dflt) {            // tp.get_float_texture(n, dflt)
+        Child c; uint32_t t = 0; float v = dflt;
+        lookup_float(p, p, n, &v, &t);
+        if (t) { c.is_node = true; c.node = t - 1; } else c.v[0] = c.v[1] = c.v[2] = v;
+        return c;
+    }
+    Child child_rgb(const ParamSet& p, const char* n, float dflt) {              // tp.get_spectrum_texture(n, Spectrum(dflt))
+        Child c; uint32_t t = 0; float v[3] = {dflt, dflt, dflt};
+        lookup_rgb(p, p, n, v, &t);
+        if (t) { c.is_node = true; c.node = t - 1; } else { c.v[0] = v[0]; c.v[1] = v[1]; c.v[2] = v[2]; }
+        return c;
+    }
+    static void set_child(pt_texture& t, int k, const Child& c) {
+        t.tex[k] = c.is_node ? (int32_t)c.node : -1;
+        if (!c.is_node) { t.value[k][0] = c.v[0]; t.value[k][1] = c.v[1]; t.value[k][2] = c.v[2]; }
+    }
+    // create_texture_mapping2d (mapping2d.rs:178-214)
+    bool set_mapping2d(const ParamSet& p, pt_texture& t) {
+        const std::string mapping = p.find_one_string("mapping", "uv");
+        const Xf& t2w = transforms.back().t[0];
+        std::memcpy(t.world_to_texture, t2w.inv.a, 64);
+        t.su = 1.0f; t.sv = 1.0f;
+        t.v1[0] = 1.0f; t.v2[1] = 1.0f;
+        if (mapping == "uv") {
+            t.mapping = PT_MAPPING_UV;
+            t.su = p.find_one_float("uscale", 1.0f); t.sv = p.find_one_float("vscale", 1.0f);
+            t.du = p.find_one_float("udelta", 0.0f); t.dv = p.find_one_float("vdelta", 0.0f);
+        } else if (mapping == "spherical") t.mapping = PT_MAPPING_SPHERICAL;
+        else if (mapping == "cylindrical") t.mapping = PT_MAPPING_CYLINDRICAL;
+        else if (mapping == "planar") {
+            t.mapping = PT_MAPPING_PLANAR;
+            if (const std::vector<float>* v = p.get_vectors("v1")) if (v->size() >= 3) { t.v1[0] = (*v)[0]; t.v1[1] = (*v)[1]; t.v1[2] = (*v)[2]; }
+            if (const std::vector<float>* v = p.get_vectors("v2")) if (v->size() >= 3) { t.v2[0] = (*v)[0]; t.v2[1] = (*v)[1]; t.v2[2] = (*v)[2]; }
+            t.du = p.find_one_float("udelta", 0.0f); t.dv = p.find_one_float("vdelta", 0.0f);
+        } else { warn("2D texture mapping \"" + mapping + "\" unknown"); return false; }
+        return true;
+    }
     void pbrt_texture(const std::string& name, const std::string& type, const std::string& tex_class, const ParamSet& p) override {
         if (!error.empty()) return;
         const bool is_float = type == "float", is_spec = type == "color" || type == "rgb" || type == "spectrum";
         if (!is_float && !is_spec) { warn("Texture type \"" + type + "\" unknown."); return; }
-        if (tex_class != "constant" && tex_class != "scale" && tex_class != "mix") {
-            unsupported_textures[name] = tex_class;       // fails only if something uses it
-            float_textures.erase(name); spectrum_textures.erase(name);
-            return;
-        }
-        if (is_float) {
-            float v = 1.0f;
-            if (tex_class == "constant") v = p.find_one_float("value", 1.0f);
-            else {
-                float t1 = 1.0f, t2 = 1.0f, amt = 0.5f;
-                lookup_float(p, p, "tex1", &t1); lookup_float(p, p, "tex2", &t2);
-                if (tex_class == "scale") v = t1 * t2;
-                else { lookup_float(p, p, "amount", &amt); v = t1 * (1.0f - amt) + t2 * amt; }
+        auto forget = [&]() {
+            float_textures.erase(name); spectrum_textures.erase(name); unsupported_textures.erase(name);
+            (is_float ? node_float_textures : node_spectrum_textures).erase(name);
+        };
+        auto child = [&](const char* n, float dflt) { return is_float ? child_float(p, n, dflt) : child_rgb(p, n, dflt); };
+        auto add_node = [&](const pt_texture& t) {
+            forget();
+            textures.push_back(t);
+            (is_float ? node_float_textures : node_spectrum_textures)[name] = (uint32_t)textures.size() - 1;
+        };
+        pt_texture t;
+        std::memset(&t, 0, sizeof(t));
+        t.tex[0] = t.tex[1] = t.tex[2] = -1;
+        if (tex_class == "constant") {
+            float c[3] = {1.0f, 1.0f, 1.0f};
+            if (is_float) c[0] = c[1] = c[2] = p.find_one_float("value", 1.0f); else spectrum_from(p, "value", c);
+            if (!error.empty()) return;
+            forget();
+            if (is_float) float_textures[name] = c[0]; else spectrum_textures[name] = {c[0], c[1], c[2]};
+        } else if (tex_class == "scale" || tex_class == "mix") {
+            const bool mix = tex_class == "mix";
+            Child t1 = child("tex1", 1.0f), t2 = child("tex2", 1.0f), amt;
+            if (mix) amt = child_float(p, "amount", 0.5f);
+            if (!error.empty()) return;
+            if (!t1.is_node && !t2.is_node && !amt.is_node) {                 // folds (scale.rs:20-24, mix.rs:27-32)
+                float v[3];
+                for (int i = 0; i < 3; i++) v[i] = mix ? t1.v[i] * (1.0f - amt.v[0]) + t2.v[i] * amt.v[0] : t1.v[i] * t2.v[i];
+                forget();
+                if (is_float) float_textures[name] = v[0]; else spectrum_textures[name] = {v[0], v[1], v[2]};
+                return;
+            }
+            t.type = mix ? PT_TEX_MIX : PT_TEX_SCALE;
+            set_child(t, 0, t1); set_child(t, 1, t2);
+            if (mix) set_child(t, 2, amt);
+            add_node(t);
+        } else if (tex_class == "checkerboard") {                             // checkerboard.rs:134-185
+            const int dim = p.find_one_int("dimension", 2);
+            if (dim != 2 && dim != 3) { warn(std::to_string(dim) + " dimensional checkerboard texture not supported"); return; }
+            Child t1 = child("tex1", 1.0f), t2 = child("tex2", 0.0f);
+            if (!error.empty()) return;
+            set_child(t, 0, t1); set_child(t, 1, t2);
+            if (dim == 2) {
+                t.type = PT_TEX_CHECKERBOARD_2D;
+                if (!set_mapping2d(p, t)) return;
+                const std::string aa = p.find_one_string("aamode", "closedform");
+                if (aa == "none") t.aa_none = 1;
+                else if (aa != "closedform") { warn("Antialiasing mode \"" + aa + "\" not understood by \"Checkerboard2DTexture\""); return; }
+            } else {
+                t.type = PT_TEX_CHECKERBOARD_3D;
+                std::memcpy(t.world_to_texture, transforms.back().t[0].m.a, 64);   // IdentityMapping3D::new(tex2world), as the reference passes it
+            }
+            add_node(t);
+        } else if (tex_class == "uv" && is_spec) {                            // uv.rs:27-33
+            t.type = PT_TEX_UV;
+            if (!set_mapping2d(p, t)) return;
+            add_node(t);
+        } else if (tex_class == "bilerp") {                                   // bilerp.rs:34-63
+            t.type = PT_TEX_BILERP;
+            if (!set_mapping2d(p, t)) return;
+            const char* names[4] = {"v00", "v01", "v10", "v11"};
+            const float dflt[4] = {0.0f, 1.0f, 0.0f, 1.0f};
+            for (int k = 0; k < 4; k++) {
+                float c[3] = {dflt[k], dflt[k], dflt[k]};
+                if (is_float) c[0] = c[1] = c[2] = p.find_one_float(names[k], dflt[k]); else spectrum_from(p, names[k], c);
+                t.value[k][0] = c[0]; t.value[k][1] = c[1]; t.value[k][2] = c[2];
             }
             if (!error.empty()) return;
-            float_textures[name] = v;
-            unsupported_textures.erase(name);
+            add_node(t);
         } else {
-            std::array<float, 3> v = {1.0f, 1.0f, 1.0f};
-            if (tex_class == "constant") { float c[3] = {1.0f, 1.0f, 1.0f}; spectrum_from(p, "value", c); v = {c[0], c[1], c[2]}; }
-            else {
-                float t1[3] = {1.0f, 1.0f, 1.0f}, t2[3] = {1.0f, 1.0f, 1.0f}, amt = 0.5f;
-                lookup_rgb(p, p, "tex1", t1); lookup_rgb(p, p, "tex2", t2);
-                if (tex_class == "scale") v = {t1[0] * t2[0], t1[1] * t2[1], t1[2] * t2[2]};
-                else {
-                    lookup_float(p, p, "amount", &amt);
-                    for (int i = 0; i < 3; i++) v[i] = t1[i] * (1.0f - amt) + t2[i] * amt;
-                }
-            }
-            if (!error.empty()) return;
-            spectrum_textures[name] = v;
-            unsupported_textures.erase(name);
+            forget();
+            unsupported_textures[name] = tex_class;       // fails only if something uses it
         }
     }
     void pbrt_material(const std::string& name, const ParamSet& p) override {
@@ -313,8 +393,16 @@ public:
         return nullptr;
     }
     // get_spectrum_texture_or_null (texture_params.rs:126-139) for textures that fold to a constant
-    bool lookup_rgb(const ParamSet& geom, const ParamSet& mat, const std::string& n, float out[3]) {
+    // tex_out: receives node index + 1 when the bound texture is evaluated on the device; a parameter that cannot be
+    // texture-driven there (tex_out == nullptr) reports it.
+    bool lookup_rgb(const ParamSet& geom, const ParamSet& mat, const std::string& n, float out[3], uint32_t* tex_out = nullptr) {
         if (const std::string* tex = bound_texture(geom, mat, n)) {
+            auto nd = node_spectrum_textures.find(*tex);
+            if (nd != node_spectrum_textures.end()) {
+                if (!tex_out) { fail("parameter \"" + n + "\" uses texture \"" + *tex + "\", which varies over the surface: not supported for this parameter"); return false; }
+                *tex_out = nd->second + 1;
+                return true;
+            }
             auto it = spectrum_textures.find(*tex);
             if (it == spectrum_textures.end()) {
                 if (float_textures.count(*tex)) warn("Couldn't find spectrum texture named \"" + *tex + "\" for parameter \"" + n + "\"");
@@ -329,8 +417,14 @@ public:
         return spectrum_from(geom, n, out);
     }
     // TextureParams::get_float_texture(_or_null) for constant values (texture_params.rs:36-54, :107-124): material first, then shape
-    bool lookup_float(const ParamSet& geom, const ParamSet& mat, const std::string& n, float* out) {
+    bool lookup_float(const ParamSet& geom, const ParamSet& mat, const std::string& n, float* out, uint32_t* tex_out = nullptr) {
         if (const std::string* tex = bound_texture(geom, mat, n)) {
+            auto nd = node_float_textures.find(*tex);
+            if (nd != node_float_textures.end()) {
+                if (!tex_out) { fail("parameter \"" + n + "\" uses texture \"" + *tex + "\", which varies over the surface: only colour parameters and Matte's sigma may (roughness / eta textures must be constant)"); return false; }
+                *tex_out = nd->second + 1;
+                return true;
+            }
             auto it = float_textures.find(*tex);
             if (it == float_textures.end()) {
                 if (unsupported_textures.count(*tex)) fail("parameter \"" + n + "\" uses texture \"" + *tex + "\" (" + unsupported_textures[*tex] + "): only textures that fold to a constant are on the accelerated path");
@@ -362,27 +456,27 @@ public:
         if (mi.name == "matte") {                                   // matte.rs:56-61
             m.type = PT_MATERIAL_MATTE;
             set3(m.kd, 0.5f);
-            lookup_rgb(geom, mp, "Kd", m.kd);
-            lookup_float(geom, mp, "sigma", &m.sigma);
+            lookup_rgb(geom, mp, "Kd", m.kd, &m.tex_kd);
+            lookup_float(geom, mp, "sigma", &m.sigma, &m.tex_sigma);
         } else if (mi.name == "plastic") {                          // plastic.rs:73-86
             m.type = PT_MATERIAL_PLASTIC;
             set3(m.kd, 0.25f); set3(m.ks, 0.25f); m.roughness = 0.1f;
-            lookup_rgb(geom, mp, "Kd", m.kd); lookup_rgb(geom, mp, "Ks", m.ks);
+            lookup_rgb(geom, mp, "Kd", m.kd, &m.tex_kd); lookup_rgb(geom, mp, "Ks", m.ks, &m.tex_ks);
             lookup_float(geom, mp, "roughness", &m.roughness);
         } else if (mi.name == "mirror") {                           // mirror.rs:43-47
             m.type = PT_MATERIAL_MIRROR;
             set3(m.kr, 0.9f);
-            lookup_rgb(geom, mp, "Kr", m.kr);
+            lookup_rgb(geom, mp, "Kr", m.kr, &m.tex_kr);
         } else if (mi.name == "glass") {                            // glass.rs:124-143
             m.type = PT_MATERIAL_GLASS;
             set3(m.kr, 1.0f); set3(m.kt, 1.0f); m.uroughness = m.vroughness = 0.0f;
-            lookup_rgb(geom, mp, "Kr", m.kr); lookup_rgb(geom, mp, "Kt", m.kt);
+            lookup_rgb(geom, mp, "Kr", m.kr, &m.tex_kr); lookup_rgb(geom, mp, "Kt", m.kt, &m.tex_kt);
             lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
             eta_or_index();
         } else if (mi.name == "metal") {                            // metal.rs:127-149
             m.type = PT_MATERIAL_METAL;
             m.roughness = 0.01f;
-            bool have_eta = lookup_rgb(geom, mp, "eta", m.metal_eta), have_k = lookup_rgb(geom, mp, "k", m.metal_k);
+            bool have_eta = lookup_rgb(geom, mp, "eta", m.metal_eta, &m.tex_metal_eta), have_k = lookup_rgb(geom, mp, "k", m.metal_k, &m.tex_metal_k);
             if (!have_eta || !have_k) {                 // defaults: the measured copper spectrum (metal.rs:87-132)
                 std::string err;
                 const SpectrumTables* T = spectrum_tables(&err);
@@ -395,16 +489,16 @@ public:
         } else if (mi.name == "uber") {                             // uber.rs:142-168
             m.type = PT_MATERIAL_UBER;
             set3(m.kd, 0.25f); set3(m.ks, 0.25f); m.roughness = 0.1f;
-            lookup_rgb(geom, mp, "Kd", m.kd); lookup_rgb(geom, mp, "Ks", m.ks);
-            lookup_rgb(geom, mp, "Kr", m.kr); lookup_rgb(geom, mp, "Kt", m.kt);
-            lookup_rgb(geom, mp, "opacity", m.opacity);
+            lookup_rgb(geom, mp, "Kd", m.kd, &m.tex_kd); lookup_rgb(geom, mp, "Ks", m.ks, &m.tex_ks);
+            lookup_rgb(geom, mp, "Kr", m.kr, &m.tex_kr); lookup_rgb(geom, mp, "Kt", m.kt, &m.tex_kt);
+            lookup_rgb(geom, mp, "opacity", m.opacity, &m.tex_opacity);
             lookup_float(geom, mp, "roughness", &m.roughness);
             lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
             eta_or_index();
         } else if (mi.name == "substrate") {                        // substrate.rs:70-86
             m.type = PT_MATERIAL_SUBSTRATE;
             set3(m.kd, 0.5f); set3(m.ks, 0.5f); m.uroughness = m.vroughness = 0.1f;
-            lookup_rgb(geom, mp, "Kd", m.kd); lookup_rgb(geom, mp, "Ks", m.ks);
+            lookup_rgb(geom, mp, "Kd", m.kd, &m.tex_kd); lookup_rgb(geom, mp, "Ks", m.ks, &m.tex_ks);
             lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
         } else {
             fail("Material \"" + mi.name + "\": outside the accelerated path (matte, plastic, mirror, glass, metal, uber, substrate are supported)");
@@ -688,6 +782,8 @@ public:
         desc.meshes = meshes.data();
         desc.n_spheres = (uint32_t)spheres.size();
         desc.spheres = spheres.empty() ? nullptr : spheres.data();
+        desc.n_textures = (uint32_t)textures.size();
+        desc.textures = textures.empty() ? nullptr : textures.data();
         desc.n_materials = (uint32_t)materials.size();
         desc.materials = materials.data();
         desc.n_area_lights = (uint32_t)area_lights.size();

@@ -372,14 +372,19 @@ class SceneBuilder:
                 t.value[i][:] = [float(x) for x in (c if isinstance(c, (tuple, list)) else (c, c, c))]
         for i, v in enumerate(values):
             t.value[i][:] = [float(x) for x in (v if isinstance(v, (tuple, list)) else (v, v, v))]
-        t.mapping = {"uv": capi.PT_MAPPING_UV, "spherical": capi.PT_MAPPING_SPHERICAL, "cylindrical": capi.PT_MAPPING_CYLINDRICAL,
-                     "planar": capi.PT_MAPPING_PLANAR}[mapping]
-        t.aa_none = 1 if aamode == "none" else 0
-        t.su, t.sv, t.du, t.dv = uscale, vscale, udelta, vdelta
-        t.v1[:] = [float(x) for x in v1]
-        t.v2[:] = [float(x) for x in v2]
-        w2t = np.eye(4, dtype=np.float32).reshape(-1) if to_world is None else np.asarray(to_world[1], np.float32).reshape(-1)
-        t.world_to_texture[:] = [float(x) for x in w2t]
+        if typ in (capi.PT_TEX_CHECKERBOARD_2D, capi.PT_TEX_UV, capi.PT_TEX_BILERP):       # create_texture_mapping2d
+            t.mapping = {"uv": capi.PT_MAPPING_UV, "spherical": capi.PT_MAPPING_SPHERICAL, "cylindrical": capi.PT_MAPPING_CYLINDRICAL,
+                         "planar": capi.PT_MAPPING_PLANAR}[mapping]
+            t.aa_none = 1 if (aamode == "none" and typ == capi.PT_TEX_CHECKERBOARD_2D) else 0
+            t.su, t.sv = (uscale, vscale) if mapping == "uv" else (1.0, 1.0)
+            t.du, t.dv = (udelta, vdelta) if mapping in ("uv", "planar") else (0.0, 0.0)
+            t.v1[:] = [float(x) for x in (v1 if mapping == "planar" else (1, 0, 0))]
+            t.v2[:] = [float(x) for x in (v2 if mapping == "planar" else (0, 1, 0))]
+            w2t = np.eye(4, dtype=np.float32).reshape(-1) if to_world is None else np.asarray(to_world[1], np.float32).reshape(-1)
+            t.world_to_texture[:] = [float(x) for x in w2t]
+        elif typ == capi.PT_TEX_CHECKERBOARD_3D:
+            w2t = np.eye(4, dtype=np.float32).reshape(-1) if to_world is None else np.asarray(to_world[0], np.float32).reshape(-1)
+            t.world_to_texture[:] = [float(x) for x in w2t]
         self.textures.append(t)
         return Tex(len(self.textures) - 1)
 
@@ -394,11 +399,7 @@ class SceneBuilder:
 
     def texture_checkerboard(self, tex1=1.0, tex2=0.0, dimension=2, **kw):
         if dimension == 3:      # IdentityMapping3D is handed tex2world itself, not its inverse (checkerboard.rs:159, mapping3d.rs:19-24)
-            tw = kw.pop("to_world", None)
-            t = self._texture(capi.PT_TEX_CHECKERBOARD_3D, children=[tex1, tex2], **kw)
-            if tw is not None:
-                self.textures[t.index].world_to_texture[:] = [float(x) for x in np.asarray(tw[0], np.float32).reshape(-1)]
-            return t
+            return self._texture(capi.PT_TEX_CHECKERBOARD_3D, children=[tex1, tex2], **kw)
         return self._texture(capi.PT_TEX_CHECKERBOARD_2D, children=[tex1, tex2], **kw)
 
     def texture_uv(self, **kw):

@@ -281,3 +281,47 @@ def scene_textures(res=48, spp=8, depth=5, sampler="sobol", aamode="closedform",
     b.material_metal(eta=b.texture_checkerboard((0.2, 0.92, 1.1), (1.5, 0.9, 0.4), uscale=4.0, vscale=8.0), k=(3.9, 2.45, 2.14), roughness=0.1)
     b.shape_sphere(radius=0.5, object_to_world=tm[0], world_to_object=tm[1])
     return b.build()
+
+
+# The scene of test_host_frontend.py::test_texture_directives_equal_programmatic_scene as .pbrt text (also rendered on the
+# device by test_gpu_features.py): every texture class on the path, bound through shape and material parameter lists.
+TEXTURED_PBRT = '''
+    LookAt 0 0 -6.5  0 0 0  0 1 0
+    Camera "perspective" "float fov" 40
+    Film "image" "integer xresolution" 32 "integer yresolution" 32
+    Sampler "sobol" "integer pixelsamples" 4
+    Integrator "path" "integer maxdepth" 4
+    WorldBegin
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [10 9 8]
+        Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [0.5 1.99 -0.5  0.5 1.99 0.5  -0.5 1.99 0.5  -0.5 1.99 -0.5]
+      AttributeEnd
+      Texture "uvt" "spectrum" "uv" "float uscale" 3 "float vscale" 2
+      Texture "amt" "float" "bilerp" "float v00" 0.1 "float v01" 0.9 "float v10" 0.6 "float v11" 0.3
+      Texture "mixt" "color" "mix" "rgb tex1" [0.8 0.2 0.1] "rgb tex2" [0.1 0.3 0.8] "texture amount" "amt"
+      Texture "floor" "spectrum" "checkerboard" "texture tex1" "mixt" "texture tex2" "uvt" "float uscale" 6 "float vscale" 6
+              "float udelta" 0.25 "float vdelta" 0.1
+      Material "matte" "texture Kd" "floor"
+      Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [2 -2 -2  -2 -2 -2  -2 -2 2  2 -2 2]
+      Texture "planar" "spectrum" "checkerboard" "rgb tex1" [0.9 0.9 0.2] "rgb tex2" [0.2 0.2 0.2] "string mapping" "planar"
+              "vector v1" [1.5 0 0] "vector v2" [0 1.5 0.3] "float udelta" 0.2 "float vdelta" 0.4 "string aamode" "none"
+      Texture "fine" "spectrum" "checkerboard" "rgb tex1" [1 1 1] "rgb tex2" [0.2 0.2 0.2] "float uscale" 10 "float vscale" 10
+      Texture "ks" "spectrum" "scale" "rgb tex1" [0.5 0.5 0.5] "texture tex2" "fine"
+      Material "plastic" "texture Kd" "planar" "texture Ks" "ks" "float roughness" 0.05
+      Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [2 -2 2  -2 -2 2  -2 2 2  2 2 2]
+      AttributeBegin
+        Rotate 25 1 0 0
+        Scale 3 3 3
+        Texture "c3" "spectrum" "checkerboard" "integer dimension" 3 "rgb tex1" [0.9 0.5 0.1] "rgb tex2" [0.1 0.1 0.4]
+      AttributeEnd
+      AttributeBegin
+        Translate 0.9 -1.3 -0.2
+        Texture "sph" "spectrum" "checkerboard" "string mapping" "spherical" "rgb tex1" [0.8 0.8 0.8] "rgb tex2" [0.15 0.3 0.15]
+        Texture "sig" "float" "bilerp" "float v00" 0 "float v01" 40 "float v10" 10 "float v11" 60
+        Material "matte" "texture Kd" "c3"
+        Shape "sphere" "float radius" 0.65 "texture sigma" "sig"
+      AttributeEnd
+      Material "uber" "texture Kd" "sph" "rgb Ks" [0.2 0.2 0.2]
+      Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-2 -2 2  -2 -2 -2  -2 2 0]
+    WorldEnd
+    '''

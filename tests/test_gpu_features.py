@@ -361,6 +361,22 @@ def test_killeroo_simple_shaped_scene(gpu_ctx, oracle, tmp_path):
     osc.close()
 
 
+def test_pbrt_text_with_textures(gpu_ctx, oracle):
+    """Texture directives -> pt_texture nodes -> device evaluation with camera-ray differentials, against the oracle on the
+    same flattened scene."""
+    ps = pkg.capi.ParsedScene(text=fs.TEXTURED_PBRT)
+    assert ps.desc.n_textures == 10
+    osc = oracle.scene(ps)
+    gpu_ctx.upload(ps)
+    sb = list(gpu_ctx.info.sample_bounds)
+    tile = (sb[0] + 2, sb[1] + 2, sb[0] + 30, sb[1] + 30)
+    g, r = gpu_ctx.radiance_samples(tile), osc.radiance_samples(tile)
+    assert r.sum() > 0
+    same = np.all(bits(g) == bits(r), axis=-1)
+    assert same.all(), float(1 - same.mean())
+    osc.close()
+
+
 def test_pass_structure_does_not_change_the_film(gpu_ctx):
     """The pool size only decides how the samples are cut into passes / pixel chunks (render_tiles): a film rendered
     in 1 pass, in 3 unequal-looking passes (7 spp -> 3,2,2) and in pixel chunks must agree -- bit for bit where a

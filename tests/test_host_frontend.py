@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+import feature_scenes as fs
 from helpers import bits, pkg, scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -497,9 +498,67 @@ def test_constant_folding_textures():
     m2 = d.materials[d.meshes[2].material]          # the shape's texture binding beats the material's constant Kd
     want = [f(f(f(c1) * f(f(1.0) - f(0.25))) + f(f(c2) * f(0.25))) for c1, c2 in zip((0.8, 0.1, 0.1), (0.0, 0.0, 1.0))]
     assert np.array_equal(bits(list(m2.kd)), bits(want))
+    # a checkerboard varies over the surface: it becomes a device texture node bound to the parameter
+    ps2 = capi.ParsedScene(text=text.replace('"texture Kd" "blend"', '"texture Kd" "chk"'))
+    d2 = ps2.desc
+    m3 = d2.materials[d2.meshes[2].material]
+    assert d2.n_textures == 1 and m3.tex_kd == 1 and d2.textures[0].type == capi.PT_TEX_CHECKERBOARD_2D
+    # ... which roughness cannot be, and image maps are not on the path at all
     with pytest.raises(capi.PtError) as e:
-        capi.ParsedScene(text=text.replace('"texture Kd" "blend"', '"texture Kd" "chk"'))
-    assert e.value.status == 4 and "checkerboard" in str(e.value)
+        capi.ParsedScene(text=text.replace('Texture "chk" "spectrum" "checkerboard"', 'Texture "fchk" "float" "checkerboard"')
+                         .replace('"texture roughness" "rough"', '"texture roughness" "fchk"'))
+    assert e.value.status == 4 and "varies over the surface" in str(e.value)
+    with pytest.raises(capi.PtError) as e:
+        capi.ParsedScene(text=text.replace('"spectrum" "checkerboard"', '"spectrum" "imagemap" "string filename" "x.png"')
+                         .replace('"texture Kd" "blend"', '"texture Kd" "chk"'))
+    assert e.value.status == 4 and "imagemap" in str(e.value)
+
+
+def test_texture_directives_equal_programmatic_scene(oracle):
+    """Texture "checkerboard" (2-D with uv / planar / spherical mappings, 3-D under a CTM), "uv", "bilerp", and "scale" /
+    "mix" over them, bound to material parameters through the shape-first / material-first rules: the flattened scene must
+    render exactly like the SceneBuilder one (textures/*.rs, mapping2d.rs:178-214, texture_params.rs)."""
+    text = fs.TEXTURED_PBRT
+    ps = capi.ParsedScene(text=text)
+    d = ps.desc
+    assert d.n_textures == 10
+    T = scenes
+    b = scenes.SceneBuilder()
+    b.look_at((0, 0, -6.5), (0, 0, 0), (0, 1, 0)); b.camera_perspective(fov=40.0); b.film(xresolution=32, yresolution=32)
+    b.pixel_filter_box(); b.sampler_sobol(4); b.integrator_path(maxdepth=4)
+    b.area_light_source_diffuse(L=(10, 9, 8))
+    b.shape_trianglemesh([(0.5, 1.99, -0.5), (0.5, 1.99, 0.5), (-0.5, 1.99, 0.5), (-0.5, 1.99, -0.5)], [0, 1, 2, 0, 2, 3])
+    b.no_area_light()
+    uvt = b.texture_uv(uscale=3.0, vscale=2.0)
+    amt = b.texture_bilerp(0.1, 0.9, 0.6, 0.3)
+    mixt = b.texture_mix((0.8, 0.2, 0.1), (0.1, 0.3, 0.8), amount=amt)
+    floor = b.texture_checkerboard(mixt, uvt, uscale=6.0, vscale=6.0, udelta=0.25, vdelta=0.1)
+    b.material_matte(floor)
+    b.shape_trianglemesh([(2, -2, -2), (-2, -2, -2), (-2, -2, 2), (2, -2, 2)], [0, 1, 2, 0, 2, 3])
+    planar = b.texture_checkerboard((0.9, 0.9, 0.2), (0.2, 0.2, 0.2), mapping="planar", v1=(1.5, 0.0, 0.0), v2=(0.0, 1.5, 0.3), udelta=0.2, vdelta=0.4, aamode="none")
+    fine = b.texture_checkerboard(1.0, 0.2, uscale=10.0, vscale=10.0)
+    ks = b.texture_scale((0.5, 0.5, 0.5), fine)
+    b.material_plastic(Kd=planar, Ks=ks, roughness=0.05)
+    b.shape_trianglemesh([(2, -2, 2), (-2, -2, 2), (-2, 2, 2), (2, 2, 2)], [0, 1, 2, 0, 2, 3])
+    t3 = T.transform_mul(T.transform_rotate_x(25.0), T.transform_scale(3.0, 3.0, 3.0))
+    c3 = b.texture_checkerboard((0.9, 0.5, 0.1), (0.1, 0.1, 0.4), dimension=3, to_world=t3)
+    ts = T.transform_translate(0.9, -1.3, -0.2)
+    sph = b.texture_checkerboard((0.8, 0.8, 0.8), (0.15, 0.3, 0.15), mapping="spherical", to_world=ts)
+    sig = b.texture_bilerp(0.0, 40.0, 10.0, 60.0, to_world=ts)       # the CTM is recorded whatever the mapping
+    b.material_matte(c3, sigma=sig)
+    b.shape_sphere(radius=0.65, object_to_world=ts[0], world_to_object=ts[1])
+    b.material_uber(Kd=sph, Ks=(0.2, 0.2, 0.2))
+    b.shape_trianglemesh([(-2, -2, 2), (-2, -2, -2), (-2, 2, 0)], [0, 1, 2])
+    ref = b.build()
+    assert ref.desc.n_textures == 10
+    for i in range(10):
+        ta, tb = d.textures[i], ref.desc.textures[i]
+        assert bytes(ta) == bytes(tb), i
+    a, r = oracle.scene(ps), oracle.scene(ref)
+    xa, ca, _ = a.render(threads=2)
+    xr, cr, _ = r.render(threads=2)
+    assert np.array_equal(bits(xa), bits(xr)) and ca == cr and xa[..., :3].max() > 0
+    a.close(); r.close()
 
 
 def test_parse_options_quick_and_pixelsamples():
