@@ -61,8 +61,8 @@ typedef struct pt_context pt_context;
 /* Procedural textures (src/textures/, src/core/texture/mapping2d.rs, mapping3d.rs).  A texture evaluates to an RGB triple;
  * a float texture is one whose three channels are equal (consumers read channel 0), so scale / mix / checkerboard are the
  * same arithmetic per channel as the reference's generic Texture<T>.  textures[] is in definition order: a child index is
- * always smaller than the index of the texture that uses it.  Image maps (imagemap.rs, mipmap.rs) and the noise textures
- * are not on the accelerated path yet. */
+ * always smaller than the index of the texture that uses it.  Image maps (imagemap.rs, mipmap.rs) are not on the
+ * accelerated path yet. */
 typedef enum {
     PT_TEX_CONSTANT = 0,         /* core/texture/constant.rs: value[0] */
     PT_TEX_SCALE = 1,            /* textures/scale.rs: tex1 * tex2 */
@@ -70,7 +70,12 @@ typedef enum {
     PT_TEX_CHECKERBOARD_2D = 3,  /* textures/checkerboard.rs:13-84: point-sampled or closed-form box-filtered */
     PT_TEX_CHECKERBOARD_3D = 4,  /* textures/checkerboard.rs:86-122 over the identity 3-D mapping */
     PT_TEX_UV = 5,               /* textures/uv.rs: (frac s, frac t, 0) */
-    PT_TEX_BILERP = 6            /* textures/bilerp.rs: value[0..3] = v00 v01 v10 v11 */
+    PT_TEX_BILERP = 6,           /* textures/bilerp.rs: value[0..3] = v00 v01 v10 v11 */
+    PT_TEX_DOTS = 7,             /* textures/dots.rs: tex1 outside, tex2 inside noise-placed dots; 2-D mapping */
+    PT_TEX_FBM = 8,              /* textures/fbm.rs: noise.rs fbm(p, dpdx, dpdy, omega, octaves) over the 3-D mapping */
+    PT_TEX_WRINKLED = 9,         /* textures/wrinkled.rs: turbulence(...) */
+    PT_TEX_WINDY = 10,           /* textures/windy.rs: |fbm(.1p, .., .5, 3)| * fbm(p, .., .5, 6) */
+    PT_TEX_MARBLE = 11           /* textures/marble.rs: spline over sin(scale*p.y + variation * fbm(...)) */
 } pt_texture_type;
 typedef enum {
     PT_MAPPING_UV = 0,           /* UVMapping2D: su sv du dv */
@@ -86,7 +91,12 @@ typedef struct {
     int32_t aa_none;            /* checkerboard "aamode" "none" (default "closedform") */
     float su, sv, du, dv;       /* "uscale" "vscale" "udelta" "vdelta" (defaults 1 1 0 0) */
     float v1[3], v2[3];         /* planar "v1" (1 0 0), "v2" (0 1 0) */
-    float world_to_texture[16]; /* inverse of the CTM at the Texture directive: spherical / cylindrical / 3-D mappings */
+    float world_to_texture[16]; /* inverse of the CTM at the Texture directive for spherical / cylindrical mappings; the 3-D
+                                 * textures (checkerboard 3-D, fbm, wrinkled, windy, marble) take the CTM itself, which is what the
+                                 * reference hands IdentityMapping3D (checkerboard.rs:159, fbm.rs:40) */
+    int32_t octaves;            /* fbm / wrinkled / marble "octaves" (8) */
+    float omega;                /* "roughness" (0.5) */
+    float scale, variation;     /* marble "scale" (1), "variation" (0.2) */
 } pt_texture;
 
 /* Material::compute_scattering_functions variants (src/materials/).  Colour parameters and Matte's sigma may be

@@ -14,7 +14,8 @@
  *               materials; colours as rgb, .spd "spectrum" files or "blackbody" (metal defaults to the
  *               measured copper spectrum); Texture "constant" / "scale" / "mix" (folded when constant), "checkerboard"
  *               (2-D with uv / spherical / cylindrical / planar mapping, closed-form or point-sampled; 3-D), "uv",
- *               "bilerp" on colour parameters and Matte's sigma (evaluated per hit with ray differentials)
+ *               "bilerp", "dots", "fbm", "wrinkled", "windy", "marble" on colour parameters and Matte's sigma
+ *               (evaluated per hit with ray differentials)
  *   lights      diffuse area lights
  *   camera      perspective;  filters box / gaussian / mitchell / sinc / triangle
  *   samplers    halton (the default), sobol;  integrator path;  accelerator bvh (sah, hlbvh, middle, equal)

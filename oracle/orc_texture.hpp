@@ -7,6 +7,7 @@
 #pragma once
 #include "orc_accel.hpp"
 #include "../include/pbrtgpu.h"
+#include "../include/pbrtgpu_noise_perm.h"
 
 namespace orc {
 
@@ -118,6 +119,66 @@ inline Float bump_int(Float x) {                      // checkerboard.rs:36-39
     return std::floor(x / 2.0f) + 2.0f * fmax_(x / 2.0f - std::floor(x / 2.0f) - 0.5f, 0.0f);
 }
 
+// ---- Perlin noise, fBm, turbulence (core/texture/noise.rs)
+static const uint8_t kNoisePerm[512] = {PT_NOISE_PERM_256, PT_NOISE_PERM_256};
+inline Float noise_grad(uint32_t x, uint32_t y, uint32_t z, Float dx, Float dy, Float dz) {     // noise.rs:10-19
+    uint32_t h = kNoisePerm[kNoisePerm[kNoisePerm[x] + y] + z] & 15u;
+    Float u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+    Float v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+    return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+inline Float noise_weight(Float t) { Float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; }
+inline Float noise3(Float x, Float y, Float z) {                                              // noise.rs:64-96
+    int32_t ixi = f2i(std::floor(x)), iyi = f2i(std::floor(y)), izi = f2i(std::floor(z));
+    Float dx = x - (Float)ixi, dy = y - (Float)iyi, dz = z - (Float)izi;
+    uint32_t ix = (uint32_t)ixi & 255u, iy = (uint32_t)iyi & 255u, iz = (uint32_t)izi & 255u;
+    Float w000 = noise_grad(ix, iy, iz, dx, dy, dz);
+    Float w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    Float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz);
+    Float w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    Float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f);
+    Float w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    Float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f);
+    Float w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    Float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+    Float x00 = lerpf(wx, w000, w100), x10 = lerpf(wx, w010, w110), x01 = lerpf(wx, w001, w101), x11 = lerpf(wx, w011, w111);
+    Float y0 = lerpf(wy, x00, x10), y1 = lerpf(wy, x01, x11);
+    return lerpf(wz, y0, y1);
+}
+inline Float smooth_step(Float mn, Float mx, Float value) {
+    Float v = clampf((value - mn) / (mx - mn), 0.0f, 1.0f);
+    return v * v * (-2.0f * v + 3.0f);
+}
+// fbm / turbulence (noise.rs:98-150); `turb` adds |noise| and the tail of 0.2-weighted octaves
+inline Float fbm_turb(V3 p, V3 dpdx, V3 dpdy, Float omega, uint32_t max_octaves, bool turb) {
+    Float len2 = fmax_(length_squared(dpdx), length_squared(dpdy));
+    Float n = clampf(-1.0f - 0.5f * std::log2(len2), 0.0f, (Float)max_octaves);
+    Float nf = std::floor(n);
+    size_t n_int = nf != nf ? 0 : (nf <= 0.0f ? 0 : (size_t)nf);          // `as usize`: saturating
+    Float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (size_t i = 0; i < n_int; i++) {
+        V3 lp = lambda * p;
+        Float nz = noise3(lp.x, lp.y, lp.z);
+        sum += o * (turb ? std::fabs(nz) : nz);
+        lambda *= 1.99f;
+        o *= omega;
+    }
+    Float n_partial = n - (Float)n_int;
+    V3 lp = lambda * p;
+    sum += o * smooth_step(0.3f, 0.7f, n_partial) * noise3(lp.x, lp.y, lp.z);
+    if (turb)
+        for (size_t i = 0; i < n_int; i++) { sum += o * 0.2f; o *= omega; }
+    return sum;
+}
+// IdentityMapping3D::map (mapping3d.rs:24-31): both differentials come back as dpdx (as written)
+inline void map3d(const pt_texture& t, const TexHit& si, V3* p, V3* dpdx, V3* dpdy) {
+    Mat4 m;
+    std::memcpy(m.m, t.world_to_texture, sizeof(m.m));
+    *p = m.transform_point(si.p);
+    *dpdx = m.transform_vector(si.dpdx);
+    *dpdy = m.transform_vector(si.dpdx);
+}
+
 // Texture<T>::evaluate over the flattened texture array; float textures are RGB with equal channels.
 inline RGB texture_eval(const pt_texture* tex, int32_t index, const TexHit& si);
 inline RGB texture_child(const pt_texture* tex, const pt_texture& t, int k, const TexHit& si) {
@@ -165,6 +226,51 @@ inline RGB texture_eval(const pt_texture* tex, int32_t index, const TexHit& si) 
             V2 st, dx, dy;
             map2d(t, si, &st, &dx, &dy);
             return RGB(st.x - std::floor(st.x), st.y - std::floor(st.y), 0.0f);
+        }
+        case PT_TEX_DOTS: {                                       // dots.rs:27-43
+            V2 st, dx, dy;
+            map2d(t, si, &st, &dx, &dy);
+            Float s_cell = std::floor(st.x + 0.5f), t_cell = std::floor(st.y + 0.5f);
+            if (noise3(s_cell + 0.5f, t_cell + 0.5f, 0.0f) > 0.0f) {
+                Float radius = 0.35f;
+                Float max_shift = 0.5f - radius;
+                Float s_center = s_cell + max_shift * noise3(s_cell + 1.5f, t_cell + 2.8f, 0.0f);
+                Float t_center = t_cell + max_shift * noise3(s_cell + 4.5f, t_cell + 9.8f, 0.0f);
+                V2 dst = st - V2(s_center, t_center);
+                if (dst.x * dst.x + dst.y * dst.y < radius * radius) return texture_child(tex, t, 1, si);
+            }
+            return texture_child(tex, t, 0, si);
+        }
+        case PT_TEX_FBM: case PT_TEX_WRINKLED: {
+            V3 p, dpdx, dpdy;
+            map3d(t, si, &p, &dpdx, &dpdy);
+            return RGB(fbm_turb(p, dpdx, dpdy, t.omega, (uint32_t)t.octaves, t.type == PT_TEX_WRINKLED));
+        }
+        case PT_TEX_WINDY: {                                      // windy.rs:14-19
+            V3 p, dpdx, dpdy;
+            map3d(t, si, &p, &dpdx, &dpdy);
+            Float wind_strength = fbm_turb(0.1f * p, 0.1f * dpdx, 0.1f * dpdy, 0.5f, 3, false);
+            Float wave_height = fbm_turb(p, dpdx, dpdy, 0.5f, 6, false);
+            return RGB(std::fabs(wind_strength) * wave_height);
+        }
+        case PT_TEX_MARBLE: {                                     // marble.rs:35-62
+            static const Float C[9][3] = {{0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.5f, 0.5f, 0.5f}, {0.6f, 0.59f, 0.58f},
+                                          {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.2f, 0.2f, 0.33f}, {0.58f, 0.58f, 0.6f}};
+            V3 p, dpdx, dpdy;
+            map3d(t, si, &p, &dpdx, &dpdy);
+            p = t.scale * p;
+            Float marble = p.y + t.variation * fbm_turb(p, t.scale * dpdx, t.scale * dpdy, t.omega, (uint32_t)t.octaves, false);
+            Float tt = 0.5f + 0.5f * std::sin(marble);
+            const int nseg = 9 - 3;
+            Float fl = std::floor(tt * (Float)nseg);
+            size_t first = std::min<size_t>(1, fl != fl ? 0 : (fl <= 0.0f ? 0 : (size_t)fl));
+            tt = tt * (Float)nseg - (Float)first;
+            auto col = [&](size_t k) { return RGB(C[k][0], C[k][1], C[k][2]); };
+            auto lerps = [](RGB c0, RGB c1, Float u) { return c0 * (1.0f - u) + c1 * u; };
+            RGB c0 = col(first), c1 = col(first + 1), c2 = col(first + 2), c3 = col(first + 3);
+            RGB s0 = lerps(c0, c1, tt), s1 = lerps(c1, c2, tt), s2 = lerps(c2, c3, tt);
+            s0 = lerps(s0, s1, tt); s1 = lerps(s1, s2, tt);
+            return lerps(s0, s1, tt) * 1.5f;
         }
         case PT_TEX_BILERP: {
             V2 st, dx, dy;

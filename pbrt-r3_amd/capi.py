@@ -43,10 +43,12 @@ class pt_material(C.Structure):
 class pt_texture(C.Structure):
     _fields_ = [("type", C.c_int32), ("tex", C.c_int32 * 3), ("value", (C.c_float * 3) * 4), ("mapping", C.c_int32),
                 ("aa_none", C.c_int32), ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float),
-                ("v1", C.c_float * 3), ("v2", C.c_float * 3), ("world_to_texture", C.c_float * 16)]
+                ("v1", C.c_float * 3), ("v2", C.c_float * 3), ("world_to_texture", C.c_float * 16),
+                ("octaves", C.c_int32), ("omega", C.c_float), ("scale", C.c_float), ("variation", C.c_float)]
 
 
-PT_TEX_CONSTANT, PT_TEX_SCALE, PT_TEX_MIX, PT_TEX_CHECKERBOARD_2D, PT_TEX_CHECKERBOARD_3D, PT_TEX_UV, PT_TEX_BILERP = range(7)
+(PT_TEX_CONSTANT, PT_TEX_SCALE, PT_TEX_MIX, PT_TEX_CHECKERBOARD_2D, PT_TEX_CHECKERBOARD_3D, PT_TEX_UV, PT_TEX_BILERP, PT_TEX_DOTS, PT_TEX_FBM,
+ PT_TEX_WRINKLED, PT_TEX_WINDY, PT_TEX_MARBLE) = range(12)
 PT_MAPPING_UV, PT_MAPPING_SPHERICAL, PT_MAPPING_CYLINDRICAL, PT_MAPPING_PLANAR = range(4)
 
 

@@ -312,6 +312,26 @@ public:
                 std::memcpy(t.world_to_texture, transforms.back().t[0].m.a, 64);   // IdentityMapping3D::new(tex2world), as the reference passes it
             }
             add_node(t);
+        } else if (tex_class == "dots") {                                     // dots.rs:45-62
+            t.type = PT_TEX_DOTS;
+            if (!set_mapping2d(p, t)) return;
+            Child t1 = child("tex1", 1.0f), t2 = child("tex2", 0.0f);
+            if (!error.empty()) return;
+            set_child(t, 0, t1); set_child(t, 1, t2);
+            add_node(t);
+        } else if (tex_class == "fbm" || tex_class == "wrinkled" || tex_class == "windy" || (tex_class == "marble" && is_spec)) {
+            // fbm.rs:35-56, wrinkled.rs:35-56, windy.rs:31-48, marble.rs:82-95 (no float marble: create_texture.rs:52-54)
+            t.type = tex_class == "fbm" ? PT_TEX_FBM : (tex_class == "wrinkled" ? PT_TEX_WRINKLED : (tex_class == "windy" ? PT_TEX_WINDY : PT_TEX_MARBLE));
+            std::memcpy(t.world_to_texture, transforms.back().t[0].m.a, 64);       // IdentityMapping3D::new(tex2world)
+            if (t.type != PT_TEX_WINDY) {
+                t.octaves = p.find_one_int("octaves", 8);
+                t.omega = p.find_one_float("roughness", 0.5f);
+            }
+            if (t.type == PT_TEX_MARBLE) {
+                t.scale = p.find_one_float("scale", 1.0f);
+                t.variation = p.find_one_float("variation", 0.2f);
+            }
+            add_node(t);
         } else if (tex_class == "uv" && is_spec) {                            // uv.rs:27-33
             t.type = PT_TEX_UV;
             if (!set_mapping2d(p, t)) return;
@@ -328,9 +348,11 @@ public:
             }
             if (!error.empty()) return;
             add_node(t);
-        } else {
+        } else if (tex_class == "imagemap" || (tex_class == "normal" && is_spec)) {
             forget();
-            unsupported_textures[name] = tex_class;       // fails only if something uses it
+            unsupported_textures[name] = tex_class;       // known to the reference, not on the path: fails only if something uses it
+        } else {                                           // create_texture.rs:57-60, :106-109: not created
+            warn(std::string(is_float ? "Float" : "Spectrum") + " texture \"" + tex_class + "\" unknown.");
         }
     }
     void pbrt_material(const std::string& name, const ParamSet& p) override {

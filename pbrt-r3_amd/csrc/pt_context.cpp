@@ -408,7 +408,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     for (uint32_t i = 0; i < d->n_textures; i++) {
         const pt_texture& t = d->textures[i];
-        if (t.type < PT_TEX_CONSTANT || t.type > PT_TEX_BILERP) return ctx->fail(PT_ERR_UNSUPPORTED, "texture class not on the accelerated path");
+        if (t.type < PT_TEX_CONSTANT || t.type > PT_TEX_MARBLE) return ctx->fail(PT_ERR_UNSUPPORTED, "texture class not on the accelerated path");
         if (t.mapping < PT_MAPPING_UV || t.mapping > PT_MAPPING_PLANAR) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown texture mapping");
         for (int k = 0; k < 3; k++)
             if (t.tex[k] >= (int32_t)i) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "texture child index must be smaller than the texture's own (definition order)");
@@ -533,7 +533,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         while (!stack.empty()) {
             auto& top = stack.back();
             const pt_texture& t = d->textures[top.first];
-            const int n_children = t.type == PT_TEX_MIX ? 3 : ((t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD_2D || t.type == PT_TEX_CHECKERBOARD_3D) ? 2 : 0);
+            const int n_children = t.type == PT_TEX_MIX ? 3 : ((t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD_2D || t.type == PT_TEX_CHECKERBOARD_3D || t.type == PT_TEX_DOTS) ? 2 : 0);
             if (top.second < n_children) {
                 int32_t c = t.tex[top.second++];
                 if (c >= 0 && pos[c] < 0) stack.push_back({(uint32_t)c, 0});

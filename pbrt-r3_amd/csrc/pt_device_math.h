@@ -234,6 +234,44 @@ PT_DEV float pt_atan2f(float y, float x) {
     return (z - pi_lo) - pi;
 }
 
+// log2f: glibc's (ARM optimized-routines log2f: 16-entry table of 1/c and log2(c), degree-4 polynomial in f64, one final
+// rounding), restated with its published constants; compared with libm.so.6 over every positive float: 0 mismatches
+// (tools/check_log2f_port.c).
+PT_DEV float pt_log2f(float x) {
+    const double T[16][2] = {
+        {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2}, {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},
+        {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2}, {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+        {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4}, {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5},
+        {0x1p+0, 0x0p+0}, {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4}, {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+        {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3}, {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2}, {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},
+        {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+    const double A0 = -0x1.712b6f70a7e4dp-2, A1 = 0x1.ecabf496832ep-2, A2 = -0x1.715479ffae3dep-1, A3 = 0x1.715475f35c8b8p0;
+    uint32_t ix = __float_as_uint(x);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix * 2u == 0u) return -PT_INF;
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return __uint_as_float(0x7fc00000u);
+        ix = __float_as_uint(x * 0x1p23f);
+        ix -= 23u << 23;
+    }
+    uint32_t tmp = ix - 0x3f330000u;
+    int i = (int)((tmp >> 19) % 16u);
+    uint32_t top = tmp & 0xff800000u;
+    uint32_t iz = ix - top;
+    int k = (int32_t)tmp >> 23;
+    double invc = T[i][0], logc = T[i][1];
+    double z = (double)__uint_as_float(iz);
+    double r = z * invc - 1.0;
+    double y0 = logc + (double)k;
+    double r2 = r * r;
+    double y = A1 * r + A2;
+    y = A0 * r2 + y;
+    double p = A3 * r + y0;
+    y = y * r2 + p;
+    return (float)y;
+}
+
 // spectrum
 PT_DEV float lum_y(V3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }
 PT_DEV bool is_black(V3 c) { return c.x == 0.0f && c.y == 0.0f && c.z == 0.0f; }

@@ -9,6 +9,7 @@
 #include "pt_device.h"
 #include "pt_device_math.h"
 #include "../../include/pbrtgpu.h"
+#include "../../include/pbrtgpu_noise_perm.h"
 
 
 struct TexHit {                     // what SurfaceInteraction offers a texture
@@ -105,6 +106,60 @@ PT_DEV int32_t f2i_sat(float f) {           // Rust `as i32`: saturating, NaN ->
 }
 PT_DEV bool even_sum(int32_t a, int32_t b) { return ((int32_t)((uint32_t)a + (uint32_t)b) % 2) == 0; }
 
+// ---- Perlin noise, fBm, turbulence (core/texture/noise.rs)
+__device__ const unsigned char pt_noise_perm[512] = {PT_NOISE_PERM_256, PT_NOISE_PERM_256};
+PT_DEV float noise_grad(uint32_t x, uint32_t y, uint32_t z, float dx, float dy, float dz) {
+    uint32_t h = pt_noise_perm[pt_noise_perm[pt_noise_perm[x] + y] + z] & 15u;
+    float u = (h < 8u || h == 12u || h == 13u) ? dx : dy;
+    float v = (h < 4u || h == 12u || h == 13u) ? dy : dz;
+    return ((h & 1u) ? -u : u) + ((h & 2u) ? -v : v);
+}
+PT_DEV float noise_weight(float t) { float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; }
+__device__ __noinline__ float noise3(float x, float y, float z) {
+    int32_t ixi = f2i_sat(floorf(x)), iyi = f2i_sat(floorf(y)), izi = f2i_sat(floorf(z));
+    float dx = x - (float)ixi, dy = y - (float)iyi, dz = z - (float)izi;
+    uint32_t ix = (uint32_t)ixi & 255u, iy = (uint32_t)iyi & 255u, iz = (uint32_t)izi & 255u;
+    float w000 = noise_grad(ix, iy, iz, dx, dy, dz);
+    float w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz);
+    float w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f);
+    float w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f);
+    float w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+    float x00 = lerpf(wx, w000, w100), x10 = lerpf(wx, w010, w110), x01 = lerpf(wx, w001, w101), x11 = lerpf(wx, w011, w111);
+    float y0 = lerpf(wy, x00, x10), y1 = lerpf(wy, x01, x11);
+    return lerpf(wz, y0, y1);
+}
+PT_DEV float smooth_step(float mn, float mx, float value) {
+    float v = clampf((value - mn) / (mx - mn), 0.0f, 1.0f);
+    return v * v * (-2.0f * v + 3.0f);
+}
+__device__ __noinline__ float fbm_turb(V3 p, V3 dpdx, V3 dpdy, float omega, uint32_t max_octaves, bool turb) {     // noise.rs:98-150
+    float len2 = fmaxf(length_squared(dpdx), length_squared(dpdy));
+    float n = clampf(-1.0f - 0.5f * pt_log2f(len2), 0.0f, (float)max_octaves);
+    float nf = floorf(n);
+    uint32_t n_int = nf != nf ? 0u : (nf <= 0.0f ? 0u : (uint32_t)nf);
+    float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (uint32_t i = 0; i < n_int; i++) {
+        V3 lp = lambda * p;
+        float nz = noise3(lp.x, lp.y, lp.z);
+        sum += o * (turb ? fabsf(nz) : nz);
+        lambda *= 1.99f;
+        o *= omega;
+    }
+    float n_partial = n - (float)n_int;
+    V3 lp = lambda * p;
+    sum += o * smooth_step(0.3f, 0.7f, n_partial) * noise3(lp.x, lp.y, lp.z);
+    if (turb)
+        for (uint32_t i = 0; i < n_int; i++) { sum += o * 0.2f; o *= omega; }
+    return sum;
+}
+PT_DEV V3 tex_vector(const float* m, V3 v) {
+    return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+
 // One node, its children already evaluated (c0, c1, c2 = tex1, tex2, amount).
 PT_DEV V3 tex_node(const pt_texture& t, const TexHit& si, V3 c0, V3 c1, V3 c2) {
     switch (t.type) {
@@ -133,6 +188,50 @@ PT_DEV V3 tex_node(const pt_texture& t, const TexHit& si, V3 c0, V3 c1, V3 c2) {
             V2 st, dx, dy;
             map2d(t, si, &st, &dx, &dy);
             return mk3(st.x - floorf(st.x), st.y - floorf(st.y), 0.0f);
+        }
+        case PT_TEX_DOTS: {                                       // dots.rs:27-43
+            V2 st, dx, dy;
+            map2d(t, si, &st, &dx, &dy);
+            float s_cell = floorf(st.x + 0.5f), t_cell = floorf(st.y + 0.5f);
+            if (noise3(s_cell + 0.5f, t_cell + 0.5f, 0.0f) > 0.0f) {
+                float radius = 0.35f;
+                float max_shift = 0.5f - radius;
+                float s_center = s_cell + max_shift * noise3(s_cell + 1.5f, t_cell + 2.8f, 0.0f);
+                float t_center = t_cell + max_shift * noise3(s_cell + 4.5f, t_cell + 9.8f, 0.0f);
+                float ddx = st.x - s_center, ddy = st.y - t_center;
+                if (ddx * ddx + ddy * ddy < radius * radius) return c1;
+            }
+            return c0;
+        }
+        case PT_TEX_FBM: case PT_TEX_WRINKLED: case PT_TEX_WINDY: case PT_TEX_MARBLE: {
+            // IdentityMapping3D::map (mapping3d.rs:24-31): both differentials come back as dpdx (as written)
+            V3 p = tex_point(t.world_to_texture, si.p);
+            V3 dpdx = tex_vector(t.world_to_texture, si.dpdx), dpdy = dpdx;
+            if (t.type == PT_TEX_WINDY) {                         // windy.rs:14-19
+                float wind_strength = fbm_turb(0.1f * p, 0.1f * dpdx, 0.1f * dpdy, 0.5f, 3u, false);
+                float wave_height = fbm_turb(p, dpdx, dpdy, 0.5f, 6u, false);
+                float v = fabsf(wind_strength) * wave_height;
+                return mk3(v, v, v);
+            }
+            if (t.type != PT_TEX_MARBLE) {
+                float v = fbm_turb(p, dpdx, dpdy, t.omega, (uint32_t)t.octaves, t.type == PT_TEX_WRINKLED);
+                return mk3(v, v, v);
+            }
+            // marble.rs:35-62
+            p = t.scale * p;
+            float marble = p.y + t.variation * fbm_turb(p, t.scale * dpdx, t.scale * dpdy, t.omega, (uint32_t)t.octaves, false);
+            float sn, cs;
+            pt_sincosf(marble, &sn, &cs);
+            float tt = 0.5f + 0.5f * sn;
+            const float nseg = 6.0f;
+            float fl = floorf(tt * nseg);
+            const bool second = !(fl != fl) && fl >= 1.0f;          // first = min(1, floor(t * nseg) as usize)
+            tt = tt * nseg - (second ? 1.0f : 0.0f);
+            const V3 ca = mk3(0.58f, 0.58f, 0.6f), cb = mk3(0.5f, 0.5f, 0.5f), cc = mk3(0.6f, 0.59f, 0.58f);
+            V3 k0 = ca, k1 = ca, k2 = second ? cb : ca, k3 = second ? cc : cb;     // C[first .. first+3]
+            V3 s0 = k0 * (1.0f - tt) + k1 * tt, s1 = k1 * (1.0f - tt) + k2 * tt, s2 = k2 * (1.0f - tt) + k3 * tt;
+            s0 = s0 * (1.0f - tt) + s1 * tt; s1 = s1 * (1.0f - tt) + s2 * tt;
+            return (s0 * (1.0f - tt) + s1 * tt) * 1.5f;
         }
         case PT_TEX_BILERP: {
             V2 st, dx, dy;

@@ -359,7 +359,7 @@ class SceneBuilder:
     # ---- textures (src/textures/): each returns a Tex handle usable as a material parameter or as a child texture.
     # `to_world` = (m, m_inv) of the CTM at the Texture directive (spherical / cylindrical / 3-D mappings use its inverse).
     def _texture(self, typ, children=(), values=(), mapping="uv", uscale=1.0, vscale=1.0, udelta=0.0, vdelta=0.0, v1=(1, 0, 0), v2=(0, 1, 0),
-                 to_world=None, aamode="closedform"):
+                 to_world=None, aamode="closedform", octaves=0, omega=0.0, scale=0.0, variation=0.0):
         t = capi.pt_texture()
         t.type = typ
         for i in range(3):
@@ -372,7 +372,8 @@ class SceneBuilder:
                 t.value[i][:] = [float(x) for x in (c if isinstance(c, (tuple, list)) else (c, c, c))]
         for i, v in enumerate(values):
             t.value[i][:] = [float(x) for x in (v if isinstance(v, (tuple, list)) else (v, v, v))]
-        if typ in (capi.PT_TEX_CHECKERBOARD_2D, capi.PT_TEX_UV, capi.PT_TEX_BILERP):       # create_texture_mapping2d
+        t.octaves, t.omega, t.scale, t.variation = int(octaves), float(omega), float(scale), float(variation)
+        if typ in (capi.PT_TEX_CHECKERBOARD_2D, capi.PT_TEX_UV, capi.PT_TEX_BILERP, capi.PT_TEX_DOTS):       # create_texture_mapping2d
             t.mapping = {"uv": capi.PT_MAPPING_UV, "spherical": capi.PT_MAPPING_SPHERICAL, "cylindrical": capi.PT_MAPPING_CYLINDRICAL,
                          "planar": capi.PT_MAPPING_PLANAR}[mapping]
             t.aa_none = 1 if (aamode == "none" and typ == capi.PT_TEX_CHECKERBOARD_2D) else 0
@@ -382,7 +383,7 @@ class SceneBuilder:
             t.v2[:] = [float(x) for x in (v2 if mapping == "planar" else (0, 1, 0))]
             w2t = np.eye(4, dtype=np.float32).reshape(-1) if to_world is None else np.asarray(to_world[1], np.float32).reshape(-1)
             t.world_to_texture[:] = [float(x) for x in w2t]
-        elif typ == capi.PT_TEX_CHECKERBOARD_3D:
+        elif typ in (capi.PT_TEX_CHECKERBOARD_3D, capi.PT_TEX_FBM, capi.PT_TEX_WRINKLED, capi.PT_TEX_WINDY, capi.PT_TEX_MARBLE):
             w2t = np.eye(4, dtype=np.float32).reshape(-1) if to_world is None else np.asarray(to_world[0], np.float32).reshape(-1)
             t.world_to_texture[:] = [float(x) for x in w2t]
         self.textures.append(t)
@@ -401,6 +402,21 @@ class SceneBuilder:
         if dimension == 3:      # IdentityMapping3D is handed tex2world itself, not its inverse (checkerboard.rs:159, mapping3d.rs:19-24)
             return self._texture(capi.PT_TEX_CHECKERBOARD_3D, children=[tex1, tex2], **kw)
         return self._texture(capi.PT_TEX_CHECKERBOARD_2D, children=[tex1, tex2], **kw)
+
+    def texture_dots(self, tex1=1.0, tex2=0.0, **kw):
+        return self._texture(capi.PT_TEX_DOTS, children=[tex1, tex2], **kw)
+
+    def texture_fbm(self, octaves=8, roughness=0.5, to_world=None):
+        return self._texture(capi.PT_TEX_FBM, octaves=octaves, omega=roughness, to_world=to_world)
+
+    def texture_wrinkled(self, octaves=8, roughness=0.5, to_world=None):
+        return self._texture(capi.PT_TEX_WRINKLED, octaves=octaves, omega=roughness, to_world=to_world)
+
+    def texture_windy(self, to_world=None):
+        return self._texture(capi.PT_TEX_WINDY, to_world=to_world)
+
+    def texture_marble(self, octaves=8, roughness=0.5, scale=1.0, variation=0.2, to_world=None):
+        return self._texture(capi.PT_TEX_MARBLE, octaves=octaves, omega=roughness, scale=scale, variation=variation, to_world=to_world)
 
     def texture_uv(self, **kw):
         return self._texture(capi.PT_TEX_UV, **kw)

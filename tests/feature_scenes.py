@@ -325,3 +325,37 @@ TEXTURED_PBRT = '''
       Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-2 -2 2  -2 -2 -2  -2 2 0]
     WorldEnd
     '''
+
+
+def scene_noise_textures(res=48, spp=8, depth=4, sampler="sobol"):
+    """Perlin-noise textures (core/texture/noise.rs): dots on the floor, fbm / wrinkled / windy as Matte sigma and as colours
+    through scale / mix, marble on a sphere; each under its own 3-D mapping transform (the octave count of fbm follows the
+    camera ray's differentials at the first hit and is max_octaves afterwards)."""
+    b = base(res=res, spp=spp, depth=depth)
+    if sampler == "halton":
+        b.sampler_halton(spp)
+    T = scenes
+    s = 2.0
+    dots = b.texture_dots((0.8, 0.8, 0.7), (0.7, 0.1, 0.1), uscale=5.0, vscale=5.0)
+    b.material_matte(dots)
+    scenes._quad(b, (s, -s, -s), (-s, -s, -s), (-s, -s, s), (s, -s, s))
+    t1 = T.transform_scale(2.0, 2.0, 2.0)
+    wr = b.texture_wrinkled(octaves=6, roughness=0.6, to_world=t1)
+    b.material_matte(b.texture_scale((0.9, 0.8, 0.5), wr))
+    scenes._quad(b, (s, -s, s), (-s, -s, s), (-s, s, s), (s, s, s))
+    t2 = T.transform_mul(T.transform_rotate_x(40.0), T.transform_scale(1.5, 1.5, 1.5))
+    fb = b.texture_fbm(octaves=8, roughness=0.5, to_world=t2)
+    b.material_plastic(Kd=b.texture_mix((0.1, 0.2, 0.7), (0.9, 0.9, 0.9), amount=fb), Ks=(0.2, 0.2, 0.2), roughness=0.1)
+    scenes._quad(b, (-s, -s, s), (-s, -s, -s), (-s, s, -s), (-s, s, s))
+    b.material_matte(b.texture_scale((0.4, 0.6, 0.9), b.texture_windy(to_world=T.transform_scale(3.0, 3.0, 3.0))), sigma=b.texture_scale(60.0, b.texture_fbm(octaves=3)))
+    scenes._quad(b, (s, -s, -s), (s, -s, s), (s, s, s), (s, s, -s))
+    b.material_matte((0.7, 0.7, 0.7))
+    scenes._quad(b, (s, s, -s), (s, s, s), (-s, s, s), (-s, s, -s))
+    b.area_light_source_diffuse(L=(10, 9, 8))
+    h = 0.999 * s
+    scenes._quad(b, (0.5, h, -0.5), (0.5, h, 0.5), (-0.5, h, 0.5), (-0.5, h, -0.5))
+    b.no_area_light()
+    tm = T.transform_translate(0.0, -1.0, 0.3)
+    b.material_matte(b.texture_marble(octaves=8, roughness=0.5, scale=4.0, variation=0.4, to_world=tm))
+    b.shape_sphere(radius=0.9, object_to_world=tm[0], world_to_object=tm[1])
+    return b.build()

@@ -239,6 +239,53 @@ def test_sphere_shape_from_pbrt_text(oracle):
     a.close(); r.close()
 
 
+def test_noise_texture_directives(oracle):
+    """Texture "dots" / "fbm" / "wrinkled" / "windy" / "marble" (create_texture.rs:44-110): parameters, defaults and the CTM they
+    record, against the SceneBuilder's nodes byte for byte; float "marble" does not exist in the reference."""
+    text = '''
+    Sampler "sobol" "integer pixelsamples" 1
+    WorldBegin
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [1 1 1]
+        Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 2 0 1 2 0 0 2 1]
+      AttributeEnd
+      Texture "d" "spectrum" "dots" "rgb tex1" [0.8 0.8 0.7] "rgb tex2" [0.7 0.1 0.1] "float uscale" 5 "float vscale" 5
+      AttributeBegin
+        Scale 2 2 2
+        Texture "w" "float" "wrinkled" "integer octaves" 6 "float roughness" 0.6
+        Texture "f" "float" "fbm"
+        Texture "wi" "spectrum" "windy"
+        Texture "m" "spectrum" "marble" "float scale" 4 "float variation" 0.4
+        Texture "fm" "float" "marble"
+      AttributeEnd
+      Material "matte" "texture Kd" "m" "texture sigma" "w"
+      Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]
+      Material "matte" "texture Kd" "d" "texture sigma" "f"
+      Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 1 1 0 1 0 1 1]
+      Material "matte" "texture Kd" "wi" "texture sigma" "fm"
+      Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 2 1 0 2 0 1 2]
+    WorldEnd
+    '''
+    ps = capi.ParsedScene(text=text)
+    d = ps.desc
+    assert d.n_textures == 5 and 'Float texture "marble" unknown' in ps.warnings
+    b = scenes.SceneBuilder()
+    t = scenes.transform_scale(2.0, 2.0, 2.0)
+    b.texture_dots((0.8, 0.8, 0.7), (0.7, 0.1, 0.1), uscale=5.0, vscale=5.0)
+    b.texture_wrinkled(octaves=6, roughness=0.6, to_world=t)
+    b.texture_fbm(to_world=t)
+    b.texture_windy(to_world=t)
+    b.texture_marble(scale=4.0, variation=0.4, to_world=t)
+    for i in range(5):
+        assert bytes(d.textures[i]) == bytes(b.textures[i]), i
+    m = [d.materials[d.meshes[i].material] for i in (1, 2, 3)]
+    assert (m[0].tex_kd, m[0].tex_sigma) == (5, 2) and (m[1].tex_kd, m[1].tex_sigma) == (1, 3) and (m[2].tex_kd, m[2].tex_sigma) == (4, 0)
+    sc = oracle.scene(ps)
+    x, _, _ = sc.render(threads=2)
+    assert np.isfinite(x).all()
+    sc.close()
+
+
 def test_materials_from_pbrt_text():
     """Material / MakeNamedMaterial for every supported type: parameters, defaults (create_*_material) and
     TextureParams' precedence (core/param_set/texture_params.rs:36-83: constant values come from the material
