@@ -100,7 +100,7 @@ typedef struct {
 } pt_texture;
 
 /* Material::compute_scattering_functions variants (src/materials/).  Colour parameters and Matte's sigma may be
- * textures (tex_* below); roughness and eta textures must fold to constants, bump maps are outside the accelerated path. */
+ * textures (tex_* below) and a procedural bump map is applied (tex_bump); roughness and eta textures must fold to constants. */
 typedef enum {
     PT_MATERIAL_NONE = 0,      /* GeometricPrimitive.material == None: ray passes through (path.rs:108-111) */
     PT_MATERIAL_MATTE = 1,     /* materials/matte.rs:25-53      Kd, sigma */
@@ -134,7 +134,8 @@ typedef struct {
     /* ABI 4: index + 1 of the texture that drives the parameter at each hit (Texture::evaluate(si)), 0 = the constant
      * above.  Zero-initialised materials are therefore constant. */
     uint32_t tex_kd, tex_ks, tex_kr, tex_kt, tex_opacity, tex_sigma, tex_metal_eta, tex_metal_k;
-    float reserved[3];
+    uint32_t tex_bump;      /* "bumpmap" (core/material.rs:31-72): index + 1 of the displacement (float) texture, 0 = none */
+    float reserved[2];
 } pt_material;
 
 /* DiffuseAreaLight parameters shared by every triangle of one emissive shape

@@ -38,6 +38,7 @@ struct SurfHit {
     V2 uv;
     V3 dpdu, dpdv;
     V3 sh_n, sh_dpdu, sh_dpdv;
+    V3 dndu, dndv, sh_dndu, sh_dndv;         // read by bump mapping only (core/material.rs:31-72)
     Float b0 = 0, b1 = 0, b2 = 0;
     int32_t prim = -1;          // index into the scene's primitive list (Geometry::prim_ref)
 };
@@ -193,6 +194,7 @@ struct TriRef {
         si->n = n;
         si->dpdu = dpdu; si->dpdv = dpdv;
         si->sh_n = n; si->sh_dpdu = dpdu; si->sh_dpdv = dpdv;
+        si->dndu = V3(0, 0, 0); si->dndv = V3(0, 0, 0); si->sh_dndu = V3(0, 0, 0); si->sh_dndv = V3(0, 0, 0);
         si->b0 = b0; si->b1 = b1; si->b2 = b2;
         si->prim = (int32_t)tri;
         if (mf->has_n || mf->has_s) {
@@ -212,6 +214,19 @@ struct TriRef {
                 ss = normalize(cross(ts, ns));
             } else {
                 coordinate_system(ns, &ss, &ts);
+            }
+            if (mf->has_n) {             // shading dndu / dndv from the vertex normals (triangle.rs:405-437)
+                V2 duv02 = uv[0] - uv[2], duv12 = uv[1] - uv[2];
+                V3 dn1 = g->N[i0] - g->N[i2], dn2 = g->N[i1] - g->N[i2];
+                Float determinant = duv02.x * duv12.y - duv02.y * duv12.x;
+                if (std::fabs(determinant) < 1e-8f) {
+                    V3 dn = cross(g->N[i2] - g->N[i0], g->N[i1] - g->N[i0]);
+                    if (length_squared(dn) != 0.0f) coordinate_system(dn, &si->sh_dndu, &si->sh_dndv);
+                } else {
+                    Float inv_det = 1.0f / determinant;
+                    si->sh_dndu = (duv12.y * dn1 - duv02.y * dn2) * inv_det;
+                    si->sh_dndv = (-duv12.x * dn1 + duv02.x * dn2) * inv_det;
+                }
             }
             if (mf->reverse_orientation) ts = ts * -1.0f;
             // set_shading_geometry(ss, ts, .., orientation_is_authoritative=true)

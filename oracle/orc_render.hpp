@@ -459,14 +459,37 @@ inline bool make_bsdf_from_material(const pt_material& m, const SurfHit& si, BSD
 }
 // Parameter textures are evaluated at the hit (TextureParams::get_spectrum_texture / get_float_texture bound at material
 // creation; Texture::evaluate(si) inside each compute_scattering_functions), then the constant-parameter code runs.
-inline bool make_bsdf(const Scene& sc, const SurfHit& si, BSDF* b, const RayDiff& rd = RayDiff()) {
+// material_bump (core/material.rs:31-72): the displacement texture at the hit and at two shifted points bends the shading
+// frame.  The shifted evaluation points differ from the hit in p and uv only (the differentials are copied, :15-29).
+inline void material_bump(const pt_texture* tex, int32_t d, const TexHit& th, SurfHit& si) {
+    Float du = 0.5f * (std::fabs(th.dudx) + std::fabs(th.dudy));
+    if (du == 0.0f) du = 0.0005f;
+    TexHit ev = th;
+    ev.p = si.p + du * si.sh_dpdu;
+    ev.uv = si.uv + V2(du, 0.0f);
+    Float u_displace = texture_eval(tex, d, ev).c[0];
+    Float dv = 0.5f * (std::fabs(th.dvdx) + std::fabs(th.dvdy));
+    if (dv == 0.0f) dv = 0.0005f;
+    ev.p = si.p + dv * si.sh_dpdv;
+    ev.uv = si.uv + V2(0.0f, dv);
+    Float v_displace = texture_eval(tex, d, ev).c[0];
+    Float displace = texture_eval(tex, d, th).c[0];
+    V3 dpdu = si.sh_dpdu + (u_displace - displace) / du * si.sh_n + displace * si.sh_dndu;
+    V3 dpdv = si.sh_dpdv + (v_displace - displace) / dv * si.sh_n + displace * si.sh_dndv;
+    // set_shading_geometry(.., orientation_is_authoritative = false) (surface_interaction.rs:140-161)
+    si.sh_n = face_forward(normalize(cross(dpdu, dpdv)), si.n);
+    si.sh_dpdu = dpdu; si.sh_dpdv = dpdv;
+}
+inline bool make_bsdf(const Scene& sc, SurfHit& si, BSDF* b, const RayDiff& rd = RayDiff()) {
     int32_t mid = sc.prim_material(si.prim);
     if (mid < 0) return false;
     const pt_material& m0 = sc.materials[mid];
-    if (!(m0.tex_kd | m0.tex_ks | m0.tex_kr | m0.tex_kt | m0.tex_opacity | m0.tex_sigma | m0.tex_metal_eta | m0.tex_metal_k))
+    if (m0.type == PT_MATERIAL_NONE ||
+        !(m0.tex_kd | m0.tex_ks | m0.tex_kr | m0.tex_kt | m0.tex_opacity | m0.tex_sigma | m0.tex_metal_eta | m0.tex_metal_k | m0.tex_bump))
         return make_bsdf_from_material(m0, si, b);
     pt_material m = m0;
     TexHit th = compute_differentials(si, rd);                  // SurfaceInteraction::compute_scattering_functions :284-295
+    if (m.tex_bump) material_bump(sc.textures.data(), (int32_t)m.tex_bump - 1, th, si);      // first thing every material does
     auto spec = [&](uint32_t t, float* out) {
         if (!t) return;
         RGB v = texture_eval(sc.textures.data(), (int32_t)t - 1, th);
@@ -816,7 +839,7 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
         for (int k = 0; k < 3; k++)
             if (textures[i].tex[k] >= (int32_t)i) { if (err) *err = "texture child index must be smaller than the texture's own"; return false; }
     for (const pt_material& m : materials) {
-        const uint32_t refs[8] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k};
+        const uint32_t refs[9] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k, m.tex_bump};
         for (uint32_t r : refs) if (r > d.n_textures) { if (err) *err = "material texture index out of range"; return false; }
     }
     // spheres, spliced into the primitive list at before_triangle

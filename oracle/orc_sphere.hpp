@@ -188,8 +188,17 @@ struct Sphere {
         Float sin_phi = p_hit.y * inv_z_radius;
         V3 dpdu(-phi_max * p_hit.y, phi_max * p_hit.x, 0.0f);
         V3 dpdv = V3(p_hit.z * cos_phi, p_hit.z * sin_phi, -radius * std::sin(theta)) * dtheta;
+        // Weingarten equations (sphere.rs:156-176)
+        V3 d2pduu = V3(p_hit.x, p_hit.y, 0.0f) * (-phi_max * phi_max);
+        V3 d2pduv = V3(-sin_phi, cos_phi, 0.0f) * (p_hit.z * dtheta * phi_max);
+        V3 d2pdvv = V3(p_hit.x, p_hit.y, p_hit.z) * (-dtheta * dtheta);
+        Float E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
         V3 n = normalize(cross(dpdu, dpdv));                       // BaseShape::calc_normal (base_shape.rs:27-33)
         if (reverse_orientation ^ swaps_handedness) n = n * -1.0f;
+        Float ee = dot(n, d2pduu), ff = dot(n, d2pduv), gg = dot(n, d2pdvv);
+        Float inv_egf2 = 1.0f / (E * G - F * F);
+        V3 dndu = dpdu * ((ff * F - ee * G) * inv_egf2) + dpdv * ((ee * F - ff * E) * inv_egf2);
+        V3 dndv = dpdu * ((gg * F - ff * G) * inv_egf2) + dpdv * ((ff * F - gg * E) * inv_egf2);
         V3 p_error = kGamma5 * vabs(p_hit);
         // -> world
         const Float* m = o2w.m;
@@ -209,6 +218,8 @@ struct Sphere {
         si->dpdv = o2w.transform_vector(dpdv);
         si->sh_n = face_forward(normalize(normal_to_world(n)), si->n);
         si->sh_dpdu = si->dpdu; si->sh_dpdv = si->dpdv;
+        si->dndu = normal_to_world(dndu); si->dndv = normal_to_world(dndv);      // transform_normal, not renormalised (transform.rs:309-310)
+        si->sh_dndu = si->dndu; si->sh_dndv = si->dndv;
         si->b0 = si->b1 = si->b2 = 0.0f;
         *t_hit = t;
         return true;

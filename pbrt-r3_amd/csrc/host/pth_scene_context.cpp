@@ -463,7 +463,6 @@ public:
     int material_for_shape(const ParamSet& geom) {
         const MaterialInstance& mi = gstates.back().material;
         if (mi.none) return -1;
-        if (geom.textures.count("bumpmap") || mi.params.textures.count("bumpmap")) { fail("bumpmap: outside the accelerated path"); return -1; }
         const ParamSet& mp = mi.params;
         pt_material m;
         std::memset(&m, 0, sizeof(m));
@@ -525,6 +524,23 @@ public:
         } else {
             fail("Material \"" + mi.name + "\": outside the accelerated path (matte, plastic, mirror, glass, metal, uber, substrate are supported)");
             return -1;
+        }
+        {   // "bumpmap": get_float_texture_or_null (texture_params.rs:107-116) -- a named float texture, else a number
+            // (a constant texture, which still tilts the frame where dndu != 0), else none
+            float bv = 0.0f;
+            uint32_t bt = 0;
+            if (lookup_float(geom, mp, "bumpmap", &bv, &bt)) {
+                if (!bt) {
+                    pt_texture t;
+                    std::memset(&t, 0, sizeof(t));
+                    t.type = PT_TEX_CONSTANT;
+                    t.tex[0] = t.tex[1] = t.tex[2] = -1;
+                    t.value[0][0] = t.value[0][1] = t.value[0][2] = bv;
+                    textures.push_back(t);
+                    bt = (uint32_t)textures.size();
+                }
+                m.tex_bump = bt;
+            }
         }
         if (!error.empty()) return -1;
         for (size_t i = 0; i < materials.size(); i++)

@@ -963,6 +963,7 @@ struct Surf {            // what SurfaceInteraction carries for this path (surfa
     int32_t material, light;     // from the triangle record (-1 = none)
     V2 uv;                       // read by textures only (dead in the kernels without them)
     V3 dpdu, dpdv;               // geometric partials (compute_differentials)
+    V3 sh_dpdv, sh_dndu, sh_dndv;    // bump mapping
 };
 
 // Triangle::get_dpdu_dpdv (triangle.rs:132-186)
@@ -1007,6 +1008,7 @@ PT_DEV bool make_surf_tv(const PtScene& sc, V3 ro, V3 rd, const TriVerts& tv, ui
     tri_dpdu(sc, has_attr, ti, tv.p0, tv.p1, tv.p2, &dpdu, &dpdv, uvs);
     s.uv = mk2(h.b0 * uvs[0].x + h.b1 * uvs[1].x + h.b2 * uvs[2].x, h.b0 * uvs[0].y + h.b1 * uvs[1].y + h.b2 * uvs[2].y);   // triangle.rs:352
     s.dpdu = dpdu; s.dpdv = dpdv;
+    s.sh_dpdv = dpdv; s.sh_dndu = mk3(0.0f, 0.0f, 0.0f); s.sh_dndv = s.sh_dndu;
     float xa = fabsf(h.b0 * tv.p0.x) + fabsf(h.b1 * tv.p1.x) + fabsf(h.b2 * tv.p2.x);
     float ya = fabsf(h.b0 * tv.p0.y) + fabsf(h.b1 * tv.p1.y) + fabsf(h.b2 * tv.p2.y);
     float za = fabsf(h.b0 * tv.p0.z) + fabsf(h.b1 * tv.p1.z) + fabsf(h.b2 * tv.p2.z);
@@ -1038,7 +1040,22 @@ PT_DEV bool make_surf_tv(const PtScene& sc, V3 ro, V3 rd, const TriVerts& tv, ui
         } else {
             coordinate_system(ns, &ss, &ts);
         }
+        if (has_n) {             // shading dndu / dndv from the vertex normals (triangle.rs:405-437); bump mapping reads them
+            V3 n0 = ld3(sc.N + 3 * (size_t)ti.v[0]), n1 = ld3(sc.N + 3 * (size_t)ti.v[1]), n2 = ld3(sc.N + 3 * (size_t)ti.v[2]);
+            float du02x = uvs[0].x - uvs[2].x, du02y = uvs[0].y - uvs[2].y, du12x = uvs[1].x - uvs[2].x, du12y = uvs[1].y - uvs[2].y;
+            V3 dn1 = n0 - n2, dn2 = n1 - n2;
+            float determinant = du02x * du12y - du02y * du12x;
+            if (fabsf(determinant) < 1e-8f) {
+                V3 dn = cross(n2 - n0, n1 - n0);
+                if (length_squared(dn) != 0.0f) coordinate_system(dn, &s.sh_dndu, &s.sh_dndv);
+            } else {
+                float inv_det = 1.0f / determinant;
+                s.sh_dndu = (du12y * dn1 - du02y * dn2) * inv_det;
+                s.sh_dndv = (-du12x * dn1 + du02x * dn2) * inv_det;
+            }
+        }
         if (ti.mesh_flags & PT_MESH_REVERSE_ORIENTATION) ts = ts * -1.0f;
+        s.sh_dpdv = ts;
         s.sh_n = normalize(cross(ss, ts));          // set_shading_geometry, orientation authoritative
         s.n = face_forward(s.n, s.sh_n);
         s.sh_dpdu = ss;
@@ -1068,8 +1085,8 @@ PT_DEV bool make_surf_any(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s
             SphHit sh;
             const PtSphere& sp = sc.spheres[__float_as_uint(a.x)];
             if (!sph_hit_test(sp, ro, rd, PT_INF, PT_PI, &sh)) return false;
-            sph_interaction(sp, sh, &s.p, &s.p_error, &s.n, &s.wo, &s.sh_n, &s.sh_dpdu, &s.dpdv, &s.uv);
-            s.dpdu = s.sh_dpdu;
+            sph_interaction(sp, sh, &s.p, &s.p_error, &s.n, &s.wo, &s.sh_n, &s.sh_dpdu, &s.dpdv, &s.uv, &s.sh_dndu, &s.sh_dndv);
+            s.dpdu = s.sh_dpdu; s.sh_dpdv = s.dpdv;
             s.prim = __float_as_uint(a.w);
             s.material = (int32_t)(flags >> PT_TRI_MATERIAL_SHIFT) - 1;
             s.light = (int32_t)__float_as_uint(q[2].w) - 1;
@@ -1392,8 +1409,29 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 // Textured material at a hit: evaluate the parameter textures (Texture::evaluate(si) inside each
 // compute_scattering_functions) into a copy of the parameter block, then build the BxDF list the host builds for constant
 // materials (pt_lobes.h).
-__device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material, const TexHit& th, PtMaterial* out) {
+// bump: material_bump (core/material.rs:31-72) first -- it bends the shading frame (sh_n, sh_dpdu) in place.
+__device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material, const TexHit& th, PtMaterial* out, V3 n, V2 uv, V3* sh_n, V3* sh_dpdu,
+                                            V3 sh_dpdv, V3 sh_dndu, V3 sh_dndv) {
     PtMatParams mp = sc.mat_params[material];
+    if (mp.prog[8]) {
+        const uint32_t* prog = sc.tex_prog + mp.prog[8];
+        float du = 0.5f * (fabsf(th.dudx) + fabsf(th.dudy));
+        if (du == 0.0f) du = 0.0005f;
+        TexHit ev = th;
+        ev.p = th.p + du * *sh_dpdu;
+        ev.uv = mk2(uv.x + du, uv.y + 0.0f);
+        float u_displace = tex_eval(sc.textures, prog, ev).x;
+        float dv = 0.5f * (fabsf(th.dvdx) + fabsf(th.dvdy));
+        if (dv == 0.0f) dv = 0.0005f;
+        ev.p = th.p + dv * sh_dpdv;
+        ev.uv = mk2(uv.x + 0.0f, uv.y + dv);
+        float v_displace = tex_eval(sc.textures, prog, ev).x;
+        float displace = tex_eval(sc.textures, prog, th).x;
+        V3 dpdu = *sh_dpdu + (u_displace - displace) / du * *sh_n + displace * sh_dndu;
+        V3 dpdv = sh_dpdv + (v_displace - displace) / dv * *sh_n + displace * sh_dndv;
+        *sh_n = face_forward(normalize(cross(dpdu, dpdv)), n);       // set_shading_geometry(.., false) (surface_interaction.rs:140-161)
+        *sh_dpdu = dpdu;
+    }
     float* dst[8] = {mp.m.kd, mp.m.ks, mp.m.kr, mp.m.kt, mp.m.opacity, nullptr, mp.m.metal_eta, mp.m.metal_k};
     for (int k = 0; k < 8; k++) {
         if (!mp.prog[k]) continue;
@@ -1475,7 +1513,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                             camera_differentials(sc, mk2(pf.x, pf.y), u_lens, ro, rd, rdf);
                         }
                         compute_differentials(th, s.p, s.n, s.dpdu, s.dpdv, has_diff, rdf);
-                        textured_lobes(sc, s.material, th, &tm);
+                        textured_lobes(sc, s.material, th, &tm, s.n, s.uv, &s.sh_n, &s.sh_dpdu, s.sh_dpdv, s.sh_dndu, s.sh_dndv);
                         use_tm = true;
                         no_bsdf = tm.has_bsdf == 0;
                     }

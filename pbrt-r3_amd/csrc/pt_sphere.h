@@ -136,7 +136,8 @@ __device__ __noinline__ bool sph_hit_test(const PtSphere& s, V3 ro, V3 rd, float
 }
 // World-space interaction of a hit (sphere.rs:130-198 + transform_surface_interaction, transform.rs:299-323).
 // Only what the path consumes: p, p_error, n, wo, shading n and dpdu (u, v, dndu, dndv feed textures).
-PT_DEV void sph_interaction(const PtSphere& s, const SphHit& h, V3* p, V3* p_error, V3* n, V3* wo, V3* sh_n, V3* dpdu_w, V3* dpdv_w, V2* uv) {
+PT_DEV void sph_interaction(const PtSphere& s, const SphHit& h, V3* p, V3* p_error, V3* n, V3* wo, V3* sh_n, V3* dpdu_w, V3* dpdv_w, V2* uv,
+                            V3* dndu_w, V3* dndv_w) {
     V3 ph = h.p_hit;
     float dtheta = s.theta_max - s.theta_min;
     float theta = pt_acosf(clampf(ph.z / s.radius, -1.0f, 1.0f));
@@ -159,6 +160,18 @@ PT_DEV void sph_interaction(const PtSphere& s, const SphHit& h, V3* p, V3* p_err
     *dpdu_w = sph_vector(s.o2w, dpdu);
     *dpdv_w = sph_vector(s.o2w, dpdv);
     *uv = mk2(h.phi / s.phi_max, (theta - s.theta_min) / dtheta);      // sphere.rs:136-140 (read by textures only)
+    {   // Weingarten equations (sphere.rs:156-176); read by bump mapping only
+        V3 d2pduu = mk3(ph.x, ph.y, 0.0f) * (-s.phi_max * s.phi_max);
+        V3 d2pduv = mk3(-sin_phi, cos_phi, 0.0f) * (ph.z * dtheta * s.phi_max);
+        V3 d2pdvv = mk3(ph.x, ph.y, ph.z) * (-dtheta * dtheta);
+        float E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+        float ee = dot(nn, d2pduu), ff = dot(nn, d2pduv), gg = dot(nn, d2pdvv);
+        float inv_egf2 = 1.0f / (E * G - F * F);
+        V3 dndu = dpdu * ((ff * F - ee * G) * inv_egf2) + dpdv * ((ee * F - ff * E) * inv_egf2);
+        V3 dndv = dpdu * ((gg * F - ff * G) * inv_egf2) + dpdv * ((ff * F - gg * E) * inv_egf2);
+        *dndu_w = sph_normal(s.w2o, dndu);
+        *dndv_w = sph_normal(s.w2o, dndv);
+    }
 }
 // Sphere::sample (sphere.rs:286-304)
 PT_DEV void sph_sample(const PtSphere& s, V2 u, V3* p, V3* n, V3* p_error) {

@@ -346,6 +346,9 @@ class SceneBuilder:
         m.eta, m.remap_roughness = 1.5, 1
         m.uroughness = m.vroughness = capi.PT_ROUGHNESS_UNSET
         kw = dict(kw, kd=kd, sigma=sigma)
+        bump = kw.pop("bump", None)             # "bumpmap": a float texture, or a number (a constant texture, texture_params.rs:107-116)
+        if bump is not None:
+            m.tex_bump = (bump if isinstance(bump, Tex) else self.texture_constant(float(bump))).index + 1
         for k, v in kw.items():
             if isinstance(v, Tex):
                 setattr(m, "tex_" + k, v.index + 1)
@@ -424,17 +427,17 @@ class SceneBuilder:
     def texture_bilerp(self, v00=0.0, v01=1.0, v10=0.0, v11=1.0, **kw):
         return self._texture(capi.PT_TEX_BILERP, values=[v00, v01, v10, v11], **kw)
 
-    def material_matte(self, Kd=(0.5, 0.5, 0.5), sigma=0.0):
-        self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, Kd, sigma)
+    def material_matte(self, Kd=(0.5, 0.5, 0.5), sigma=0.0, bumpmap=None):
+        self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, Kd, sigma, bump=bumpmap)
 
     # defaults below are the reference's create_*_material defaults
-    def material_plastic(self, Kd=(0.25,) * 3, Ks=(0.25,) * 3, roughness=0.1, remaproughness=True):
+    def material_plastic(self, Kd=(0.25,) * 3, Ks=(0.25,) * 3, roughness=0.1, remaproughness=True, bumpmap=None):
         """materials/plastic.rs:73-86."""
-        self.cur_material = self._add_material(capi.PT_MATERIAL_PLASTIC, Kd, ks=Ks, roughness=float(roughness), remap_roughness=int(remaproughness))
+        self.cur_material = self._add_material(capi.PT_MATERIAL_PLASTIC, Kd, ks=Ks, roughness=float(roughness), remap_roughness=int(remaproughness), bump=bumpmap)
 
-    def material_mirror(self, Kr=(0.9,) * 3):
+    def material_mirror(self, Kr=(0.9,) * 3, bumpmap=None):
         """materials/mirror.rs:43-47."""
-        self.cur_material = self._add_material(capi.PT_MATERIAL_MIRROR, kr=Kr)
+        self.cur_material = self._add_material(capi.PT_MATERIAL_MIRROR, kr=Kr, bump=bumpmap)
 
     def material_glass(self, Kr=(1.0,) * 3, Kt=(1.0,) * 3, eta=1.5, uroughness=0.0, vroughness=0.0, remaproughness=True):
         """materials/glass.rs:124-143."""

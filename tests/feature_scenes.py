@@ -359,3 +359,39 @@ def scene_noise_textures(res=48, spp=8, depth=4, sampler="sobol"):
     b.material_matte(b.texture_marble(octaves=8, roughness=0.5, scale=4.0, variation=0.4, to_world=tm))
     b.shape_sphere(radius=0.9, object_to_world=tm[0], world_to_object=tm[1])
     return b.build()
+
+
+def scene_bump(res=48, spp=8, depth=4, lens=False):
+    """Bump mapping (core/material.rs:31-72): displacement textures bending the shading frame of a plain quad (zero dndu),
+    a smooth-shaded mesh (dndu / dndv from vertex normals, triangle.rs:405-437), an analytic sphere (Weingarten dndu / dndv)
+    and a mirror; a constant bump map given as a number; displacement evaluated at the shifted points with the camera ray's
+    differentials at the first hit and with the 0.0005 fallback afterwards."""
+    b = base(res=res, spp=spp, depth=depth)
+    if lens:
+        b.camera_perspective(fov=40.0, lensradius=0.05, focaldistance=6.0)
+    T = scenes
+    s = 2.0
+    wr = b.texture_scale(0.05, b.texture_wrinkled(octaves=5, roughness=0.5, to_world=T.transform_scale(4.0, 4.0, 4.0)))
+    b.material_matte((0.6, 0.6, 0.6), bumpmap=wr)
+    scenes._quad(b, (s, -s, -s), (-s, -s, -s), (-s, -s, s), (s, -s, s))
+    chk = b.texture_checkerboard(0.03, 0.0, uscale=8.0, vscale=8.0)
+    b.material_plastic(Kd=(0.7, 0.3, 0.2), Ks=(0.3, 0.3, 0.3), roughness=0.1, bumpmap=chk)
+    scenes._quad(b, (s, -s, s), (-s, -s, s), (-s, s, s), (s, s, s))
+    b.material_mirror(bumpmap=b.texture_scale(0.02, b.texture_dots(1.0, 0.0, uscale=6.0, vscale=6.0)))
+    scenes._quad(b, (-s, -s, s), (-s, -s, -s), (-s, s, -s), (-s, s, s))
+    b.material_matte((0.7, 0.2, 0.2), bumpmap=0.1)
+    scenes._quad(b, (s, -s, -s), (s, -s, s), (s, s, s), (s, s, -s))
+    b.material_matte((0.7, 0.7, 0.7))
+    scenes._quad(b, (s, s, -s), (s, s, s), (-s, s, s), (-s, s, -s))
+    b.area_light_source_diffuse(L=(10, 9, 8))
+    h = 0.999 * s
+    scenes._quad(b, (0.5, h, -0.5), (0.5, h, 0.5), (-0.5, h, 0.5), (-0.5, h, -0.5))
+    b.no_area_light()
+    fb = b.texture_scale(0.2, b.texture_fbm(octaves=6, to_world=T.transform_scale(5.0, 5.0, 5.0)))
+    b.material_matte((0.3, 0.5, 0.8), sigma=30.0, bumpmap=fb)
+    P, N, UV, idx = uv_sphere((-0.9, -1.2, 0.3), 0.75)
+    b.shape_trianglemesh(P, idx, N=N, uv=UV)
+    ts = T.transform_translate(0.9, -1.25, -0.3)
+    b.material_plastic(Kd=(0.2, 0.6, 0.3), Ks=(0.4, 0.4, 0.4), roughness=0.05, bumpmap=b.texture_scale(0.1, b.texture_windy(to_world=T.transform_scale(6.0, 6.0, 6.0))))
+    b.shape_sphere(radius=0.7, object_to_world=ts[0], world_to_object=ts[1])
+    return b.build()

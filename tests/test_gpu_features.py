@@ -71,6 +71,8 @@ def _compare(ctx, osc, exact_film, frac_limit=0.0):
     ("textures_thin_lens", lambda: fs.scene_textures(lens=True), True),
     ("textures_noise", lambda: fs.scene_noise_textures(), True),
     ("textures_noise_halton", lambda: fs.scene_noise_textures(sampler="halton"), True),
+    ("bump", lambda: fs.scene_bump(), True),
+    ("bump_thin_lens", lambda: fs.scene_bump(lens=True), True),
 ])
 def test_feature_scene(gpu_ctx, oracle, name, make, exact):
     sd = make()

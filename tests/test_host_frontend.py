@@ -286,6 +286,39 @@ def test_noise_texture_directives(oracle):
     sc.close()
 
 
+def test_bumpmap_parameter(oracle):
+    """"bumpmap" (get_float_texture_or_null, texture_params.rs:107-116): a named float texture, or a number (a constant texture)."""
+    tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]'
+    text = '''
+    Sampler "sobol" "integer pixelsamples" 1
+    WorldBegin
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [1 1 1]
+        %(tri)s
+      AttributeEnd
+      Texture "w" "float" "wrinkled"
+      Texture "k" "float" "constant" "float value" 0.25
+      Material "matte" "texture bumpmap" "w"
+      %(tri)s
+      Material "plastic" "float bumpmap" 0.1
+      %(tri)s
+      Material "mirror"
+      %(tri)s "texture bumpmap" "k"
+    WorldEnd
+    ''' % {"tri": tri}
+    ps = capi.ParsedScene(text=text)
+    d = ps.desc
+    m = [d.materials[d.meshes[i].material] for i in (1, 2, 3)]
+    assert d.n_textures == 3 and d.textures[0].type == capi.PT_TEX_WRINKLED
+    assert m[0].tex_bump == 1
+    assert m[1].tex_bump == 2 and d.textures[1].type == capi.PT_TEX_CONSTANT and abs(d.textures[1].value[0][0] - 0.1) < 1e-7
+    assert m[2].tex_bump == 3 and d.textures[2].value[0][0] == 0.25
+    sc = oracle.scene(ps)
+    x, _, _ = sc.render(threads=2)
+    assert np.isfinite(x).all()
+    sc.close()
+
+
 def test_materials_from_pbrt_text():
     """Material / MakeNamedMaterial for every supported type: parameters, defaults (create_*_material) and
     TextureParams' precedence (core/param_set/texture_params.rs:36-83: constant values come from the material
