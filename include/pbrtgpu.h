@@ -61,8 +61,7 @@ typedef struct pt_context pt_context;
 /* Procedural textures (src/textures/, src/core/texture/mapping2d.rs, mapping3d.rs).  A texture evaluates to an RGB triple;
  * a float texture is one whose three channels are equal (consumers read channel 0), so scale / mix / checkerboard are the
  * same arithmetic per channel as the reference's generic Texture<T>.  textures[] is in definition order: a child index is
- * always smaller than the index of the texture that uses it.  Image maps (imagemap.rs, mipmap.rs) are not on the
- * accelerated path yet. */
+ * always smaller than the index of the texture that uses it. */
 typedef enum {
     PT_TEX_CONSTANT = 0,         /* core/texture/constant.rs: value[0] */
     PT_TEX_SCALE = 1,            /* textures/scale.rs: tex1 * tex2 */
@@ -75,8 +74,20 @@ typedef enum {
     PT_TEX_FBM = 8,              /* textures/fbm.rs: noise.rs fbm(p, dpdx, dpdy, omega, octaves) over the 3-D mapping */
     PT_TEX_WRINKLED = 9,         /* textures/wrinkled.rs: turbulence(...) */
     PT_TEX_WINDY = 10,           /* textures/windy.rs: |fbm(.1p, .., .5, 3)| * fbm(p, .., .5, 6) */
-    PT_TEX_MARBLE = 11           /* textures/marble.rs: spline over sin(scale*p.y + variation * fbm(...)) */
+    PT_TEX_MARBLE = 11,          /* textures/marble.rs: spline over sin(scale*p.y + variation * fbm(...)) */
+    PT_TEX_IMAGEMAP = 12         /* textures/imagemap.rs: MIPMap::lookup_delta over images[image]; 2-D mapping */
 } pt_texture_type;
+typedef enum { PT_WRAP_REPEAT = 0, PT_WRAP_BLACK = 1, PT_WRAP_CLAMP = 2 } pt_image_wrap;      /* core/texture/texture.rs:7-12 */
+/* A MIP pyramid as MIPMap::new leaves it (core/texture/mipmap.rs:406-485): level 0 has power-of-two width x height (the
+ * caller resamples, :316-404), each further level halves the dimensions that are still > 1 (box filter), down to 1 x 1.
+ * texels: all levels back to back, level 0 first, row-major, `channels` floats per texel (1 = float image, 3 = RGB), already
+ * inverse-gamma'd, scaled and flipped in y as ImageTexture does (textures/imagemap.rs). */
+typedef struct {
+    uint32_t width, height;     /* level 0; powers of two */
+    uint32_t channels;          /* 1 or 3 */
+    uint32_t n_levels;          /* 1 + log2(max(width, height)) */
+    const float* texels;
+} pt_image;
 typedef enum {
     PT_MAPPING_UV = 0,           /* UVMapping2D: su sv du dv */
     PT_MAPPING_SPHERICAL = 1,    /* SphericalMapping2D: world_to_texture */
@@ -97,6 +108,11 @@ typedef struct {
     int32_t octaves;            /* fbm / wrinkled / marble "octaves" (8) */
     float omega;                /* "roughness" (0.5) */
     float scale, variation;     /* marble "scale" (1), "variation" (0.2) */
+    int32_t image;              /* imagemap: index into images[] */
+    int32_t trilinear;          /* imagemap "trilinear" (false: EWA) */
+    float max_anisotropy;       /* imagemap "maxanisotropy" (8) */
+    int32_t swrap, twrap;       /* pt_image_wrap ("wrap", default repeat) */
+    int32_t reserved[3];
 } pt_texture;
 
 /* Material::compute_scattering_functions variants (src/materials/).  Colour parameters and Matte's sigma may be
@@ -241,6 +257,8 @@ typedef struct {
     /* ---- procedural textures (ABI 4), referenced by pt_material.tex_* */
     uint32_t n_textures;
     const pt_texture* textures;
+    uint32_t n_images;
+    const pt_image* images;     /* MIP pyramids of the imagemap textures */
     int32_t reserved[2];
 } pt_scene_desc;
 

@@ -124,6 +124,7 @@ struct Scene {
     QBVH bvh;
     std::vector<pt_material> materials;
     std::vector<pt_texture> textures;
+    std::vector<MipImage> images;
     std::vector<int32_t> mesh_material, mesh_light_params;
     std::vector<int32_t> sphere_material;
     std::vector<int32_t> prim_light;    // light index per primitive or -1
@@ -461,19 +462,19 @@ inline bool make_bsdf_from_material(const pt_material& m, const SurfHit& si, BSD
 // creation; Texture::evaluate(si) inside each compute_scattering_functions), then the constant-parameter code runs.
 // material_bump (core/material.rs:31-72): the displacement texture at the hit and at two shifted points bends the shading
 // frame.  The shifted evaluation points differ from the hit in p and uv only (the differentials are copied, :15-29).
-inline void material_bump(const pt_texture* tex, int32_t d, const TexHit& th, SurfHit& si) {
+inline void material_bump(const pt_texture* tex, int32_t d, const TexHit& th, SurfHit& si, const MipImage* images) {
     Float du = 0.5f * (std::fabs(th.dudx) + std::fabs(th.dudy));
     if (du == 0.0f) du = 0.0005f;
     TexHit ev = th;
     ev.p = si.p + du * si.sh_dpdu;
     ev.uv = si.uv + V2(du, 0.0f);
-    Float u_displace = texture_eval(tex, d, ev).c[0];
+    Float u_displace = texture_eval(tex, d, ev, images).c[0];
     Float dv = 0.5f * (std::fabs(th.dvdx) + std::fabs(th.dvdy));
     if (dv == 0.0f) dv = 0.0005f;
     ev.p = si.p + dv * si.sh_dpdv;
     ev.uv = si.uv + V2(0.0f, dv);
-    Float v_displace = texture_eval(tex, d, ev).c[0];
-    Float displace = texture_eval(tex, d, th).c[0];
+    Float v_displace = texture_eval(tex, d, ev, images).c[0];
+    Float displace = texture_eval(tex, d, th, images).c[0];
     V3 dpdu = si.sh_dpdu + (u_displace - displace) / du * si.sh_n + displace * si.sh_dndu;
     V3 dpdv = si.sh_dpdv + (v_displace - displace) / dv * si.sh_n + displace * si.sh_dndv;
     // set_shading_geometry(.., orientation_is_authoritative = false) (surface_interaction.rs:140-161)
@@ -489,15 +490,15 @@ inline bool make_bsdf(const Scene& sc, SurfHit& si, BSDF* b, const RayDiff& rd =
         return make_bsdf_from_material(m0, si, b);
     pt_material m = m0;
     TexHit th = compute_differentials(si, rd);                  // SurfaceInteraction::compute_scattering_functions :284-295
-    if (m.tex_bump) material_bump(sc.textures.data(), (int32_t)m.tex_bump - 1, th, si);      // first thing every material does
+    if (m.tex_bump) material_bump(sc.textures.data(), (int32_t)m.tex_bump - 1, th, si, sc.images.data());      // first thing every material does
     auto spec = [&](uint32_t t, float* out) {
         if (!t) return;
-        RGB v = texture_eval(sc.textures.data(), (int32_t)t - 1, th);
+        RGB v = texture_eval(sc.textures.data(), (int32_t)t - 1, th, sc.images.data());
         out[0] = v.c[0]; out[1] = v.c[1]; out[2] = v.c[2];
     };
     spec(m.tex_kd, m.kd); spec(m.tex_ks, m.ks); spec(m.tex_kr, m.kr); spec(m.tex_kt, m.kt); spec(m.tex_opacity, m.opacity);
     spec(m.tex_metal_eta, m.metal_eta); spec(m.tex_metal_k, m.metal_k);
-    if (m.tex_sigma) m.sigma = texture_eval(sc.textures.data(), (int32_t)m.tex_sigma - 1, th).c[0];
+    if (m.tex_sigma) m.sigma = texture_eval(sc.textures.data(), (int32_t)m.tex_sigma - 1, th, sc.images.data()).c[0];
     return make_bsdf_from_material(m, si, b);
 }
 
@@ -835,6 +836,10 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
     }
     materials.assign(d.materials, d.materials + d.n_materials);
     if (d.n_textures) textures.assign(d.textures, d.textures + d.n_textures);
+    images.resize(d.n_images);
+    for (uint32_t i = 0; i < d.n_images; i++) images[i].init(d.images[i]);
+    for (uint32_t i = 0; i < d.n_textures; i++)
+        if (textures[i].type == PT_TEX_IMAGEMAP && (textures[i].image < 0 || (uint32_t)textures[i].image >= d.n_images)) { if (err) *err = "imagemap image index out of range"; return false; }
     for (uint32_t i = 0; i < d.n_textures; i++)
         for (int k = 0; k < 3; k++)
             if (textures[i].tex[k] >= (int32_t)i) { if (err) *err = "texture child index must be smaller than the texture's own"; return false; }

@@ -8,6 +8,8 @@
 #include "orc_accel.hpp"
 #include "../include/pbrtgpu.h"
 #include "../include/pbrtgpu_noise_perm.h"
+#include "../include/pbrtgpu_ewa_lut.h"
+#include <vector>
 
 namespace orc {
 
@@ -179,14 +181,134 @@ inline void map3d(const pt_texture& t, const TexHit& si, V3* p, V3* dpdx, V3* dp
     *dpdy = m.transform_vector(si.dpdx);
 }
 
+// ---- MIPMap (core/texture/mipmap.rs) over a caller-built pyramid
+struct MipImage {
+    uint32_t channels = 3;
+    int swrap = 0, twrap = 0;
+    std::vector<int32_t> w, h;
+    std::vector<const float*> level;
+    void init(const pt_image& im) {
+        channels = im.channels;
+        w.clear(); h.clear(); level.clear();
+        int32_t cw = (int32_t)im.width, ch = (int32_t)im.height;
+        const float* p = im.texels;
+        for (uint32_t l = 0; l < im.n_levels; l++) {          // make_pyramid (:406-441): halve what is still > 1
+            w.push_back(cw); h.push_back(ch); level.push_back(p);
+            p += (size_t)cw * ch * channels;
+            if (cw > 1) cw /= 2;
+            if (ch > 1) ch /= 2;
+        }
+    }
+    size_t levels() const { return w.size(); }
+    RGB fetch(size_t l, size_t i) const {                     // MIPMapTexel::lookup (:83-96)
+        const float* d = level[l];
+        return channels == 1 ? RGB(d[i]) : RGB(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    }
+    // texel_static (:503-544)
+    RGB texel(size_t l, int32_t s, int32_t t) const {
+        int32_t ww = w[l], hh = h[l];
+        if (swrap == PT_WRAP_REPEAT) s &= ww - 1;
+        else if (swrap == PT_WRAP_CLAMP) s = s < 0 ? 0 : (s > ww - 1 ? ww - 1 : s);
+        else if (s < 0 || ww <= s) return RGB();
+        if (twrap == PT_WRAP_REPEAT) t &= hh - 1;
+        else if (twrap == PT_WRAP_CLAMP) t = t < 0 ? 0 : (t > hh - 1 ? hh - 1 : t);
+        else if (t < 0 || hh <= t) return RGB();
+        return fetch(l, (size_t)t * ww + s);
+    }
+    // triangle (:711-765).  With a "black" wrap mode on either axis the reference indexes the level unwrapped (and panics when
+    // that leaves the image); texel() semantics are used there instead.
+    RGB triangle(size_t l, V2 st) const {
+        if (l > levels() - 1) l = levels() - 1;
+        int32_t ww = w[l], hh = h[l];
+        Float s = st.x * (Float)ww - 0.5f, t = st.y * (Float)hh - 0.5f;
+        int32_t s0 = f2i(std::floor(s)), t0 = f2i(std::floor(t));
+        Float ds = s - (Float)s0, dt = t - (Float)t0;
+        int32_t s1 = s0 + 1, t1 = t0 + 1;
+        return texel(l, s0, t0) * ((1.0f - ds) * (1.0f - dt)) + texel(l, s0, t1) * ((1.0f - ds) * dt) + texel(l, s1, t0) * (ds * (1.0f - dt)) +
+               texel(l, s1, t1) * (ds * dt);
+    }
+    // lookup (:620-637): trilinear
+    RGB lookup(V2 st, Float width) const {
+        Float max_level = (Float)(levels() - 1);
+        Float lvl = max_level + std::log2(fmax_(width, 1e-8f));
+        if (lvl < 0.0f) return triangle(0, st);
+        if (lvl >= max_level) return texel(levels() - 1, 0, 0);
+        size_t il = (size_t)std::floor(lvl);
+        Float delta = clampf(lvl - (Float)il, 0.0f, 1.0f);
+        RGB a = triangle(il, st), b = triangle(il + 1, st);
+        return a * (1.0f - delta) + b * delta;
+    }
+    // ewa_rgb / ewa_float (:785-817, :876-911) = make_ewa_params + ewa_core (:141-217)
+    RGB ewa(size_t l, V2 st0, V2 d0, V2 d1) const {
+        static const Float lut[PT_EWA_LUT_SIZE] = {PT_EWA_LUT_VALUES};
+        if (l >= levels()) return texel(levels() - 1, 0, 0);
+        Float ww = (Float)w[l], hh = (Float)h[l];
+        V2 st(st0.x * ww - 0.5f, st0.y * hh - 0.5f);
+        V2 dst0(d0.x * ww, d0.y * hh), dst1(d1.x * ww, d1.y * hh);
+        Float a = dst0.y * dst0.y + dst1.y * dst1.y + 1.0f;
+        Float b = -2.0f * (dst0.x * dst0.y + dst1.x * dst1.y);
+        Float c = dst0.x * dst0.x + dst1.x * dst1.x + 1.0f;
+        Float inv_f = 1.0f / (a * c - b * b * 0.25f);
+        a = a * inv_f; b = b * inv_f; c = c * inv_f;
+        Float det = -b * b + 4.0f * a * c;
+        Float inv_det = 1.0f / det;
+        Float u_sqrt = std::sqrt(det * c), v_sqrt = std::sqrt(det * a);
+        int32_t s0 = f2i(std::ceil(st.x - 2.0f * inv_det * u_sqrt)), s1 = f2i(std::floor(st.x + 2.0f * inv_det * u_sqrt));
+        int32_t t0 = f2i(std::ceil(st.y - 2.0f * inv_det * v_sqrt)), t1 = f2i(std::floor(st.y + 2.0f * inv_det * v_sqrt));
+        RGB sum;
+        Float sum_wts = 0.0f;
+        for (int64_t it = t0; it <= t1; it++) {
+            Float tt = (Float)(int32_t)it - st.y;
+            for (int64_t is = s0; is <= s1; is++) {
+                Float ss = (Float)(int32_t)is - st.x;
+                Float r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+                if (r2 < 1.0f) {
+                    Float fi = r2 * (Float)PT_EWA_LUT_SIZE;
+                    size_t index = fi != fi ? 0 : (fi <= 0.0f ? 0 : (size_t)fi);
+                    if (index > PT_EWA_LUT_SIZE - 1) index = PT_EWA_LUT_SIZE - 1;
+                    Float weight = lut[index];
+                    RGB v = texel(l, (int32_t)is, (int32_t)it);
+                    for (int k = 0; k < 3; k++) sum.c[k] += v.c[k] * weight;
+                    sum_wts += weight;
+                }
+            }
+        }
+        Float inv_sum = 1.0f / sum_wts;
+        return RGB(sum.c[0] * inv_sum, sum.c[1] * inv_sum, sum.c[2] * inv_sum);
+    }
+    // lookup_delta_rgb / lookup_delta_float (:819-852, :913-946)
+    RGB lookup_delta(V2 st, V2 dst0, V2 dst1, bool trilinear, Float max_aniso) const {
+        if (trilinear) {
+            Float width = fmax_(fmax_(std::fabs(dst0.x), std::fabs(dst0.y)), fmax_(std::fabs(dst1.x), std::fabs(dst1.y)));
+            return lookup(st, width);
+        }
+        if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) std::swap(dst0, dst1);
+        Float major_length = std::sqrt(dst0.x * dst0.x + dst0.y * dst0.y);
+        Float minor_length = std::sqrt(dst1.x * dst1.x + dst1.y * dst1.y);
+        if (minor_length * max_aniso < major_length && minor_length > 0.0f) {
+            Float scale = major_length / (minor_length * max_aniso);
+            dst1 = dst1 * scale;
+            minor_length *= scale;
+        }
+        if (minor_length <= 0.0f) return lookup(st, 0.0f);
+        Float lod = fmax_(0.0f, (Float)levels() - 1.0f + std::log2(minor_length));
+        size_t ilod = (size_t)std::floor(lod);
+        Float t = lod - (Float)ilod;
+        RGB e0 = ewa(ilod, st, dst0, dst1), e1 = ewa(ilod + 1, st, dst0, dst1);
+        return RGB(lerpf(t, e0.c[0], e1.c[0]), lerpf(t, e0.c[1], e1.c[1]), lerpf(t, e0.c[2], e1.c[2]));
+    }
+};
+struct TexCtx { const pt_texture* tex; const MipImage* images; };
+
 // Texture<T>::evaluate over the flattened texture array; float textures are RGB with equal channels.
-inline RGB texture_eval(const pt_texture* tex, int32_t index, const TexHit& si);
-inline RGB texture_child(const pt_texture* tex, const pt_texture& t, int k, const TexHit& si) {
-    if (t.tex[k] >= 0) return texture_eval(tex, t.tex[k], si);
+inline RGB texture_eval(const pt_texture* tex, int32_t index, const TexHit& si, const MipImage* images = nullptr);
+inline RGB texture_child_i(const pt_texture* tex, const pt_texture& t, int k, const TexHit& si, const MipImage* images) {
+    if (t.tex[k] >= 0) return texture_eval(tex, t.tex[k], si, images);
     return RGB(t.value[k][0], t.value[k][1], t.value[k][2]);
 }
-inline RGB texture_eval(const pt_texture* tex, int32_t index, const TexHit& si) {
+inline RGB texture_eval(const pt_texture* tex, int32_t index, const TexHit& si, const MipImage* images) {
     const pt_texture& t = tex[index];
+    auto texture_child = [&](const pt_texture* tx, const pt_texture& tt, int k, const TexHit& s2) { return texture_child_i(tx, tt, k, s2, images); };
     switch (t.type) {
         case PT_TEX_SCALE: {
             RGB a = texture_child(tex, t, 0, si), b = texture_child(tex, t, 1, si);
@@ -226,6 +348,13 @@ inline RGB texture_eval(const pt_texture* tex, int32_t index, const TexHit& si) 
             V2 st, dx, dy;
             map2d(t, si, &st, &dx, &dy);
             return RGB(st.x - std::floor(st.x), st.y - std::floor(st.y), 0.0f);
+        }
+        case PT_TEX_IMAGEMAP: {                                   // imagemap.rs:57-70
+            V2 st, dx, dy;
+            map2d(t, si, &st, &dx, &dy);
+            MipImage im = images[t.image];
+            im.swrap = t.swrap; im.twrap = t.twrap;
+            return im.lookup_delta(st, dx, dy, t.trilinear != 0, t.max_anisotropy);
         }
         case PT_TEX_DOTS: {                                       // dots.rs:27-43
             V2 st, dx, dy;

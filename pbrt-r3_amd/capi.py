@@ -44,11 +44,21 @@ class pt_texture(C.Structure):
     _fields_ = [("type", C.c_int32), ("tex", C.c_int32 * 3), ("value", (C.c_float * 3) * 4), ("mapping", C.c_int32),
                 ("aa_none", C.c_int32), ("su", C.c_float), ("sv", C.c_float), ("du", C.c_float), ("dv", C.c_float),
                 ("v1", C.c_float * 3), ("v2", C.c_float * 3), ("world_to_texture", C.c_float * 16),
-                ("octaves", C.c_int32), ("omega", C.c_float), ("scale", C.c_float), ("variation", C.c_float)]
+                ("octaves", C.c_int32), ("omega", C.c_float), ("scale", C.c_float), ("variation", C.c_float),
+                ("image", C.c_int32), ("trilinear", C.c_int32), ("max_anisotropy", C.c_float), ("swrap", C.c_int32), ("twrap", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
+
+
+class pt_image(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32), ("n_levels", C.c_uint32),
+                ("texels", C.POINTER(C.c_float))]
+
+
+PT_WRAP_REPEAT, PT_WRAP_BLACK, PT_WRAP_CLAMP = range(3)
 
 
 (PT_TEX_CONSTANT, PT_TEX_SCALE, PT_TEX_MIX, PT_TEX_CHECKERBOARD_2D, PT_TEX_CHECKERBOARD_3D, PT_TEX_UV, PT_TEX_BILERP, PT_TEX_DOTS, PT_TEX_FBM,
- PT_TEX_WRINKLED, PT_TEX_WINDY, PT_TEX_MARBLE) = range(12)
+ PT_TEX_WRINKLED, PT_TEX_WINDY, PT_TEX_MARBLE, PT_TEX_IMAGEMAP) = range(13)
 PT_MAPPING_UV, PT_MAPPING_SPHERICAL, PT_MAPPING_CYLINDRICAL, PT_MAPPING_PLANAR = range(4)
 
 
@@ -89,7 +99,8 @@ class pt_scene_desc(C.Structure):
         ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
         ("halton_sample_at_center", C.c_int32),
         ("n_spheres", C.c_uint32), ("spheres", C.POINTER(pt_sphere)),
-        ("n_textures", C.c_uint32), ("textures", C.POINTER(pt_texture)), ("reserved", C.c_int32 * 2),
+        ("n_textures", C.c_uint32), ("textures", C.POINTER(pt_texture)),
+        ("n_images", C.c_uint32), ("images", C.POINTER(pt_image)), ("reserved", C.c_int32 * 2),
     ]
 
 

@@ -61,7 +61,7 @@ struct pt_context {
     bool have_scene = false;
     PtScene sc;
     pt_scene_info info;
-    DevBuf d_nodes, d_tris, d_tri_info, d_spheres, d_textures, d_tex_prog, d_mat_params, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab, d_hdims, d_hperms;
+    DevBuf d_nodes, d_tris, d_tri_info, d_spheres, d_textures, d_tex_prog, d_mat_params, d_images, d_image_texels, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab, d_hdims, d_hperms;
     std::vector<uint32_t> sobol_m32;
     std::vector<uint64_t> sobol_vdc, sobol_inv;
     uint32_t sobol_n_vdc = 0, sobol_n_inv = 0, sobol_msize = 52;
@@ -408,10 +408,22 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     for (uint32_t i = 0; i < d->n_textures; i++) {
         const pt_texture& t = d->textures[i];
-        if (t.type < PT_TEX_CONSTANT || t.type > PT_TEX_MARBLE) return ctx->fail(PT_ERR_UNSUPPORTED, "texture class not on the accelerated path");
+        if (t.type < PT_TEX_CONSTANT || t.type > PT_TEX_IMAGEMAP) return ctx->fail(PT_ERR_UNSUPPORTED, "texture class not on the accelerated path");
         if (t.mapping < PT_MAPPING_UV || t.mapping > PT_MAPPING_PLANAR) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown texture mapping");
         for (int k = 0; k < 3; k++)
             if (t.tex[k] >= (int32_t)i) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "texture child index must be smaller than the texture's own (definition order)");
+        if (t.type == PT_TEX_IMAGEMAP) {
+            if (t.image < 0 || (uint32_t)t.image >= d->n_images || !d->images) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "imagemap image index out of range");
+            if (t.swrap < PT_WRAP_REPEAT || t.swrap > PT_WRAP_CLAMP || t.twrap < PT_WRAP_REPEAT || t.twrap > PT_WRAP_CLAMP) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown image wrap mode");
+        }
+    }
+    for (uint32_t i = 0; i < d->n_images; i++) {
+        const pt_image& im = d->images[i];
+        auto pow2 = [](uint32_t v) { return v != 0 && (v & (v - 1)) == 0; };
+        uint32_t lv = 1;
+        for (uint32_t m = std::max(im.width, im.height); m > 1; m >>= 1) lv++;
+        if (!pow2(im.width) || !pow2(im.height) || (im.channels != 1 && im.channels != 3) || !im.texels || im.n_levels != lv || lv > PT_MAX_MIP_LEVELS)
+            return ctx->fail(PT_ERR_INVALID_ARGUMENT, "image pyramid: level 0 must be power-of-two sized, 1 or 3 channels, with 1 + log2(max(w, h)) levels");
     }
     for (uint32_t i = 0; i < d->n_spheres; i++) {
         const pt_sphere& sp = d->spheres[i];
@@ -585,6 +597,40 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if ((st = upload(ctx, ctx->d_materials, mats.data(), mats.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_lights, lights.data(), lights.size())) != PT_OK) return st;
     if (d->n_spheres) { if ((st = upload(ctx, ctx->d_spheres, sph.data(), sph.size())) != PT_OK) return st; } else ctx->d_spheres.release();
+    std::vector<PtImage> dimages(d->n_images);
+    if (any_textured && d->n_images) {           // all pyramids in one buffer
+        size_t total = 0;
+        for (uint32_t i = 0; i < d->n_images; i++) {
+            const pt_image& im = d->images[i];
+            PtImage& o = dimages[i];
+            std::memset(&o, 0, sizeof(o));
+            o.width = im.width; o.height = im.height; o.channels = im.channels; o.n_levels = im.n_levels;
+            uint32_t w = im.width, h = im.height;
+            size_t off = 0;
+            for (uint32_t l = 0; l < im.n_levels; l++) {
+                if (off > 0xffffffffull) return ctx->fail(PT_ERR_UNSUPPORTED, "image pyramid larger than 2^32 floats");
+                o.level_off[l] = (uint32_t)off;
+                off += (size_t)w * h * im.channels;
+                if (w > 1) w /= 2;
+                if (h > 1) h /= 2;
+            }
+            total += off;
+        }
+        std::vector<float> all(total);
+        size_t at = 0;
+        std::vector<size_t> base(d->n_images);
+        for (uint32_t i = 0; i < d->n_images; i++) {
+            size_t n = 0;
+            uint32_t w = d->images[i].width, h = d->images[i].height;
+            for (uint32_t l = 0; l < d->images[i].n_levels; l++) { n += (size_t)w * h * d->images[i].channels; if (w > 1) w /= 2; if (h > 1) h /= 2; }
+            std::memcpy(all.data() + at, d->images[i].texels, n * sizeof(float));
+            base[i] = at;
+            at += n;
+        }
+        if ((st = upload(ctx, ctx->d_image_texels, all.data(), all.size())) != PT_OK) return st;
+        for (uint32_t i = 0; i < d->n_images; i++) dimages[i].texels = ctx->d_image_texels.as<float>() + base[i];
+        if ((st = upload(ctx, ctx->d_images, dimages.data(), dimages.size())) != PT_OK) return st;
+    } else { ctx->d_image_texels.release(); ctx->d_images.release(); }
     if (any_textured) {
         if ((st = upload(ctx, ctx->d_textures, d->textures, d->n_textures)) != PT_OK) return st;
         if ((st = upload(ctx, ctx->d_tex_prog, tex_prog.data(), tex_prog.size())) != PT_OK) return st;
@@ -610,6 +656,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     sc.textured = any_textured ? 1u : 0u;
     sc.textures = any_textured ? ctx->d_textures.as<pt_texture>() : nullptr;
     sc.tex_prog = any_textured ? ctx->d_tex_prog.as<uint32_t>() : nullptr;
+    sc.images = (any_textured && d->n_images) ? ctx->d_images.as<PtImage>() : nullptr;
     sc.mat_params = any_textured ? ctx->d_mat_params.as<PtMatParams>() : nullptr;
     sc.spheres = d->n_spheres ? ctx->d_spheres.as<PtSphere>() : nullptr;
     sc.n_spheres = d->n_spheres;

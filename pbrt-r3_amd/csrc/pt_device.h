@@ -88,6 +88,16 @@ struct PtMaterial {
     uint32_t pad[3];
     PtLobe lobes[PT_MAX_LOBES];
 };
+// One MIP pyramid (core/texture/mipmap.rs) in HBM: all levels back to back, level l at texels + level_off[l] floats.
+#define PT_MAX_MIP_LEVELS 16
+struct PtImage {
+    const float* texels;
+    uint32_t width, height;      // level 0 (powers of two); level l is max(1, width >> l) x max(1, height >> l)
+    uint32_t channels;           // 1 or 3
+    uint32_t n_levels;
+    uint32_t level_off[PT_MAX_MIP_LEVELS];
+    uint32_t pad[2];
+};
 #define PT_TEX_PROG_MAX 12          // nodes one parameter's texture graph may need
 #define PT_TEX_CHILD_CONST 15u      // texture program entry, child slot: the node's own constant (pt_texture.h)
 // A material with texture-driven parameters: the caller's parameter block, the roughness values after the optional
@@ -194,6 +204,7 @@ struct PtScene {
     const PtSphere* spheres;
     const pt_texture* textures;  // pt_scene_desc.textures as given
     const uint32_t* tex_prog;    // texture programs (pt_texture.h)
+    const PtImage* images;       // MIP pyramids of the imagemap textures
     const PtMatParams* mat_params;   // per material; read for textured materials only
     uint32_t textured;           // 1: some material is textured (k_shade_general_full runs)
     uint32_t n_spheres;          // > 0: the sphere-capable kernel instantiations run

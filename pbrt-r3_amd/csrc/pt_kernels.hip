@@ -1420,13 +1420,13 @@ __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material,
         TexHit ev = th;
         ev.p = th.p + du * *sh_dpdu;
         ev.uv = mk2(uv.x + du, uv.y + 0.0f);
-        float u_displace = tex_eval(sc.textures, prog, ev).x;
+        float u_displace = tex_eval(sc.textures, prog, ev, sc.images).x;
         float dv = 0.5f * (fabsf(th.dvdx) + fabsf(th.dvdy));
         if (dv == 0.0f) dv = 0.0005f;
         ev.p = th.p + dv * sh_dpdv;
         ev.uv = mk2(uv.x + 0.0f, uv.y + dv);
-        float v_displace = tex_eval(sc.textures, prog, ev).x;
-        float displace = tex_eval(sc.textures, prog, th).x;
+        float v_displace = tex_eval(sc.textures, prog, ev, sc.images).x;
+        float displace = tex_eval(sc.textures, prog, th, sc.images).x;
         V3 dpdu = *sh_dpdu + (u_displace - displace) / du * *sh_n + displace * sh_dndu;
         V3 dpdv = sh_dpdv + (v_displace - displace) / dv * *sh_n + displace * sh_dndv;
         *sh_n = face_forward(normalize(cross(dpdu, dpdv)), n);       // set_shading_geometry(.., false) (surface_interaction.rs:140-161)
@@ -1435,7 +1435,7 @@ __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material,
     float* dst[8] = {mp.m.kd, mp.m.ks, mp.m.kr, mp.m.kt, mp.m.opacity, nullptr, mp.m.metal_eta, mp.m.metal_k};
     for (int k = 0; k < 8; k++) {
         if (!mp.prog[k]) continue;
-        V3 v = tex_eval(sc.textures, sc.tex_prog + mp.prog[k], th);
+        V3 v = tex_eval(sc.textures, sc.tex_prog + mp.prog[k], th, sc.images);
         if (k == 5) mp.m.sigma = v.x;
         else { dst[k][0] = v.x; dst[k][1] = v.y; dst[k][2] = v.z; }
     }

@@ -10,6 +10,7 @@
 #include "pt_device_math.h"
 #include "../../include/pbrtgpu.h"
 #include "../../include/pbrtgpu_noise_perm.h"
+#include "../../include/pbrtgpu_ewa_lut.h"
 
 
 struct TexHit {                     // what SurfaceInteraction offers a texture
@@ -160,9 +161,116 @@ PT_DEV V3 tex_vector(const float* m, V3 v) {
     return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
 
+// ---- MIPMap (core/texture/mipmap.rs) over a pyramid in HBM; float images read as RGB with equal channels
+__device__ const float pt_ewa_lut[PT_EWA_LUT_SIZE] = {PT_EWA_LUT_VALUES};
+struct MipRef { const PtImage* im; int swrap, twrap; };
+PT_DEV void mip_dims(const PtImage& im, uint32_t l, int32_t* w, int32_t* h) {
+    uint32_t ww = im.width >> l, hh = im.height >> l;
+    *w = (int32_t)(ww ? ww : 1u); *h = (int32_t)(hh ? hh : 1u);
+}
+PT_DEV V3 mip_texel(const MipRef& m, uint32_t l, int32_t s, int32_t t) {           // texel_static (:503-544)
+    int32_t w, h;
+    mip_dims(*m.im, l, &w, &h);
+    if (m.swrap == PT_WRAP_REPEAT) s &= w - 1;
+    else if (m.swrap == PT_WRAP_CLAMP) s = s < 0 ? 0 : (s > w - 1 ? w - 1 : s);
+    else if (s < 0 || w <= s) return mk3(0.0f, 0.0f, 0.0f);
+    if (m.twrap == PT_WRAP_REPEAT) t &= h - 1;
+    else if (m.twrap == PT_WRAP_CLAMP) t = t < 0 ? 0 : (t > h - 1 ? h - 1 : t);
+    else if (t < 0 || h <= t) return mk3(0.0f, 0.0f, 0.0f);
+    const float* d = m.im->texels + m.im->level_off[l];
+    const size_t i = (size_t)t * (size_t)w + (size_t)s;
+    if (m.im->channels == 1) { float v = d[i]; return mk3(v, v, v); }
+    return mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+}
+PT_DEV V3 mip_triangle(const MipRef& m, uint32_t l, V2 st) {                       // triangle (:711-765)
+    if (l > m.im->n_levels - 1) l = m.im->n_levels - 1;
+    int32_t w, h;
+    mip_dims(*m.im, l, &w, &h);
+    float s = st.x * (float)w - 0.5f, t = st.y * (float)h - 0.5f;
+    int32_t s0 = f2i_sat(floorf(s)), t0 = f2i_sat(floorf(t));
+    float ds = s - (float)s0, dt = t - (float)t0;
+    return mip_texel(m, l, s0, t0) * ((1.0f - ds) * (1.0f - dt)) + mip_texel(m, l, s0, t0 + 1) * ((1.0f - ds) * dt) +
+           mip_texel(m, l, s0 + 1, t0) * (ds * (1.0f - dt)) + mip_texel(m, l, s0 + 1, t0 + 1) * (ds * dt);
+}
+__device__ __noinline__ V3 mip_lookup(const MipRef& m, V2 st, float width) {       // lookup (:620-637)
+    float max_level = (float)(m.im->n_levels - 1);
+    float lvl = max_level + pt_log2f(fmaxf(width, 1e-8f));
+    if (lvl < 0.0f) return mip_triangle(m, 0, st);
+    if (lvl >= max_level) return mip_texel(m, m.im->n_levels - 1, 0, 0);
+    uint32_t il = (uint32_t)floorf(lvl);
+    float delta = clampf(lvl - (float)il, 0.0f, 1.0f);
+    V3 a = mip_triangle(m, il, st), b = mip_triangle(m, il + 1, st);
+    return a * (1.0f - delta) + b * delta;
+}
+__device__ __noinline__ V3 mip_ewa(const MipRef& m, uint32_t l, V2 st0, V2 d0, V2 d1) {     // make_ewa_params + ewa_core (:141-217)
+    if (l >= m.im->n_levels) return mip_texel(m, m.im->n_levels - 1, 0, 0);
+    int32_t wi, hi;
+    mip_dims(*m.im, l, &wi, &hi);
+    float ww = (float)wi, hh = (float)hi;
+    V2 st = mk2(st0.x * ww - 0.5f, st0.y * hh - 0.5f);
+    V2 dst0 = mk2(d0.x * ww, d0.y * hh), dst1 = mk2(d1.x * ww, d1.y * hh);
+    float a = dst0.y * dst0.y + dst1.y * dst1.y + 1.0f;
+    float b = -2.0f * (dst0.x * dst0.y + dst1.x * dst1.y);
+    float c = dst0.x * dst0.x + dst1.x * dst1.x + 1.0f;
+    float inv_f = 1.0f / (a * c - b * b * 0.25f);
+    a = a * inv_f; b = b * inv_f; c = c * inv_f;
+    float det = -b * b + 4.0f * a * c;
+    float inv_det = 1.0f / det;
+    float u_sqrt = sqrtf(det * c), v_sqrt = sqrtf(det * a);
+    int32_t s0 = f2i_sat(ceilf(st.x - 2.0f * inv_det * u_sqrt)), s1 = f2i_sat(floorf(st.x + 2.0f * inv_det * u_sqrt));
+    int32_t t0 = f2i_sat(ceilf(st.y - 2.0f * inv_det * v_sqrt)), t1 = f2i_sat(floorf(st.y + 2.0f * inv_det * v_sqrt));
+    V3 sum = mk3(0.0f, 0.0f, 0.0f);
+    float sum_wts = 0.0f;
+    for (long long it = t0; it <= t1; it++) {
+        float tt = (float)(int32_t)it - st.y;
+        for (long long is = s0; is <= s1; is++) {
+            float ss = (float)(int32_t)is - st.x;
+            float r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+            if (r2 < 1.0f) {
+                float fi = r2 * (float)PT_EWA_LUT_SIZE;
+                uint32_t index = fi != fi ? 0u : (fi <= 0.0f ? 0u : (uint32_t)fi);
+                if (index > PT_EWA_LUT_SIZE - 1) index = PT_EWA_LUT_SIZE - 1;
+                float weight = pt_ewa_lut[index];
+                V3 v = mip_texel(m, l, (int32_t)is, (int32_t)it);
+                sum.x += v.x * weight; sum.y += v.y * weight; sum.z += v.z * weight;
+                sum_wts += weight;
+            }
+        }
+    }
+    float inv_sum = 1.0f / sum_wts;
+    return mk3(sum.x * inv_sum, sum.y * inv_sum, sum.z * inv_sum);
+}
+PT_DEV V3 mip_lookup_delta(const MipRef& m, V2 st, V2 dst0, V2 dst1, bool trilinear, float max_aniso) {     // :819-852, :913-946
+    if (trilinear) {
+        float width = fmaxf(fmaxf(fabsf(dst0.x), fabsf(dst0.y)), fmaxf(fabsf(dst1.x), fabsf(dst1.y)));
+        return mip_lookup(m, st, width);
+    }
+    if (dst0.x * dst0.x + dst0.y * dst0.y < dst1.x * dst1.x + dst1.y * dst1.y) { V2 tmp = dst0; dst0 = dst1; dst1 = tmp; }
+    float major_length = sqrtf(dst0.x * dst0.x + dst0.y * dst0.y);
+    float minor_length = sqrtf(dst1.x * dst1.x + dst1.y * dst1.y);
+    if (minor_length * max_aniso < major_length && minor_length > 0.0f) {
+        float scale = major_length / (minor_length * max_aniso);
+        dst1 = mk2(dst1.x * scale, dst1.y * scale);
+        minor_length *= scale;
+    }
+    if (minor_length <= 0.0f) return mip_lookup(m, st, 0.0f);
+    float lod = fmaxf(0.0f, (float)m.im->n_levels - 1.0f + pt_log2f(minor_length));
+    uint32_t ilod = (uint32_t)floorf(lod);
+    float t = lod - (float)ilod;
+    V3 e0 = mip_ewa(m, ilod, st, dst0, dst1), e1 = mip_ewa(m, ilod + 1, st, dst0, dst1);
+    return mk3(lerpf(t, e0.x, e1.x), lerpf(t, e0.y, e1.y), lerpf(t, e0.z, e1.z));
+}
+
 // One node, its children already evaluated (c0, c1, c2 = tex1, tex2, amount).
-PT_DEV V3 tex_node(const pt_texture& t, const TexHit& si, V3 c0, V3 c1, V3 c2) {
+PT_DEV V3 tex_node(const pt_texture& t, const TexHit& si, V3 c0, V3 c1, V3 c2, const PtImage* images) {
     switch (t.type) {
+        case PT_TEX_IMAGEMAP: {                                   // imagemap.rs:57-70
+            V2 st, dx, dy;
+            map2d(t, si, &st, &dx, &dy);
+            MipRef m;
+            m.im = images + t.image; m.swrap = t.swrap; m.twrap = t.twrap;
+            return mip_lookup_delta(m, st, dx, dy, t.trilinear != 0, t.max_anisotropy);
+        }
         case PT_TEX_SCALE: return c0 * c1;
         case PT_TEX_MIX: { float amt = c2.x; return c0 * (1.0f - amt) + c1 * amt; }
         case PT_TEX_CHECKERBOARD_2D: {
@@ -243,7 +351,7 @@ PT_DEV V3 tex_node(const pt_texture& t, const TexHit& si, V3 c0, V3 c1, V3 c2) {
     }
 }
 // prog[0] = n; prog[1..n]: node index | child slots (positions in this list, or PT_TEX_CHILD_CONST) << 16 / 20 / 24
-__device__ __noinline__ V3 tex_eval(const pt_texture* textures, const uint32_t* prog, const TexHit& si) {
+__device__ __noinline__ V3 tex_eval(const pt_texture* textures, const uint32_t* prog, const TexHit& si, const PtImage* images) {
     V3 val[PT_TEX_PROG_MAX];
     const uint32_t n = prog[0];
     V3 last = mk3(0.0f, 0.0f, 0.0f);
@@ -255,7 +363,7 @@ __device__ __noinline__ V3 tex_eval(const pt_texture* textures, const uint32_t* 
             const uint32_t slot = (e >> (16 + 4 * k)) & 15u;
             c[k] = slot == PT_TEX_CHILD_CONST ? ld3(t.value[k]) : val[slot];
         }
-        last = tex_node(t, si, c[0], c[1], c[2]);
+        last = tex_node(t, si, c[0], c[1], c[2], images);
         val[i] = last;
     }
     return last;

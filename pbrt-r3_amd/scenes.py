@@ -232,6 +232,7 @@ class SceneBuilder:
         self.meshes, self.materials, self.area_lights = [], [], []
         self.spheres = []
         self.textures = []
+        self.images = []            # (pt_image, texel buffer)
         self.n_vertices = 0
         self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, (0.5, 0.5, 0.5), 0.0)   # default matte
         self.cur_area_light = -1
@@ -376,7 +377,7 @@ class SceneBuilder:
         for i, v in enumerate(values):
             t.value[i][:] = [float(x) for x in (v if isinstance(v, (tuple, list)) else (v, v, v))]
         t.octaves, t.omega, t.scale, t.variation = int(octaves), float(omega), float(scale), float(variation)
-        if typ in (capi.PT_TEX_CHECKERBOARD_2D, capi.PT_TEX_UV, capi.PT_TEX_BILERP, capi.PT_TEX_DOTS):       # create_texture_mapping2d
+        if typ in (capi.PT_TEX_CHECKERBOARD_2D, capi.PT_TEX_UV, capi.PT_TEX_BILERP, capi.PT_TEX_DOTS, capi.PT_TEX_IMAGEMAP):       # create_texture_mapping2d
             t.mapping = {"uv": capi.PT_MAPPING_UV, "spherical": capi.PT_MAPPING_SPHERICAL, "cylindrical": capi.PT_MAPPING_CYLINDRICAL,
                          "planar": capi.PT_MAPPING_PLANAR}[mapping]
             t.aa_none = 1 if (aamode == "none" and typ == capi.PT_TEX_CHECKERBOARD_2D) else 0
@@ -405,6 +406,38 @@ class SceneBuilder:
         if dimension == 3:      # IdentityMapping3D is handed tex2world itself, not its inverse (checkerboard.rs:159, mapping3d.rs:19-24)
             return self._texture(capi.PT_TEX_CHECKERBOARD_3D, children=[tex1, tex2], **kw)
         return self._texture(capi.PT_TEX_CHECKERBOARD_2D, children=[tex1, tex2], **kw)
+
+    def image_pyramid(self, base):
+        """MIPMap::new's pyramid (core/texture/mipmap.rs:406-441) over a power-of-two image `base` (H, W) or (H, W, 3), already in
+        texture orientation (row 0 = t 0): each level halves the dimensions still > 1 with a*0.5 + b*0.5.  Returns the image index."""
+        a = np.ascontiguousarray(base, np.float32)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        h, w, c = a.shape
+        assert c in (1, 3) and (w & (w - 1)) == 0 and (h & (h - 1)) == 0
+        levels = [a]
+        while levels[-1].shape[0] * levels[-1].shape[1] != 1:
+            cur = levels[-1]
+            if cur.shape[1] > 1:
+                cur = (cur[:, 0::2] * f32(0.5) + cur[:, 1::2] * f32(0.5)).astype(np.float32)
+            if cur.shape[0] > 1:
+                cur = (cur[0::2] * f32(0.5) + cur[1::2] * f32(0.5)).astype(np.float32)
+            levels.append(cur)
+        buf = np.ascontiguousarray(np.concatenate([l.reshape(-1) for l in levels]), np.float32)
+        im = capi.pt_image()
+        im.width, im.height, im.channels, im.n_levels = w, h, c, len(levels)
+        im.texels = buf.ctypes.data_as(C.POINTER(C.c_float))
+        self.images.append((im, buf))
+        return len(self.images) - 1
+
+    def texture_imagemap(self, image, trilinear=False, maxanisotropy=8.0, wrap="repeat", swrap=None, twrap=None, **kw):
+        """textures/imagemap.rs over an image_pyramid() index."""
+        t = self._texture(capi.PT_TEX_IMAGEMAP, **kw)
+        tx = self.textures[t.index]
+        modes = {"repeat": capi.PT_WRAP_REPEAT, "black": capi.PT_WRAP_BLACK, "clamp": capi.PT_WRAP_CLAMP}
+        tx.image, tx.trilinear, tx.max_anisotropy = int(image), 1 if trilinear else 0, float(maxanisotropy)
+        tx.swrap, tx.twrap = modes[swrap or wrap], modes[twrap or wrap]
+        return t
 
     def texture_dots(self, tex1=1.0, tex2=0.0, **kw):
         return self._texture(capi.PT_TEX_DOTS, children=[tex1, tex2], **kw)
@@ -597,6 +630,11 @@ class SceneBuilder:
             tex = (capi.pt_texture * len(self.textures))(*self.textures)
             sd.buffers["textures"] = tex
             d.n_textures, d.textures = len(self.textures), tex
+        if self.images:
+            ims = (capi.pt_image * len(self.images))(*[im for im, _ in self.images])
+            sd.buffers["images"] = ims
+            sd.buffers["image_texels"] = [buf for _, buf in self.images]
+            d.n_images, d.images = len(self.images), ims
         if self.spheres:
             sph = (capi.pt_sphere * len(self.spheres))(*self.spheres)
             sd.buffers["spheres"] = sph

@@ -395,3 +395,51 @@ def scene_bump(res=48, spp=8, depth=4, lens=False):
     b.material_plastic(Kd=(0.2, 0.6, 0.3), Ks=(0.4, 0.4, 0.4), roughness=0.05, bumpmap=b.texture_scale(0.1, b.texture_windy(to_world=T.transform_scale(6.0, 6.0, 6.0))))
     b.shape_sphere(radius=0.7, object_to_world=ts[0], world_to_object=ts[1])
     return b.build()
+
+
+def test_image(w, h, channels=3, seed=3):
+    """A deterministic image with structure at several scales (so MIP levels differ) in texture orientation."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = 0.5 + 0.5 * np.sin(x * (2 * np.pi * 3 / w)) * np.cos(y * (2 * np.pi * 2 / h))
+    stripes = ((x.astype(np.int32) // max(1, w // 16) + y.astype(np.int32) // max(1, h // 8)) % 2).astype(np.float32)
+    noise = rng.random((h, w), dtype=np.float32)
+    chans = [0.6 * base + 0.3 * stripes + 0.1 * noise, 0.3 * base + 0.5 * noise + 0.2 * stripes, 0.8 * stripes * base + 0.2 * noise]
+    img = np.stack(chans[:channels], -1).astype(np.float32)
+    return img
+
+
+def scene_imagemaps(res=48, spp=8, depth=4, sampler="sobol", trilinear=False, lens=False):
+    """Image-map textures (textures/imagemap.rs, core/texture/mipmap.rs) over caller-built pyramids: EWA (default) or trilinear
+    lookups, repeat / clamp / black wrap modes, a non-square RGB image on the floor under a uv scale, a float image driving
+    Matte sigma and a bump map, spherical mapping on an analytic sphere, a planar mapping on the back wall."""
+    b = base(res=res, spp=spp, depth=depth)
+    if sampler == "halton":
+        b.sampler_halton(spp)
+    if lens:
+        b.camera_perspective(fov=40.0, lensradius=0.05, focaldistance=6.0)
+    T = scenes
+    s = 2.0
+    rgb = b.image_pyramid(test_image(64, 32, 3))
+    gray = b.image_pyramid(test_image(32, 32, 1, seed=7)[..., 0])
+    small = b.image_pyramid(test_image(8, 16, 3, seed=11))
+    b.material_matte(b.texture_imagemap(rgb, trilinear=trilinear, uscale=3.0, vscale=2.0, udelta=0.13, vdelta=0.4))
+    scenes._quad(b, (s, -s, -s), (-s, -s, -s), (-s, -s, s), (s, -s, s))
+    b.material_plastic(Kd=b.texture_imagemap(small, trilinear=trilinear, wrap="clamp", mapping="planar", v1=(0.4, 0.0, 0.0), v2=(0.0, 0.4, 0.0), udelta=0.5, vdelta=0.5),
+                       Ks=(0.2, 0.2, 0.2), roughness=0.1)
+    scenes._quad(b, (s, -s, s), (-s, -s, s), (-s, s, s), (s, s, s))
+    b.material_matte(b.texture_scale((0.9, 0.6, 0.3), b.texture_imagemap(rgb, trilinear=trilinear, swrap="black", twrap="repeat", uscale=1.6, vscale=1.6, udelta=-0.3)),
+                     sigma=b.texture_scale(60.0, b.texture_imagemap(gray, trilinear=trilinear, maxanisotropy=2.0)))
+    scenes._quad(b, (-s, -s, s), (-s, -s, -s), (-s, s, -s), (-s, s, s))
+    b.material_matte((0.7, 0.3, 0.3), bumpmap=b.texture_scale(0.08, b.texture_imagemap(gray, trilinear=trilinear, uscale=2.0, vscale=2.0)))
+    scenes._quad(b, (s, -s, -s), (s, -s, s), (s, s, s), (s, s, -s))
+    b.material_matte((0.7, 0.7, 0.7))
+    scenes._quad(b, (s, s, -s), (s, s, s), (-s, s, s), (-s, s, -s))
+    b.area_light_source_diffuse(L=(10, 9, 8))
+    h = 0.999 * s
+    scenes._quad(b, (0.5, h, -0.5), (0.5, h, 0.5), (-0.5, h, 0.5), (-0.5, h, -0.5))
+    b.no_area_light()
+    ts = T.transform_translate(0.3, -1.1, 0.2)
+    b.material_uber(Kd=b.texture_imagemap(rgb, trilinear=trilinear, mapping="spherical", to_world=ts), Ks=(0.3, 0.3, 0.3), roughness=0.05)
+    b.shape_sphere(radius=0.85, object_to_world=ts[0], world_to_object=ts[1])
+    return b.build()
