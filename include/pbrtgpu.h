@@ -111,7 +111,7 @@ typedef struct {
     int32_t image;              /* imagemap: index into images[] */
     int32_t trilinear;          /* imagemap "trilinear" (false: EWA) */
     float max_anisotropy;       /* imagemap "maxanisotropy" (8) */
-    int32_t swrap, twrap;       /* pt_image_wrap ("wrap", default repeat) */
+    int32_t swrap, twrap;       /* a pt_image_wrap value: "wrap" / "swrap" / "twrap", default repeat */
     int32_t reserved[3];
 } pt_texture;
 
