@@ -20,7 +20,9 @@
 #include "../../../include/pbrtgpu_host.h"
 #include "../pt_host_math.h"
 #include "pth_parse_context.h"
+#include <memory>
 #include "pth_ply.h"
+#include "pth_texture_image.h"
 #include "pth_spectrum.h"
 
 namespace pth {
@@ -125,6 +127,8 @@ public:
     std::map<std::string, float> float_textures;                        // constant-folded named textures (global, see pbrt_texture)
     std::map<std::string, std::array<float, 3>> spectrum_textures;
     std::map<std::string, std::string> unsupported_textures;          // name -> class of textures that are not on the path
+    std::vector<std::unique_ptr<Pyramid>> pyramids;                     // MIP pyramids of the imagemap textures (stable addresses)
+    std::vector<pt_image> images;
     std::vector<pt_texture> textures;                                   // textures that depend on the hit: evaluated on the device
     std::map<std::string, uint32_t> node_float_textures, node_spectrum_textures;   // name -> index into textures
     std::vector<pt_area_light> area_lights;
@@ -312,6 +316,30 @@ public:
                 std::memcpy(t.world_to_texture, transforms.back().t[0].m.a, 64);   // IdentityMapping3D::new(tex2world), as the reference passes it
             }
             add_node(t);
+        } else if (tex_class == "imagemap") {                                 // imagemap.rs:84-229
+            t.type = PT_TEX_IMAGEMAP;
+            if (!set_mapping2d(p, t)) return;
+            std::string file = p.find_one_string("filename", "");
+            if (file.empty()) { fail("Texture \"" + name + "\": imagemap without a filename"); return; }
+            if (file[0] != '/' && !p.base_dir.empty()) file = p.base_dir + "/" + file;
+            auto wrap_mode = [](const std::string& m) { return m == "black" ? PT_WRAP_BLACK : (m == "clamp" ? PT_WRAP_CLAMP : PT_WRAP_REPEAT); };
+            const std::string wrap = p.find_one_string("wrap", "repeat");
+            t.swrap = wrap_mode(p.find_one_string("swrap", wrap));
+            t.twrap = wrap_mode(p.find_one_string("twrap", wrap));
+            t.max_anisotropy = p.find_one_float("maxanisotropy", 8.0f);
+            t.trilinear = p.find_one_bool("trilinear", false) ? 1 : 0;
+            const float scale = p.find_one_float("scale", 1.0f);
+            auto has_ext = [&](const char* e) { size_t n = std::strlen(e); return file.size() > n && file.compare(file.size() - n, n, e) == 0 && file[file.size() - n - 1] == '.'; };
+            bool gamma = !has_ext("exr");
+            if (file.find("_alpha") != std::string::npos || file.find("_bump") != std::string::npos) gamma = false;      // "Fixed in pbrt-r3" (:118-122)
+            gamma = p.find_one_bool("gamma", gamma);
+            RgbImage img;
+            std::string ierr;
+            if (!read_image_file(file, &img, &ierr)) { fail("Texture \"" + name + "\": " + ierr); return; }
+            pyramids.emplace_back(new Pyramid());
+            build_pyramid(img, is_float ? 1 : 3, scale, gamma, t.swrap, t.twrap, pyramids.back().get());
+            t.image = (int32_t)pyramids.size() - 1;
+            add_node(t);
         } else if (tex_class == "dots") {                                     // dots.rs:45-62
             t.type = PT_TEX_DOTS;
             if (!set_mapping2d(p, t)) return;
@@ -348,7 +376,7 @@ public:
             }
             if (!error.empty()) return;
             add_node(t);
-        } else if (tex_class == "imagemap" || (tex_class == "normal" && is_spec)) {
+        } else if (tex_class == "normal" && is_spec) {
             forget();
             unsupported_textures[name] = tex_class;       // known to the reference, not on the path: fails only if something uses it
         } else {                                           // create_texture.rs:57-60, :106-109: not created
@@ -822,6 +850,10 @@ public:
         desc.spheres = spheres.empty() ? nullptr : spheres.data();
         desc.n_textures = (uint32_t)textures.size();
         desc.textures = textures.empty() ? nullptr : textures.data();
+        images.clear();
+        for (auto& py : pyramids) { py->desc.texels = py->texels.data(); images.push_back(py->desc); }
+        desc.n_images = (uint32_t)images.size();
+        desc.images = images.empty() ? nullptr : images.data();
         desc.n_materials = (uint32_t)materials.size();
         desc.materials = materials.data();
         desc.n_area_lights = (uint32_t)area_lights.size();

@@ -384,6 +384,49 @@ def test_pbrt_text_with_textures(gpu_ctx, oracle):
     osc.close()
 
 
+def test_pbrt_text_with_imagemap(gpu_ctx, oracle, tmp_path):
+    """Texture "imagemap" end to end: a 13 x 6 PNG (resampled to 16 x 8, inverse gamma) on Kd with EWA filtering, a float
+    PFM as a trilinear bump map; front end -> device against front end -> oracle."""
+    from test_image_textures import write_png
+    rng = np.random.default_rng(21)
+    write_png(tmp_path / "tiles.png", rng.integers(0, 256, (6, 13, 3)))
+    g = fs.test_image(8, 8, 1, seed=4)[..., 0]
+    with open(tmp_path / "height_bump.pfm", "wb") as f:
+        f.write(b"Pf\n8 8\n-1.0\n")
+        f.write(g.astype("<f4").tobytes())
+    text = '''
+    LookAt 0 0 -6.5  0 0 0  0 1 0
+    Camera "perspective" "float fov" 40
+    Film "image" "integer xresolution" 40 "integer yresolution" 40
+    Sampler "sobol" "integer pixelsamples" 4
+    Integrator "path" "integer maxdepth" 4
+    WorldBegin
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [10 9 8]
+        Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [0.5 1.99 -0.5  0.5 1.99 0.5  -0.5 1.99 0.5  -0.5 1.99 -0.5]
+      AttributeEnd
+      Texture "tiles" "spectrum" "imagemap" "string filename" "tiles.png" "float uscale" 2 "float vscale" 2
+      Texture "h" "float" "imagemap" "string filename" "height_bump.pfm" "bool trilinear" "true" "float scale" 0.1 "float uscale" 3 "float vscale" 3
+      Material "matte" "texture Kd" "tiles" "texture bumpmap" "h"
+      Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [2 -2 -2  -2 -2 -2  -2 -2 2  2 -2 2]
+      Material "plastic" "texture Kd" "tiles"
+      Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [2 -2 2  -2 -2 2  -2 2 2  2 2 2] "float uv" [0 0 1 0 1 1 0 1]
+    WorldEnd
+    '''
+    ps = pkg.capi.ParsedScene(text=text, work_dir=str(tmp_path))
+    d = ps.desc
+    assert d.n_images == 2 and (d.images[0].width, d.images[0].height, d.images[0].channels) == (16, 8, 3) and d.images[1].channels == 1
+    osc = oracle.scene(ps)
+    gpu_ctx.upload(ps)
+    sb = list(gpu_ctx.info.sample_bounds)
+    tile = (sb[0] + 4, sb[1] + 4, sb[0] + 38, sb[1] + 38)
+    g_, r_ = gpu_ctx.radiance_samples(tile), osc.radiance_samples(tile)
+    assert r_.sum() > 0
+    same = np.all(bits(g_) == bits(r_), axis=-1)
+    assert same.all(), float(1 - same.mean())
+    osc.close()
+
+
 def test_pass_structure_does_not_change_the_film(gpu_ctx):
     """The pool size only decides how the samples are cut into passes / pixel chunks (render_tiles): a film rendered
     in 1 pass, in 3 unequal-looking passes (7 spp -> 3,2,2) and in pixel chunks must agree -- bit for bit where a

@@ -583,7 +583,7 @@ def test_constant_folding_textures():
     d2 = ps2.desc
     m3 = d2.materials[d2.meshes[2].material]
     assert d2.n_textures == 1 and m3.tex_kd == 1 and d2.textures[0].type == capi.PT_TEX_CHECKERBOARD_2D
-    # ... which roughness cannot be, and image maps are not on the path at all
+    # ... which roughness cannot be; an image map whose file is missing is reported
     with pytest.raises(capi.PtError) as e:
         capi.ParsedScene(text=text.replace('Texture "chk" "spectrum" "checkerboard"', 'Texture "fchk" "float" "checkerboard"')
                          .replace('"texture roughness" "rough"', '"texture roughness" "fchk"'))
@@ -591,7 +591,7 @@ def test_constant_folding_textures():
     with pytest.raises(capi.PtError) as e:
         capi.ParsedScene(text=text.replace('"spectrum" "checkerboard"', '"spectrum" "imagemap" "string filename" "x.png"')
                          .replace('"texture Kd" "blend"', '"texture Kd" "chk"'))
-    assert e.value.status == 4 and "imagemap" in str(e.value)
+    assert e.value.status == 4 and "File not found" in str(e.value)
 
 
 def test_texture_directives_equal_programmatic_scene(oracle):

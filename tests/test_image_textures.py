@@ -1,0 +1,272 @@
+"""Texture "imagemap" through the front end: image files -> MIP pyramids (textures/imagemap.rs:84-229, core/imageio/read_image.rs,
+core/texture/mipmap.rs:291-485).  The pyramids the C++ front end builds are compared float for float with a numpy restatement of
+the same pipeline (pixel conversion, inverse gamma, luminance, scale, y flip, Lanczos resampling to powers of two with the wrap
+modes, box-filtered levels) on PNG / PFM / TGA files written here.  No GPU needed."""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import feature_scenes as fs
+from helpers import bits, pkg, scenes
+
+capi = pkg.capi
+f32 = np.float32
+_libm = C.CDLL("libm.so.6")
+_libm.powf.restype = C.c_float; _libm.powf.argtypes = [C.c_float, C.c_float]
+_libm.sinf.restype = C.c_float; _libm.sinf.argtypes = [C.c_float]
+
+
+def write_png(path, a, depth=8):
+    """a: (H, W) or (H, W, C) integers; colour type from the channel count."""
+    a = np.asarray(a)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    rows = []
+    for y in range(h):
+        row = a[y].astype(">u2" if depth == 16 else np.uint8).tobytes()
+        rows.append(b"\x00" + row)                           # filter 0; the reader's other filters are exercised by zlib-free unit data below
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) +
+                           chunk(b"IDAT", zlib.compress(b"".join(rows))) + chunk(b"IEND", b""))
+
+
+def write_png_filtered(path, a):
+    """8-bit RGB with PNG filters 1-4 cycling over the rows (Sub, Up, Average, Paeth)."""
+    a = np.asarray(a, np.uint8)
+    h, w, c = a.shape
+    bpp = c
+    raw = bytearray()
+    prev = np.zeros(w * c, np.int32)
+    for y in range(h):
+        cur = a[y].reshape(-1).astype(np.int32)
+        ft = 1 + (y % 4)
+        out = np.zeros_like(cur)
+        for i in range(len(cur)):
+            left = cur[i - bpp] if i >= bpp else 0
+            up = prev[i]
+            ul = prev[i - bpp] if i >= bpp else 0
+            if ft == 1: pred = left
+            elif ft == 2: pred = up
+            elif ft == 3: pred = (left + up) >> 1
+            else:
+                p = left + up - ul
+                pa, pb, pc = abs(p - left), abs(p - up), abs(p - ul)
+                pred = left if (pa <= pb and pa <= pc) else (up if pb <= pc else ul)
+            out[i] = (cur[i] - pred) & 255
+        raw += bytes([ft]) + out.astype(np.uint8).tobytes()
+        prev = cur
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                           chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+
+
+def inverse_gamma(v):
+    v = f32(v)
+    if v <= f32(0.04045):
+        return f32(f32(v * f32(1.0)) / f32(12.92))
+    return f32(_libm.powf(float(f32(f32(f32(v + f32(0.055)) * f32(1.0)) / f32(1.055))), 2.4))
+
+
+def lanczos(x, tau):
+    x = abs(f32(x))
+    if x < f32(1e-5):
+        return f32(1.0)
+    if x > f32(1.0):
+        return f32(0.0)
+    x = f32(x * f32(np.pi))
+    s = f32(f32(_libm.sinf(float(f32(x * tau)))) / f32(x * tau))
+    l = f32(f32(_libm.sinf(float(x))) / x)
+    return f32(s * l)
+
+
+def resample_weights(old, new):
+    out = []
+    for i in range(new):
+        center = f32(f32(f32(i) + f32(0.5)) * f32(f32(old) / f32(new)))
+        first = f32(np.floor(f32(f32(center - f32(2.0)) + f32(0.5))))
+        w = [lanczos(f32(f32(f32(first + f32(j)) + f32(0.5)) - center) / f32(2.0), f32(2.0)) for j in range(4)]
+        inv = f32(f32(1.0) / f32(f32(f32(w[0] + w[1]) + w[2]) + w[3]))
+        out.append((int(first), [f32(x * inv) for x in w]))
+    return out
+
+
+def wrap_index(i, n, mode):
+    if mode == "repeat":
+        return i % n
+    if mode == "clamp":
+        return min(max(i, 0), n - 1)
+    return i
+
+
+def pyramid_ref(rgb, channels, scale, gamma, swrap, twrap):
+    """rgb: (H, W, 3) f32 as read_image returns it (top row first).  Returns the list of levels."""
+    h, w, _ = rgb.shape
+    data = np.zeros((h, w, channels), np.float32)
+    for y in range(h):
+        for x in range(w):
+            p = rgb[y, x]
+            if channels == 1:
+                lum = f32(f32(f32(f32(0.212671) * p[0]) + f32(f32(0.715160) * p[1])) + f32(f32(0.072169) * p[2]))
+                data[h - 1 - y, x, 0] = f32(f32(scale) * (inverse_gamma(lum) if gamma else lum))
+            else:
+                for k in range(3):
+                    data[h - 1 - y, x, k] = f32((inverse_gamma(p[k]) if gamma else p[k]) * f32(scale))
+    pw, ph = 1 << (w - 1).bit_length(), 1 << (h - 1).bit_length()
+    if (pw, ph) != (w, h):
+        r = np.zeros((h, pw, channels), np.float32)
+        sw = resample_weights(w, pw)
+        for t in range(h):
+            for s in range(pw):
+                for j in range(4):
+                    o = wrap_index(sw[s][0] + j, w, swrap)
+                    if 0 <= o < w:
+                        r[t, s] = (r[t, s] + data[t, o] * sw[s][1][j]).astype(np.float32)
+        full = np.zeros((ph, pw, channels), np.float32)
+        tw = resample_weights(h, ph)
+        for s in range(pw):
+            for t in range(ph):
+                acc = np.zeros(channels, np.float32)
+                for j in range(4):
+                    o = wrap_index(tw[t][0] + j, h, twrap)
+                    if 0 <= o < h:
+                        acc = (acc + r[o, s] * tw[t][1][j]).astype(np.float32)
+                full[t, s] = acc
+        data = np.maximum(full, f32(0.0))
+    levels = [data]
+    while levels[-1].shape[0] * levels[-1].shape[1] != 1:
+        cur = levels[-1]
+        if cur.shape[1] > 1:
+            cur = (cur[:, 0::2] * f32(0.5) + cur[:, 1::2] * f32(0.5)).astype(np.float32)
+        if cur.shape[0] > 1:
+            cur = (cur[0::2] * f32(0.5) + cur[1::2] * f32(0.5)).astype(np.float32)
+        levels.append(cur)
+    return levels
+
+
+def parse_with_texture(tmp_path, tex_line):
+    text = '''
+    Sampler "sobol" "integer pixelsamples" 1
+    WorldBegin
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [1 1 1]
+        Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 2 0 1 2 0 0 2 1]
+      AttributeEnd
+      %s
+      Material "matte" "texture %s" "t"
+      Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]
+    WorldEnd
+    ''' % (tex_line, "sigma" if '"float"' in tex_line.split('"t"')[1][:12] else "Kd")
+    return capi.ParsedScene(text=text, work_dir=str(tmp_path))
+
+
+def front_end_levels(ps, index=0):
+    im = ps.desc.images[index]
+    out, off, w, h = [], 0, im.width, im.height
+    for _ in range(im.n_levels):
+        n = w * h * im.channels
+        out.append(np.ctypeslib.as_array(im.texels, (off + n,))[off:].reshape(h, w, im.channels).copy())
+        off += n
+        w, h = max(1, w // 2), max(1, h // 2)
+    return out
+
+
+@pytest.mark.parametrize("case", ["png_rgb_npot", "png_gray_float", "png16", "png_filters_clamp", "pfm", "tga_rle", "png_rgba_bump_name"])
+def test_front_end_pyramid_matches_numpy_restatement(tmp_path, case):
+    rng = np.random.default_rng(5)
+    if case == "png_rgb_npot":              # 13 x 6 -> 16 x 8, gamma on, repeat
+        a = rng.integers(0, 256, (6, 13, 3))
+        write_png(tmp_path / "a.png", a)
+        rgb = (a.astype(np.float32) / f32(255.0)).astype(np.float32)
+        ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.png" "float scale" 0.8')
+        want = pyramid_ref(rgb, 3, 0.8, True, "repeat", "repeat")
+    elif case == "png_gray_float":          # gray + alpha, float texture (luminance), no resampling
+        a = rng.integers(0, 256, (8, 8, 2))
+        write_png(tmp_path / "a.png", a)
+        g = (a[..., 0].astype(np.float32) / f32(255.0)).astype(np.float32)
+        ps = parse_with_texture(tmp_path, 'Texture "t" "float" "imagemap" "string filename" "a.png" "bool gamma" "false"')
+        want = pyramid_ref(np.stack([g, g, g], -1), 1, 1.0, False, "repeat", "repeat")
+    elif case == "png16":                   # 16-bit RGB: value / 65535
+        a = rng.integers(0, 65536, (4, 8, 3))
+        write_png(tmp_path / "a.png", a, depth=16)
+        rgb = (a.astype(np.float32) / f32(65535.0)).astype(np.float32)
+        ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.png" "bool trilinear" "true" "float maxanisotropy" 4')
+        want = pyramid_ref(rgb, 3, 1.0, True, "repeat", "repeat")
+        t = ps.desc.textures[0]
+        assert t.trilinear == 1 and t.max_anisotropy == 4.0
+    elif case == "png_filters_clamp":       # every PNG row filter; clamp wrap in the resampling
+        a = rng.integers(0, 256, (5, 7, 3))
+        write_png_filtered(tmp_path / "a.png", a)
+        rgb = (a.astype(np.float32) / f32(255.0)).astype(np.float32)
+        ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.png" "string wrap" "clamp" "string twrap" "black"')
+        want = pyramid_ref(rgb, 3, 1.0, True, "clamp", "black")
+        t = ps.desc.textures[0]
+        assert (t.swrap, t.twrap) == (capi.PT_WRAP_CLAMP, capi.PT_WRAP_BLACK)
+    elif case == "pfm":                     # little-endian PFM, scale 2 in the header, rows bottom-up; gamma on (not .exr)
+        a = rng.random((6, 4, 3), dtype=np.float32)
+        with open(tmp_path / "a.pfm", "wb") as f:
+            f.write(b"PF\n4 6\n-2.0\n")
+            f.write(a[::-1].astype("<f4").tobytes())
+        ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.pfm"')
+        want = pyramid_ref((a * f32(2.0)).astype(np.float32), 3, 1.0, True, "repeat", "repeat")
+    elif case == "tga_rle":                 # 24-bit RLE TGA, bottom-up origin
+        a = rng.integers(0, 256, (4, 4, 3))
+        a[1, 1:4] = a[1, 0]                  # a run
+        body = bytearray()
+        for y in range(3, -1, -1):           # bottom row first
+            x = 0
+            while x < 4:
+                run = 1
+                while x + run < 4 and np.array_equal(a[y, x + run], a[y, x]):
+                    run += 1
+                if run > 1:
+                    body += bytes([128 | (run - 1)]) + bytes(a[y, x][::-1].astype(np.uint8))
+                else:
+                    body += bytes([0]) + bytes(a[y, x][::-1].astype(np.uint8))
+                x += run
+        hdr = bytes([0, 0, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 0, 4, 0, 24, 0])
+        open(tmp_path / "a.tga", "wb").write(hdr + bytes(body))
+        rgb = (a.astype(np.float32) / f32(255.0)).astype(np.float32)
+        ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.tga"')
+        want = pyramid_ref(rgb, 3, 1.0, True, "repeat", "repeat")
+    else:                                   # "_bump" in the name switches gamma off (imagemap.rs:118-122); alpha ignored
+        a = rng.integers(0, 256, (4, 4, 4))
+        write_png(tmp_path / "wall_bump.png", a)
+        rgb = (a[..., :3].astype(np.float32) / f32(255.0)).astype(np.float32)
+        ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "wall_bump.png"')
+        want = pyramid_ref(rgb, 3, 1.0, False, "repeat", "repeat")
+    got = front_end_levels(ps)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        assert np.array_equal(bits(g), bits(w))
+
+
+def test_unsupported_image_inputs_fail_loudly(tmp_path):
+    open(tmp_path / "a.jpg", "wb").write(b"\xff\xd8\xff")
+    with pytest.raises(capi.PtError) as e:
+        parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.jpg"')
+    assert e.value.status == 4 and "not on the accelerated path" in str(e.value)
+    with pytest.raises(capi.PtError) as e:
+        parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "missing.png"')
+    assert "File not found" in str(e.value)
+
+
+def test_builder_pyramid_equals_front_end(tmp_path):
+    """scenes.SceneBuilder.image_pyramid (what the GPU parity scenes use) builds the same levels as the front end."""
+    img = fs.test_image(16, 8, 3)
+    with open(tmp_path / "a.pfm", "wb") as f:
+        f.write(b"PF\n16 8\n-1.0\n")
+        f.write(img.astype("<f4").tobytes())            # PFM rows are bottom-up = texture orientation
+    ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.pfm" "bool gamma" "false"')
+    b = scenes.SceneBuilder()
+    b.image_pyramid(img)
+    im, buf = b.images[0]
+    got = np.concatenate([l.reshape(-1) for l in front_end_levels(ps)])
+    assert np.array_equal(bits(got), bits(buf))
