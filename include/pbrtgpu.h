@@ -172,8 +172,8 @@ typedef struct {
 typedef struct {
     uint32_t flags;
     int32_t material;       /* index into materials[], or -1 for none */
-    int32_t area_light;     /* index into area_lights[], or -1 */
-    uint32_t reserved;
+    int32_t area_light;     /* index into area_lights[], or -1 (ignored inside an object, scene_context.rs:1302-1304) */
+    uint32_t object;        /* 0: the mesh is a world primitive; k: it belongs to object k - 1 (ObjectBegin ... ObjectEnd) */
 } pt_mesh;
 
 /* Sphere (src/shapes/sphere.rs:7-41, create_sphere_shape :401-420).  The only analytic shape on the
@@ -193,7 +193,25 @@ typedef struct {
     uint32_t before_triangle;   /* position in the primitive list: the sphere precedes triangle number
                                  * `before_triangle` (n_triangles = after the last one).  Non-decreasing
                                  * over spheres[]; equal values keep array order. */
+    uint32_t object;            /* 0: world primitive; k: belongs to object k - 1 */
+    uint32_t order;             /* creation order among spheres and instances that share a before_triangle value */
+    uint32_t reserved[2];
 } pt_sphere;
+
+/* ObjectInstance (scene_context.rs:1349-1391): a TransformedPrimitive (core/primitive/transformed_primitive.rs) over the
+ * accelerator built from the primitives of one object (the same Accelerator settings as the scene's; a single-primitive object
+ * is wrapped directly).  Objects are the meshes / spheres tagged with `object`; their primitive order is their order in the
+ * triangle array with their spheres spliced in by before_triangle, exactly as for the world list.  Rays are taken to instance
+ * space with the stored inverse (Transform::inverse swaps m and m_inv) and hits brought back with
+ * transform_surface_interaction.  Animated instance transforms are outside the accelerated path. */
+typedef struct {
+    float instance_to_world[16];    /* CTM at the ObjectInstance directive */
+    float world_to_instance[16];
+    uint32_t object;                /* index of the instanced object (0-based) */
+    uint32_t before_triangle;       /* position in the WORLD primitive list, as for spheres */
+    uint32_t order;                 /* creation order among spheres and instances sharing a before_triangle value */
+    uint32_t reserved;
+} pt_instance;
 
 typedef enum { PT_SPLIT_SAH = 0, PT_SPLIT_HLBVH = 1, PT_SPLIT_MIDDLE = 2, PT_SPLIT_EQUAL_COUNTS = 3 } pt_split_method;
 typedef enum {
@@ -259,6 +277,8 @@ typedef struct {
     const pt_texture* textures;
     uint32_t n_images;
     const pt_image* images;     /* MIP pyramids of the imagemap textures */
+    uint32_t n_instances;
+    const pt_instance* instances;
     int32_t reserved[2];
 } pt_scene_desc;
 

@@ -41,7 +41,9 @@ struct SurfHit {
     V3 dndu, dndv, sh_dndu, sh_dndv;         // read by bump mapping only (core/material.rs:31-72)
     Float b0 = 0, b1 = 0, b2 = 0;
     int32_t prim = -1;          // index into the scene's primitive list (Geometry::prim_ref)
+    uint32_t shape_ref = 0;     // the shape that was hit: triangle index or PRIM_SPHERE | sphere index (inside an instance too)
 };
+struct BvhStats { uint64_t nodes = 0, tris = 0; };
 
 }  // namespace orc
 #include "orc_sphere.hpp"
@@ -52,6 +54,10 @@ namespace orc {
 // prim_ref lists the scene's primitives in creation order (render_options.primitives,
 // scene_context.rs:1301-1316): a triangle index, or PRIM_SPHERE | sphere index.
 static const uint32_t PRIM_SPHERE = 0x80000000u;
+static const uint32_t PRIM_INSTANCE = 0x40000000u;
+struct QBVH;
+// ObjectInstance -> TransformedPrimitive (core/primitive/transformed_primitive.rs) with a static transform
+struct Instance { Mat4 m, minv; uint32_t object = 0; };
 struct Geometry {
     std::vector<V3> P, N, S;
     std::vector<V2> UV;
@@ -59,6 +65,8 @@ struct Geometry {
     std::vector<uint32_t> tri_mesh;   // mesh id per triangle
     std::vector<MeshFlags> mesh;
     std::vector<Sphere> spheres;
+    std::vector<Instance> instances;
+    std::vector<const QBVH*> object_bvh;     // per object: the accelerator over its primitives (owned by the Scene)
     std::vector<uint32_t> prim_ref;   // empty = triangles only, prim == triangle index
     size_t n_tris() const { return idx.size() / 3; }
     size_t n_prims() const { return prim_ref.empty() ? n_tris() : prim_ref.size(); }
@@ -283,18 +291,21 @@ struct TriRef {
 };
 
 // Primitive dispatch (the reference's Arc<dyn Primitive> -> GeometricPrimitive -> dyn Shape chain).
-inline bool prim_intersect(const Geometry* g, size_t prim, const Ray& r, Float* t, SurfHit* si) {
-    uint32_t ref = g->ref(prim);
+bool instance_intersect(const Geometry* g, uint32_t inst, const Ray& r, Float* t, SurfHit* si, BvhStats* st);
+bool instance_intersect_p(const Geometry* g, uint32_t inst, const Ray& r, BvhStats* st);
+Bounds3 instance_world_bound(const Geometry* g, uint32_t inst);
+inline bool ref_intersect(const Geometry* g, uint32_t ref, const Ray& r, Float* t, SurfHit* si, BvhStats* st) {
+    if (ref & PRIM_INSTANCE) return instance_intersect(g, ref & ~PRIM_INSTANCE, r, t, si, st);
     bool hit = (ref & PRIM_SPHERE) ? g->spheres[ref & ~PRIM_SPHERE].intersect(r, t, si) : TriRef(g, ref).intersect(r, t, si);
-    if (hit) si->prim = (int32_t)prim;
+    if (hit) si->shape_ref = ref;
     return hit;
 }
-inline bool prim_intersect_p(const Geometry* g, size_t prim, const Ray& r) {
-    uint32_t ref = g->ref(prim);
+inline bool ref_intersect_p(const Geometry* g, uint32_t ref, const Ray& r, BvhStats* st) {
+    if (ref & PRIM_INSTANCE) return instance_intersect_p(g, ref & ~PRIM_INSTANCE, r, st);
     return (ref & PRIM_SPHERE) ? g->spheres[ref & ~PRIM_SPHERE].intersect_p(r) : TriRef(g, ref).intersect_p(r);
 }
-inline Bounds3 prim_world_bound(const Geometry* g, size_t prim) {
-    uint32_t ref = g->ref(prim);
+inline Bounds3 ref_world_bound(const Geometry* g, uint32_t ref) {
+    if (ref & PRIM_INSTANCE) return instance_world_bound(g, ref & ~PRIM_INSTANCE);
     return (ref & PRIM_SPHERE) ? g->spheres[ref & ~PRIM_SPHERE].world_bound() : TriRef(g, ref).world_bound();
 }
 
@@ -602,7 +613,11 @@ struct QBVH {
     // single-threaded diagnostic use only
     mutable std::vector<uint8_t>* step_log = nullptr;
     // traversal statistics (thread-unsafe; callers keep one copy per thread or ignore)
-    struct Stats { uint64_t nodes = 0, tris = 0; };
+    typedef BvhStats Stats;
+    std::vector<uint32_t> refs;    // an object's own primitive list (ObjectBegin .. ObjectEnd); empty: the scene's list (geom->ref)
+    bool own_refs = false;
+    uint32_t ref_of(size_t prim) const { return own_refs ? refs[prim] : geom->ref(prim); }
+    size_t n_prims() const { return own_refs ? refs.size() : geom->n_prims(); }
 
     size_t flatten(const BuildNode* node) {  // qbvh_x86.rs:93-176
         size_t offset = nodes.size();
@@ -652,11 +667,11 @@ struct QBVH {
     // QBVHAccel::new (qbvh_x86.rs:352-370) + create_bvh_node (build/node.rs:107-151)
     bool build(const Geometry* g, size_t max_prims_in_node, SplitMethod method) {
         geom = g;
-        size_t n = g->n_prims();
+        size_t n = n_prims();
         const Float eps = std::numeric_limits<Float>::epsilon() * 2.0f;  // BOUND_EPS node.rs:13
         std::vector<PrimInfo> info(n);
         for (size_t i = 0; i < n; i++) {
-            Bounds3 b = prim_world_bound(g, i);
+            Bounds3 b = ref_world_bound(g, ref_of(i));
             V3 mn = b.min, mx = b.max;
             mn.x -= eps; mn.y -= eps; mn.z -= eps;
             mx.x += eps; mx.y += eps; mx.z += eps;
@@ -746,7 +761,8 @@ struct QBVH {
                     if (st) st->tris++;
                     Float t;
                     SurfHit si;
-                    if (prim_intersect(geom, prims[i], r, &t, &si)) {
+                    if (ref_intersect(geom, ref_of(prims[i]), r, &t, &si, st)) {
+                        si.prim = (int32_t)prims[i];
                         r.t_max = t;                      // GeometricPrimitive::intersect :41-58
                         *out = si;
                         leaf_hit = true;
@@ -789,7 +805,7 @@ struct QBVH {
                 size_t start = nd.children[0], end = start + nd.children[1];
                 for (size_t i = start; i < end; i++) {
                     if (st) st->tris++;
-                    if (prim_intersect_p(geom, prims[i], r)) {
+                    if (ref_intersect_p(geom, ref_of(prims[i]), r, st)) {
                         if (step_log) { step_log->push_back((uint8_t)std::min<size_t>(i - start + 1, 250)); step_log->push_back(255); }
                         return true;
                     }
@@ -803,13 +819,99 @@ struct QBVH {
     // accelerators/exhaustive: brute force over every primitive, used as a cross-check
     bool intersect_exhaustive(const Ray& r, SurfHit* out) const {
         bool hit = false;
-        for (size_t i = 0; i < geom->n_prims(); i++) {
+        for (size_t i = 0; i < n_prims(); i++) {
             Float t;
             SurfHit si;
-            if (prim_intersect(geom, i, r, &t, &si)) { r.t_max = t; *out = si; hit = true; }
+            if (ref_intersect(geom, ref_of(i), r, &t, &si, nullptr)) { si.prim = (int32_t)i; r.t_max = t; *out = si; hit = true; }
         }
         return hit;
     }
 };
+
+// ---- TransformedPrimitive (core/primitive/transformed_primitive.rs:26-66) for a static primitive_to_world
+// Transform::transform_ray with the instance's inverse (transform.rs:184-203, :245-282)
+inline Ray instance_ray(const Instance& in, const Ray& r) {
+    const Float* m = in.minv.m;
+    V3 p = r.o, v = r.d;
+    V3 op = in.minv.transform_point(p);
+    V3 o_err = kGamma3 * V3(std::fabs(m[0] * p.x) + std::fabs(m[1] * p.y) + std::fabs(m[2] * p.z) + std::fabs(m[3]),
+                            std::fabs(m[4] * p.x) + std::fabs(m[5] * p.y) + std::fabs(m[6] * p.z) + std::fabs(m[7]),
+                            std::fabs(m[8] * p.x) + std::fabs(m[9] * p.y) + std::fabs(m[10] * p.z) + std::fabs(m[11]));
+    V3 dd = in.minv.transform_vector(v);
+    Float ls = length_squared(dd);
+    if (ls > 0.0f) {
+        Float dt = dot(vabs(dd), o_err) / ls;
+        op += dd * dt;
+    }
+    return Ray(op, dd, r.t_max);
+}
+// Transform::transform_surface_interaction (transform.rs:299-323)
+inline void transform_surf(const Instance& in, SurfHit* si) {
+    const Float* m = in.m.m;
+    const Float* mi = in.minv.m;
+    auto nrm = [&](V3 n) { return V3(mi[0] * n.x + mi[4] * n.y + mi[8] * n.z, mi[1] * n.x + mi[5] * n.y + mi[9] * n.z, mi[2] * n.x + mi[6] * n.y + mi[10] * n.z); };
+    V3 p = si->p, pe = si->p_error;
+    si->p = in.m.transform_point(p);
+    V3 e;
+    for (int i = 0; i < 3; i++) {
+        const Float* row = m + 4 * i;
+        Float v1 = (kGamma3 + 1.0f) * (std::fabs(row[0]) * pe.x + std::fabs(row[1]) * pe.y + std::fabs(row[2]) * pe.z) +
+                   kGamma3 * (std::fabs(row[0] * p.x) + std::fabs(row[1] * p.y) + std::fabs(row[2] * p.z) + std::fabs(row[3]));
+        if (i == 0) e.x = v1; else if (i == 1) e.y = v1; else e.z = v1;
+    }
+    si->p_error = e;
+    si->n = normalize(nrm(si->n));
+    si->wo = normalize(in.m.transform_vector(si->wo));
+    si->dpdu = in.m.transform_vector(si->dpdu);
+    si->dpdv = in.m.transform_vector(si->dpdv);
+    si->dndu = nrm(si->dndu);
+    si->dndv = nrm(si->dndv);
+    si->sh_n = normalize(nrm(si->sh_n));
+    si->sh_dpdu = in.m.transform_vector(si->sh_dpdu);
+    si->sh_dpdv = in.m.transform_vector(si->sh_dpdv);
+    si->sh_dndu = nrm(si->sh_dndu);
+    si->sh_dndv = nrm(si->sh_dndv);
+    si->sh_n = face_forward(si->sh_n, si->n);
+}
+inline bool instance_intersect(const Geometry* g, uint32_t inst, const Ray& r, Float* t, SurfHit* si, BvhStats* st) {
+    const Instance& in = g->instances[inst];
+    Ray ray = instance_ray(in, r);
+    const QBVH* b = g->object_bvh[in.object];
+    bool hit;
+    if (b->n_prims() == 1) {            // a single primitive is wrapped without an accelerator (scene_context.rs:1370-1377)
+        Float tt;
+        hit = ref_intersect(g, b->ref_of(0), ray, &tt, si, st);
+        if (hit) { si->prim = 0; ray.t_max = tt; }
+    } else {
+        hit = b->intersect(ray, si, st);
+    }
+    if (!hit) return false;
+    *t = ray.t_max;                       // r.t_max.set(ray.t_max.get())
+    transform_surf(in, si);
+    return true;
+}
+inline bool instance_intersect_p(const Geometry* g, uint32_t inst, const Ray& r, BvhStats* st) {
+    const Instance& in = g->instances[inst];
+    Ray ray = instance_ray(in, r);
+    const QBVH* b = g->object_bvh[in.object];
+    if (b->n_prims() == 1) return ref_intersect_p(g, b->ref_of(0), ray, st);
+    return b->intersect_p(ray, st);
+}
+inline Bounds3 instance_world_bound(const Geometry* g, uint32_t inst) {          // motion_bounds, not animated: transform_bounds
+    const Instance& in = g->instances[inst];
+    const QBVH* ob = g->object_bvh[in.object];
+    Bounds3 b = ob->n_prims() == 1 ? ref_world_bound(g, ob->ref_of(0)) : ob->bounds;
+    V3 mn, mx;
+    for (int i = 0; i < 8; i++) {
+        V3 c((i & 4) ? b.max.x : b.min.x, (i & 2) ? b.max.y : b.min.y, (i & 1) ? b.max.z : b.min.z);
+        V3 q = in.m.transform_point(c);
+        if (i == 0) { mn = q; mx = q; }
+        else {
+            mn = V3(fmin_(mn.x, q.x), fmin_(mn.y, q.y), fmin_(mn.z, q.z));
+            mx = V3(fmax_(mx.x, q.x), fmax_(mx.y, q.y), fmax_(mx.z, q.z));
+        }
+    }
+    return Bounds3(mn, mx);
+}
 
 }  // namespace orc

@@ -128,8 +128,8 @@ struct Scene {
     std::vector<int32_t> mesh_material, mesh_light_params;
     std::vector<int32_t> sphere_material;
     std::vector<int32_t> prim_light;    // light index per primitive or -1
-    int32_t prim_material(int32_t prim) const {
-        uint32_t ref = geom.ref((size_t)prim);
+    std::vector<std::unique_ptr<QBVH>> objects;     // accelerators of the ObjectBegin .. ObjectEnd groups
+    int32_t shape_material(uint32_t ref) const {
         return (ref & PRIM_SPHERE) ? sphere_material[ref & ~PRIM_SPHERE] : mesh_material[geom.tri_mesh[ref]];
     }
     std::vector<AreaLight> lights;
@@ -482,7 +482,7 @@ inline void material_bump(const pt_texture* tex, int32_t d, const TexHit& th, Su
     si.sh_dpdu = dpdu; si.sh_dpdv = dpdv;
 }
 inline bool make_bsdf(const Scene& sc, SurfHit& si, BSDF* b, const RayDiff& rd = RayDiff()) {
-    int32_t mid = sc.prim_material(si.prim);
+    int32_t mid = sc.shape_material(si.shape_ref);
     if (mid < 0) return false;
     const pt_material& m0 = sc.materials[mid];
     if (m0.type == PT_MATERIAL_NONE ||
@@ -847,29 +847,62 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
         const uint32_t refs[9] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k, m.tex_bump};
         for (uint32_t r : refs) if (r > d.n_textures) { if (err) *err = "material texture index out of range"; return false; }
     }
-    // spheres, spliced into the primitive list at before_triangle
-    if (d.n_spheres > 0) {
-        geom.spheres.resize(d.n_spheres);
-        sphere_material.resize(d.n_spheres);
-        uint32_t s = 0;
-        for (uint32_t t = 0; t <= d.n_triangles; t++) {
-            while (s < d.n_spheres && d.spheres[s].before_triangle <= t) {
-                if (d.spheres[s].before_triangle < t) { if (err) *err = "spheres[] must be ordered by before_triangle"; return false; }
-                const pt_sphere& ps = d.spheres[s];
-                geom.spheres[s].init(ps.object_to_world, ps.world_to_object, (ps.flags & PT_SPHERE_REVERSE_ORIENTATION) != 0, ps.radius, ps.zmin,
-                                     ps.zmax, ps.phimax);
-                sphere_material[s] = ps.material;
-                geom.prim_ref.push_back(PRIM_SPHERE | s);
-                s++;
-            }
-            if (t < d.n_triangles) geom.prim_ref.push_back(t);
-        }
-        if (s != d.n_spheres) { if (err) *err = "sphere before_triangle exceeds n_triangles"; return false; }
+    // spheres and object instances, spliced into the primitive lists at before_triangle (ties: creation order)
+    geom.spheres.resize(d.n_spheres);
+    sphere_material.resize(d.n_spheres);
+    for (uint32_t s = 0; s < d.n_spheres; s++) {
+        const pt_sphere& ps = d.spheres[s];
+        if (ps.before_triangle > d.n_triangles) { if (err) *err = "sphere before_triangle exceeds n_triangles"; return false; }
+        geom.spheres[s].init(ps.object_to_world, ps.world_to_object, (ps.flags & PT_SPHERE_REVERSE_ORIENTATION) != 0, ps.radius, ps.zmin, ps.zmax, ps.phimax);
+        sphere_material[s] = ps.material;
     }
+    uint32_t n_objects = 0;
+    for (uint32_t i = 0; i < d.n_meshes; i++) n_objects = std::max(n_objects, d.meshes[i].object);
+    for (uint32_t s = 0; s < d.n_spheres; s++) n_objects = std::max(n_objects, d.spheres[s].object);
+    geom.instances.resize(d.n_instances);
+    for (uint32_t i = 0; i < d.n_instances; i++) {
+        const pt_instance& pi = d.instances[i];
+        if (pi.object >= n_objects || pi.before_triangle > d.n_triangles) { if (err) *err = "instance object / position out of range"; return false; }
+        std::memcpy(geom.instances[i].m.m, pi.instance_to_world, 64);
+        std::memcpy(geom.instances[i].minv.m, pi.world_to_instance, 64);
+        geom.instances[i].object = pi.object;
+    }
+    // list 0 = the world, list k = object k - 1
+    auto make_list = [&](uint32_t tag, std::vector<uint32_t>* out) {
+        struct Extra { uint32_t before, order, ref; };
+        std::vector<Extra> extra;
+        for (uint32_t s = 0; s < d.n_spheres; s++) if (d.spheres[s].object == tag) extra.push_back({d.spheres[s].before_triangle, d.spheres[s].order, PRIM_SPHERE | s});
+        if (tag == 0) for (uint32_t i = 0; i < d.n_instances; i++) extra.push_back({d.instances[i].before_triangle, d.instances[i].order, PRIM_INSTANCE | i});
+        std::stable_sort(extra.begin(), extra.end(), [](const Extra& x, const Extra& y) { return x.before != y.before ? x.before < y.before : x.order < y.order; });
+        size_t e = 0;
+        for (uint32_t t = 0; t <= d.n_triangles; t++) {
+            while (e < extra.size() && extra[e].before <= t) out->push_back(extra[e++].ref);
+            if (t < d.n_triangles && d.meshes[d.tri_mesh[t]].object == tag) out->push_back(t);
+        }
+    };
+    const bool plain = d.n_spheres == 0 && d.n_instances == 0 && n_objects == 0;
+    if (!plain) make_list(0, &geom.prim_ref);
+    objects.resize(n_objects);
+    geom.object_bvh.resize(n_objects);
+    for (uint32_t k = 0; k < n_objects; k++) {
+        objects[k].reset(new QBVH());
+        QBVH& ob = *objects[k];
+        ob.own_refs = true;
+        ob.geom = &geom;
+        make_list(k + 1, &ob.refs);
+        geom.object_bvh[k] = &ob;
+        if (ob.refs.size() > 1 && !ob.build(&geom, (size_t)(d.max_node_prims > 0 ? d.max_node_prims : 4), (SplitMethod)d.split_method)) {
+            if (err) *err = "hlbvh: degenerate treelet centroids in an object (the reference panics here)";
+            return false;
+        }
+    }
+    for (uint32_t i = 0; i < d.n_instances; i++)
+        if (objects[d.instances[i].object]->refs.empty()) { if (err) *err = "instance of an empty object"; return false; }
     // one DiffuseAreaLight per emissive primitive, in primitive order (scene_context.rs:1218-1231)
     prim_light.assign(geom.n_prims(), -1);
     for (size_t p = 0; p < geom.n_prims(); p++) {
         uint32_t ref = geom.ref(p);
+        if (ref & PRIM_INSTANCE) continue;              // TransformedPrimitive::get_area_light is None
         int32_t lp = (ref & PRIM_SPHERE) ? d.spheres[ref & ~PRIM_SPHERE].area_light : mesh_light_params[geom.tri_mesh[ref]];
         if (lp >= 0) {
             AreaLight al;

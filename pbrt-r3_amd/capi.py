@@ -67,14 +67,19 @@ class pt_area_light(C.Structure):
 
 
 class pt_mesh(C.Structure):
-    _fields_ = [("flags", C.c_uint32), ("material", C.c_int32), ("area_light", C.c_int32), ("reserved", C.c_uint32)]
+    _fields_ = [("flags", C.c_uint32), ("material", C.c_int32), ("area_light", C.c_int32), ("object", C.c_uint32)]
 
 
 class pt_sphere(C.Structure):
     _fields_ = [("object_to_world", C.c_float * 16), ("world_to_object", C.c_float * 16),
                 ("radius", C.c_float), ("zmin", C.c_float), ("zmax", C.c_float), ("phimax", C.c_float),
                 ("flags", C.c_uint32), ("material", C.c_int32), ("area_light", C.c_int32),
-                ("before_triangle", C.c_uint32)]
+                ("before_triangle", C.c_uint32), ("object", C.c_uint32), ("order", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
+class pt_instance(C.Structure):
+    _fields_ = [("instance_to_world", C.c_float * 16), ("world_to_instance", C.c_float * 16), ("object", C.c_uint32),
+                ("before_triangle", C.c_uint32), ("order", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 PT_SPHERE_REVERSE_ORIENTATION = 1
@@ -100,7 +105,8 @@ class pt_scene_desc(C.Structure):
         ("halton_sample_at_center", C.c_int32),
         ("n_spheres", C.c_uint32), ("spheres", C.POINTER(pt_sphere)),
         ("n_textures", C.c_uint32), ("textures", C.POINTER(pt_texture)),
-        ("n_images", C.c_uint32), ("images", C.POINTER(pt_image)), ("reserved", C.c_int32 * 2),
+        ("n_images", C.c_uint32), ("images", C.POINTER(pt_image)),
+        ("n_instances", C.c_uint32), ("instances", C.POINTER(pt_instance)), ("reserved", C.c_int32 * 2),
     ]
 
 

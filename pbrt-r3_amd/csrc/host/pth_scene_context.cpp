@@ -693,7 +693,7 @@ public:
         if (!uv.empty()) mesh.flags |= PT_MESH_HAS_UV;
         mesh.material = material_for_shape(p);
         mesh.area_light = area_light_for_shape();
-        mesh.reserved = 0;
+        mesh.object = 0;
         if (!error.empty()) return;
 
         uint32_t base = (uint32_t)(P.size() / 3);

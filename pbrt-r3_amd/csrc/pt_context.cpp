@@ -381,6 +381,12 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     ctx->have_scene = false;
     // ---- validation (the kernels index these arrays unchecked)
     if (d->n_triangles == 0 && d->n_spheres == 0) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no primitives");
+    {
+        bool objects = d->n_instances > 0;
+        for (uint32_t i = 0; i < d->n_meshes && !objects; i++) objects = d->meshes[i].object != 0;
+        for (uint32_t i = 0; i < d->n_spheres && !objects; i++) objects = d->spheres[i].object != 0;
+        if (objects) return ctx->fail(PT_ERR_UNSUPPORTED, "object instancing: device traversal not built yet");
+    }
     if (d->n_triangles > 0 && (!d->P || !d->indices || !d->tri_mesh || !d->meshes)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "triangle arrays missing");
     if (d->n_spheres > 0 && !d->spheres) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "spheres array missing");
     if (d->xres <= 0 || d->yres <= 0 || d->spp <= 0 || d->max_depth < 0 || d->max_depth > 250) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "bad film / sampler / integrator parameters");

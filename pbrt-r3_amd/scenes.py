@@ -233,6 +233,10 @@ class SceneBuilder:
         self.spheres = []
         self.textures = []
         self.images = []            # (pt_image, texel buffer)
+        self.instances = []
+        self.objects = {}           # name -> object index
+        self.cur_object = 0         # 0 = world, k = inside ObjectBegin of object k - 1
+        self.n_extra = 0            # creation counter of spheres and instances (ties at one before_triangle)
         self.n_vertices = 0
         self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, (0.5, 0.5, 0.5), 0.0)   # default matte
         self.cur_area_light = -1
@@ -554,7 +558,7 @@ class SceneBuilder:
             flags |= capi.PT_MESH_HAS_S
         if UV is not None:
             flags |= capi.PT_MESH_HAS_UV
-        mesh = capi.pt_mesh(flags, self.cur_material, self.cur_area_light, 0)
+        mesh = capi.pt_mesh(flags, self.cur_material, self.cur_area_light, self.cur_object)
         self.meshes.append(mesh)
         mid = len(self.meshes) - 1
         self.P.append(P)
@@ -585,8 +589,33 @@ class SceneBuilder:
         sp.flags = capi.PT_SPHERE_REVERSE_ORIENTATION if self.reverse_orientation else 0
         sp.material, sp.area_light = self.cur_material, self.cur_area_light
         sp.before_triangle = sum(len(i) for i in self.idx)
+        sp.object, sp.order = self.cur_object, self.n_extra
+        self.n_extra += 1
         self.spheres.append(sp)
         return len(self.spheres) - 1
+
+    # ---- object instancing (scene_context.rs:1327-1391)
+    def object_begin(self, name):
+        self.objects[name] = len(self.objects)
+        self.cur_object = self.objects[name] + 1
+
+    def object_end(self):
+        self.cur_object = 0
+
+    def object_instance(self, name, to_world=None):
+        """ObjectInstance under the CTM `to_world` = (m, m_inv)."""
+        if self.cur_object:
+            return                          # ignored inside an object definition (:1352-1357)
+        it = capi.pt_instance()
+        m = np.eye(4, dtype=np.float32).reshape(-1) if to_world is None else np.asarray(to_world[0], np.float32).reshape(-1)
+        mi = np.eye(4, dtype=np.float32).reshape(-1) if to_world is None else np.asarray(to_world[1], np.float32).reshape(-1)
+        it.instance_to_world[:] = [float(v) for v in m]
+        it.world_to_instance[:] = [float(v) for v in mi]
+        it.object = self.objects[name]
+        it.before_triangle = sum(len(i) for i in self.idx)
+        it.order = self.n_extra
+        self.n_extra += 1
+        self.instances.append(it)
 
     def shape_trianglemesh_fast(self, P, indices, twosided=True):
         """Bulk path for meshes whose triangles do not share vertices (indices == arange):
@@ -630,6 +659,10 @@ class SceneBuilder:
             tex = (capi.pt_texture * len(self.textures))(*self.textures)
             sd.buffers["textures"] = tex
             d.n_textures, d.textures = len(self.textures), tex
+        if self.instances:
+            ins = (capi.pt_instance * len(self.instances))(*self.instances)
+            sd.buffers["instances"] = ins
+            d.n_instances, d.instances = len(self.instances), ins
         if self.images:
             ims = (capi.pt_image * len(self.images))(*[im for im, _ in self.images])
             sd.buffers["images"] = ims

@@ -443,3 +443,43 @@ def scene_imagemaps(res=48, spp=8, depth=4, sampler="sobol", trilinear=False, le
     b.material_uber(Kd=b.texture_imagemap(rgb, trilinear=trilinear, mapping="spherical", to_world=ts), Ks=(0.3, 0.3, 0.3), roughness=0.05)
     b.shape_sphere(radius=0.85, object_to_world=ts[0], world_to_object=ts[1])
     return b.build()
+
+
+def scene_instances(split="sah", res=48, spp=8, depth=5, sampler="sobol"):
+    """Object instancing (scene_context.rs:1327-1391, core/primitive/transformed_primitive.rs): an object of a smooth-shaded
+    blob + an analytic glass sphere + a plastic quad instanced four times (translate, rotate + non-uniform scale, a mirrored
+    = handedness-swapping transform, a tiny far copy), a one-triangle object (wrapped without an accelerator), instances
+    interleaved with world triangles and spheres in the primitive order, a light inside an object (ignored)."""
+    b = base(res=res, spp=spp, depth=depth)
+    if sampler == "halton":
+        b.sampler_halton(spp)
+    b.accelerator_bvh(splitmethod=split)
+    T = scenes
+    b.object_begin("thing")
+    b.material_matte((0.3, 0.5, 0.8), sigma=20.0)
+    P, N, UV, idx = uv_sphere((0.0, 0.0, 0.0), 0.45, nt=6, nphi=8)
+    b.shape_trianglemesh(P, idx, N=N, uv=UV)
+    b.material_glass()
+    ts = T.transform_translate(0.0, 0.75, 0.0)
+    b.shape_sphere(radius=0.3, object_to_world=ts[0], world_to_object=ts[1])
+    b.material_plastic(Kd=b.texture_checkerboard((0.9, 0.8, 0.2), (0.2, 0.2, 0.2), uscale=4.0, vscale=4.0), Ks=(0.3, 0.3, 0.3), roughness=0.1)
+    b.area_light_source_diffuse(L=(50, 50, 50))             # "Area lights not supported with object instancing": ignored
+    scenes._quad(b, (-0.6, -0.46, -0.6), (0.6, -0.46, -0.6), (0.6, -0.46, 0.6), (-0.6, -0.46, 0.6))
+    b.no_area_light()
+    b.object_end()
+    b.object_begin("shard")
+    b.material_mirror()
+    b.shape_trianglemesh([(-0.5, 0.0, 0.0), (0.5, 0.0, 0.1), (0.0, 0.9, 0.05)], [0, 1, 2])
+    b.object_end()
+    # an instance ahead of every world triangle
+    b.object_instance("thing", T.transform_translate(-1.1, -1.5, 0.5))
+    room(b)
+    b.object_instance("thing", T.transform_mul(T.transform_translate(1.0, -1.3, 0.2), T.transform_mul(T.transform_rotate_x(35.0), T.transform_scale(1.2, 0.7, 1.0))))
+    b.material_matte((0.6, 0.6, 0.6))
+    ts2 = T.transform_translate(0.0, 1.2, 1.2)
+    b.shape_sphere(radius=0.25, object_to_world=ts2[0], world_to_object=ts2[1])
+    b.object_instance("thing", T.transform_mul(T.transform_translate(-0.2, 0.3, 1.4), T.transform_scale(-0.8, 0.8, 0.8)))
+    b.object_instance("shard", T.transform_translate(0.2, -1.9, -0.9))
+    b.object_instance("shard", T.transform_mul(T.transform_translate(-1.5, -0.5, 1.6), T.transform_rotate_x(-20.0)))
+    b.object_instance("thing", T.transform_mul(T.transform_translate(1.6, 1.5, 1.7), T.transform_scale(0.2, 0.2, 0.2)))
+    return b.build()
