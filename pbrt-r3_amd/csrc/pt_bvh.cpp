@@ -392,48 +392,23 @@ struct Collapser {
 
 }  // namespace
 
-bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, const SpherePrim* spheres, uint32_t n_spheres,
-           int split_method, int max_node_prims, Result* out) {
+// Generic entry: any mix of primitives, each with its world bound and its ready-made 48-byte leaf record.
+bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_node_prims, Result* out) {
     out->nodes.clear(); out->tris.clear(); out->rec_of_prim.clear();
     out->n_leaves = 0; out->max_stack = 1;
-    const uint64_t n_prims64 = (uint64_t)n_tris + n_spheres;
-    if (n_prims64 == 0) { out->root_ref = PT_EMPTY_REF; return true; }
-    if (n_prims64 >= PT_LEAF_FIRST_MASK - 16u) return false;      // a leaf reference keeps 28 bits for the first record
-    const uint32_t n_prims = (uint32_t)n_prims64;
+    if (n_prims == 0) { out->root_ref = PT_EMPTY_REF; return true; }
+    if (n_prims >= PT_LEAF_FIRST_MASK - 16u) return false;      // a leaf reference keeps 28 bits for the first record
     std::vector<Item> items(n_prims), scratch(n_prims);
-    // primitive -> triangle index, or 0x80000000 | sphere index
-    std::vector<uint32_t> ref(n_spheres ? n_prims : 0);
     const float eps = std::numeric_limits<float>::epsilon() * 2.0f;   // BOUND_EPS (build/node.rs:13)
-    uint32_t si = 0, pi = 0;
-    for (uint32_t t = 0; t <= n_tris; t++) {
-        while (si < n_spheres && spheres[si].before_triangle <= t) {
-            if (spheres[si].before_triangle < t) return false;        // not ordered
-            Item& it = items[pi];
-            for (int i = 0; i < 3; i++) {
-                it.lo[i] = spheres[si].lo[i] - eps;
-                it.hi[i] = spheres[si].hi[i] + eps;
-                it.c[i] = (it.lo[i] + it.hi[i]) * 0.5f;
-            }
-            it.prim = pi;
-            ref[pi++] = 0x80000000u | si++;
-        }
-        if (t == n_tris) break;
-        const float* p0 = P + 3 * (size_t)indices[3 * (size_t)t];
-        const float* p1 = P + 3 * (size_t)indices[3 * (size_t)t + 1];
-        const float* p2 = P + 3 * (size_t)indices[3 * (size_t)t + 2];
+    for (uint32_t pi = 0; pi < n_prims; pi++) {
         Item& it = items[pi];
         for (int i = 0; i < 3; i++) {
-            float lo = std::fmin(std::fmin(p0[i], p1[i]), p2[i]);   // union3 (triangle.rs:189-200)
-            float hi = std::fmax(std::fmax(p0[i], p1[i]), p2[i]);
-            it.lo[i] = lo - eps;
-            it.hi[i] = hi + eps;
+            it.lo[i] = prims[pi].lo[i] - eps;
+            it.hi[i] = prims[pi].hi[i] + eps;
             it.c[i] = (it.lo[i] + it.hi[i]) * 0.5f;
         }
         it.prim = pi;
-        if (n_spheres) ref[pi] = t;
-        pi++;
     }
-    if (si != n_spheres) return false;                                // before_triangle > n_tris
     const uint32_t n_items = n_prims;
     Builder bld;
     bld.items = items.data();
@@ -464,27 +439,15 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
 
     std::memcpy(out->root_lo, tree[root].lo, 12);
     std::memcpy(out->root_hi, tree[root].hi, 12);
-    // triangle records in final item order; PT_TRI_LAST closes each leaf
+    // leaf records in final item order; PT_TRI_LAST closes each leaf
     out->tris.resize(n_items);
     out->rec_of_prim.resize(n_items);
     for (uint32_t r = 0; r < n_items; r++) {
         const uint32_t prim = items[r].prim;
-        uint32_t t = n_spheres ? ref[prim] : prim;
         PtTri& tr = out->tris[r];
-        if (t & 0x80000000u) {                 // sphere: the record carries its index instead of vertices
-            const uint32_t sidx = t & 0x7fffffffu;
-            std::memset(&tr, 0, sizeof(tr));
-            std::memcpy(&tr.p0[0], &sidx, 4);
-            tr.prim = prim;
-            tr.flags = (spheres[sidx].flags | PT_TRI_SPHERE) & ~PT_TRI_LAST;
-            out->rec_of_prim[prim] = r;
-            continue;
-        }
-        std::memcpy(tr.p0, P + 3 * (size_t)indices[3 * (size_t)t], 12);
-        std::memcpy(tr.p1, P + 3 * (size_t)indices[3 * (size_t)t + 1], 12);
-        std::memcpy(tr.p2, P + 3 * (size_t)indices[3 * (size_t)t + 2], 12);
+        tr = prims[prim].rec;
         tr.prim = prim;
-        tr.flags = tri_flags[t] & ~(PT_TRI_LAST | PT_TRI_SPHERE);
+        tr.flags &= ~PT_TRI_LAST;
         tr.light1 = 0;            // filled by the caller once lights are numbered
         out->rec_of_prim[prim] = r;
     }
@@ -507,6 +470,51 @@ bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, u
     out->root_ref = col.emit(root, 1);
     out->max_stack = 3 * col.max_depth4 + 2;
     return true;
+}
+
+
+// Triangles (+ spheres spliced in before `before_triangle`) as one primitive list.
+bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, const SpherePrim* spheres, uint32_t n_spheres,
+           int split_method, int max_node_prims, Result* out) {
+    const uint64_t n_prims64 = (uint64_t)n_tris + n_spheres;
+    if (n_prims64 >= PT_LEAF_FIRST_MASK - 16u) return false;
+    std::vector<Prim> prims((size_t)n_prims64);
+    uint32_t si = 0, pi = 0;
+    for (uint32_t t = 0; t <= n_tris; t++) {
+        while (si < n_spheres && spheres[si].before_triangle <= t) {
+            if (spheres[si].before_triangle < t) return false;        // not ordered
+            Prim& pr = prims[pi++];
+            std::memcpy(pr.lo, spheres[si].lo, 12); std::memcpy(pr.hi, spheres[si].hi, 12);
+            sphere_record(si, spheres[si].flags, &pr.rec);
+            si++;
+        }
+        if (t == n_tris) break;
+        triangle_prim(P, indices, t, tri_flags[t], &prims[pi++]);
+    }
+    if (si != n_spheres) return false;                                // before_triangle > n_tris
+    return build_prims(prims.data(), (uint32_t)prims.size(), split_method, max_node_prims, out);
+}
+void sphere_record(uint32_t sphere_index, uint32_t flags, PtTri* rec) {
+    std::memset(rec, 0, sizeof(*rec));
+    std::memcpy(&rec->p0[0], &sphere_index, 4);
+    rec->flags = (flags | PT_TRI_SPHERE) & ~PT_TRI_LAST;
+}
+void instance_record(uint32_t instance_index, PtTri* rec) {
+    std::memset(rec, 0, sizeof(*rec));
+    std::memcpy(&rec->p0[0], &instance_index, 4);
+    rec->flags = PT_TRI_INSTANCE;
+}
+void triangle_prim(const float* P, const uint32_t* indices, uint32_t t, uint32_t flags, Prim* pr) {
+    const float* p0 = P + 3 * (size_t)indices[3 * (size_t)t];
+    const float* p1 = P + 3 * (size_t)indices[3 * (size_t)t + 1];
+    const float* p2 = P + 3 * (size_t)indices[3 * (size_t)t + 2];
+    for (int i = 0; i < 3; i++) {
+        pr->lo[i] = std::fmin(std::fmin(p0[i], p1[i]), p2[i]);   // union3 (triangle.rs:189-200)
+        pr->hi[i] = std::fmax(std::fmax(p0[i], p1[i]), p2[i]);
+    }
+    std::memset(&pr->rec, 0, sizeof(pr->rec));
+    std::memcpy(pr->rec.p0, p0, 12); std::memcpy(pr->rec.p1, p1, 12); std::memcpy(pr->rec.p2, p2, 12);
+    pr->rec.flags = flags & ~(PT_TRI_LAST | PT_TRI_SPHERE | PT_TRI_INSTANCE);
 }
 
 }  // namespace ptbvh

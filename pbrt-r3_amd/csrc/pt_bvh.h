@@ -25,6 +25,13 @@ struct Result {
 // Sphere::world_bound, flags the record flags (PT_TRI_SPHERE | material field).  Primitive numbering (PtTri::prim, rec_of_prim) is the
 // merged list; with no spheres it is the triangle index.
 struct SpherePrim { float lo[3], hi[3]; uint32_t flags; uint32_t before_triangle; };
+// One primitive of a list: its world bound (before the builder's epsilon inflation) and its leaf record (prim / light1 / the LAST
+// bit are filled in by the builder and the caller).
+struct Prim { float lo[3], hi[3]; PtTri rec; };
+void triangle_prim(const float* P, const uint32_t* indices, uint32_t t, uint32_t flags, Prim* out);
+void sphere_record(uint32_t sphere_index, uint32_t flags, PtTri* rec);
+void instance_record(uint32_t instance_index, PtTri* rec);
+bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_node_prims, Result* out);
 bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, const SpherePrim* spheres, uint32_t n_spheres,
            int split_method, int max_node_prims, Result* out);
 

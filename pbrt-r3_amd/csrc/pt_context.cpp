@@ -61,7 +61,7 @@ struct pt_context {
     bool have_scene = false;
     PtScene sc;
     pt_scene_info info;
-    DevBuf d_nodes, d_tris, d_tri_info, d_spheres, d_textures, d_tex_prog, d_mat_params, d_images, d_image_texels, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab, d_hdims, d_hperms;
+    DevBuf d_nodes, d_tris, d_tri_info, d_spheres, d_instances, d_hit_inst, d_textures, d_tex_prog, d_mat_params, d_images, d_image_texels, d_N, d_S, d_UV, d_materials, d_lights, d_m32, d_vdc, d_vdc_inv, d_grid, d_bytetab, d_hdims, d_hperms;
     std::vector<uint32_t> sobol_m32;
     std::vector<uint64_t> sobol_vdc, sobol_inv;
     uint32_t sobol_n_vdc = 0, sobol_n_inv = 0, sobol_msize = 52;
@@ -135,6 +135,10 @@ pt_status upload(pt_context* ctx, DevBuf& b, const T* src, size_t n) {
 }
 
 pt_status ensure_pool(pt_context* ctx, size_t n_paths) {
+    if (ctx->sc.n_instances && ctx->d_hit_inst.bytes < std::max(n_paths, ctx->pool_paths) * 4) {      // scenes with object instances only
+        PT_HIP(ctx->d_hit_inst.alloc(std::max(n_paths, ctx->pool_paths) * 4));
+        ctx->paths.hit_inst = ctx->d_hit_inst.as<uint32_t>();
+    }
     if (ctx->pool_paths >= n_paths && ctx->d_pool.p) return PT_OK;
     // 11 float4 + float2 + u64 + 6 x 4-byte + 1 byte per path
     const size_t per_path = 11 * 16 + 8 + 8 + 6 * 4 + 4;
@@ -381,11 +385,15 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     ctx->have_scene = false;
     // ---- validation (the kernels index these arrays unchecked)
     if (d->n_triangles == 0 && d->n_spheres == 0) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no primitives");
-    {
-        bool objects = d->n_instances > 0;
-        for (uint32_t i = 0; i < d->n_meshes && !objects; i++) objects = d->meshes[i].object != 0;
-        for (uint32_t i = 0; i < d->n_spheres && !objects; i++) objects = d->spheres[i].object != 0;
-        if (objects) return ctx->fail(PT_ERR_UNSUPPORTED, "object instancing: device traversal not built yet");
+    if (d->n_instances > 0 && !d->instances) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "instances array missing");
+    for (uint32_t i = 0; i < d->n_instances; i++) {
+        const pt_instance& in = d->instances[i];
+        if (in.before_triangle > d->n_triangles) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "instance before_triangle exceeds n_triangles");
+        for (int k = 0; k < 2; k++) {
+            const float* m = k ? in.world_to_instance : in.instance_to_world;
+            if (m[12] != 0.0f || m[13] != 0.0f || m[14] != 0.0f || m[15] != 1.0f)
+                return ctx->fail(PT_ERR_UNSUPPORTED, "object instance under a projective transform (last matrix row must be 0 0 0 1)");
+        }
     }
     if (d->n_triangles > 0 && (!d->P || !d->indices || !d->tri_mesh || !d->meshes)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "triangle arrays missing");
     if (d->n_spheres > 0 && !d->spheres) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "spheres array missing");
@@ -437,8 +445,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (sp.area_light >= (int32_t)d->n_area_lights) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "sphere area light index out of range");
         if (sp.material >= 0 && (d->materials[sp.material].type < PT_MATERIAL_NONE || d->materials[sp.material].type > PT_MATERIAL_SUBSTRATE))
             return ctx->fail(PT_ERR_UNSUPPORTED, "material type not on the accelerated path");
-        if (sp.before_triangle > d->n_triangles || (i > 0 && sp.before_triangle < d->spheres[i - 1].before_triangle))
-            return ctx->fail(PT_ERR_INVALID_ARGUMENT, "spheres[] must be ordered by before_triangle <= n_triangles");
+        if (sp.before_triangle > d->n_triangles) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "sphere before_triangle exceeds n_triangles");
         if (!(sp.radius > 0.0f)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "sphere radius must be positive");
         for (int k = 0; k < 2; k++) {
             const float* m = k ? sp.world_to_object : sp.object_to_world;
@@ -463,42 +470,139 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     std::vector<PtSphere> sph;
     std::vector<ptbvh::SpherePrim> sprims;
     build_spheres(d, sph, sprims);
+    // Primitive lists (render_options.primitives and each object's list, scene_context.rs:1301-1316): triangles in array order with
+    // the spheres / instances of the list spliced in before triangle `before_triangle`, ties in creation order.
+    struct Entry { uint32_t kind, idx; };          // 0 triangle, 1 sphere, 2 instance
+    uint32_t n_objects = 0;
+    for (uint32_t i = 0; i < d->n_meshes; i++) n_objects = std::max(n_objects, d->meshes[i].object);
+    for (uint32_t i = 0; i < d->n_spheres; i++) n_objects = std::max(n_objects, d->spheres[i].object);
+    auto make_list = [&](uint32_t tag) {
+        struct Extra { uint32_t before, order, kind, idx; };
+        std::vector<Extra> extra;
+        for (uint32_t i = 0; i < d->n_spheres; i++) if (d->spheres[i].object == tag) extra.push_back({d->spheres[i].before_triangle, d->spheres[i].order, 1u, i});
+        if (tag == 0) for (uint32_t i = 0; i < d->n_instances; i++) extra.push_back({d->instances[i].before_triangle, d->instances[i].order, 2u, i});
+        std::stable_sort(extra.begin(), extra.end(), [](const Extra& x, const Extra& y) { return x.before != y.before ? x.before < y.before : x.order < y.order; });
+        std::vector<Entry> out;
+        size_t e = 0;
+        for (uint32_t t = 0; t <= d->n_triangles; t++) {
+            while (e < extra.size() && extra[e].before <= t) { out.push_back({extra[e].kind, extra[e].idx}); e++; }
+            if (t < d->n_triangles && d->meshes[d->tri_mesh[t]].object == tag) out.push_back({0u, t});
+        }
+        return out;
+    };
+    const int max_node_prims = d->max_node_prims > 0 ? d->max_node_prims : 4;
+    const char* hlbvh_msg = "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)";
+    // objects first: an instance's bound is its object's root bound under the instance transform
+    struct ObjectBvh { std::vector<Entry> list; ptbvh::Result res; float lo[3], hi[3]; bool direct = false; };
+    std::vector<ObjectBvh> objs(n_objects);
+    auto fill_prim = [&](const Entry& en, ptbvh::Prim* pr) {
+        if (en.kind == 0) ptbvh::triangle_prim(d->P, d->indices, en.idx, tri_flags[en.idx], pr);
+        else {
+            std::memcpy(pr->lo, sprims[en.idx].lo, 12); std::memcpy(pr->hi, sprims[en.idx].hi, 12);
+            ptbvh::sphere_record(en.idx, sprims[en.idx].flags, &pr->rec);
+        }
+    };
+    for (uint32_t k = 0; k < n_objects; k++) {
+        ObjectBvh& ob = objs[k];
+        ob.list = make_list(k + 1);
+        std::vector<ptbvh::Prim> prims(ob.list.size());
+        for (size_t i = 0; i < ob.list.size(); i++) fill_prim(ob.list[i], &prims[i]);
+        if (prims.size() == 1) {             // a single primitive is wrapped without an accelerator (scene_context.rs:1370-1377)
+            ob.direct = true;
+            ob.res.tris.assign(1, prims[0].rec);
+            ob.res.tris[0].prim = 0; ob.res.tris[0].flags |= PT_TRI_LAST; ob.res.tris[0].light1 = 0;
+            ob.res.max_stack = 0; ob.res.max_leaf = 1;
+            std::memcpy(ob.lo, prims[0].lo, 12); std::memcpy(ob.hi, prims[0].hi, 12);
+        } else if (!prims.empty()) {
+            if (!ptbvh::build_prims(prims.data(), (uint32_t)prims.size(), d->split_method, max_node_prims, &ob.res)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, hlbvh_msg);
+            ob.res.tris.pop_back();          // the pad record: one for the whole array, below
+            std::memcpy(ob.lo, ob.res.root_lo, 12); std::memcpy(ob.hi, ob.res.root_hi, 12);
+        }
+    }
+    for (uint32_t i = 0; i < d->n_instances; i++)
+        if (d->instances[i].object >= n_objects || objs[d->instances[i].object].list.empty()) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "instance of an unknown or empty object");
+    std::vector<PtInstance> dinst(d->n_instances);
+    std::vector<Entry> world = make_list(0);
+    if (world.empty()) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no world primitives (objects are only rendered through ObjectInstance)");
+    if ((uint64_t)world.size() >= PT_LEAF_FIRST_MASK - 16u) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "more than 2^28 primitives");
     ptbvh::Result bvh;
-    if (!ptbvh::build(d->P, d->indices, tri_flags.data(), d->n_triangles, sprims.data(), d->n_spheres, d->split_method,
-                      d->max_node_prims > 0 ? d->max_node_prims : 4, &bvh))
-        return ctx->fail(PT_ERR_INVALID_ARGUMENT, (uint64_t)d->n_triangles + d->n_spheres >= PT_LEAF_FIRST_MASK - 16u ? "more than 2^28 primitives" : "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)");
+    {
+        std::vector<ptbvh::Prim> prims(world.size());
+        for (size_t i = 0; i < world.size(); i++) {
+            const Entry& en = world[i];
+            if (en.kind != 2) { fill_prim(en, &prims[i]); continue; }
+            const pt_instance& in = d->instances[en.idx];
+            const ObjectBvh& ob = objs[in.object];
+            const float* m = in.instance_to_world;          // motion_bounds of a static transform = transform_bounds (transform.rs:134-182)
+            for (int c = 0; c < 8; c++) {
+                const float x = (c & 4) ? ob.hi[0] : ob.lo[0], y = (c & 2) ? ob.hi[1] : ob.lo[1], z = (c & 1) ? ob.hi[2] : ob.lo[2];
+                float q[3] = {m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]};
+                const float wq = m[12] * x + m[13] * y + m[14] * z + m[15];
+                if (wq != 1.0f) { q[0] /= wq; q[1] /= wq; q[2] /= wq; }
+                for (int a2 = 0; a2 < 3; a2++) {
+                    prims[i].lo[a2] = c == 0 ? q[a2] : std::fmin(prims[i].lo[a2], q[a2]);
+                    prims[i].hi[a2] = c == 0 ? q[a2] : std::fmax(prims[i].hi[a2], q[a2]);
+                }
+            }
+            ptbvh::instance_record(en.idx, &prims[i].rec);
+        }
+        if (!ptbvh::build_prims(prims.data(), (uint32_t)prims.size(), d->split_method, max_node_prims, &bvh)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, hlbvh_msg);
+    }
+    for (size_t prim = 0; prim < world.size(); prim++) if (world[prim].kind == 2) dinst[world[prim].idx].world_prim = (uint32_t)prim;
+    // one node array and one record array: the world first, then each object with its references shifted
+    std::vector<Entry> rec_entry(bvh.tris.size() - 1);        // record -> what it stands for (shading records below)
+    for (size_t prim = 0; prim < world.size(); prim++) rec_entry[bvh.rec_of_prim[prim]] = world[prim];
+    uint32_t max_inner_stack = 0;
+    if (n_objects) {
+        bvh.tris.pop_back();
+        std::vector<uint32_t> node_off(n_objects), rec_off(n_objects);
+        for (uint32_t k = 0; k < n_objects; k++) {
+            ObjectBvh& ob = objs[k];
+            node_off[k] = (uint32_t)bvh.nodes.size(); rec_off[k] = (uint32_t)bvh.tris.size();
+            if ((uint64_t)rec_off[k] + ob.res.tris.size() >= PT_LEAF_FIRST_MASK - 16u) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "more than 2^28 primitives");
+            auto shift = [&](uint32_t ref) {
+                if (ref == PT_EMPTY_REF) return ref;
+                return (ref & PT_LEAF_BIT) ? ((ref & ~PT_LEAF_FIRST_MASK) | ((ref & PT_LEAF_FIRST_MASK) + rec_off[k])) : ref + node_off[k];
+            };
+            for (PtNode nd : ob.res.nodes) { for (int c = 0; c < 4; c++) nd.child[c] = shift(nd.child[c]); bvh.nodes.push_back(nd); }
+            for (size_t r = 0; r < ob.res.tris.size(); r++) {
+                bvh.tris.push_back(ob.res.tris[r]);
+                rec_entry.push_back(ob.direct ? ob.list[0] : ob.list[ob.res.tris[r].prim]);
+            }
+            ob.res.root_ref = ob.direct ? rec_off[k] : shift(ob.res.root_ref);
+            max_inner_stack = std::max(max_inner_stack, ob.res.max_stack);
+            bvh.max_leaf = std::max(bvh.max_leaf, ob.res.max_leaf);
+        }
+        PtTri pad;
+        std::memset(&pad, 0, sizeof(pad));
+        pad.flags = PT_TRI_LAST;
+        bvh.tris.push_back(pad);
+        for (uint32_t i = 0; i < d->n_instances; i++) {
+            const pt_instance& in = d->instances[i];
+            const ObjectBvh& ob = objs[in.object];
+            PtInstance& o = dinst[i];
+            const uint32_t wp = o.world_prim;
+            std::memset(&o, 0, sizeof(o));
+            o.world_prim = wp;
+            std::memcpy(o.m, in.instance_to_world, 48); std::memcpy(o.minv, in.world_to_instance, 48);
+            o.root_ref = ob.res.root_ref; o.direct = ob.direct ? 1u : 0u;
+            std::memcpy(o.root_lo, ob.lo, 12); std::memcpy(o.root_hi, ob.hi, 12);
+        }
+    }
     double t1 = now_ms();
-    ctx->max_stack = bvh.max_stack;
+    ctx->max_stack = bvh.max_stack + max_inner_stack;
 
     // ---- shading records ----------------------------------------------------
-    const uint32_t n_prims = d->n_triangles + d->n_spheres;
-    std::vector<PtTriInfo> tinfo(n_prims);      // indexed by primitive (sphere entries unused)
-    std::vector<PtLight> lights;
-    for (uint32_t prim = 0, t = 0, si = 0; prim < n_prims; prim++) {
-        if (si < d->n_spheres && d->spheres[si].before_triangle <= t) {       // a sphere sits here in the primitive list
-            const pt_sphere& in = d->spheres[si];
-            std::memset(&tinfo[prim], 0, sizeof(PtTriInfo));
-            tinfo[prim].light = -1; tinfo[prim].material = in.material;
-            if (in.area_light >= 0) {       // one DiffuseAreaLight for the sphere (scene_context.rs:1218-1231)
-                const pt_area_light& al = d->area_lights[in.area_light];
-                PtLight L;
-                std::memset(&L, 0, sizeof(L));
-                std::memcpy(&L.p0[0], &si, 4);
-                L.area = sph[si].area;
-                L.mesh_flags = PT_LIGHT_SPHERE;
-                L.two_sided = al.two_sided;
-                std::memcpy(L.L, al.L, 12);
-                L.tri_rec = bvh.rec_of_prim[prim];
-                L.prim = prim;
-                tinfo[prim].light = (int32_t)lights.size();
-                bvh.tris[bvh.rec_of_prim[prim]].light1 = (uint32_t)lights.size() + 1u;
-                lights.push_back(L);
-            }
-            si++;
-            continue;
-        }
+    std::vector<PtTriInfo> tinfo(bvh.tris.size() - 1);      // per leaf record (sphere / instance entries unused)
+    for (size_t r = 0; r < tinfo.size(); r++) {
+        PtTriInfo& ti = tinfo[r];
+        std::memset(&ti, 0, sizeof(ti));
+        ti.light = -1; ti.material = -1;
+        const Entry& en = rec_entry[r];
+        if (en.kind == 1) ti.material = d->spheres[en.idx].material;
+        if (en.kind != 0) continue;
+        const uint32_t t = en.idx;
         const pt_mesh& m = d->meshes[d->tri_mesh[t]];
-        PtTriInfo& ti = tinfo[prim];
         ti.v[0] = d->indices[3 * (size_t)t]; ti.v[1] = d->indices[3 * (size_t)t + 1]; ti.v[2] = d->indices[3 * (size_t)t + 2];
         ti.mesh = d->tri_mesh[t];
         ti.material = m.material;
@@ -507,10 +611,30 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (!d->S) mf &= ~PT_MESH_HAS_S;
         if (!d->UV) mf &= ~PT_MESH_HAS_UV;
         ti.mesh_flags = mf;
-        ti.pad = 0;
-        ti.light = -1;
-        if (m.area_light >= 0) {     // one DiffuseAreaLight per emissive triangle, in primitive order
-            const pt_area_light& al = d->area_lights[m.area_light];
+    }
+    // one DiffuseAreaLight per emissive world primitive, in primitive order (scene_context.rs:1218-1231); lights inside objects are
+    // dropped as in the reference (:1302-1304), instances carry none (TransformedPrimitive::get_area_light)
+    std::vector<PtLight> lights;
+    for (uint32_t prim = 0; prim < world.size(); prim++) {
+        const Entry& en = world[prim];
+        const uint32_t rec = bvh.rec_of_prim[prim];
+        if (en.kind == 1 && d->spheres[en.idx].area_light >= 0) {
+            const pt_area_light& al = d->area_lights[d->spheres[en.idx].area_light];
+            PtLight L;
+            std::memset(&L, 0, sizeof(L));
+            std::memcpy(&L.p0[0], &en.idx, 4);
+            L.area = sph[en.idx].area;
+            L.mesh_flags = PT_LIGHT_SPHERE;
+            L.two_sided = al.two_sided;
+            std::memcpy(L.L, al.L, 12);
+            L.tri_rec = rec;
+            L.prim = prim;
+            tinfo[rec].light = (int32_t)lights.size();
+            bvh.tris[rec].light1 = (uint32_t)lights.size() + 1u;
+            lights.push_back(L);
+        } else if (en.kind == 0 && d->meshes[d->tri_mesh[en.idx]].area_light >= 0) {
+            const pt_area_light& al = d->area_lights[d->meshes[d->tri_mesh[en.idx]].area_light];
+            const PtTriInfo& ti = tinfo[rec];
             PtLight L;
             std::memset(&L, 0, sizeof(L));
             const float* p0 = d->P + 3 * (size_t)ti.v[0]; const float* p1 = d->P + 3 * (size_t)ti.v[1]; const float* p2 = d->P + 3 * (size_t)ti.v[2];
@@ -520,19 +644,18 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             float bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
             float cx = (ay * bz) - (az * by), cy = (az * bx) - (ax * bz), cz = (ax * by) - (ay * bx);
             L.area = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);
-            L.mesh_flags = mf;
+            L.mesh_flags = ti.mesh_flags;
             L.two_sided = al.two_sided;
             std::memcpy(L.L, al.L, 12);
-            L.tri_rec = bvh.rec_of_prim[prim];
+            L.tri_rec = rec;
             L.prim = prim;
-            if (mf & PT_MESH_HAS_N) {
+            if (ti.mesh_flags & PT_MESH_HAS_N) {
                 std::memcpy(L.n0, d->N + 3 * (size_t)ti.v[0], 12); std::memcpy(L.n1, d->N + 3 * (size_t)ti.v[1], 12); std::memcpy(L.n2, d->N + 3 * (size_t)ti.v[2], 12);
             }
-            ti.light = (int32_t)lights.size();
-            bvh.tris[bvh.rec_of_prim[prim]].light1 = (uint32_t)lights.size() + 1u;
+            tinfo[rec].light = (int32_t)lights.size();
+            bvh.tris[rec].light1 = (uint32_t)lights.size() + 1u;
             lights.push_back(L);
         }
-        t++;
     }
     if (lights.size() >= (1u << 24)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^24 emissive primitives");
     std::vector<PtMaterial> mats(std::max<uint32_t>(d->n_materials, 1));
@@ -587,7 +710,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                 any_textured = true;
             }
         }
-        const bool general = d->materials[i].type != PT_MATERIAL_NONE && (d->materials[i].type != PT_MATERIAL_MATTE || mats[i].textured);
+        // (with object instances every material rides in the general half: only k_shade_general_inst knows how to bring a hit back)
+        const bool general = d->materials[i].type != PT_MATERIAL_NONE && (d->materials[i].type != PT_MATERIAL_MATTE || mats[i].textured || d->n_instances > 0);
         if (general) general_materials = true;
         // shade-queue bin: one per material while they last, the remainder of a class shares its last bin
         mats[i].sort_bin = general ? PT_SORT_GENERAL0 + std::min(n_general_bins++, PT_SORT_BINS - PT_SORT_GENERAL0 - 1u)
@@ -603,6 +727,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if ((st = upload(ctx, ctx->d_materials, mats.data(), mats.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_lights, lights.data(), lights.size())) != PT_OK) return st;
     if (d->n_spheres) { if ((st = upload(ctx, ctx->d_spheres, sph.data(), sph.size())) != PT_OK) return st; } else ctx->d_spheres.release();
+    if (d->n_instances) { if ((st = upload(ctx, ctx->d_instances, dinst.data(), dinst.size())) != PT_OK) return st; } else ctx->d_instances.release();
     std::vector<PtImage> dimages(d->n_images);
     if (any_textured && d->n_images) {           // all pyramids in one buffer
         size_t total = 0;
@@ -665,8 +790,11 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     sc.images = (any_textured && d->n_images) ? ctx->d_images.as<PtImage>() : nullptr;
     sc.mat_params = any_textured ? ctx->d_mat_params.as<PtMatParams>() : nullptr;
     sc.spheres = d->n_spheres ? ctx->d_spheres.as<PtSphere>() : nullptr;
+    sc.instances = d->n_instances ? ctx->d_instances.as<PtInstance>() : nullptr;
+    sc.n_instances = d->n_instances;
     sc.n_spheres = d->n_spheres;
     if (d->n_spheres) sc.general_materials = 1;     // sphere scenes run the sphere-capable kernel instantiations (sorted shade queue)
+    if (d->n_instances) { sc.general_materials = 1; sc.dist_leaves = 0; }      // k_trace_inst walks leaves per lane; one shade kernel handles everything
     sc.root_ref = bvh.root_ref;
     std::memcpy(sc.wb_min, bvh.root_lo, 12);
     std::memcpy(sc.wb_max, bvh.root_hi, 12);

@@ -34,6 +34,7 @@ struct PtNode {
 #define PT_TRI_FLIP 4u           // reverse_orientation ^ swaps_handedness
 #define PT_TRI_HAS_ATTR 8u       // mesh carries N / S / UV: shading must also read PtTriInfo
 #define PT_TRI_SPHERE 16u        // the record stands for a sphere: p0[0] holds its index into PtScene::spheres (as bits)
+#define PT_TRI_INSTANCE 32u      // the record stands for an object instance: p0[0] holds its index into PtScene::instances (as bits)
 #define PT_TRI_MATERIAL_SHIFT 16 // bits 16..31: material index + 1 (0 = no material)
 struct PtTri {
     float p0[3];
@@ -131,6 +132,16 @@ struct PtSphere {                // 144 bytes
     uint32_t flags;
     uint32_t pad[4];
 };
+// ObjectInstance: TransformedPrimitive over an object's accelerator (affine, static).
+struct PtInstance {              // 144 bytes
+    float m[12];                 // rows 0..2 of instance_to_world
+    float minv[12];              // rows 0..2 of its stored inverse
+    uint32_t root_ref;           // the object's root (node index or leaf reference); direct: its single record's index
+    uint32_t direct;             // 1: one primitive, wrapped without an accelerator (no root box test)
+    float root_lo[3], root_hi[3];// the accelerator's bound (QBVHAccel::intersect starts with it)
+    uint32_t world_prim;         // the instance's index in the world primitive list (pt_hit.prim)
+    uint32_t pad[3];
+};
 #define PT_LIGHT_SPHERE 0x80000000u   // PtLight::mesh_flags: the light's shape is sphere number bits(p0[0])
 
 struct PtCamera {
@@ -202,6 +213,9 @@ struct PtScene {
     const PtMaterial* materials;
     const PtLight* lights;
     const PtSphere* spheres;
+    const PtInstance* instances;
+    uint32_t n_instances;        // > 0: k_trace_inst / k_shade_general_inst run
+    uint32_t pad_inst;
     const pt_texture* textures;  // pt_scene_desc.textures as given
     const uint32_t* tex_prog;    // texture programs (pt_texture.h)
     const PtImage* images;       // MIP pyramids of the imagemap textures
@@ -241,6 +255,7 @@ struct PtPaths {
     uint32_t* nee;       // bit0 shadow ray live, bit1 probe live, bits 8.. light index
     uint8_t* occluded;
     int32_t* probe_rec;
+    uint32_t* hit_inst;  // instance index + 1 of the closest hit (0 = a world primitive); allocated for scenes with instances only
 };
 
 #define PT_ST_SPECULAR 1u

@@ -377,17 +377,20 @@ PT_DEV uint32_t stk_pop(TravCtx& c, uint32_t& top, uint32_t& sp) {      // preco
 }
 
 // Bounds3f::intersect_p on the root (bounds3.rs:154-163, intersect.rs:46-65): NaN-ignoring max/min.
-PT_DEV bool root_test(const PtScene& sc, V3 o, V3 idir, uint32_t sbits, float t_max, float& tmin, float& tmax) {
+PT_DEV bool box_root_test(const float* bmin, const float* bmax, V3 o, V3 idir, uint32_t sbits, float t_max, float& tmin, float& tmax) {
     float t0 = 0.0f, t1 = t_max;
     float lo, hi;
-    lo = (sbits & 1) ? sc.wb_max[0] : sc.wb_min[0]; hi = (sbits & 1) ? sc.wb_min[0] : sc.wb_max[0];
+    lo = (sbits & 1) ? bmax[0] : bmin[0]; hi = (sbits & 1) ? bmin[0] : bmax[0];
     t0 = fmaxf(t0, (lo - o.x) * idir.x); t1 = fminf(t1, (hi - o.x) * idir.x);
-    lo = (sbits & 2) ? sc.wb_max[1] : sc.wb_min[1]; hi = (sbits & 2) ? sc.wb_min[1] : sc.wb_max[1];
+    lo = (sbits & 2) ? bmax[1] : bmin[1]; hi = (sbits & 2) ? bmin[1] : bmax[1];
     t0 = fmaxf(t0, (lo - o.y) * idir.y); t1 = fminf(t1, (hi - o.y) * idir.y);
-    lo = (sbits & 4) ? sc.wb_max[2] : sc.wb_min[2]; hi = (sbits & 4) ? sc.wb_min[2] : sc.wb_max[2];
+    lo = (sbits & 4) ? bmax[2] : bmin[2]; hi = (sbits & 4) ? bmin[2] : bmax[2];
     t0 = fmaxf(t0, (lo - o.z) * idir.z); t1 = fminf(t1, (hi - o.z) * idir.z);
     if (t0 <= t1) { tmin = t0; tmax = t1; return true; }
     return false;
+}
+PT_DEV bool root_test(const PtScene& sc, V3 o, V3 idir, uint32_t sbits, float t_max, float& tmin, float& tmax) {
+    return box_root_test(sc.wb_min, sc.wb_max, o, idir, sbits, t_max, tmin, tmax);
 }
 
 // One node: 4 slab tests (test_aabb) + ORDER_TABLE in closed form:
@@ -458,6 +461,7 @@ struct LaneRay {
     uint32_t sbits;              // bits 0-2: direction signs, bit 3: needs the EXACT slab form
     uint32_t sp, top;            // top == PT_EMPTY_REF: traversal finished
     int32_t best;
+    uint32_t best_inst;          // INST kernels: instance index + 1 of `best` (0 = a world primitive)
 };
 PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max) {
     r.o = o;
@@ -466,6 +470,7 @@ PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max) {
     r.sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
     if (!(fabsf(r.idir.x) < PT_INF) || !(fabsf(r.idir.y) < PT_INF) || !(fabsf(r.idir.z) < PT_INF)) r.sbits |= 8u;
     r.best = -1;
+    r.best_inst = 0;
     r.ray_tmax = t_max;
     r.sp = 0;
     r.top = PT_EMPTY_REF;
@@ -499,52 +504,128 @@ PT_DEV bool prim_test(const PtScene& sc, const TriVerts& tv, const LaneRay& r, b
     }
     return tri_test(r.rp, tv.p0, tv.p1, tv.p2, tv.flags, r.ray_tmax, h);
 }
+// Transform::transform_ray with the instance's inverse (transformed_primitive.rs:27-29, transform.rs:184-203, :245-282)
+PT_DEV void instance_ray(const PtInstance& in, V3 ro, V3 rd, V3* o_out, V3* d_out) {
+    const float* m = in.minv;
+    V3 o = sph_point(m, ro);
+    V3 oe = PT_GAMMA(3.0f) * mk3(fabsf(m[0] * ro.x) + fabsf(m[1] * ro.y) + fabsf(m[2] * ro.z) + fabsf(m[3]),
+                                  fabsf(m[4] * ro.x) + fabsf(m[5] * ro.y) + fabsf(m[6] * ro.z) + fabsf(m[7]),
+                                  fabsf(m[8] * ro.x) + fabsf(m[9] * ro.y) + fabsf(m[10] * ro.z) + fabsf(m[11]));
+    V3 d = sph_vector(m, rd);
+    float ls = length_squared(d);
+    if (ls > 0.0f) {
+        float dt = dot(vabs(d), oe) / ls;
+        o = o + d * dt;
+    }
+    *o_out = o; *d_out = d;
+}
+template <bool SPH, bool INST>
+PT_DEV void ray_step_tri(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c, uint32_t base = 0);
+PT_DEV void ray_step_node(const PtScene& sc, LaneRay& r, TravCtx& c);
+// TransformedPrimitive::intersect / intersect_p (transformed_primitive.rs:26-48): the ray goes to instance space, the object's
+// accelerator is walked to the end on the stack above the caller's entries (the other lanes of the wave wait: instances are a
+// breadth feature, not the hot path), t carries over because the direction is not renormalised.
 template <bool SPH>
-PT_DEV void ray_step_tri(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
+__device__ __noinline__ bool instance_rec_test(const PtScene& sc, uint32_t inst, const LaneRay& r, bool any_hit, TravCtx& c, float* t_out, int32_t* rec_out) {
+    const PtInstance& in = sc.instances[inst];
+    V3 o, d;
+    instance_ray(in, r.o, r.d, &o, &d);
+    LaneRay ri;
+    ri.o = o; ri.d = d;
+    ri.idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    ri.sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+    if (!(fabsf(ri.idir.x) < PT_INF) || !(fabsf(ri.idir.y) < PT_INF) || !(fabsf(ri.idir.z) < PT_INF)) ri.sbits |= 8u;
+    ri.best = -1; ri.best_inst = 0;
+    ri.ray_tmax = r.ray_tmax;
+    ray_precompute(ri.rp, o, d);
+    const uint32_t base = r.sp;
+    ri.sp = base; ri.top = PT_EMPTY_REF;
+    if (in.direct) {                     // a single primitive, wrapped without an accelerator: no root box, not a counted leaf test
+        TriVerts tv = load_tri(sc.tris, in.root_ref);
+        TriHit h;
+        if (prim_test<SPH>(sc, tv, ri, any_hit, h)) { ri.best = (int32_t)in.root_ref; ri.ray_tmax = h.t; }
+    } else if (box_root_test(in.root_lo, in.root_hi, o, ri.idir, ri.sbits, ri.ray_tmax, ri.tmin, ri.tmax)) {
+        ri.top = in.root_ref; ri.sp = base + 1;
+        while (ri.sp > base) {
+            if (ri.top & PT_LEAF_BIT) ray_step_tri<SPH, false>(sc, ri, any_hit, c, base);
+            else ray_step_node(sc, ri, c);
+        }
+    }
+    if (ri.best < 0) return false;
+    *t_out = ri.ray_tmax; *rec_out = ri.best;
+    return true;
+}
+template <bool SPH, bool INST>
+PT_DEV void ray_step_tri(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c, uint32_t base) {
     uint32_t rec = stk_pop(c, r.top, r.sp) & PT_LEAF_FIRST_MASK;
     bool leaf_hit = false;
+    if constexpr (!INST) {
+        for (;;) {
+            TriVerts t0 = load_tri(sc.tris, rec), t1 = load_tri(sc.tris, rec + 1);   // array is padded by one record
+            TriHit h;
+            c.n_tris++;
+            if (prim_test<SPH>(sc, t0, r, any_hit, h)) {
+                r.best = (int32_t)rec; leaf_hit = true;
+                if (any_hit) { r.sp = base; r.top = PT_EMPTY_REF; return; }
+                r.ray_tmax = h.t;                           // GeometricPrimitive::intersect: r.t_max = t_hit
+            }
+            if (t0.flags & PT_TRI_LAST) break;
+            c.n_tris++;
+            if (prim_test<SPH>(sc, t1, r, any_hit, h)) {
+                r.best = (int32_t)(rec + 1); leaf_hit = true;
+                if (any_hit) { r.sp = base; r.top = PT_EMPTY_REF; return; }
+                r.ray_tmax = h.t;
+            }
+            if (t1.flags & PT_TRI_LAST) break;
+            rec += 2;
+        }
+        if (leaf_hit) r.tmax = r.ray_tmax;                  // intersect_simd: tmax shrinks after the whole leaf
+        return;
+    }
     for (;;) {
-        TriVerts t0 = load_tri(sc.tris, rec), t1 = load_tri(sc.tris, rec + 1);   // array is padded by one record
+        TriVerts t0 = load_tri(sc.tris, rec);
         TriHit h;
         c.n_tris++;
-        if (prim_test<SPH>(sc, t0, r, any_hit, h)) {
-            r.best = (int32_t)rec; leaf_hit = true;
-            if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; return; }
+        bool hit;
+        int32_t hit_rec = (int32_t)rec;
+        uint32_t hit_inst = 0;
+        if (INST && (t0.flags & PT_TRI_INSTANCE)) {
+            hit_inst = __float_as_uint(t0.p0.x) + 1u;
+            hit = instance_rec_test<SPH>(sc, hit_inst - 1u, r, any_hit, c, &h.t, &hit_rec);
+        } else hit = prim_test<SPH>(sc, t0, r, any_hit, h);
+        if (hit) {
+            r.best = hit_rec; leaf_hit = true;
+            if (INST) r.best_inst = hit_inst;
+            if (any_hit) { r.sp = base; r.top = PT_EMPTY_REF; return; }
             r.ray_tmax = h.t;                           // GeometricPrimitive::intersect: r.t_max = t_hit
         }
         if (t0.flags & PT_TRI_LAST) break;
-        c.n_tris++;
-        if (prim_test<SPH>(sc, t1, r, any_hit, h)) {
-            r.best = (int32_t)(rec + 1); leaf_hit = true;
-            if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; return; }
-            r.ray_tmax = h.t;
-        }
-        if (t1.flags & PT_TRI_LAST) break;
-        rec += 2;
+        rec++;
     }
     if (leaf_hit) r.tmax = r.ray_tmax;                  // intersect_simd: tmax shrinks after the whole leaf
 }
-template <bool SPH>
+template <bool SPH, bool INST>
 PT_DEV void ray_step(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
-    if (ray_wants_tri(r)) ray_step_tri<SPH>(sc, r, any_hit, c);
+    if (ray_wants_tri(r)) ray_step_tri<SPH, INST>(sc, r, any_hit, c);
     else ray_step_node(sc, r, c);
 }
 
 // intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
-template <bool SPH>
-PT_DEV int32_t trace_closest(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c, float* t_out) {
+template <bool SPH, bool INST>
+PT_DEV int32_t trace_closest(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c, float* t_out, uint32_t* inst_out) {
     LaneRay r;
     ray_begin(sc, r, o, d, t_max);
-    while (!ray_done(r)) ray_step<SPH>(sc, r, false, c);
+    while (!ray_done(r)) ray_step<SPH, INST>(sc, r, false, c);
     *t_out = r.ray_tmax;
+    *inst_out = r.best_inst;
     return r.best;
 }
 // intersect_simd_p (qbvh_x86.rs:289-343): any hit
-template <bool SPH>
+template <bool SPH, bool INST>
 PT_DEV bool trace_any(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c) {
     LaneRay r;
     ray_begin(sc, r, o, d, t_max);
-    while (!ray_done(r)) ray_step<SPH>(sc, r, true, c);
+    while (!ray_done(r)) ray_step<SPH, INST>(sc, r, true, c);
     return r.best >= 0;
 }
 
@@ -601,7 +682,7 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #endif
 // DIST: every leaf holds at most 8 triangles and its reference carries the count, so a leaf phase can pool the
 // triangles of all parked lanes and hand one (ray, triangle) test to each lane of the wave.
-template <bool DIST, bool SPH>
+template <bool DIST, bool SPH, bool INST = false>
 PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
     __shared__ uint32_t s_stack[PT_LDS_STACK * PT_BLOCK];
     __shared__ unsigned long long s_cnt[4];
@@ -685,7 +766,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         }
         // ---- retire finished rays: stores only
         if (kind != 0 && ray_done(r)) {
-            if (kind == 1) { P.hit_t[p] = r.ray_tmax; P.hit_rec[p] = r.best; }
+            if (kind == 1) { P.hit_t[p] = r.ray_tmax; P.hit_rec[p] = r.best; if (INST) P.hit_inst[p] = r.best_inst; }
             else if (kind == 2) P.occluded[p] = r.best >= 0 ? 1 : 0;
             else P.probe_rec[p] = r.best;
             kind = 0;
@@ -815,7 +896,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             prof[0] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[1] += 1; prof[2] += (unsigned long long)__popcll(m_node);
 #endif
         } else {
-            if (w_tri) ray_step_tri<SPH>(sc, r, kind == 2, c);
+            if (w_tri) ray_step_tri<SPH, INST>(sc, r, kind == 2, c);
 #ifdef PT_PROFILE_PHASES
             prof[3] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[4] += 1; prof[5] += (unsigned long long)__popcll(m_tri);
 #endif
@@ -838,6 +919,11 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace_s
                                                                   uint32_t spill_depth, uint32_t* err) {
     trace_body<false, false>(sc, P, Q, cnt, spill, spill_depth, err);
 }
+// scenes with object instances (and possibly spheres): a leaf record may stand for a TransformedPrimitive
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, 2) k_trace_inst(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+                                                                       uint32_t spill_depth, uint32_t* err) {
+    trace_body<false, true, true>(sc, P, Q, cnt, spill, spill_depth, err);
+}
 // scenes with spheres: a leaf record may stand for a sphere
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace_sph_dist(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                                            uint32_t spill_depth, uint32_t* err) {
@@ -849,7 +935,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 2) k_trace_sph(PtScene sc
 }
 
 // ============================================================ hooks: plain ray batches
-template <bool SPH>
+template <bool SPH, bool INST = false>
 PT_DEV void trace_batch_body(const PtScene& sc, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out, uint8_t* occ_out, int any_hit,
                              uint32_t* ticket, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
     __shared__ uint32_t s_stack[PT_LDS_STACK * PT_BLOCK];
@@ -869,14 +955,17 @@ PT_DEV void trace_batch_body(const PtScene& sc, uint32_t n, const float* o, cons
         V3 ro = ld3(o + 3 * (size_t)i), rd = ld3(d + 3 * (size_t)i);
         if (any_hit) {
             shadow++;
-            occ_out[i] = trace_any<SPH>(sc, ro, rd, tmax[i], c) ? 1 : 0;
+            occ_out[i] = trace_any<SPH, INST>(sc, ro, rd, tmax[i], c) ? 1 : 0;
         } else {
             regular++;
             float t;
-            int32_t rec = trace_closest<SPH>(sc, ro, rd, tmax[i], c, &t);
+            uint32_t inst = 0;
+            int32_t rec = trace_closest<SPH, INST>(sc, ro, rd, tmax[i], c, &t, &inst);
             pt_hit h;
             h.t = 0.0f; h.prim = -1; h.b0 = 0.0f; h.b1 = 0.0f;
-            if (rec >= 0) {
+            if (rec >= 0 && INST && inst) {          // the hit is reported as the instance's own world primitive
+                h.t = t; h.prim = (int32_t)sc.instances[inst - 1u].world_prim;
+            } else if (rec >= 0) {
                 TriVerts tv = load_tri(sc.tris, (uint32_t)rec);
                 h.t = t; h.prim = (int32_t)tv.prim;
                 if (!(SPH && (tv.flags & PT_TRI_SPHERE))) {
@@ -902,6 +991,11 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace_batch_sph(PtScene
                                                                         pt_hit* out, uint8_t* occ_out, int any_hit, uint32_t* ticket, PtCounters* cnt,
                                                                         uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
     trace_batch_body<true>(sc, n, o, d, tmax, out, occ_out, any_hit, ticket, cnt, spill, spill_depth, err);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace_batch_inst(PtScene sc, uint32_t n, const float* o, const float* d, const float* tmax,
+                                                                         pt_hit* out, uint8_t* occ_out, int any_hit, uint32_t* ticket, PtCounters* cnt,
+                                                                         uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
+    trace_batch_body<true, true>(sc, n, o, d, tmax, out, occ_out, any_hit, ticket, cnt, spill, spill_depth, err);
 }
 
 // ============================================================ K_GEN: camera samples
@@ -991,7 +1085,7 @@ PT_DEV void tri_dpdu(const PtScene& sc, bool has_attr, const PtTriInfo& ti, V3 p
 // Triangle::intersect's back half (triangle.rs:349-449): rebuild the interaction from the ray and
 // the triangle's vertices.  Everything shading needs for an attribute-less mesh (material, light,
 // orientation) rides in the 48-byte record, so the common case costs one dependent fetch.
-PT_DEV bool make_surf_tv(const PtScene& sc, V3 ro, V3 rd, const TriVerts& tv, uint32_t light1, Surf& s, float* t_out) {
+PT_DEV bool make_surf_tv(const PtScene& sc, V3 ro, V3 rd, const TriVerts& tv, uint32_t light1, Surf& s, float* t_out, uint32_t rec = 0) {
     RayPre rp;
     ray_precompute(rp, ro, rd);
     TriHit h;
@@ -999,7 +1093,7 @@ PT_DEV bool make_surf_tv(const PtScene& sc, V3 ro, V3 rd, const TriVerts& tv, ui
     const bool has_attr = (tv.flags & PT_TRI_HAS_ATTR) != 0;
     PtTriInfo ti;
     ti.mesh_flags = 0; ti.v[0] = ti.v[1] = ti.v[2] = 0;
-    if (has_attr) ti = sc.tri_info[tv.prim];
+    if (has_attr) ti = sc.tri_info[rec];        // per leaf record
     V3 n = cross(tv.p0 - tv.p2, tv.p1 - tv.p2);
     if (tv.flags & PT_TRI_FLIP) n = n * -1.0f;
     n = normalize(n);
@@ -1070,7 +1164,7 @@ PT_DEV bool make_surf(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, fl
     tv.p0 = mk3(a.x, a.y, a.z); tv.prim = __float_as_uint(a.w);
     tv.p1 = mk3(b.x, b.y, b.z); tv.flags = __float_as_uint(b.w);
     tv.p2 = mk3(c.x, c.y, c.z);
-    return make_surf_tv(sc, ro, rd, tv, __float_as_uint(c.w), s, t_out);
+    return make_surf_tv(sc, ro, rd, tv, __float_as_uint(c.w), s, t_out, rec);
 }
 
 // A record of a sphere-capable scene: Sphere::intersect again on the same ray (deterministic, and t_max only ever
@@ -1095,6 +1189,29 @@ PT_DEV bool make_surf_any(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s
         }
     }
     return make_surf(sc, ro, rd, rec, s, t_out);
+}
+
+// A hit inside an object instance: Shape::intersect again in instance space, then Transform::transform_surface_interaction
+// back to the world (transformed_primitive.rs:30-38, transform.rs:299-323).
+template <bool SPH>
+PT_DEV bool make_surf_inst(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, uint32_t inst1, Surf& s, float* t_out) {
+    if (inst1 == 0) return make_surf_any<SPH>(sc, ro, rd, rec, s, t_out);
+    const PtInstance& in = sc.instances[inst1 - 1u];
+    V3 o, d;
+    instance_ray(in, ro, rd, &o, &d);
+    if (!make_surf_any<SPH>(sc, o, d, rec, s, t_out)) return false;
+    V3 p = s.p, pe = s.p_error;
+    s.p = sph_point(in.m, p);
+    s.p_error = sph_point_abs_error(in.m, p, pe);
+    s.n = normalize(sph_normal(in.minv, s.n));
+    s.wo = normalize(sph_vector(in.m, s.wo));
+    s.dpdu = sph_vector(in.m, s.dpdu); s.dpdv = sph_vector(in.m, s.dpdv);
+    s.sh_n = normalize(sph_normal(in.minv, s.sh_n));
+    s.sh_dpdu = sph_vector(in.m, s.sh_dpdu); s.sh_dpdv = sph_vector(in.m, s.sh_dpdv);
+    s.sh_dndu = sph_normal(in.minv, s.sh_dndu); s.sh_dndv = sph_normal(in.minv, s.sh_dndv);
+    s.sh_n = face_forward(s.sh_n, s.n);
+    s.light = -1;                                 // TransformedPrimitive::get_area_light is None
+    return true;
 }
 
 // ---- BSDF with at most one diffuse-reflection lobe (Matte: Lambertian or OrenNayar)
@@ -1308,7 +1425,8 @@ PT_DEV uint32_t path_sort_bin(const PtScene& sc, const PtPaths& P, uint32_t p) {
     int32_t rec = P.hit_rec[p];
     if (rec < 0) return 0xffffffffu;                                   // miss: nothing to shade
     uint32_t m1 = sc.tris[rec].flags >> PT_TRI_MATERIAL_SHIFT;         // material index + 1, 0 = none
-    return m1 == 0 ? 0u : sc.materials[m1 - 1].sort_bin;               // material-less surfaces ride with bin 0
+    // material-less surfaces ride with bin 0 (with object instances: the first general bin -- one kernel shades everything there)
+    return m1 == 0 ? (sc.n_instances ? PT_SORT_GENERAL0 : 0u) : sc.materials[m1 - 1].sort_bin;
 }
 // One atomic per (wave, distinct bin): returns this lane's slot among the lanes of its bin.
 PT_DEV uint32_t wave_bin_reserve(uint32_t* counters, uint32_t bin, bool valid) {
@@ -1443,7 +1561,7 @@ __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material,
     for (uint32_t i = 0; i < sizeof(PtMaterial); i++) z[i] = 0;
     build_lobes(mp.m, mp.a_r, mp.a_u, mp.a_v, *out);
 }
-template <bool GENERAL, bool SPH, bool TEX = false>
+template <bool GENERAL, bool SPH, bool TEX = false, bool INST = false>
 PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, const uint32_t* list, uint32_t begin, uint32_t end,
                        uint32_t* ticket) {
     __shared__ unsigned long long s_vert;
@@ -1478,7 +1596,9 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             float eta_scale = beta4.w;
             Surf s;
             float thit;
-            bool found = rec >= 0 && make_surf_any<SPH>(sc, ro, rd, (uint32_t)rec, s, &thit);
+            bool found;
+            if constexpr (INST) found = rec >= 0 && make_surf_inst<SPH>(sc, ro, rd, (uint32_t)rec, P.hit_inst[p], s, &thit);
+            else found = rec >= 0 && make_surf_any<SPH>(sc, ro, rd, (uint32_t)rec, s, &thit);
             // emitted radiance at the first vertex / after a specular bounce (path.rs:87-98)
             if (found && (bounces == 0 || (flags & PT_ST_SPECULAR))) {
                 int32_t li = s.light;
@@ -1713,6 +1833,11 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_matte_sorted_s
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
+}
+// scenes with object instances: hits inside an instance are rebuilt in instance space and transformed back; every material
+// rides in the general half of the sorted queue, so this one kernel shades them all
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_inst(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
 }
 // scenes with textured materials (and possibly spheres): lobes are built per hit for the textured ones
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
@@ -1950,7 +2075,8 @@ extern "C" __global__ void k_bsdf_sample(PtScene sc, uint32_t material, uint32_t
 
 hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err) {
-    if (sc.n_spheres && sc.dist_leaves) hipLaunchKernelGGL(k_trace_sph_dist, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    if (sc.n_instances) hipLaunchKernelGGL(k_trace_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    else if (sc.n_spheres && sc.dist_leaves) hipLaunchKernelGGL(k_trace_sph_dist, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else if (sc.n_spheres) hipLaunchKernelGGL(k_trace_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else if (sc.dist_leaves) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else hipLaunchKernelGGL(k_trace_seq, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
@@ -1962,7 +2088,8 @@ hipError_t ptk_nee_resolve(hipStream_t st, int grid, const PtScene& sc, const Pt
 }
 hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out,
                            uint8_t* occ, int any_hit, uint32_t* ticket, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
-    if (sc.n_spheres) hipLaunchKernelGGL(k_trace_batch_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, n, o, d, tmax, out, occ, any_hit, ticket, cnt, spill, spill_depth, err);
+    if (sc.n_instances) hipLaunchKernelGGL(k_trace_batch_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, n, o, d, tmax, out, occ, any_hit, ticket, cnt, spill, spill_depth, err);
+    else if (sc.n_spheres) hipLaunchKernelGGL(k_trace_batch_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, n, o, d, tmax, out, occ, any_hit, ticket, cnt, spill, spill_depth, err);
     else hipLaunchKernelGGL(k_trace_batch, dim3(grid), dim3(PT_BLOCK), 0, st, sc, n, o, d, tmax, out, occ, any_hit, ticket, cnt, spill, spill_depth, err);
     return PT_LAUNCH_CHECK();
 }
@@ -1980,7 +2107,9 @@ hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths&
         hipLaunchKernelGGL(k_sort_count, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(PT_SORT_BINS), 0, st, Q);
         hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
-        if (sc.textured) {
+        if (sc.n_instances) {
+            hipLaunchKernelGGL(k_shade_general_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        } else if (sc.textured) {
             if (sc.n_spheres) hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
             else hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
             hipLaunchKernelGGL(k_shade_general_tex, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);

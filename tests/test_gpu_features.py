@@ -71,6 +71,9 @@ def _compare(ctx, osc, exact_film, frac_limit=0.0):
     ("textures_thin_lens", lambda: fs.scene_textures(lens=True), True),
     ("textures_noise", lambda: fs.scene_noise_textures(), True),
     ("textures_noise_halton", lambda: fs.scene_noise_textures(sampler="halton"), True),
+    # object instancing: TransformedPrimitive over per-object accelerators
+    ("instances_sah", lambda: fs.scene_instances(), True),
+    ("instances_hlbvh_halton", lambda: fs.scene_instances(split="hlbvh", sampler="halton"), True),
     ("imagemaps_ewa", lambda: fs.scene_imagemaps(), True),
     ("imagemaps_trilinear_halton", lambda: fs.scene_imagemaps(trilinear=True, sampler="halton"), True),
     ("imagemaps_ewa_thin_lens", lambda: fs.scene_imagemaps(lens=True), True),
