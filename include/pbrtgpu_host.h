@@ -20,7 +20,7 @@
  *   lights      diffuse area lights
  *   camera      perspective;  filters box / gaussian / mitchell / sinc / triangle
  *   samplers    halton (the default), sobol;  integrator path;  accelerator bvh (sah, hlbvh, middle, equal)
- *   the full transform / attribute stack, named coordinate systems, Include
+ *   the full transform / attribute stack, named coordinate systems, Include, ObjectBegin / ObjectEnd / ObjectInstance
  * Anything else is reported as PT_ERR_UNSUPPORTED with a message naming the directive -- never silently
  * approximated.
  *

@@ -21,6 +21,7 @@
 #include "../pt_host_math.h"
 #include "pth_parse_context.h"
 #include <memory>
+#include <set>
 #include "pth_ply.h"
 #include "pth_texture_image.h"
 #include "pth_spectrum.h"
@@ -122,6 +123,11 @@ public:
     std::vector<uint32_t> indices, tri_mesh;
     std::vector<pt_mesh> meshes;
     std::vector<pt_sphere> spheres;                                     // Shape "sphere", spliced into the primitive order by before_triangle
+    std::vector<pt_instance> instances;
+    std::map<std::string, uint32_t> object_ids;
+    std::set<uint32_t> object_redefined;
+    uint32_t cur_object = 0;                                            // 0: world; k: inside ObjectBegin of object k - 1
+    uint32_t n_extra = 0;                                               // creation counter of spheres and instances
     bool quick_render = false, quick_full_resolution = false;          // PbrtOptions (--quick, --quick_full_resolution)
     std::vector<pt_material> materials;
     std::map<std::string, float> float_textures;                        // constant-folded named textures (global, see pbrt_texture)
@@ -410,9 +416,37 @@ public:
         gstates.back().area_light_params = p;
     }
     void pbrt_reverse_orientation() override { gstates.back().reverse_orientation = !gstates.back().reverse_orientation; }
-    void pbrt_object_begin(const std::string&) override { fail("ObjectBegin: object instancing is outside the accelerated path"); }
-    void pbrt_object_end() override {}
-    void pbrt_object_instance(const std::string&) override { fail("ObjectInstance: object instancing is outside the accelerated path"); }
+    // Object instancing (scene_context.rs:1327-1391): shapes between ObjectBegin / ObjectEnd go to the named object (tagged in
+    // pt_mesh.object / pt_sphere.object), ObjectInstance records the CTM and its stored inverse.
+    void pbrt_object_begin(const std::string& name) override {
+        pbrt_attribute_begin();
+        auto it = object_ids.find(name);
+        if (it == object_ids.end()) { object_ids[name] = (uint32_t)object_ids.size(); it = object_ids.find(name); }
+        else object_redefined.insert(it->second);           // instances.insert(name, Vec::new()) replaces the list (:1333)
+        cur_object = it->second + 1;
+        if (object_redefined.count(it->second)) fail("ObjectBegin \"" + name + "\" defined twice: redefinition is outside the accelerated path");
+    }
+    void pbrt_object_end() override {
+        cur_object = 0;
+        pbrt_attribute_end();
+    }
+    void pbrt_object_instance(const std::string& name) override {
+        if (!error.empty() || cur_object) return;                    // ignored inside an object definition (:1352-1357)
+        auto it = object_ids.find(name);
+        if (it == object_ids.end()) return;                          // unknown name: nothing happens (:1365)
+        const TransformSet& ts = transforms.back();
+        if (std::memcmp(&ts.t[0].m, &ts.t[1].m, sizeof(M44)) != 0) { fail("animated instance transforms are outside the accelerated path"); return; }
+        const Xf& c = ts.t[0];
+        if (c.m.a[12] != 0.0f || c.m.a[13] != 0.0f || c.m.a[14] != 0.0f || c.m.a[15] != 1.0f) { fail("ObjectInstance under a projective transform is outside the accelerated path"); return; }
+        pt_instance in;
+        std::memset(&in, 0, sizeof(in));
+        std::memcpy(in.instance_to_world, c.m.a, 64);
+        std::memcpy(in.world_to_instance, c.inv.a, 64);
+        in.object = it->second;
+        in.before_triangle = (uint32_t)tri_mesh.size();
+        in.order = n_extra++;
+        instances.push_back(in);
+    }
 
     // TextureParams (core/param_set/texture_params.rs:36-105): a texture binding is looked up in the shape's
     // parameters first, but constant float / spectrum VALUES come from the material's parameters first and
@@ -624,6 +658,9 @@ public:
             sp.area_light = area_light_for_shape();
             if (!error.empty()) return;
             sp.before_triangle = (uint32_t)tri_mesh.size();
+            sp.object = cur_object;
+            sp.order = n_extra++;
+            if (cur_object) sp.area_light = -1;                     // "Area lights not supported with object instancing" (:1302-1304)
             spheres.push_back(sp);
             return;
         }
@@ -693,7 +730,8 @@ public:
         if (!uv.empty()) mesh.flags |= PT_MESH_HAS_UV;
         mesh.material = material_for_shape(p);
         mesh.area_light = area_light_for_shape();
-        mesh.object = 0;
+        mesh.object = cur_object;
+        if (cur_object) mesh.area_light = -1;                       // "Area lights not supported with object instancing" (:1302-1304)
         if (!error.empty()) return;
 
         uint32_t base = (uint32_t)(P.size() / 3);
@@ -848,6 +886,8 @@ public:
         desc.meshes = meshes.data();
         desc.n_spheres = (uint32_t)spheres.size();
         desc.spheres = spheres.empty() ? nullptr : spheres.data();
+        desc.n_instances = (uint32_t)instances.size();
+        desc.instances = instances.empty() ? nullptr : instances.data();
         desc.n_textures = (uint32_t)textures.size();
         desc.textures = textures.empty() ? nullptr : textures.data();
         images.clear();

@@ -596,11 +596,14 @@ class SceneBuilder:
 
     # ---- object instancing (scene_context.rs:1327-1391)
     def object_begin(self, name):
+        """ObjectBegin opens an attribute scope (scene_context.rs:1330): material / area light / orientation set inside do not leak."""
+        self._saved_gstate = (self.cur_material, self.cur_area_light, self.reverse_orientation)
         self.objects[name] = len(self.objects)
         self.cur_object = self.objects[name] + 1
 
     def object_end(self):
         self.cur_object = 0
+        self.cur_material, self.cur_area_light, self.reverse_orientation = self._saved_gstate
 
     def object_instance(self, name, to_world=None):
         """ObjectInstance under the CTM `to_world` = (m, m_inv)."""

@@ -319,6 +319,98 @@ def test_bumpmap_parameter(oracle):
     sc.close()
 
 
+def test_object_instancing_from_pbrt_text(oracle):
+    """ObjectBegin / ObjectEnd / ObjectInstance (scene_context.rs:1327-1391): object membership of meshes and spheres, the
+    instance CTMs with their stored inverses, positions in the world primitive order, the dropped area light inside an object,
+    ObjectInstance ignored inside a definition; rendered against the SceneBuilder scene bit for bit."""
+    text = '''
+    LookAt 0 0 -6.5  0 0 0  0 1 0
+    Camera "perspective" "float fov" 40
+    Film "image" "integer xresolution" 32 "integer yresolution" 32
+    Sampler "sobol" "integer pixelsamples" 4
+    Integrator "path" "integer maxdepth" 4
+    WorldBegin
+      ObjectBegin "thing"
+        Material "matte" "rgb Kd" [0.3 0.5 0.8]
+        Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-0.5 -0.4 -0.5  0.5 -0.4 -0.5  0.5 -0.4 0.5  -0.5 -0.4 0.5]
+        Material "glass"
+        AttributeBegin
+          Translate 0 0.2 0
+          AreaLightSource "diffuse" "rgb L" [50 50 50]
+          Shape "sphere" "float radius" 0.35
+        AttributeEnd
+        ObjectInstance "thing"
+      ObjectEnd
+      ObjectBegin "shard"
+        Material "mirror"
+        Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-0.5 0 0  0.5 0 0.1  0 0.9 0.05]
+      ObjectEnd
+      AttributeBegin
+        Translate -1.1 -1.5 0.5
+        ObjectInstance "thing"
+      AttributeEnd
+      AttributeBegin
+        AreaLightSource "diffuse" "rgb L" [10 9 8]
+        Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [0.5 1.99 -0.5  0.5 1.99 0.5  -0.5 1.99 0.5  -0.5 1.99 -0.5]
+      AttributeEnd
+      Material "matte" "rgb Kd" [0.7 0.7 0.7]
+      Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [2 -2 -2  -2 -2 -2  -2 -2 2  2 -2 2]
+      AttributeBegin
+        Translate 1.0 -1.3 0.2
+        Rotate 35 1 0 0
+        Scale 1.2 0.7 1.0
+        ObjectInstance "thing"
+        ObjectInstance "nothing"
+      AttributeEnd
+      Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [2 -2 2  -2 -2 2  -2 2 2  2 2 2]
+      AttributeBegin
+        Translate 0.2 -1.9 -0.9
+        ObjectInstance "shard"
+      AttributeEnd
+    WorldEnd
+    '''
+    ps = capi.ParsedScene(text=text)
+    d = ps.desc
+    assert d.n_instances == 3 and d.n_spheres == 1 and d.n_triangles == 9
+    assert [d.meshes[i].object for i in range(d.n_meshes)] == [1, 2, 0, 0, 0]
+    assert d.spheres[0].object == 1 and d.spheres[0].area_light == -1
+    assert [(d.instances[i].object, d.instances[i].before_triangle) for i in range(3)] == [(0, 3), (0, 7), (1, 9)]
+    T = scenes
+    b = scenes.SceneBuilder()
+    b.look_at((0, 0, -6.5), (0, 0, 0), (0, 1, 0)); b.camera_perspective(fov=40.0); b.film(xresolution=32, yresolution=32)
+    b.pixel_filter_box(); b.sampler_sobol(4); b.integrator_path(maxdepth=4)
+    b.object_begin("thing")
+    b.material_matte((0.3, 0.5, 0.8))
+    b.shape_trianglemesh([(-0.5, -0.4, -0.5), (0.5, -0.4, -0.5), (0.5, -0.4, 0.5), (-0.5, -0.4, 0.5)], [0, 1, 2, 0, 2, 3])
+    b.material_glass()
+    ts = T.transform_translate(0.0, 0.2, 0.0)
+    b.shape_sphere(radius=0.35, object_to_world=ts[0], world_to_object=ts[1])
+    b.object_end()
+    b.object_begin("shard")
+    b.material_mirror()
+    b.shape_trianglemesh([(-0.5, 0.0, 0.0), (0.5, 0.0, 0.1), (0.0, 0.9, 0.05)], [0, 1, 2])
+    b.object_end()
+    b.object_instance("thing", T.transform_translate(-1.1, -1.5, 0.5))
+    b.area_light_source_diffuse(L=(10, 9, 8))
+    b.shape_trianglemesh([(0.5, 1.99, -0.5), (0.5, 1.99, 0.5), (-0.5, 1.99, 0.5), (-0.5, 1.99, -0.5)], [0, 1, 2, 0, 2, 3])
+    b.no_area_light()
+    b.material_matte((0.7, 0.7, 0.7))
+    b.shape_trianglemesh([(2, -2, -2), (-2, -2, -2), (-2, -2, 2), (2, -2, 2)], [0, 1, 2, 0, 2, 3])
+    b.object_instance("thing", T.transform_mul(T.transform_mul(T.transform_translate(1.0, -1.3, 0.2), T.transform_rotate_x(35.0)), T.transform_scale(1.2, 0.7, 1.0)))
+    b.shape_trianglemesh([(2, -2, 2), (-2, -2, 2), (-2, 2, 2), (2, 2, 2)], [0, 1, 2, 0, 2, 3])
+    b.object_instance("shard", T.transform_translate(0.2, -1.9, -0.9))
+    ref = b.build()
+    for i in range(3):
+        assert np.array_equal(bits(list(d.instances[i].instance_to_world)), bits(list(ref.desc.instances[i].instance_to_world))), i
+        assert np.array_equal(bits(list(d.instances[i].world_to_instance)), bits(list(ref.desc.instances[i].world_to_instance))), i
+    a, r = oracle.scene(ps), oracle.scene(ref)
+    assert a.info.n_lights == 2
+    xa, ca, _ = a.render(threads=2)
+    xr, cr, _ = r.render(threads=2)
+    assert np.array_equal(bits(xa), bits(xr)) and ca == cr and xa[..., :3].max() > 0
+    a.close(); r.close()
+
+
 def test_materials_from_pbrt_text():
     """Material / MakeNamedMaterial for every supported type: parameters, defaults (create_*_material) and
     TextureParams' precedence (core/param_set/texture_params.rs:36-83: constant values come from the material
