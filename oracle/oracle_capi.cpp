@@ -148,6 +148,19 @@ void orc_rng_floats(uint64_t seq, int use_seq, uint32_t n, float* out_f, uint32_
     if (use_seq) r.set_sequence(seq);
     for (uint32_t i = 0; i < n; i++) { if (out_u) out_u[i] = r.uniform_uint32(); else out_f[i] = r.uniform_float(); }
 }
+// core/base/functions.rs:64-152, bounds3.rs:184-195 (the reference's tests/bitops.rs, find_interval.rs, bounds.rs)
+uint32_t orc_log2int(uint32_t v) { return log2int(v); }
+uint32_t orc_log2int64(uint64_t v) { return 63u - (uint32_t)__builtin_clzll(v); }
+uint32_t orc_round_up_pow2(uint32_t v) { return round_up_pow2(v); }
+uint32_t orc_ctz(uint32_t v) { return v ? (uint32_t)__builtin_ctz(v) : 32u; }
+uint32_t orc_find_interval_cdf(const float* cdf, uint32_t n, float u) { return (uint32_t)Distribution1D::find_interval_cdf(std::vector<Float>(cdf, cdf + n), u); }
+float orc_bounds_distance_squared(const float b[6], const float p[3]) { return Bounds3(V3(b[0], b[1], b[2]), V3(b[3], b[4], b[5])).distance_squared(V3(p[0], p[1], p[2])); }
+void orc_bounds_union(const float a[6], int a_default, const float b[6], int b_is_point, float out[6]) {
+    Bounds3 ba = a_default ? Bounds3() : Bounds3(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]));
+    Bounds3 r = b_is_point == 1 ? bunion_p(ba, V3(b[0], b[1], b[2]))
+                                : bunion(ba, b_is_point == 2 ? Bounds3() : Bounds3(V3(b[0], b[1], b[2]), V3(b[3], b[4], b[5])));      // 2: Bounds3::default()
+    out[0] = r.min.x; out[1] = r.min.y; out[2] = r.min.z; out[3] = r.max.x; out[4] = r.max.y; out[5] = r.max.z;
+}
 float orc_next_float_up(float v) { return next_float_up(v); }
 float orc_next_float_down(float v) { return next_float_down(v); }
 // Distribution1D: returns offset; writes pdf / remapped

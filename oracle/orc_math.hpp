@@ -155,6 +155,18 @@ struct Bounds3 {
         return 2.0f * (d.x * d.y + d.x * d.z + d.y * d.z);
     }
     V3 lerp(V3 t) const { return V3(lerpf(t.x, min.x, max.x), lerpf(t.y, min.y, max.y), lerpf(t.z, min.z, max.z)); }
+    // bounds3.rs:184-195
+    Float distance_squared(V3 p) const {
+        Float d = 0.0f;
+        for (int i = 0; i < 3; i++) {
+            Float a = min[i] - p[i], b = p[i] - max[i];
+            Float m = a >= b ? a : b;
+            Float delta = 0.0f >= m ? 0.0f : m;
+            d += delta * delta;
+        }
+        return d;
+    }
+    Float distance(V3 p) const { return std::sqrt(distance_squared(p)); }
 };
 inline Float min_le(Float a, Float b) { return a <= b ? a : b; }   // bounds3.rs:40-46
 inline Float max_ge(Float a, Float b) { return a >= b ? a : b; }

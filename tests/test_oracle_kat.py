@@ -188,6 +188,69 @@ def test_next_float(oracle):
     assert lib.orc_next_float_up(0.0) > 0 and lib.orc_next_float_down(0.0) < 0
 
 
+def test_l0_helpers(oracle):
+    """tests/bitops.rs:5-57 (log2, power-of-two, ctz, round_up_pow2), tests/find_interval.rs:5-29 (through find_interval_cdf, the
+    only instantiation on the path), tests/bounds.rs:46-117 (point distance, unions), src/core/base/functions.rs:210-232."""
+    L = oracle.lib
+    for f, rt in (("orc_log2int", C.c_uint32), ("orc_log2int64", C.c_uint32), ("orc_round_up_pow2", C.c_uint32), ("orc_ctz", C.c_uint32),
+                  ("orc_find_interval_cdf", C.c_uint32), ("orc_bounds_distance_squared", C.c_float)):
+        getattr(L, f).restype = rt
+    L.orc_log2int.argtypes = [C.c_uint32]; L.orc_round_up_pow2.argtypes = [C.c_uint32]; L.orc_ctz.argtypes = [C.c_uint32]
+    L.orc_log2int64.argtypes = [C.c_uint64]
+    L.orc_find_interval_cdf.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+    L.orc_bounds_distance_squared.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_bounds_union.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_bounds_union.restype = None
+    for i in range(32):
+        assert L.orc_log2int(1 << i) == i and L.orc_log2int64(1 << i) == i and L.orc_ctz(1 << i) == i
+    for i in range(1, 31):
+        assert L.orc_log2int((1 << i) + 1) == i and L.orc_log2int64((1 << i) + 1) == i
+    for i in range(64):
+        assert L.orc_log2int64(1 << i) == i
+    assert [L.orc_round_up_pow2(v) for v in (1, 2, 3, 4, 5, 7)] == [1, 2, 4, 4, 8, 8]
+    assert [L.orc_log2int(v) for v in (2, 3, 4)] == [1, 1, 2]
+    rng = np.random.default_rng(1)
+    for v in np.concatenate([rng.integers(1, 1 << 24, 20000), [(1 << k) + d for k in range(1, 24) for d in (-1, 0, 1)]]):
+        v = int(v)
+        if v < 1:
+            continue
+        want = v if (v & (v - 1)) == 0 else 1 << (v.bit_length())
+        assert L.orc_round_up_pow2(v) == want
+    a = np.arange(10, dtype=np.float32)
+
+    def fi(u):
+        return L.orc_find_interval_cdf(a.ctypes.data, len(a), float(u))
+    assert fi(-1.5) == 0 and fi(100.0) == len(a) - 2
+    for i in range(len(a) - 1):
+        assert fi(float(i)) == i and fi(i + 0.25) == i
+        if i > 0:
+            assert fi(i - 0.5) == i - 1
+
+    def d2(b, p):
+        b = np.array(b, np.float32); p = np.array(p, np.float32)
+        return L.orc_bounds_distance_squared(b.ctypes.data, p.ctypes.data)
+    unit = (0, 0, 0, 1, 1, 1)
+    for p in ((0.5, 0.5, 0.5), (0, 1, 1), (0.25, 0.8, 1), (0, 0.25, 0.8), (0.7, 0, 0.8)):
+        assert d2(unit, p) == 0.0
+    for p, want in (((6, 1, 1), 5), ((0, -10, 1), 10), ((0.5, 0.5, 3), 2), ((0.5, 0.5, -3), 3), ((0.5, 3, 0.5), 2), ((0.5, -3, 0.5), 3), ((3, 0.5, 0.5), 2), ((-3, 0.5, 0.5), 3)):
+        assert d2(unit, p) == want * want
+    assert d2(unit, (4, 8, -10)) == 3 * 3 + 7 * 7 + 10 * 10 and d2(unit, (-6, -10, 8)) == 6 * 6 + 10 * 10 + 7 * 7
+    odd = (-1, -3, 5, 2, -2, 18)
+    assert d2(odd, (-0.99, -2, 5)) == 0.0 and d2(odd, (-3, -9, 22)) == 2 * 2 + 6 * 6 + 4 * 4
+
+    def union(a_, a_default, b_, point):
+        out = np.zeros(6, np.float32)
+        aa = np.array(a_, np.float32); bb = np.array(b_, np.float32)
+        L.orc_bounds_union(aa.ctypes.data, int(a_default), bb.ctypes.data, int(point), out.ctypes.data)
+        return [float(x) for x in out]
+    A = (-10, -10, 5, 0, 20, 10)
+    fmax, fmin = float(np.finfo(np.float32).max), float(np.finfo(np.float32).min)
+    default = [fmax, fmax, fmax, fmin, fmin, fmin]
+    assert union(A, False, default, 2) == [float(x) for x in A]                     # a.union(Bounds3::default()) == a
+    assert union(default, True, default, 2) == default
+    assert union(A, False, (-15, 10, 30), True) == [-15.0, -10.0, 5.0, 0.0, 20.0, 30.0]
+
+
 def test_pcg32_vectorised_matches_sequential(oracle):
     """scenes.pcg32_* (closed-form LCG jump) == the oracle's sequential RNG (core/rng.rs:8-67)."""
     for seq in (None, 0, 1, 12111, 2 ** 40 + 7):
