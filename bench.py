@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--max-depth", type=int, default=8)
-    ap.add_argument("--materials", default="matte", choices=["matte", "mixed"],
+    ap.add_argument("--materials", default="matte", choices=["matte", "mixed", "textured"],
                     help="matte = BASELINE config 2 (the headline); mixed = killeroo-class stand-in for config 4 (secondary number)")
     ap.add_argument("--sampler", default="sobol", choices=["sobol", "halton"], help="sobol = the headline; halton = the reference's default sampler (secondary number)")
     ap.add_argument("--light", default="quad", choices=["quad", "sphere"], help="quad = the headline; sphere = an analytic sphere light instead (secondary number: k_trace_sph / k_shade_*_sph)")
@@ -239,7 +239,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RT1M: %d random %s triangles%s, %dx%d, %s %d spp, path maxdepth %d, BVH sah/4, spatial lights"
-                                   % (sd.desc.n_triangles, "matte" if args.materials == "matte" else "mixed-material (matte/plastic/metal/glass/mirror/substrate)",
+                                   % (sd.desc.n_triangles, "matte" if args.materials == "matte" else ("mixed-material (matte/plastic/metal/glass/mirror/substrate)" + (", texture-driven colours and bump maps" if args.materials == "textured" else "")),
                                       " + a sphere area light" if args.light == "sphere" else "", args.res, args.res, "Sobol" if args.sampler == "sobol" else "Halton", info.spp, args.max_depth),
                        "partition": "16x16 film tiles round-robin over %d rank(s), RCCL all-reduce of the XYZW film" % world,
                        "rays_per_step": int(rays / max(1, args.steps)), "camera_samples_per_step": int(tot[8] / max(1, args.steps)),

@@ -661,7 +661,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     std::vector<PtMaterial> mats(std::max<uint32_t>(d->n_materials, 1));
     std::memset(mats.data(), 0, mats.size() * sizeof(PtMaterial));
     bool general_materials = false;
-    uint32_t n_matte_bins = 0, n_general_bins = 0;
+    uint32_t n_matte_bins = 0, n_general_bins = 0, n_tex_bins = 0;
     // textured materials: parameter block + one evaluation program per texture-driven parameter (pt_texture.h)
     std::vector<PtMatParams> mparams(mats.size());
     std::memset(mparams.data(), 0, mparams.size() * sizeof(PtMatParams));
@@ -714,8 +714,11 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         const bool general = d->materials[i].type != PT_MATERIAL_NONE && (d->materials[i].type != PT_MATERIAL_MATTE || mats[i].textured || d->n_instances > 0);
         if (general) general_materials = true;
         // shade-queue bin: one per material while they last, the remainder of a class shares its last bin
-        mats[i].sort_bin = general ? PT_SORT_GENERAL0 + std::min(n_general_bins++, PT_SORT_BINS - PT_SORT_GENERAL0 - 1u)
-                                   : std::min(n_matte_bins++, PT_SORT_GENERAL0 - 1u);
+        // (textured materials get the last 32 bins: their own queue segment and kernel; with object instances everything is
+        // shaded by one kernel, which reads the whole general..end range)
+        if (general && mats[i].textured && d->n_instances == 0) mats[i].sort_bin = PT_SORT_TEX0 + std::min(n_tex_bins++, PT_SORT_BINS - PT_SORT_TEX0 - 1u);
+        else mats[i].sort_bin = general ? PT_SORT_GENERAL0 + std::min(n_general_bins++, PT_SORT_TEX0 - PT_SORT_GENERAL0 - 1u)
+                                        : std::min(n_matte_bins++, PT_SORT_GENERAL0 - 1u);
     }
 
     PtScene& sc = ctx->sc;

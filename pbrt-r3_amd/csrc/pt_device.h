@@ -275,15 +275,18 @@ struct PtQueues {
 };
 #define PT_Q_CUR 0u          // items in cur
 #define PT_Q_MATTE_END 1u    // material sort: end of the Matte segment of sorted
-#define PT_Q_GENERAL_END 2u  // material sort: end of the general segment
+#define PT_Q_GENERAL_END 2u  // material sort: end of the sorted queue (= end of the textured segment)
+#define PT_Q_TEX_BEGIN 3u    // material sort: end of the general segment = start of the textured-material segment
 #define PT_Q_NEXT 32u        // items pushed to next
 #define PT_Q_NEE 64u         // paths with a pending NEE resolve
 #define PT_Q_TICKET 96u      // work ticket (k_trace, k_shade Matte segment)
 #define PT_Q_TICKET2 128u    // work ticket of k_shade_general
+#define PT_Q_TICKET3 224u    // work ticket of k_shade_general_tex (textured-material segment)
 #define PT_Q_SHADOW 160u     // shadow rays queued
 #define PT_Q_PROBE 192u      // probe rays queued
 #define PT_SORT_BINS 256u
 #define PT_SORT_GENERAL0 128u
+#define PT_SORT_TEX0 224u       // bins [224, 256): materials with texture-driven parameters (lobes built per hit)
 #define PT_SORT_COUNT0 256u                       // [+256) bin counts
 #define PT_SORT_CURSOR0 (256u + 256u)             // [+256) bin cursors
 #define PT_Q_SEG_TICKET0 768u                     // k_trace: one ticket per queue segment (8 segments, 128 B apart)

@@ -1040,7 +1040,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_gen(PtScene sc, PtPaths
 extern "C" __global__ void k_prep(PtQueues Q, int mode) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (mode == 0) {            // before SHADE: nee and next start empty
-            Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_NEE] = 0; Q.counts[PT_Q_TICKET] = 0; Q.counts[PT_Q_TICKET2] = 0; Q.counts[PT_Q_SHADOW] = 0; Q.counts[PT_Q_PROBE] = 0;
+            Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_NEE] = 0; Q.counts[PT_Q_TICKET] = 0; Q.counts[PT_Q_TICKET2] = 0; Q.counts[PT_Q_TICKET3] = 0; Q.counts[PT_Q_SHADOW] = 0; Q.counts[PT_Q_PROBE] = 0;
             for (uint32_t k = 0; k < 8u; k++) Q.counts[PT_Q_SEG_TICKET0 + 32u * k] = 0;
         } else {                    // after SHADE: next becomes cur (host swaps the pointers)
             Q.counts[PT_Q_CUR] = Q.counts[PT_Q_NEXT]; Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_TICKET] = 0;
@@ -1486,6 +1486,7 @@ extern "C" __global__ void k_sort_scan(PtQueues Q) {          // one block of PT
     Q.counts[PT_SORT_CURSOR0 + t] = excl;
     Q.counts[PT_SORT_COUNT0 + t] = 0;                           // ready for the next bounce
     if (t == PT_SORT_GENERAL0) Q.counts[PT_Q_MATTE_END] = excl;
+    if (t == PT_SORT_TEX0) Q.counts[PT_Q_TEX_BEGIN] = excl;
     if (t == PT_SORT_BINS - 1) Q.counts[PT_Q_GENERAL_END] = s[t];
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc, PtPaths P, PtQueues Q) {
@@ -1557,8 +1558,6 @@ __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material,
         if (k == 5) mp.m.sigma = v.x;
         else { dst[k][0] = v.x; dst[k][1] = v.y; dst[k][2] = v.z; }
     }
-    unsigned char* z = reinterpret_cast<unsigned char*>(out);
-    for (uint32_t i = 0; i < sizeof(PtMaterial); i++) z[i] = 0;
     build_lobes(mp.m, mp.a_r, mp.a_u, mp.a_v, *out);
 }
 template <bool GENERAL, bool SPH, bool TEX = false, bool INST = false>
@@ -1825,14 +1824,14 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade_m
     shade_body<false, false>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], &Q.counts[PT_Q_TICKET]);
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<true, false>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
+    shade_body<true, false>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_TEX_BEGIN], &Q.counts[PT_Q_TICKET2]);
 }
 // scenes with spheres: hits and lights may be spheres
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_matte_sorted_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<false, true>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], &Q.counts[PT_Q_TICKET]);
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
+    shade_body<true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_TEX_BEGIN], &Q.counts[PT_Q_TICKET2]);
 }
 // scenes with object instances: hits inside an instance are rebuilt in instance space and transformed back; every material
 // rides in the general half of the sorted queue, so this one kernel shades them all
@@ -1841,7 +1840,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_inst(P
 }
 // scenes with textured materials (and possibly spheres): lobes are built per hit for the textured ones
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
-    shade_body<true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
+    shade_body<true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
 }
 
 // ============================================================ film
@@ -2109,9 +2108,14 @@ hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths&
         hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
         if (sc.n_instances) {
             hipLaunchKernelGGL(k_shade_general_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-        } else if (sc.textured) {
-            if (sc.n_spheres) hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-            else hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        } else if (sc.textured) {       // three segments: Matte | other constant materials | textured materials
+            if (sc.n_spheres) {
+                hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+                hipLaunchKernelGGL(k_shade_general_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            } else {
+                hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+                hipLaunchKernelGGL(k_shade_general, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            }
             hipLaunchKernelGGL(k_shade_general_tex, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
         } else if (sc.n_spheres) {
             hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);

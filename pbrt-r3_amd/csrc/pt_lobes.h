@@ -17,6 +17,9 @@ PT_HD inline float clamp_zero(float v) { return v < 0.0f ? 0.0f : v; }          
 PT_HD inline bool black(const float* c) { return c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f; }
 PT_HD inline PtLobe* push_lobe(PtMaterial& m, uint32_t kind, uint32_t type, const float* r) {
     PtLobe* l = &m.lobes[m.n_lobes++];
+    l->fresnel = 0;
+    l->t[0] = l->t[1] = l->t[2] = 0.0f; l->k[0] = l->k[1] = l->k[2] = 0.0f;
+    l->oa = l->ob = 0.0f;
     l->kind = kind; l->type = type;
     l->r[0] = r[0]; l->r[1] = r[1]; l->r[2] = r[2];
     l->eta_a = l->eta_b = l->fr_eta_i = l->fr_eta_t = 1.0f;
@@ -30,9 +33,10 @@ PT_HD inline void set_distribution(PtLobe* l, float ax, float ay) {             
     if (ay != ay) l->ay = 0.001f;
 }
 // a_r / a_u / a_v: "roughness" / "uroughness" / "vroughness" after the optional roughness_to_alpha remap (done by the caller on
-// the host: it needs logf).  `m` must be zero-initialised (n_lobes = 0, nonspecular = 0).
+// the host: it needs logf).  Every field of `m` read afterwards is written here.
 PT_HD inline void build_lobes(const pt_material& in, float a_r, float a_u, float a_v, PtMaterial& m) {
     m.type = in.type;
+    m.n_lobes = 0; m.nonspecular = 0; m.oren_a = 0.0f; m.oren_b = 0.0f;      // every field read afterwards is written here
     m.kd[0] = in.kd[0]; m.kd[1] = in.kd[1]; m.kd[2] = in.kd[2];
     m.sigma = in.sigma;
     m.bsdf_eta = 1.0f;

@@ -781,6 +781,23 @@ def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequ
                        lambda: b.material_glass(eta=1.5),
                        lambda: b.material_mirror(),
                        lambda: b.material_substrate(Kd=(0.2, 0.3, 0.5), Ks=(0.4, 0.4, 0.4))]
+            if materials == "textured":
+                # "crown-class" stand-in for BASELINE config 5: the mixed split with texture-driven parameters -- an image map
+                # (EWA), a closed-form checkerboard, fbm through a mix, and bump maps on two of the shapes
+                rng = np.random.default_rng(17)
+                img = b.image_pyramid(rng.random((256, 256, 3), dtype=np.float32))
+                gray = b.image_pyramid(rng.random((128, 128), dtype=np.float32))
+                t_img = b.texture_imagemap(img, uscale=4.0, vscale=4.0)
+                t_chk = b.texture_checkerboard((0.8, 0.7, 0.2), (0.2, 0.2, 0.25), uscale=8.0, vscale=8.0)
+                t_fbm = b.texture_mix((0.2, 0.3, 0.6), (0.9, 0.9, 0.9), amount=b.texture_fbm(octaves=6, to_world=transform_scale(8.0, 8.0, 8.0)))
+                t_bump = b.texture_scale(0.01, b.texture_imagemap(gray, trilinear=True, uscale=6.0, vscale=6.0))
+                t_wr = b.texture_scale(0.01, b.texture_wrinkled(octaves=4, to_world=transform_scale(10.0, 10.0, 10.0)))
+                setters = [lambda: b.material_matte(t_img, bumpmap=t_bump),
+                           lambda: b.material_plastic(Kd=t_chk, Ks=(0.3, 0.3, 0.3), roughness=0.1),
+                           lambda: b.material_metal(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=0.05),
+                           lambda: b.material_glass(eta=1.5),
+                           lambda: b.material_mirror(bumpmap=t_wr),
+                           lambda: b.material_substrate(Kd=t_fbm, Ks=(0.4, 0.4, 0.4))]
             for g, setm in enumerate(setters):
                 lo, hi = int(cuts[g]), int(cuts[g + 1])
                 if hi > lo:
