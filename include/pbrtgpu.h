@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 
 typedef enum {
     PT_OK = 0,
@@ -131,7 +131,7 @@ typedef enum {
 #define PT_ROUGHNESS_UNSET (-1.0f)   /* "uroughness"/"vroughness" not given: Metal and Uber fall back to "roughness" */
 
 /* Field defaults are the reference's create_*_material defaults; a field a material type does not
- * read is ignored.  160 bytes. */
+ * read is ignored.  156 bytes. */
 typedef struct {
     int32_t type;           /* pt_material_type */
     float kd[3];            /* "Kd": matte 0.5, plastic/uber 0.25, substrate 0.5 */
@@ -316,6 +316,8 @@ typedef struct {
     float world_bound[6];
     double bvh_build_ms;
     double upload_ms;
+    int32_t bvh_on_device;      /* ABI 5: 1 when the lower half of an HLBVH build ran on the GPU (pt_set_bvh_build) */
+    int32_t reserved;
 } pt_scene_info;
 
 /* ---- context ---------------------------------------------------------- */
@@ -382,6 +384,15 @@ pt_status pt_radiance_samples(pt_context* ctx, const pt_tile* tile, float* out_r
  * tree against the reference's ordered_prims (build/node.rs:138-151) without a GPU. */
 pt_status pt_bvh_leaf_order(const pt_scene_desc* desc, uint32_t* order_out /* n_triangles + n_spheres */,
                             uint32_t* n_nodes, uint32_t* n_leaves, uint32_t* max_stack);
+
+/* ABI 5.  Where the lower half of an HLBVH build runs (hlbvh.rs:354-428: Morton codes, radix sort, treelets, emit_lbvh): on the
+ * GPU, or in the threaded host builder.  Both produce the same tree; AUTO takes the GPU from 65536 primitives per list up.  The
+ * other split methods always build on the host.  Applies to the next pt_scene_upload. */
+typedef enum { PT_BVH_BUILD_AUTO = 0, PT_BVH_BUILD_HOST = 1, PT_BVH_BUILD_DEVICE = 2 } pt_bvh_build_where;
+pt_status pt_set_bvh_build(pt_context* ctx, int where);
+/* FNV-1a digests of the uploaded 4-wide node array and of the leaf record array (read back from the device): two uploads of one scene
+ * agree exactly when their trees and leaf orders do. */
+pt_status pt_scene_bvh_digest(pt_context* ctx, uint64_t* nodes_digest, uint64_t* records_digest);
 
 pt_status pt_get_counters(pt_context* ctx, pt_counters* out);
 pt_status pt_reset_counters(pt_context* ctx);

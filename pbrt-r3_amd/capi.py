@@ -131,7 +131,11 @@ class pt_counters(C.Structure):
 class pt_scene_info(C.Structure):
     _fields_ = [("sample_bounds", C.c_int32 * 4), ("cropped_bounds", C.c_int32 * 4), ("spp", C.c_int32),
                 ("n_lights", C.c_uint32), ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32),
-                ("world_bound", C.c_float * 6), ("bvh_build_ms", C.c_double), ("upload_ms", C.c_double)]
+                ("world_bound", C.c_float * 6), ("bvh_build_ms", C.c_double), ("upload_ms", C.c_double),
+                ("bvh_on_device", C.c_int32), ("reserved", C.c_int32)]
+
+
+BVH_BUILD_AUTO, BVH_BUILD_HOST, BVH_BUILD_DEVICE = 0, 1, 2
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<i4"), ("b0", "<f4"), ("b1", "<f4")])
@@ -142,7 +146,7 @@ SYMBOLS = [
     "pt_scene_upload", "pt_scene_info_get", "pt_film_clear", "pt_render", "pt_film_download_xyzw",
     "pt_film_device_xyzw", "pt_film_commit_xyzw", "pt_film_resolve_rgb", "pt_trace_closest", "pt_trace_any",
     "pt_generate_camera_rays", "pt_sobol_samples", "pt_radiance_samples", "pt_get_counters", "pt_reset_counters",
-    "pt_bvh_leaf_order", "pt_bsdf_eval", "pt_bsdf_sample",
+    "pt_bvh_leaf_order", "pt_bsdf_eval", "pt_bsdf_sample", "pt_set_bvh_build", "pt_scene_bvh_digest",
 ]
 
 _lib = None
@@ -182,6 +186,8 @@ def load_library(path=None):
     lib.pt_bsdf_sample.argtypes = [vp, u32, u32, vp, vp, u32, vp, vp, vp, vp]
     lib.pt_get_counters.argtypes = [vp, C.POINTER(pt_counters)]
     lib.pt_reset_counters.argtypes = [vp]
+    lib.pt_set_bvh_build.argtypes = [vp, C.c_int]
+    lib.pt_scene_bvh_digest.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.pt_bvh_leaf_order.argtypes = [C.POINTER(pt_scene_desc), vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     if path is None:
         _lib = lib
@@ -313,6 +319,16 @@ class Context:
         self._check(self.lib.pt_scene_info_get(self.h, C.byref(info)))
         self.info = info
         return info
+
+    def set_bvh_build(self, where):
+        """BVH_BUILD_AUTO / _HOST / _DEVICE: where the lower half of an HLBVH build runs at the next upload."""
+        self._check(self.lib.pt_set_bvh_build(self.h, int(where)))
+
+    def bvh_digest(self):
+        """(nodes, records) FNV-1a digests of the uploaded tree."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.pt_scene_bvh_digest(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     @property
     def film_shape(self):

@@ -15,6 +15,10 @@
 #include <cstring>
 #include <future>
 #include <limits>
+#include <memory>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace ptbvh {
 
@@ -24,12 +28,7 @@ struct Item {            // one primitive during construction (40 bytes, moved p
     float lo[3], hi[3], c[3];
     uint32_t prim;
 };
-struct BNode {
-    float lo[3], hi[3];
-    int32_t left = -1, right = -1;     // children (indices into the same vector) or -1
-    uint32_t first = 0, count = 0;     // leaf range in the item array
-    uint8_t axis = 0;
-};
+typedef LbvhNode BNode;
 struct Box {
     float lo[3], hi[3];
 };
@@ -393,33 +392,69 @@ struct Collapser {
 }  // namespace
 
 // Generic entry: any mix of primitives, each with its world bound and its ready-made 48-byte leaf record.
-bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_node_prims, Result* out) {
+bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_node_prims, Result* out, DeviceBuild* dev) {
+    const bool trace = std::getenv("PBRTGPU_BUILD_TRACE") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt[6] = {now(), 0, 0, 0, 0, 0};
+    tt[1] = tt[2] = tt[0];
     out->nodes.clear(); out->tris.clear(); out->rec_of_prim.clear();
     out->n_leaves = 0; out->max_stack = 1;
     if (n_prims == 0) { out->root_ref = PT_EMPTY_REF; return true; }
     if (n_prims >= PT_LEAF_FIRST_MASK - 16u) return false;      // a leaf reference keeps 28 bits for the first record
-    std::vector<Item> items(n_prims), scratch(n_prims);
-    const float eps = std::numeric_limits<float>::epsilon() * 2.0f;   // BOUND_EPS (build/node.rs:13)
-    for (uint32_t pi = 0; pi < n_prims; pi++) {
-        Item& it = items[pi];
-        for (int i = 0; i < 3; i++) {
-            it.lo[i] = prims[pi].lo[i] - eps;
-            it.hi[i] = prims[pi].hi[i] + eps;
-            it.c[i] = (it.lo[i] + it.hi[i]) * 0.5f;
-        }
-        it.prim = pi;
-    }
+    std::vector<Item> items, scratch;
+    std::vector<uint32_t> order;                                  // order[r] = primitive stored r-th
     const uint32_t n_items = n_prims;
+    auto init_items = [&]() {
+        items.resize(n_prims); scratch.resize(n_prims);
+        const float eps = std::numeric_limits<float>::epsilon() * 2.0f;   // BOUND_EPS (build/node.rs:13)
+        for (uint32_t pi = 0; pi < n_prims; pi++) {
+            Item& it = items[pi];
+            for (int i = 0; i < 3; i++) {
+                it.lo[i] = prims[pi].lo[i] - eps;
+                it.hi[i] = prims[pi].hi[i] + eps;
+                it.c[i] = (it.lo[i] + it.hi[i]) * 0.5f;
+            }
+            it.prim = pi;
+        }
+    };
     Builder bld;
-    bld.items = items.data();
-    bld.scratch = scratch.data();
     bld.max_prims = (uint32_t)std::min(std::max(max_node_prims, 0), 255);
     bld.method = split_method;
     bld.par_threshold = 32768;
     std::vector<BNode> tree;
     tree.reserve((size_t)n_items);
     int32_t root = 0;
-    if (split_method == PT_SPLIT_HLBVH) {
+    bool on_device = false;
+    if (split_method == PT_SPLIT_HLBVH && dev && dev->mode != PT_BVH_BUILD_HOST && n_items >= 2 &&
+        (dev->mode == PT_BVH_BUILD_DEVICE || n_items >= kDeviceMinPrims)) {
+        std::unique_ptr<float[]> raw(new float[(size_t)n_items * 6]);      // uninitialised: first touched by the threads that fill it
+        parallel_for(n_items, [&](size_t p0, size_t p1) {
+            for (size_t pi = p0; pi < p1; pi++) { std::memcpy(&raw[pi * 6], prims[pi].lo, 12); std::memcpy(&raw[pi * 6 + 3], prims[pi].hi, 12); }
+        });
+        uint32_t n_treelets = 0;
+        tt[1] = now();
+        const int rc = device_lbvh(dev->stream, raw.get(), n_items, bld.max_prims, &order, &tree, &n_treelets, &dev->err);
+        tt[2] = now();
+        if (rc < 0) return false;
+        if (rc == 0) {
+            on_device = true;
+            dev->used = true;
+            Hlbvh h{nullptr, nullptr, bld.max_prims, tree};
+            std::vector<int32_t> treelets(n_treelets);
+            for (uint32_t k = 0; k < n_treelets; k++) treelets[k] = (int32_t)k;
+            root = h.upper(treelets);
+            if (h.failed || root < 0) return false;
+        } else {
+            tree.clear();
+        }
+    }
+    if (!on_device) {
+        init_items();
+        bld.items = items.data();
+        bld.scratch = scratch.data();
+    }
+    if (on_device) {
+    } else if (split_method == PT_SPLIT_HLBVH) {
         std::vector<uint32_t> code;
         morton_sort(items, scratch, code);
         Hlbvh h{items.data(), code.data(), bld.max_prims, tree};
@@ -437,20 +472,28 @@ bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_
         bld.build(tree, 0, n_items, 0);
     }
 
+    tt[3] = now();
     std::memcpy(out->root_lo, tree[root].lo, 12);
     std::memcpy(out->root_hi, tree[root].hi, 12);
     // leaf records in final item order; PT_TRI_LAST closes each leaf
+    out->tris.reserve((size_t)n_items + 1);
     out->tris.resize(n_items);
     out->rec_of_prim.resize(n_items);
-    for (uint32_t r = 0; r < n_items; r++) {
-        const uint32_t prim = items[r].prim;
-        PtTri& tr = out->tris[r];
-        tr = prims[prim].rec;
-        tr.prim = prim;
-        tr.flags &= ~PT_TRI_LAST;
-        tr.light1 = 0;            // filled by the caller once lights are numbered
-        out->rec_of_prim[prim] = r;
+    if (!on_device) {
+        order.resize(n_items);
+        for (uint32_t r = 0; r < n_items; r++) order[r] = items[r].prim;
     }
+    parallel_for(n_items, [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; r++) {
+            const uint32_t prim = order[r];
+            PtTri& tr = out->tris[r];
+            tr = prims[prim].rec;
+            tr.prim = prim;
+            tr.flags &= ~PT_TRI_LAST;
+            tr.light1 = 0;            // filled by the caller once lights are numbered
+            out->rec_of_prim[prim] = (uint32_t)r;
+        }
+    });
     {   // one zero pad record: the kernels fetch triangle records two at a time
         PtTri pad;
         std::memset(&pad, 0, sizeof(pad));
@@ -466,9 +509,13 @@ bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_
         out->max_stack = 1;
         return true;
     }
+    tt[4] = now();
     Collapser col{tree, *out};
     out->root_ref = col.emit(root, 1);
     out->max_stack = 3 * col.max_depth4 + 2;
+    tt[5] = now();
+    if (trace) std::fprintf(stderr, "[bvh] n=%u device=%d pack %.1f lbvh %.1f tree(host)/upper %.1f records %.1f collapse %.1f ms\n", n_items, (int)on_device,
+                            tt[1] - tt[0], tt[2] - tt[1], tt[3] - (on_device ? tt[2] : tt[0]), tt[4] - tt[3], tt[5] - tt[4]);
     return true;
 }
 

@@ -2,11 +2,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <thread>
 #include <vector>
 #include "pt_device.h"
 #include "../../include/pbrtgpu.h"
 
 namespace ptbvh {
+
+// fn(begin, end) over [0, n) on up to 16 host threads; ranges below 64K items run inline.  Only for loops whose iterations are independent.
+template <class F> inline void parallel_for(size_t n, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw ? (hw < 16 ? hw : 16) : 4;
+    if (n < 65536 || nt < 2) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t step = (n + nt - 1) / nt;
+    for (size_t b = step; b < n; b += step) th.emplace_back(fn, b, b + step < n ? b + step : n);
+    fn((size_t)0, step < n ? step : n);
+    for (std::thread& t : th) t.join();
+}
 
 struct Result {
     std::vector<PtNode> nodes;          // 4-wide interior nodes, root first
@@ -31,7 +44,22 @@ struct Prim { float lo[3], hi[3]; PtTri rec; };
 void triangle_prim(const float* P, const uint32_t* indices, uint32_t t, uint32_t flags, Prim* out);
 void sphere_record(uint32_t sphere_index, uint32_t flags, PtTri* rec);
 void instance_record(uint32_t instance_index, PtTri* rec);
-bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_node_prims, Result* out);
+// Binary build node (BVHBuildNode, build/node.rs:20-60): a leaf covers items [first, first + count), an interior node has count 0.
+struct LbvhNode {
+    float lo[3], hi[3];
+    int32_t left = -1, right = -1;     // children (indices into the same array) or -1
+    uint32_t first = 0, count = 0;
+    uint8_t axis = 0;
+};
+// pt_hlbvh.hip: Morton codes, radix sort, treelets and emit_lbvh on the GPU.  raw_bounds = n x {lo[3], hi[3]} (host memory, not yet
+// inflated).  On success (0) order[k] = primitive stored k-th, nodes[0 .. n_treelets) are the treelet roots in Morton order.  Returns 1
+// when the host has to build instead (a range needs the centroid-median fallback, non-finite bounds, no memory), -1 on a HIP error.
+int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, std::vector<uint32_t>* order, std::vector<LbvhNode>* nodes,
+                uint32_t* n_treelets, hipError_t* err);
+// Where the lower half of an HLBVH build runs: PT_BVH_BUILD_AUTO picks the device from kDeviceMinPrims primitives up.
+struct DeviceBuild { hipStream_t stream; int mode; bool used; hipError_t err; };
+const uint32_t kDeviceMinPrims = 1u << 16;
+bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_node_prims, Result* out, DeviceBuild* dev = nullptr);
 bool build(const float* P, const uint32_t* indices, const uint32_t* tri_flags, uint32_t n_tris, const SpherePrim* spheres, uint32_t n_spheres,
            int split_method, int max_node_prims, Result* out);
 

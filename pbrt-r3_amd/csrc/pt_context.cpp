@@ -68,6 +68,8 @@ struct pt_context {
     uint32_t n_materials = 0;
     uint32_t max_stack = 1;
     uint32_t film_w = 0, film_h = 0;
+    int bvh_build_where = PT_BVH_BUILD_AUTO;
+    size_t n_nodes_up = 0, n_tris_up = 0;
 
     // ---- traversal scratch
     DevBuf d_spill, d_err, d_counters, d_ticket;
@@ -458,7 +460,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     double t0 = now_ms();
     // ---- BVH (host) ---------------------------------------------------------
     std::vector<uint32_t> tri_flags(d->n_triangles);
-    for (uint32_t t = 0; t < d->n_triangles; t++) {
+    ptbvh::parallel_for(d->n_triangles, [&](size_t t0_, size_t t1_) {
+    for (size_t t = t0_; t < t1_; t++) {
         uint32_t mf = d->meshes[d->tri_mesh[t]].flags, f = 0;
         if (!(mf & PT_MESH_TWO_SIDED)) f |= PT_TRI_ONE_SIDED;
         if (((mf & PT_MESH_REVERSE_ORIENTATION) != 0) ^ ((mf & PT_MESH_SWAPS_HANDEDNESS) != 0)) f |= PT_TRI_FLIP;
@@ -467,6 +470,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (mat >= 0 && d->materials[mat].type != PT_MATERIAL_NONE) f |= (uint32_t)(mat + 1) << PT_TRI_MATERIAL_SHIFT;
         tri_flags[t] = f;
     }
+    });
     std::vector<PtSphere> sph;
     std::vector<ptbvh::SpherePrim> sprims;
     build_spheres(d, sph, sprims);
@@ -493,6 +497,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     const int max_node_prims = d->max_node_prims > 0 ? d->max_node_prims : 4;
     const char* hlbvh_msg = "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)";
     // objects first: an instance's bound is its object's root bound under the instance transform
+    ptbvh::DeviceBuild dev_build{ctx->stream, ctx->bvh_build_where, false, hipSuccess};
     struct ObjectBvh { std::vector<Entry> list; ptbvh::Result res; float lo[3], hi[3]; bool direct = false; };
     std::vector<ObjectBvh> objs(n_objects);
     auto fill_prim = [&](const Entry& en, ptbvh::Prim* pr) {
@@ -514,7 +519,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             ob.res.max_stack = 0; ob.res.max_leaf = 1;
             std::memcpy(ob.lo, prims[0].lo, 12); std::memcpy(ob.hi, prims[0].hi, 12);
         } else if (!prims.empty()) {
-            if (!ptbvh::build_prims(prims.data(), (uint32_t)prims.size(), d->split_method, max_node_prims, &ob.res)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, hlbvh_msg);
+            if (!ptbvh::build_prims(prims.data(), (uint32_t)prims.size(), d->split_method, max_node_prims, &ob.res, &dev_build))
+                return dev_build.err != hipSuccess ? ctx->hip_fail(dev_build.err, "HLBVH build on the device") : ctx->fail(PT_ERR_INVALID_ARGUMENT, hlbvh_msg);
             ob.res.tris.pop_back();          // the pad record: one for the whole array, below
             std::memcpy(ob.lo, ob.res.root_lo, 12); std::memcpy(ob.hi, ob.res.root_hi, 12);
         }
@@ -528,9 +534,12 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     ptbvh::Result bvh;
     {
         std::vector<ptbvh::Prim> prims(world.size());
+        ptbvh::parallel_for(world.size(), [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) if (world[i].kind != 2) fill_prim(world[i], &prims[i]);
+        });
         for (size_t i = 0; i < world.size(); i++) {
             const Entry& en = world[i];
-            if (en.kind != 2) { fill_prim(en, &prims[i]); continue; }
+            if (en.kind != 2) continue;
             const pt_instance& in = d->instances[en.idx];
             const ObjectBvh& ob = objs[in.object];
             const float* m = in.instance_to_world;          // motion_bounds of a static transform = transform_bounds (transform.rs:134-182)
@@ -546,7 +555,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             }
             ptbvh::instance_record(en.idx, &prims[i].rec);
         }
-        if (!ptbvh::build_prims(prims.data(), (uint32_t)prims.size(), d->split_method, max_node_prims, &bvh)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, hlbvh_msg);
+        if (!ptbvh::build_prims(prims.data(), (uint32_t)prims.size(), d->split_method, max_node_prims, &bvh, &dev_build))
+            return dev_build.err != hipSuccess ? ctx->hip_fail(dev_build.err, "HLBVH build on the device") : ctx->fail(PT_ERR_INVALID_ARGUMENT, hlbvh_msg);
     }
     for (size_t prim = 0; prim < world.size(); prim++) if (world[prim].kind == 2) dinst[world[prim].idx].world_prim = (uint32_t)prim;
     // one node array and one record array: the world first, then each object with its references shifted
@@ -726,6 +736,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     pt_status st;
     if ((st = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_tris, bvh.tris.data(), bvh.tris.size())) != PT_OK) return st;
+    ctx->n_nodes_up = bvh.nodes.size(); ctx->n_tris_up = bvh.tris.size();
     if ((st = upload(ctx, ctx->d_tri_info, tinfo.data(), tinfo.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_materials, mats.data(), mats.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_lights, lights.data(), lights.size())) != PT_OK) return st;
@@ -966,6 +977,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     std::memcpy(inf.world_bound + 3, sc.wb_max, 12);
     inf.bvh_build_ms = t1 - t0;
     inf.upload_ms = t2 - t1;
+    inf.bvh_on_device = dev_build.used ? 1 : 0;
+    inf.reserved = 0;
     ctx->have_scene = true;
     return PT_OK;
 }
@@ -1349,6 +1362,30 @@ pt_status pt_bvh_leaf_order(const pt_scene_desc* d, uint32_t* order_out, uint32_
     if (n_leaves) *n_leaves = bvh.n_leaves;
     if (max_stack) *max_stack = bvh.max_stack;
     return PT_OK;
+}
+
+pt_status pt_set_bvh_build(pt_context* ctx, int where) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    if (where != PT_BVH_BUILD_AUTO && where != PT_BVH_BUILD_HOST && where != PT_BVH_BUILD_DEVICE) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown BVH build location");
+    ctx->bvh_build_where = where;
+    return PT_OK;
+}
+
+pt_status pt_scene_bvh_digest(pt_context* ctx, uint64_t* nodes_digest, uint64_t* records_digest) {
+    if (!ctx || !nodes_digest || !records_digest) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    (void)hipSetDevice(ctx->device);
+    auto digest = [&](const DevBuf& b, size_t bytes, uint64_t* out) -> pt_status {
+        std::vector<unsigned char> h(bytes);
+        if (bytes) PT_HIP(hipMemcpy(h.data(), b.p, bytes, hipMemcpyDeviceToHost));
+        uint64_t x = 1469598103934665603ull;
+        for (size_t i = 0; i < bytes; i++) { x ^= h[i]; x *= 1099511628211ull; }
+        *out = x;
+        return PT_OK;
+    };
+    pt_status st = digest(ctx->d_nodes, ctx->n_nodes_up * sizeof(PtNode), nodes_digest);
+    if (st != PT_OK) return st;
+    return digest(ctx->d_tris, ctx->n_tris_up * sizeof(PtTri), records_digest);
 }
 
 pt_status pt_get_counters(pt_context* ctx, pt_counters* out) {

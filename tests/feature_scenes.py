@@ -483,3 +483,23 @@ def scene_instances(split="sah", res=48, spp=8, depth=5, sampler="sobol"):
     b.object_instance("shard", T.transform_mul(T.transform_translate(-1.5, -0.5, 1.6), T.transform_rotate_x(-20.0)))
     b.object_instance("thing", T.transform_mul(T.transform_translate(1.6, 1.5, 1.7), T.transform_scale(0.2, 0.2, 0.2)))
     return b.build()
+
+
+def scene_hlbvh_cluster():
+    """More than maxnodeprims primitives in one Morton cell (a tight cluster, 40 exact duplicates) next to a sparse shell:
+    emit_lbvh runs out of code bits and falls back to centroid medians (hlbvh.rs:102-157, :183-192)."""
+    b = scenes.SceneBuilder()
+    b.look_at((0, 0, -5), (0, 0, 0), (0, 1, 0)); b.camera_perspective(fov=40.0)
+    b.film(xresolution=16, yresolution=16); b.pixel_filter_box(); b.sampler_sobol(1); b.integrator_path(maxdepth=1)
+    b.accelerator_bvh("hlbvh", 4)
+    b.material_matte((0.5, 0.5, 0.5))
+    rng = np.random.default_rng(2)
+    for k in range(60):
+        c = np.array([0.3, 0.2, 0.1]) + rng.random(3) * 1e-5
+        b.shape_trianglemesh([tuple(c), tuple(c + [1e-6, 0, 0]), tuple(c + [0, 1e-6, 0])], [0, 1, 2])
+    for k in range(40):
+        b.shape_trianglemesh([(-0.5, -0.5, 0.5), (-0.4, -0.5, 0.5), (-0.5, -0.4, 0.5)], [0, 1, 2])
+    for k in range(200):
+        c = rng.random(3) * 4 - 2
+        b.shape_trianglemesh([tuple(c), tuple(c + [0.05, 0, 0]), tuple(c + [0, 0.05, 0.02])], [0, 1, 2])
+    return b.build()

@@ -1,0 +1,100 @@
+"""The lower half of the HLBVH build on the GPU (pt_hlbvh.hip: Morton codes, radix sort, treelets, emit_lbvh) against the host
+builder -- which tests/test_host.py pins to the oracle's restatement of hlbvh.rs -- through the C ABI: the uploaded 4-wide node array
+and leaf record array must be byte-identical wherever the build ran."""
+import numpy as np
+import pytest
+
+import feature_scenes as fs
+from helpers import bits, pkg, random_rays, scenes
+
+pytestmark = pytest.mark.gpu
+HOST, DEVICE, AUTO = pkg.capi.BVH_BUILD_HOST, pkg.capi.BVH_BUILD_DEVICE, pkg.capi.BVH_BUILD_AUTO
+
+
+def _digests(sd, expect_device=True):
+    ctx = pkg.Context(0)
+    try:
+        ctx.set_bvh_build(HOST)
+        info = ctx.upload(sd)
+        assert info.bvh_on_device == 0
+        host = (ctx.bvh_digest(), info.n_nodes, info.n_leaves, tuple(info.world_bound))
+        o, d, tmax = random_rays(info, 20000, 5)
+        hits_host = ctx.trace_closest(o, d, tmax)
+        ctx.set_bvh_build(DEVICE)
+        info = ctx.upload(sd)
+        assert info.bvh_on_device == (1 if expect_device else 0)
+        dev = (ctx.bvh_digest(), info.n_nodes, info.n_leaves, tuple(info.world_bound))
+        hits_dev = ctx.trace_closest(o, d, tmax)
+        assert np.array_equal(hits_host["prim"], hits_dev["prim"]) and np.array_equal(bits(hits_host["t"]), bits(hits_dev["t"]))
+        return host, dev
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n,leaf", [(12, 4), (13, 1), (1024, 4), (1025, 5), (4000, 4), (70001, 4), (300000, 8), (300000, 255)])
+def test_device_build_matches_host_build(n, leaf):
+    """Sizes around the sort tile (1024 keys) and the wave (64); leaf sizes 1 .. 255.  The enclosure's ceiling and light quads are
+    four triangles whose boxes share one centre, so below four primitives per leaf emit_lbvh needs the median fallback: host build."""
+    sd = scenes.rt1m(n, res=16, spp=1, max_depth=1)
+    sd.desc.split_method = 1
+    sd.desc.max_node_prims = leaf
+    host, dev = _digests(sd, expect_device=leaf >= 4)
+    assert host == dev
+
+
+def test_device_build_clustered_geometry():
+    """Geometry concentrated in a few Morton cells: a handful of large treelets, deep bit levels, uneven level widths."""
+    rng = np.random.default_rng(11)
+    b = scenes.SceneBuilder()
+    b.look_at((0, 0, -5), (0, 0, 0), (0, 1, 0)); b.camera_perspective(fov=40.0)
+    b.film(xresolution=16, yresolution=16); b.pixel_filter_box(); b.sampler_sobol(1); b.integrator_path(maxdepth=1)
+    b.accelerator_bvh("hlbvh", 8)
+    b.material_matte((0.5, 0.5, 0.5))
+    centers = np.concatenate([rng.normal((0.5, 0.2, -0.3), 0.1, (60000, 3)), rng.normal((-0.7, -0.6, 0.6), 0.05, (30000, 3)),
+                              rng.uniform(-2, 2, (500, 3))]).astype(np.float32)
+    off = rng.uniform(-0.002, 0.002, (len(centers), 3, 3)).astype(np.float32)
+    verts = (centers[:, None, :] + off).reshape(-1, 3)
+    b.shape_trianglemesh_fast(verts, np.arange(len(verts)), twosided=True)
+    host, dev = _digests(b.build())
+    assert host == dev
+
+
+def test_device_build_gives_way_to_host_for_median_fallback():
+    """A Morton cell with more than maxnodeprims primitives needs split_node's re-sort: the device reports it, the host builds,
+    and the scene uploads as if the device had never been asked."""
+    host, dev = _digests(fs.scene_hlbvh_cluster(), expect_device=False)
+    assert host == dev
+
+
+def test_auto_picks_device_from_64k_primitives():
+    ctx = pkg.Context(0)
+    try:
+        for n, want in ((65535 - 12, 0), (70000, 1)):
+            sd = scenes.rt1m(n, res=16, spp=1, max_depth=1)
+            sd.desc.split_method = 1
+            assert ctx.upload(sd).bvh_on_device == want
+        sd.desc.split_method = 0           # SAH always builds on the host
+        ctx.set_bvh_build(DEVICE)
+        assert ctx.upload(sd).bvh_on_device == 0
+        with pytest.raises(pkg.PtError):
+            ctx.set_bvh_build(7)
+    finally:
+        ctx.close()
+
+
+def test_instanced_scene_with_device_built_object_trees(oracle):
+    """Every primitive list (the world and each object) goes through the device builder; per-sample radiance stays the oracle's."""
+    sd = fs.scene_instances(split="hlbvh")
+    ctx = pkg.Context(0)
+    try:
+        ctx.set_bvh_build(DEVICE)
+        info = ctx.upload(sd)
+        assert info.bvh_on_device == 1
+        osc = oracle.scene(sd)
+        sb = list(info.sample_bounds)
+        cx, cy = (sb[0] + sb[2]) // 2, (sb[1] + sb[3]) // 2
+        tile = (cx - 8, cy - 8, cx + 8, cy + 8)
+        assert np.array_equal(bits(ctx.radiance_samples(tile)), bits(osc.radiance_samples(tile)))
+        osc.close()
+    finally:
+        ctx.close()
