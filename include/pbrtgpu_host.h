@@ -15,7 +15,7 @@
  *               measured copper spectrum); Texture "constant" / "scale" / "mix" (folded when constant), "checkerboard"
  *               (2-D with uv / spherical / cylindrical / planar mapping, closed-form or point-sampled; 3-D), "uv",
  *               "bilerp", "dots", "fbm", "wrinkled", "windy", "marble" on colour parameters and Matte's sigma
- *               and "imagemap" (PNG / TGA / PFM files; MIP pyramid, EWA or trilinear) on colour parameters and Matte's
+ *               and "imagemap" (PNG / TGA / PFM / EXR files; MIP pyramid, EWA or trilinear) on colour parameters and Matte's
  *               sigma (evaluated per hit with ray differentials); "bumpmap" with any of those float textures or a number
  *   lights      diffuse area lights
  *   camera      perspective;  filters box / gaussian / mitchell / sinc / triangle

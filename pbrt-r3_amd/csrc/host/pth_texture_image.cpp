@@ -1,6 +1,7 @@
 // pth_texture_image.cpp -- see pth_texture_image.h.
 #include "pth_texture_image.h"
 #include <zlib.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -170,6 +171,152 @@ bool read_tga(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
     return true;
 }
 
+// ---- OpenEXR (image::open -> codecs::openexr: the R, G, B channels of a single-part scan-line file as f32; alpha is read and
+// dropped by convert_from_rgba32f, read_image.rs:112-142).  Pixel types half and float; compression none, RLE, ZIPS, ZIP -- the
+// lossless byte-stream schemes; PIZ / PXR24 / B44 / DWA files are reported, not approximated.
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {                                   // subnormal half: normalise
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+struct ExrChannel { std::string name; int type = 0; };
+
+bool exr_unpack_block(const uint8_t* src, size_t n_src, int compression, std::vector<uint8_t>* raw, std::string* err) {
+    const size_t want = raw->size();
+    if (n_src == want) { std::memcpy(raw->data(), src, want); return true; }      // stored: compression did not pay
+    std::vector<uint8_t> tmp(want);
+    if (compression == 1) {                      // RLE: count < 0 -> -count literal bytes, else count + 1 copies of the next byte
+        size_t i = 0, o = 0;
+        while (i < n_src) {
+            const int c = (int8_t)src[i++];
+            if (c < 0) {
+                const size_t k = (size_t)(-c);
+                if (i + k > n_src || o + k > want) { *err = "EXR: corrupt RLE block"; return false; }
+                std::memcpy(&tmp[o], src + i, k); i += k; o += k;
+            } else {
+                const size_t k = (size_t)c + 1;
+                if (i >= n_src || o + k > want) { *err = "EXR: corrupt RLE block"; return false; }
+                std::memset(&tmp[o], src[i++], k); o += k;
+            }
+        }
+        if (o != want) { *err = "EXR: short RLE block"; return false; }
+    } else {                                     // ZIPS / ZIP: one zlib stream per block
+        uLongf got = (uLongf)want;
+        if (uncompress(tmp.data(), &got, src, (uLong)n_src) != Z_OK || got != want) { *err = "EXR: corrupt ZIP block"; return false; }
+    }
+    for (size_t i = 1; i < want; i++) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);      // undo the byte delta predictor
+    const size_t half = (want + 1) / 2;                                                     // undo the even / odd byte split
+    for (size_t i = 0; i < want; i++) (*raw)[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
+    return true;
+}
+
+bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
+    size_t pos = 0;
+    auto need = [&](size_t n) { return pos + n <= b.size(); };
+    auto rd_i32 = [&](size_t at) { int32_t v; std::memcpy(&v, &b[at], 4); return v; };
+    auto rd_str = [&](std::string* sv) {
+        const size_t start = pos;
+        while (pos < b.size() && b[pos] != 0) pos++;
+        if (pos >= b.size()) return false;
+        sv->assign((const char*)&b[start], pos - start);
+        pos++;
+        return true;
+    };
+    if (b.size() < 8 || rd_i32(0) != 20000630) { *err = "not an OpenEXR file"; return false; }
+    const uint32_t version = (uint32_t)rd_i32(4);
+    if ((version & 0xffu) != 2 || (version & 0x1a00u)) { *err = "EXR: tiled, deep and multi-part files are not supported (single-part scan-line files are)"; return false; }
+    pos = 8;
+    std::vector<ExrChannel> channels;
+    int compression = -1, dw[4] = {0, 0, -1, -1};
+    for (;;) {
+        std::string name, type;
+        if (!rd_str(&name)) { *err = "EXR: truncated header"; return false; }
+        if (name.empty()) break;
+        if (!rd_str(&type) || !need(4)) { *err = "EXR: truncated header"; return false; }
+        const int32_t size = rd_i32(pos);
+        pos += 4;
+        if (size < 0 || !need((size_t)size)) { *err = "EXR: truncated header"; return false; }
+        const size_t end = pos + (size_t)size;
+        if (name == "channels") {
+            while (pos < end && b[pos] != 0) {
+                ExrChannel ch;
+                if (!rd_str(&ch.name) || pos + 16 > end) { *err = "EXR: bad channel list"; return false; }
+                ch.type = rd_i32(pos);
+                if (rd_i32(pos + 8) != 1 || rd_i32(pos + 12) != 1) { *err = "EXR: subsampled channels are not supported"; return false; }
+                pos += 16;
+                channels.push_back(ch);
+            }
+        } else if (name == "compression" && size == 1) compression = b[pos];
+        else if (name == "dataWindow" && size == 16) for (int i = 0; i < 4; i++) dw[i] = rd_i32(pos + 4 * (size_t)i);
+        pos = end;
+    }
+    if (channels.empty() || compression < 0 || dw[2] < dw[0] || dw[3] < dw[1]) { *err = "EXR: header lacks channels / compression / dataWindow"; return false; }
+    if (compression > 3) {
+        static const char* names[] = {"none", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
+        *err = std::string("EXR compression ") + (compression < 10 ? names[compression] : "?") + " is not supported (none, RLE, ZIPS, ZIP are)";
+        return false;
+    }
+    const int64_t w = (int64_t)dw[2] - dw[0] + 1, h = (int64_t)dw[3] - dw[1] + 1;
+    if (w > 65536 || h > 65536) { *err = "EXR: image too large"; return false; }
+    int rgb_at[3] = {-1, -1, -1};
+    size_t line_bytes = 0;
+    std::vector<size_t> ch_off(channels.size());
+    for (size_t c = 0; c < channels.size(); c++) {
+        if (channels[c].type != 1 && channels[c].type != 2) { *err = "EXR: uint channels are not supported (half and float are)"; return false; }
+        ch_off[c] = line_bytes;
+        line_bytes += (size_t)w * (channels[c].type == 1 ? 2 : 4);
+        if (channels[c].name == "R") rgb_at[0] = (int)c;
+        if (channels[c].name == "G") rgb_at[1] = (int)c;
+        if (channels[c].name == "B") rgb_at[2] = (int)c;
+    }
+    if (rgb_at[0] < 0 || rgb_at[1] < 0 || rgb_at[2] < 0) { *err = "EXR: no R, G, B channels (the reference's decoder needs an RGB layer)"; return false; }
+    const int lines_per_block = compression == 3 ? 16 : 1;
+    const size_t n_blocks = (size_t)((h + lines_per_block - 1) / lines_per_block);
+    if (!need(n_blocks * 8)) { *err = "EXR: truncated offset table"; return false; }
+    const size_t table = pos;
+    out->width = (int)w; out->height = (int)h;
+    out->rgb.assign((size_t)w * (size_t)h * 3, 0.0f);
+    std::vector<uint8_t> raw;
+    for (size_t k = 0; k < n_blocks; k++) {
+        uint64_t off;
+        std::memcpy(&off, &b[table + 8 * k], 8);
+        if (off + 8 > b.size()) { *err = "EXR: block offset outside the file"; return false; }
+        const int64_t y0 = (int64_t)rd_i32((size_t)off) - dw[1];
+        const int32_t n_src = rd_i32((size_t)off + 4);
+        if (y0 < 0 || y0 >= h || n_src < 0 || off + 8 + (uint64_t)n_src > b.size()) { *err = "EXR: bad block header"; return false; }
+        const int64_t lines = std::min<int64_t>(lines_per_block, h - y0);
+        raw.assign((size_t)lines * line_bytes, 0);
+        if (compression == 0) {
+            if ((size_t)n_src != raw.size()) { *err = "EXR: bad uncompressed block size"; return false; }
+            std::memcpy(raw.data(), &b[(size_t)off + 8], raw.size());
+        } else if (!exr_unpack_block(&b[(size_t)off + 8], (size_t)n_src, compression, &raw, err)) return false;
+        for (int64_t ly = 0; ly < lines; ly++) {
+            for (int c = 0; c < 3; c++) {
+                const ExrChannel& ch = channels[(size_t)rgb_at[c]];
+                const uint8_t* src = raw.data() + (size_t)ly * line_bytes + ch_off[(size_t)rgb_at[c]];
+                float* dst = &out->rgb[((size_t)(y0 + ly) * (size_t)w) * 3 + (size_t)c];
+                for (int64_t x = 0; x < w; x++) {
+                    if (ch.type == 1) { uint16_t hv; std::memcpy(&hv, src + 2 * x, 2); dst[3 * x] = half_to_float(hv); }
+                    else std::memcpy(&dst[3 * x], src + 4 * x, 4);
+                }
+            }
+        }
+    }
+    return true;
+}
+
 float inverse_gamma_correct(float v) {                    // core/base/functions.rs:22-28
     if (v <= 0.04045f) return v * 1.0f / 12.92f;
     return std::pow((v + 0.055f) * 1.0f / 1.055f, 2.4f);
@@ -259,7 +406,8 @@ bool read_image_file(const std::string& path, RgbImage* out, std::string* err) {
     if (ends_with(path, ".pfm")) return read_pfm(bytes, out, err);      // has_extension is case-sensitive (read_image.rs:184-186)
     if (ends_with(lower, ".png")) return read_png(bytes, out, err);
     if (ends_with(lower, ".tga")) return read_tga(bytes, out, err);
-    *err = "image format of \"" + path + "\" is not on the accelerated path (pfm, png, tga are)";
+    if (ends_with(lower, ".exr")) return read_exr(bytes, out, err);
+    *err = "image format of \"" + path + "\" is not on the accelerated path (pfm, png, tga, exr are)";
     return false;
 }
 

@@ -11,7 +11,7 @@ namespace pth {
 struct RgbImage { int width = 0, height = 0; std::vector<float> rgb; };     // 3 floats per pixel, top row first
 
 // read_image_gamma_correct(name, false): .pfm, .png (8-bit gray / gray+alpha / RGB / RGBA / palette, 16-bit RGB), .tga
-// (8-bit gray, 24 / 32-bit colour, raw or RLE).  Other formats of the reference's `image` crate are reported as unsupported.
+// (8-bit gray, 24 / 32-bit colour, raw or RLE), .exr (single-part scan-line, half / float R G B, none / RLE / ZIPS / ZIP).  Other formats of the reference's `image` crate are reported as unsupported.
 bool read_image_file(const std::string& path, RgbImage* out, std::string* err);
 
 struct Pyramid { pt_image desc; std::vector<float> texels; };

@@ -248,11 +248,112 @@ def test_front_end_pyramid_matches_numpy_restatement(tmp_path, case):
         assert np.array_equal(bits(g), bits(w))
 
 
+def write_exr(path, chans, compression, origin=(0, 0), version=2):
+    """A single-part scan-line OpenEXR file written from the format's published layout (independent of the reader under test).
+    chans: {name: (H x W array, "half" | "float")}; compression 0 none, 1 RLE, 2 ZIPS, 3 ZIP (4 = PIZ: header only)."""
+    import struct
+    names = sorted(chans)
+    h, w = chans[names[0]][0].shape
+
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(data)) + data
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", 1 if chans[n][1] == "half" else 2, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<4i", origin[0], origin[1], origin[0] + w - 1, origin[1] + h - 1)
+    hdr = struct.pack("<ii", 20000630, version) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
+    hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0))
+    hdr += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = 16 if compression == 3 else 1
+    blocks = []
+    for y0 in range(0, h, lines):
+        raw = b"".join(chans[n][0][y].astype("<f2" if chans[n][1] == "half" else "<f4").tobytes()
+                       for y in range(y0, min(h, y0 + lines)) for n in names)
+        data = raw
+        if compression in (1, 2, 3):
+            t = np.frombuffer(raw[0::2] + raw[1::2], np.uint8).astype(np.int32)
+            d = t.copy()
+            d[1:] = (t[1:] - t[:-1] + 128) & 255
+            d = d.astype(np.uint8).tobytes()
+            if compression == 1:
+                enc, i = bytearray(), 0
+                while i < len(d):
+                    run = 1
+                    while i + run < len(d) and run < 128 and d[i + run] == d[i]:
+                        run += 1
+                    if run >= 3:
+                        enc += struct.pack("b", run - 1) + d[i:i + 1]
+                        i += run
+                    else:
+                        j = i
+                        while j < len(d) and j - i < 127 and not (j + 2 < len(d) and d[j] == d[j + 1] == d[j + 2]):
+                            j += 1
+                        enc += struct.pack("b", -(j - i)) + d[i:j]
+                        i = j
+                enc = bytes(enc)
+            else:
+                enc = zlib.compress(d)
+            data = enc if len(enc) < len(raw) else raw
+        blocks.append((origin[1] + y0, data))
+    table_at = len(hdr)
+    off = table_at + 8 * len(blocks)
+    table, body = b"", b""
+    for y, data in blocks:
+        table += struct.pack("<Q", off + len(body))
+        body += struct.pack("<ii", y, len(data)) + data
+    open(path, "wb").write(hdr + table + body)
+
+
+@pytest.mark.parametrize("case", ["zip_half_rgba_window", "none_float", "rle_mixed", "zips_float_stored", "own_writer"])
+def test_exr_inputs(tmp_path, case):
+    """read_image.rs:145-183 hands .exr to the image crate: R, G, B as f32 (half widened exactly), alpha dropped; gamma is off for
+    .exr by default (imagemap.rs:116)."""
+    rng = np.random.default_rng(9)
+    if case == "zip_half_rgba_window":      # 3 blocks (16 + 16 + 5 lines), data window off the origin, a subnormal half
+        a = rng.random((37, 20, 4)).astype(np.float16)
+        a[0, 0, 0] = np.float16(6e-8)
+        a[5, 3, 1] = np.float16(-0.25)
+        write_exr(tmp_path / "a.exr", {"R": (a[..., 0], "half"), "G": (a[..., 1], "half"), "B": (a[..., 2], "half"), "A": (a[..., 3], "half")}, 3, origin=(3, -2))
+        rgb = a[..., :3].astype(np.float32)
+    elif case == "none_float":
+        rgb = rng.random((5, 9, 3), dtype=np.float32)
+        write_exr(tmp_path / "a.exr", {"R": (rgb[..., 0], "float"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "float")}, 0)
+    elif case == "rle_mixed":               # runs (flat regions) and literals; channels of different pixel types in one line
+        rgb = np.zeros((8, 16, 3), np.float32)
+        rgb[:, :8] = (0.5, 0.25, 0.125)
+        rgb[:, 8:] = rng.random((8, 8, 3)).astype(np.float16).astype(np.float32)
+        write_exr(tmp_path / "a.exr", {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "half")}, 1)
+    elif case == "zips_float_stored":       # random mantissas do not compress: blocks are stored raw at their full size
+        rgb = rng.random((4, 64, 3), dtype=np.float32)
+        write_exr(tmp_path / "a.exr", {"R": (rgb[..., 0], "float"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "float"), "Z": (rgb[..., 0], "float")}, 2)
+    else:                                   # the film writer's own output (uncompressed float), read back as a texture
+        rgb = rng.random((8, 8, 3), dtype=np.float32)
+        lib = capi.load_library()
+        lib.pth_write_image.argtypes = [C.c_char_p, C.c_void_p] + [C.c_int] * 6
+        assert lib.pth_write_image(str(tmp_path / "a.exr").encode(), rgb.ctypes.data_as(C.c_void_p), 8, 8, 0, 0, 8, 8) == 0
+    ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.exr"')
+    want = pyramid_ref(rgb, 3, 1.0, False, "repeat", "repeat")
+    got = front_end_levels(ps)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and np.array_equal(bits(g), bits(w))
+
+
+def test_exr_variants_outside_the_subset_are_reported(tmp_path):
+    y = np.ones((4, 4), np.float32)
+    write_exr(tmp_path / "piz.exr", {"R": (y, "half"), "G": (y, "half"), "B": (y, "half")}, 4)
+    write_exr(tmp_path / "lum.exr", {"Y": (y, "half")}, 0)
+    write_exr(tmp_path / "tiled.exr", {"R": (y, "half"), "G": (y, "half"), "B": (y, "half")}, 0, version=2 | 0x200)
+    for name, msg in (("piz.exr", "PIZ is not supported"), ("lum.exr", "no R, G, B channels"), ("tiled.exr", "tiled")):
+        with pytest.raises(capi.PtError) as e:
+            parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "%s"' % name)
+        assert msg in str(e.value), str(e.value)
+
+
 def test_unsupported_image_inputs_fail_loudly(tmp_path):
     open(tmp_path / "a.jpg", "wb").write(b"\xff\xd8\xff")
     with pytest.raises(capi.PtError) as e:
         parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.jpg"')
-    assert e.value.status == 4 and "not on the accelerated path" in str(e.value)
+    assert e.value.status == 4 and "not on the accelerated path (pfm, png, tga, exr are)" in str(e.value)
     with pytest.raises(capi.PtError) as e:
         parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "missing.png"')
     assert "File not found" in str(e.value)
