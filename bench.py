@@ -70,6 +70,7 @@ def main():
                     help="matte = BASELINE config 2 (the headline); mixed = killeroo-class stand-in for config 4 (secondary number)")
     ap.add_argument("--sampler", default="sobol", choices=["sobol", "halton"], help="sobol = the headline; halton = the reference's default sampler (secondary number)")
     ap.add_argument("--light", default="quad", choices=["quad", "sphere"], help="quad = the headline; sphere = an analytic sphere light instead (secondary number: k_trace_sph / k_shade_*_sph)")
+    ap.add_argument("--integrator", default="path", choices=["path", "ao"], help="path = the headline; ao = Integrator \"ao\" with 64 occlusion rays per camera sample (secondary number: an any-hit workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU sample (0 = auto, about 15 s)")
     args = ap.parse_args()
@@ -117,6 +118,8 @@ def main():
     pkg = importlib.import_module("pbrt-r3_amd")
     t0 = time.time()
     sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, materials=args.materials, sampler=args.sampler, light=args.light)
+    if args.integrator == "ao":
+        sd.desc.integrator, sd.desc.ao_samples, sd.desc.ao_cos_sample = pkg.capi.PT_INTEGRATOR_AO, 64, 1
     t_scene = time.time() - t0
     ctx = pkg.Context(local_rank)
     info = ctx.upload(sd)
@@ -196,7 +199,7 @@ def main():
         peak = 8000.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tp) and args.materials == "matte" and args.light == "quad":      # measured on the headline workload only
+        if os.path.exists(tp) and args.materials == "matte" and args.light == "quad" and args.integrator == "path":      # measured on the headline workload only
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:
@@ -247,6 +250,10 @@ def main():
                        "scene_gen_s": round(t_scene, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if args.integrator == "ao":
+            out["config"]["workload"] = out["config"]["workload"].replace("path maxdepth %d" % args.max_depth, "ao nsamples 64 cossample")
+            if roofline:
+                roofline["kernel"] = "k_trace + k_trace_batch (any hit)"
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -218,6 +218,11 @@ typedef enum {
     PT_SAMPLER_SOBOL = 0,   /* samplers/sobol.rs */
     PT_SAMPLER_HALTON = 1   /* samplers/halton.rs (the reference's default sampler) */
 } pt_sampler_type;
+/* PT_INTEGRATOR_AO: AOIntegrator::li (integrators/ao.rs:49-110) -- the camera ray's hit, then ao_samples occlusion rays over the
+ * hemisphere of the geometric normal, directions from the sampler's 2-D sample array (dimensions 5, 6 of sample number
+ * camera_sample * ao_samples + k; core/sampler/global_sampler.rs, samplers/sobol.rs:43-75).  Lights and materials play no part, except
+ * that the reference panics on a surface without a material and lets a bump map flip the frame: both are refused at upload. */
+typedef enum { PT_INTEGRATOR_PATH = 0, PT_INTEGRATOR_AO = 1 } pt_integrator_type;
 typedef enum { PT_LIGHTS_UNIFORM = 0, PT_LIGHTS_POWER = 1, PT_LIGHTS_SPATIAL = 2 } pt_light_strategy;
 
 typedef struct {
@@ -279,7 +284,11 @@ typedef struct {
     const pt_image* images;     /* MIP pyramids of the imagemap textures */
     uint32_t n_instances;
     const pt_instance* instances;
-    int32_t reserved[2];
+    /* ---- ABI 5: the SamplerIntegrator that runs on the wavefront */
+    int32_t integrator;         /* pt_integrator_type; 0 (zero-initialised descriptors) = path */
+    int32_t ao_samples;         /* ao "nsamples", default 64: one 2-D sample array of this size per camera sample (ao.rs:14-36) */
+    int32_t ao_cos_sample;      /* ao "cossample", default true */
+    int32_t reserved;
 } pt_scene_desc;
 
 /* Axis-aligned block of film *sample* pixels, half-open: the unit the reference

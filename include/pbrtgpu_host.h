@@ -19,7 +19,7 @@
  *               sigma (evaluated per hit with ray differentials); "bumpmap" with any of those float textures or a number
  *   lights      diffuse area lights
  *   camera      perspective;  filters box / gaussian / mitchell / sinc / triangle
- *   samplers    halton (the default), sobol;  integrator path;  accelerator bvh (sah, hlbvh, middle, equal)
+ *   samplers    halton (the default), sobol;  integrators path, ao;  accelerator bvh (sah, hlbvh, middle, equal)
  *   the full transform / attribute stack, named coordinate systems, Include, ObjectBegin / ObjectEnd / ObjectInstance
  * Anything else is reported as PT_ERR_UNSUPPORTED with a message naming the directive -- never silently
  * approximated.

@@ -19,6 +19,7 @@ typedef float Float;
 // core/base/constants.rs:16-36
 static const Float kPi = 3.14159265358979323846f;
 static const Float kInvPi = 0.31830988618379067154f;
+static const Float kInv2Pi = 0.15915494309189533577f;
 static const Float kPiOver2 = kPi / 2.0f;
 static const Float kPiOver4 = kPi / 4.0f;
 static const Float kOneMinusEpsilon = 0.99999994f;

@@ -149,11 +149,14 @@ struct Scene {
     // sampler / integrator
     SobolTables sobol;
     int32_t spp = 1, max_depth = 5, light_strategy = PT_LIGHTS_SPATIAL;
+    int32_t integrator = PT_INTEGRATOR_PATH, ao_samples = 64;
+    bool ao_cos_sample = true;
     int32_t sampler_kind = PT_SAMPLER_SOBOL;
     bool halton_at_center = false;
     void init_sampler(SobolSampler& sm) const {
         if (sampler_kind == PT_SAMPLER_HALTON) sm.init_halton((uint32_t)spp, sample_bounds, halton_at_center);
         else sm.init(&sobol, (uint32_t)spp, sample_bounds);
+        sm.array2d_n = integrator == PT_INTEGRATOR_AO ? (uint32_t)ao_samples : 0u;
     }
     Float rr_threshold = 1.0f;
 
@@ -639,6 +642,38 @@ inline RGB path_li(const Scene& sc, LightDistribution& ldist, Ray ray, SobolSamp
     return l;
 }
 
+// AOIntegrator::li (integrators/ao.rs:49-110).  A hit without a material makes the reference ask for the sample array a second
+// time and unwrap None; such scenes are refused before they get here, the loop body below is the first iteration.
+inline RGB ao_li(const Scene& sc, Ray ray, SobolSampler& sampler, RayCounters& rc) {
+    RGB l;
+    SurfHit isect;
+    rc.regular++;
+    QBVH::Stats st;
+    bool found = sc.bvh.intersect(ray, &isect, &st);
+    rc.nodes += st.nodes; rc.tris += st.tris;
+    if (!found) return l;
+    rc.vertices++;
+    const V3 n = face_forward(isect.n, ray.d * -1.0f);
+    const V3 s = normalize(isect.dpdu);
+    const V3 t = cross(isect.n, s);
+    const uint32_t n_samples = sampler.array2d_n;
+    for (uint32_t i = 0; i < n_samples; i++) {
+        const V2 u = sampler.array2d(i);
+        V3 wi;
+        Float pdf;
+        if (sc.ao_cos_sample) { wi = cosine_sample_hemisphere(u); pdf = std::fabs(wi.z) * kInvPi; }
+        else { wi = uniform_sample_hemisphere(u); pdf = kInv2Pi; }
+        wi = V3(wi.x * s.x + wi.y * t.x + wi.z * n.x, wi.x * s.y + wi.y * t.y + wi.z * n.y, wi.x * s.z + wi.y * t.z + wi.z * n.z);
+        Ray sh(offset_ray_origin(isect.p, isect.p_error, isect.n, wi), wi, kInfinity);
+        rc.shadow++;
+        QBVH::Stats st2;
+        bool occluded = sc.bvh.intersect_p(sh, &st2);
+        rc.nodes += st2.nodes; rc.tris += st2.tris;
+        if (!occluded) l = l + RGB(dot(wi, n) / (pdf * (Float)n_samples));
+    }
+    return l;
+}
+
 // validate_radiance_result (core/integrator/sampler.rs:151-176)
 inline RGB validate_radiance(RGB l) {
     if (!l.is_valid()) return RGB();
@@ -767,7 +802,7 @@ inline void render_tile(const Scene& sc, LightDistribution& ldist, const int32_t
                 RayDiff rdiff;
                 Ray ray = generate_ray(sc, cs, &rdiff);
                 rc.camera++;
-                RGB l = validate_radiance(path_li(sc, ldist, ray, sampler, rc, rdiff));
+                RGB l = validate_radiance(sc.integrator == PT_INTEGRATOR_AO ? ao_li(sc, ray, sampler, rc) : path_li(sc, ldist, ray, sampler, rc, rdiff));
                 if (radiance_out) { radiance_out[3 * k] = l.c[0]; radiance_out[3 * k + 1] = l.c[1]; radiance_out[3 * k + 2] = l.c[2]; k++; }
                 tile.add_sample(cs.p_film, l, 1.0f);
             } while (sampler.start_next_sample());
@@ -948,6 +983,7 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
     // Sobol' rounds the sample count up to a power of two (sobol.rs:23); Halton takes it as given
     spp = sampler_kind == PT_SAMPLER_HALTON ? std::max(1, d.spp) : (int32_t)round_up_pow2((uint32_t)std::max(1, d.spp));
     max_depth = d.max_depth; rr_threshold = d.rr_threshold; light_strategy = d.light_strategy;
+    integrator = d.integrator; ao_samples = d.ao_samples > 0 ? d.ao_samples : 64; ao_cos_sample = d.ao_cos_sample != 0;
     return true;
 }
 

@@ -222,6 +222,7 @@ struct SobolSampler {
     int64_t interval_sample_index = 0;
     static const uint32_t array_start_dim = 5;
     uint32_t array_end_dim = 5;
+    uint32_t array2d_n = 0;          // size of the one requested 2-D sample array (AOIntegrator::new, ao.rs:24-31); 0 = none
 
     void init_halton(uint32_t samples_per_pixel, const int32_t sb[4], bool at_center) {   // halton.rs:57-112
         kind = 1;
@@ -286,7 +287,13 @@ struct SobolSampler {
         current_sample = 0;
         dimension = 0;
         interval_sample_index = get_index_for_sample(0);
-        array_end_dim = array_start_dim;
+        array_end_dim = array_start_dim + (array2d_n ? 2u : 0u);      // sobol.rs:43-45, halton.rs:176-178
+    }
+    // Element k of get_2d_array(n) for the current pixel sample: start_pixel fills sample_array2d[0][j] from sample number j at
+    // dimensions (5, 6) for j < n * spp (sobol.rs:60-75), get_2d_array slices [n * current, n * current + n) (base_sampler.rs:59-70).
+    V2 array2d(uint32_t k) const {
+        const int64_t index = get_index_for_sample((int64_t)current_sample * (int64_t)array2d_n + (int64_t)k);
+        return V2(sample_dimension(index, array_start_dim), sample_dimension(index, array_start_dim + 1));
     }
     bool start_next_sample() {
         dimension = 0;
@@ -336,6 +343,12 @@ inline V3 cosine_sample_hemisphere(V2 u) {
     V2 d = concentric_sample_disk(u);
     Float z = std::sqrt(fmax_(0.0f, 1.0f - d.x * d.x - d.y * d.y));
     return V3(d.x, d.y, z);
+}
+inline V3 uniform_sample_hemisphere(V2 u) {             // sampling.rs:85-90
+    Float z = u.x;
+    Float r = std::sqrt(fmax_(0.0f, 1.0f - z * z));
+    Float phi = 2.0f * kPi * u.y;
+    return V3(r * std::cos(phi), r * std::sin(phi), z);
 }
 inline V3 uniform_sample_sphere(V2 u) {
     Float z = 1.0f - 2.0f * u.x;

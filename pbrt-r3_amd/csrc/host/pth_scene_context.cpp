@@ -863,7 +863,12 @@ public:
         desc.spp = sampler_params.find_one_int("pixelsamples", 16);
         if (quick_render) desc.spp = 1;                              // create_halton_sampler / create_sobol_sampler
         // integrator (integrators/path.rs:252-271)
-        if (integrator_name != "path") { fail("Integrator \"" + integrator_name + "\": only path is on the accelerated path"); return; }
+        if (integrator_name != "path" && integrator_name != "ao") { fail("Integrator \"" + integrator_name + "\": only path and ao are on the accelerated path"); return; }
+        desc.integrator = integrator_name == "ao" ? PT_INTEGRATOR_AO : PT_INTEGRATOR_PATH;
+        desc.ao_cos_sample = integrator_params.find_one_bool("cossample", true) ? 1 : 0;      // create_ao_integrator (ao.rs:118-138)
+        desc.ao_samples = integrator_params.find_one_int("nsamples", 64);
+        if (quick_render) desc.ao_samples = 1;
+        if (desc.integrator == PT_INTEGRATOR_AO && desc.ao_samples < 1) { fail("Integrator \"ao\": nsamples must be positive"); return; }
         desc.max_depth = integrator_params.find_one_int("maxdepth", 5);
         desc.rr_threshold = integrator_params.find_one_float("rrthreshold", 1.0f);
         std::string ls = integrator_params.find_one_string("lightsamplestrategy", "spatial");

@@ -81,6 +81,8 @@ struct pt_context {
     DevBuf d_pool;          // one slab carved into the SoA arrays of PtPaths
     PtPaths paths;
     DevBuf d_qa, d_qb, d_qnee, d_qshadow, d_qprobe, d_qsorted, d_counts, d_pixels;
+    DevBuf d_ao;             // AO integrator: occlusion-ray batch (o, d, tmax, weight, occluded) for ao_rays_cap rays
+    size_t ao_rays_cap = 0;
     size_t pixels_cap = 0;
 
     // ---- film
@@ -400,6 +402,18 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (d->n_triangles > 0 && (!d->P || !d->indices || !d->tri_mesh || !d->meshes)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "triangle arrays missing");
     if (d->n_spheres > 0 && !d->spheres) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "spheres array missing");
     if (d->xres <= 0 || d->yres <= 0 || d->spp <= 0 || d->max_depth < 0 || d->max_depth > 250) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "bad film / sampler / integrator parameters");
+    if (d->integrator != PT_INTEGRATOR_PATH && d->integrator != PT_INTEGRATOR_AO) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown integrator");
+    if (d->integrator == PT_INTEGRATOR_AO) {
+        if (d->ao_samples < 0 || d->ao_samples > 4096) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "ao: nsamples outside [1, 4096]");
+        for (uint32_t i = 0; i < d->n_meshes; i++)
+            if (d->meshes[i].material < 0 || d->materials[d->meshes[i].material].type == PT_MATERIAL_NONE)
+                return ctx->fail(PT_ERR_UNSUPPORTED, "ao: a surface without a material makes the reference request its sample array twice and panic (ao.rs:66-69, :78)");
+        for (uint32_t i = 0; i < d->n_spheres; i++)
+            if (d->spheres[i].material < 0 || d->materials[d->spheres[i].material].type == PT_MATERIAL_NONE)
+                return ctx->fail(PT_ERR_UNSUPPORTED, "ao: a surface without a material makes the reference request its sample array twice and panic (ao.rs:66-69, :78)");
+        for (uint32_t i = 0; i < d->n_materials; i++)
+            if (d->materials[i].tex_bump) return ctx->fail(PT_ERR_UNSUPPORTED, "ao: bump-mapped materials (the bump can flip the frame's normal) are not on the accelerated path");
+    }
     if (d->sampler != PT_SAMPLER_SOBOL && d->sampler != PT_SAMPLER_HALTON)
         return ctx->fail(PT_ERR_UNSUPPORTED, "sampler not on the accelerated path: only the index-addressed samplers (sobol, halton) are reproducible on a wavefront");
     if (d->n_triangles >= 0x7fffffffu) return ctx->fail(PT_ERR_UNSUPPORTED, "too many triangles");
@@ -813,6 +827,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     std::memcpy(sc.wb_min, bvh.root_lo, 12);
     std::memcpy(sc.wb_max, bvh.root_hi, 12);
     sc.max_depth = d->max_depth;
+    sc.integrator = d->integrator;
+    sc.ao_samples = d->ao_samples > 0 ? d->ao_samples : 64;
+    sc.ao_cos_sample = d->ao_cos_sample != 0;
     sc.rr_threshold = d->rr_threshold;
 
     // ---- camera ---------------------------------------------------------------
@@ -1040,6 +1057,8 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
             pool_target = std::min(pool_target, std::max<size_t>(ctx->pool_paths, std::max<size_t>(1u << 20, (free_b / 2) / per_path)));
         }
     }
+    const bool ao = sc.integrator == PT_INTEGRATOR_AO;
+    if (ao) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, ((size_t)32 << 20) / (size_t)sc.ao_samples));      // <= 32 M occlusion rays per pass
     size_t chunk_pix = std::min(pixels.size(), pool_target);
     uint32_t S = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, pool_target / chunk_pix));
     {   // equal passes: 256 spp at 63 spp per pass would leave a 4-spp runt
@@ -1078,7 +1097,44 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
             uint32_t* qb = ctx->d_qb.as<uint32_t>();
             Q.cur = qa; Q.next = qb;
             PT_HIP(ptk_gen(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q, d_pix, n_pix, s0, ns, cnt));
-            if (sc.n_lights > 0) {          // no lights: li() returns zero immediately (path.rs:71-74)
+            if (ao) {
+                // camera rays -> closest hits -> ao_samples occlusion rays per hit (compacted) -> any-hit -> ordered sum
+                const uint32_t n_paths = n_pix * ns;
+                const size_t cap = (size_t)n_paths * (size_t)sc.ao_samples;
+                if (ctx->ao_rays_cap < cap) {
+                    PT_HIP(ctx->d_ao.alloc(cap * 33 + 256));
+                    ctx->ao_rays_cap = cap;
+                }
+                float* ao_o = ctx->d_ao.as<float>();
+                float* ao_d = ao_o + 3 * ctx->ao_rays_cap;
+                float* ao_t = ao_d + 3 * ctx->ao_rays_cap;
+                float* ao_w = ao_t + ctx->ao_rays_cap;
+                uint8_t* ao_occ = reinterpret_cast<uint8_t*>(ao_w + ctx->ao_rays_cap);
+                uint32_t* ao_count = ctx->d_ticket.as<uint32_t>() + 2;
+                hipEvent_t a = get_event(ctx, ev_i), b = get_event(ctx, ev_i + 1), c = get_event(ctx, ev_i + 2);
+                if (!a || !b || !c) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
+                spans.push_back({ev_i, 0});
+                ev_i += 3;
+                PT_HIP(hipMemsetAsync(ctx->d_ticket.p, 0, 16, ctx->stream));
+                PT_HIP(ptk_ao_tag(ctx->stream, ctx->grid_wide, ctx->paths, n_pix, n_paths, s0));
+                PT_HIP(hipEventRecord(a, ctx->stream));
+                PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                ctx->trace_launches++;
+                PT_HIP(ptk_ao_rays(ctx->stream, ctx->grid_wide, sc, ctx->paths, n_paths, ao_o, ao_d, ao_t, ao_w, ao_count, cnt));
+                uint32_t n_hit = 0;
+                PT_HIP(hipMemcpyAsync(&n_hit, ao_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+                PT_HIP(hipStreamSynchronize(ctx->stream));
+                const uint32_t n_rays = n_hit * (uint32_t)sc.ao_samples;
+                if (n_rays) {
+                    PT_HIP(hipMemsetAsync(ctx->d_ticket.p, 0, 8, ctx->stream));
+                    PT_HIP(ptk_trace_batch(ctx->stream, ctx->grid_trace, sc, n_rays, ao_o, ao_d, ao_t, nullptr, ao_occ, 1, ctx->d_ticket.as<uint32_t>(), cnt,
+                                           ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                    ctx->trace_launches++;
+                }
+                PT_HIP(hipEventRecord(b, ctx->stream));
+                PT_HIP(ptk_ao_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, n_paths, ao_w, ao_occ));
+                PT_HIP(hipEventRecord(c, ctx->stream));
+            } else if (sc.n_lights > 0) {          // no lights: li() returns zero immediately (path.rs:71-74)
                 auto bounce = [&]() -> pt_status {
                     const bool timed = !no_events;
                     hipEvent_t a = nullptr, b = nullptr, c = nullptr;

@@ -227,6 +227,8 @@ struct PtScene {
     float wb_min[3], wb_max[3];  // BVH root bounds (Scene::world_bound)
     int32_t max_depth;
     float rr_threshold;
+    int32_t integrator;          // pt_integrator_type
+    int32_t ao_samples, ao_cos_sample;
     PtCamera cam;
     PtFilm film;
     PtSobol sobol;

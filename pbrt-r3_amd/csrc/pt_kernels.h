@@ -26,3 +26,7 @@ hipError_t ptk_bsdf_sample(hipStream_t st, const PtScene& sc, uint32_t material,
                            float* wi, float* pdf, uint32_t* type);
 hipError_t ptk_sobol_samples(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim,
                              float* out);
+hipError_t ptk_ao_tag(hipStream_t st, int grid, const PtPaths& P, uint32_t n_pix, uint32_t n_paths, uint32_t s0);
+hipError_t ptk_ao_rays(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+                       uint32_t* counter, PtCounters* cnt);
+hipError_t ptk_ao_resolve(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, const float* ao_w, const uint8_t* occ);

@@ -2092,6 +2092,113 @@ hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t
     else hipLaunchKernelGGL(k_trace_batch, dim3(grid), dim3(PT_BLOCK), 0, st, sc, n, o, d, tmax, out, occ, any_hit, ticket, cnt, spill, spill_depth, err);
     return PT_LAUNCH_CHECK();
 }
+// ============================================================ AOIntegrator (integrators/ao.rs:49-110)
+// After the camera rays have been traced: every path that hit something writes its n_s occlusion rays into a compacted batch
+// (one slot allocation per wave), the batch goes through the any-hit traversal, and k_ao_resolve adds the unoccluded terms in
+// sample order -- the reference's summation order, so the radiance is bit-identical.
+//   counter[0] = hit paths so far; P.nee[path] = batch slot + 1 (0 = the camera ray escaped)
+template <bool SPH, bool INST>
+PT_DEV void ao_rays_body(const PtScene& sc, const PtPaths& P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w, uint32_t* counter,
+                         PtCounters* cnt) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n_s = (uint32_t)sc.ao_samples;
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n_paths; base += gridDim.x * blockDim.x) {
+        const uint32_t p = base + lane;
+        bool found = false;
+        Surf s;
+        V3 rd = mk3(0.0f, 0.0f, 1.0f);
+        if (p < n_paths) {
+            const V3 ro = f4_3(P.ray_o[p]);
+            rd = f4_3(P.ray_d[p]);
+            const int32_t rec = P.hit_rec[p];
+            float thit;
+            if constexpr (INST) found = rec >= 0 && make_surf_inst<SPH>(sc, ro, rd, (uint32_t)rec, P.hit_inst[p], s, &thit);
+            else found = rec >= 0 && make_surf_any<SPH>(sc, ro, rd, (uint32_t)rec, s, &thit);
+        }
+        const uint64_t hits = __ballot(found);
+        uint32_t slot0 = 0;
+        if (lane == 0 && hits) {
+            slot0 = atomicAdd(counter, (uint32_t)__popcll(hits));
+            atomicAdd(&cnt->vertices, (unsigned long long)__popcll(hits));
+        }
+        slot0 = (uint32_t)__shfl((int)slot0, 0, 64);
+        if (p < n_paths) P.nee[p] = found ? slot0 + (uint32_t)__popcll(hits & ((1ull << lane) - 1ull)) + 1u : 0u;
+        if (!found) continue;
+        const size_t r0 = (size_t)(slot0 + (uint32_t)__popcll(hits & ((1ull << lane) - 1ull))) * n_s;
+        const V3 n = face_forward(s.n, -rd);               // the true geometry's frame, not the shading frame (ao.rs:73-77)
+        const V3 ss = normalize(s.dpdu);
+        const V3 tt = cross(s.n, ss);
+        const uint32_t pk = P.pixel[p];
+        const int32_t px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0], py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
+        const uint32_t cam_sample = (uint32_t)P.probe_rec[p];      // k_ao_tag stored the pixel-sample number here
+        for (uint32_t k = 0; k < n_s; k++) {
+            const uint64_t index = sampler_index(sc, (uint64_t)cam_sample * n_s + k, px, py);
+            const V2 u = mk2(sample_dimension(sc, index, 5u, px, py), sample_dimension(sc, index, 6u, px, py));
+            V3 wi;
+            float pdf;
+            if (sc.ao_cos_sample) { wi = cosine_sample_hemisphere(u); pdf = fabsf(wi.z) * PT_INV_PI; }
+            else {
+                const float z = u.x, r = sqrtf(fmaxf(0.0f, 1.0f - z * z)), phi = 2.0f * PT_PI * u.y;
+                float sn, cs;
+                pt_sincosf(phi, &sn, &cs);
+                wi = mk3(r * cs, r * sn, z);
+                pdf = PT_INV_PI * 0.5f;
+            }
+            wi = mk3(wi.x * ss.x + wi.y * tt.x + wi.z * n.x, wi.x * ss.y + wi.y * tt.y + wi.z * n.y, wi.x * ss.z + wi.y * tt.z + wi.z * n.z);
+            const V3 o = offset_ray_origin(s.p, s.p_error, s.n, wi);
+            const size_t r = r0 + k;
+            ao_o[3 * r] = o.x; ao_o[3 * r + 1] = o.y; ao_o[3 * r + 2] = o.z;
+            ao_d[3 * r] = wi.x; ao_d[3 * r + 1] = wi.y; ao_d[3 * r + 2] = wi.z;
+            ao_tmax[r] = PT_INF;
+            ao_w[r] = dot(wi, n) / (pdf * (float)n_s);
+        }
+    }
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_rays(PtScene sc, PtPaths P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+                                                                uint32_t* counter, PtCounters* cnt) {
+    ao_rays_body<false, false>(sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_rays_sph(PtScene sc, PtPaths P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+                                                                    uint32_t* counter, PtCounters* cnt) {
+    ao_rays_body<true, false>(sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_rays_inst(PtScene sc, PtPaths P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+                                                                     uint32_t* counter, PtCounters* cnt) {
+    ao_rays_body<true, true>(sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+}
+// path i of the pass took pixel-sample number s0 + i / n_pix (k_gen); the array slice of get_2d_array starts at n_s times that
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_tag(PtPaths P, uint32_t n_pix, uint32_t n_paths, uint32_t s0) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_paths; i += gridDim.x * blockDim.x) P.probe_rec[i] = (int32_t)(s0 + i / n_pix);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_resolve(PtScene sc, PtPaths P, uint32_t n_paths, const float* ao_w, const uint8_t* occ) {
+    const uint32_t n_s = (uint32_t)sc.ao_samples;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_paths; p += gridDim.x * blockDim.x) {
+        float l = 0.0f;
+        const uint32_t slot1 = P.nee[p];
+        if (slot1) {
+            const size_t r0 = (size_t)(slot1 - 1u) * n_s;
+            for (uint32_t k = 0; k < n_s; k++)
+                if (!occ[r0 + k]) l += ao_w[r0 + k];
+        }
+        P.L[p] = make_float4(l, l, l, 0.0f);
+        P.nee[p] = 0;
+    }
+}
+hipError_t ptk_ao_tag(hipStream_t st, int grid, const PtPaths& P, uint32_t n_pix, uint32_t n_paths, uint32_t s0) {
+    hipLaunchKernelGGL(k_ao_tag, dim3(grid), dim3(PT_BLOCK), 0, st, P, n_pix, n_paths, s0);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_ao_rays(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+                       uint32_t* counter, PtCounters* cnt) {
+    if (sc.n_instances) hipLaunchKernelGGL(k_ao_rays_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+    else if (sc.n_spheres) hipLaunchKernelGGL(k_ao_rays_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+    else hipLaunchKernelGGL(k_ao_rays, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_ao_resolve(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, const float* ao_w, const uint8_t* occ) {
+    hipLaunchKernelGGL(k_ao_resolve, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_w, occ);
+    return PT_LAUNCH_CHECK();
+}
 hipError_t ptk_gen(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const uint32_t* pixels, uint32_t n_pix,
                    uint32_t s0, uint32_t n_samples, PtCounters* cnt) {
     hipLaunchKernelGGL(k_gen, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, pixels, n_pix, s0, n_samples, cnt);

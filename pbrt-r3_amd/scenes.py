@@ -250,6 +250,7 @@ class SceneBuilder:
         self.filter_radius, self.filter_table = (0.5, 0.5), np.ones(256, np.float32)
         self.film_scale, self.max_sample_luminance = 1.0, float("inf")
         self.spp, self.max_depth, self.rr_threshold = 16, 5, 1.0
+        self.integrator, self.ao_samples, self.ao_cos_sample = capi.PT_INTEGRATOR_PATH, 64, True
         self.light_strategy = capi.PT_LIGHTS_SPATIAL
         self.split_method, self.max_node_prims = capi.PT_SPLIT_SAH, 4
 
@@ -336,6 +337,10 @@ class SceneBuilder:
     def integrator_path(self, maxdepth=5, rrthreshold=1.0, lightsamplestrategy="spatial"):
         self.max_depth, self.rr_threshold = int(maxdepth), float(rrthreshold)
         self.light_strategy = {"uniform": capi.PT_LIGHTS_UNIFORM, "power": capi.PT_LIGHTS_POWER}.get(lightsamplestrategy, capi.PT_LIGHTS_SPATIAL)
+
+    def integrator_ao(self, nsamples=64, cossample=True):
+        """Integrator "ao" (integrators/ao.rs:118-138)."""
+        self.integrator, self.ao_samples, self.ao_cos_sample = capi.PT_INTEGRATOR_AO, int(nsamples), bool(cossample)
 
     def accelerator_bvh(self, splitmethod="sah", maxnodeprims=4):
         self.split_method = {"sah": 0, "hlbvh": 1, "middle": 2, "equal": 3}.get(splitmethod, 0)
@@ -698,6 +703,7 @@ class SceneBuilder:
         d.sampler, d.spp = getattr(self, "sampler", capi.PT_SAMPLER_SOBOL), self.spp
         d.halton_sample_at_center = 1 if getattr(self, "halton_center", False) else 0
         d.max_depth, d.rr_threshold, d.light_strategy = self.max_depth, self.rr_threshold, self.light_strategy
+        d.integrator, d.ao_samples, d.ao_cos_sample = self.integrator, self.ao_samples, int(self.ao_cos_sample)
         return sd
 
 

@@ -503,3 +503,36 @@ def scene_hlbvh_cluster():
         c = rng.random(3) * 4 - 2
         b.shape_trianglemesh([tuple(c), tuple(c + [0.05, 0, 0]), tuple(c + [0, 0.05, 0.02])], [0, 1, 2])
     return b.build()
+
+
+def scene_ao(sampler="sobol", cossample=True, nsamples=16, spp=4, res=40, kind="boxes"):
+    """Integrator "ao": an enclosure open at the top (escaping occlusion rays) with random matte clutter; kind "spheres" adds an
+    analytic sphere with a partial sweep, "instances" the instanced object of scene_instances."""
+    if kind == "instances":
+        sd = scene_instances(split="sah", res=res, spp=spp, sampler=sampler)
+        sd.desc.integrator, sd.desc.ao_samples, sd.desc.ao_cos_sample = pkg.capi.PT_INTEGRATOR_AO, nsamples, int(cossample)
+        return sd
+    b = scenes.SceneBuilder()
+    b.look_at((0, 0.4, -3.4), (0, -0.2, 0), (0, 1, 0))
+    b.camera_perspective(fov=42.0)
+    b.film(xresolution=res, yresolution=res - 8)
+    b.pixel_filter_box()
+    b.sampler_sobol(spp) if sampler == "sobol" else b.sampler_halton(spp)
+    b.integrator_ao(nsamples=nsamples, cossample=cossample)
+    b.accelerator_bvh("sah", 4)
+    b.material_matte((0.5, 0.5, 0.5))
+    b.shape_trianglemesh([(1, -1, -1), (-1, -1, -1), (-1, -1, 1), (1, -1, 1)], [0, 1, 2, 0, 2, 3])       # floor
+    b.shape_trianglemesh([(1, -1, 1), (-1, -1, 1), (-1, 1, 1), (1, 1, 1)], [0, 1, 2, 0, 2, 3])           # back wall
+    b.shape_trianglemesh([(-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1)], [0, 1, 2, 0, 2, 3],
+                         N=[(1, 0, 0)] * 4, uv=[(0, 0), (1, 0), (1, 1), (0, 1)])                            # side wall with normals / uv
+    rng = np.random.default_rng(17)
+    c = rng.uniform(-0.8, 0.8, (300, 3)).astype(np.float32)
+    c[:, 1] = rng.uniform(-1.0, -0.2, 300)
+    off = rng.uniform(-0.12, 0.12, (300, 3, 3)).astype(np.float32)
+    b.material_plastic(Kd=(0.3, 0.3, 0.3), Ks=(0.2, 0.2, 0.2), roughness=0.1)
+    b.shape_trianglemesh_fast((c[:, None, :] + off).reshape(-1, 3), np.arange(900), twosided=True)
+    if kind == "spheres":
+        T = scenes
+        t = T.transform_mul(T.transform_translate(0.3, -0.5, 0.1), T.transform_rotate_x(30.0))
+        b.shape_sphere(radius=0.4, zmin=-0.3, zmax=0.35, phimax=300.0, object_to_world=t[0], world_to_object=t[1])
+    return b.build()
