@@ -1058,7 +1058,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
         }
     }
     const bool ao = sc.integrator == PT_INTEGRATOR_AO;
-    if (ao) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, ((size_t)32 << 20) / (size_t)sc.ao_samples));      // <= 32 M occlusion rays per pass
+    if (ao) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, ((size_t)128 << 20) / (size_t)sc.ao_samples));      // <= 128 M occlusion rays (4.4 GB) per pass: big launches amortise the drain tail
     size_t chunk_pix = std::min(pixels.size(), pool_target);
     uint32_t S = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, pool_target / chunk_pix));
     {   // equal passes: 256 spp at 63 spp per pass would leave a 4-spp runt
