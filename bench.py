@@ -74,6 +74,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU sample (0 = auto, about 15 s)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Called without a launcher: start the N ranks ourselves (fresh children of a process that has not touched the GPU)
+        # and let rank 0 of that job print the line.  n_gpus in the line is always the number of ranks that ran.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     # The contract is ONE JSON line on stdout.  Native libraries (RCCL's version banner and NCCL WARN lines, gloo's
     # connection notes) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the
     # JSON line goes to a private duplicate of the original stdout.
@@ -88,7 +99,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = max(args.gpus, world)
+    n_gpus = world          # ranks that actually run (one GPU each), whatever --gpus says
+    if args.gpus != world and rank == 0:
+        print("[bench] --gpus %d but WORLD_SIZE=%d: reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
     # BENCH_REHEARSE=gloo: run the N>1 flow (partition, reduce, barrier, max-over-ranks timing) with every rank

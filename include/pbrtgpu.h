@@ -347,7 +347,9 @@ pt_status pt_scene_info_get(const pt_context* ctx, pt_scene_info* out);
 /* Zero the device film (RGB sums + weights over the cropped pixel bounds). */
 pt_status pt_film_clear(pt_context* ctx);
 /* Render `n_tiles` tiles (all spp) and accumulate into the device film.  Tiles
- * must lie inside the sample bounds.  n_tiles == 0 with tiles == NULL renders
+ * must lie inside the sample bounds and be pairwise disjoint (overlapping tiles
+ * are rejected with PT_ERR_INVALID_ARGUMENT: a pixel's samples are folded by one
+ * thread in sample order).  n_tiles == 0 with tiles == NULL renders
  * every 16x16 tile of the sample bounds (the reference's decomposition). */
 pt_status pt_render(pt_context* ctx, const pt_tile* tiles, uint32_t n_tiles);
 /* Film as {X,Y,Z,weight} float4 per cropped pixel: the quantity

@@ -80,7 +80,7 @@ struct pt_context {
     size_t pool_paths = 0;
     DevBuf d_pool;          // one slab carved into the SoA arrays of PtPaths
     PtPaths paths;
-    DevBuf d_qa, d_qb, d_qnee, d_qshadow, d_qprobe, d_qsorted, d_counts, d_pixels;
+    DevBuf d_qa, d_qb, d_qnee, d_qshadow, d_qprobe, d_qsorted, d_counts, d_pixels, d_tiles, d_tilebits;
     DevBuf d_ao;             // AO integrator: occlusion-ray batch (o, d, tmax, weight, occluded) for ao_rays_cap rays
     size_t ao_rays_cap = 0;
     size_t pixels_cap = 0;
@@ -403,17 +403,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (d->n_spheres > 0 && !d->spheres) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "spheres array missing");
     if (d->xres <= 0 || d->yres <= 0 || d->spp <= 0 || d->max_depth < 0 || d->max_depth > 250) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "bad film / sampler / integrator parameters");
     if (d->integrator != PT_INTEGRATOR_PATH && d->integrator != PT_INTEGRATOR_AO) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown integrator");
-    if (d->integrator == PT_INTEGRATOR_AO) {
-        if (d->ao_samples < 0 || d->ao_samples > 4096) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "ao: nsamples outside [1, 4096]");
-        for (uint32_t i = 0; i < d->n_meshes; i++)
-            if (d->meshes[i].material < 0 || d->materials[d->meshes[i].material].type == PT_MATERIAL_NONE)
-                return ctx->fail(PT_ERR_UNSUPPORTED, "ao: a surface without a material makes the reference request its sample array twice and panic (ao.rs:66-69, :78)");
-        for (uint32_t i = 0; i < d->n_spheres; i++)
-            if (d->spheres[i].material < 0 || d->materials[d->spheres[i].material].type == PT_MATERIAL_NONE)
-                return ctx->fail(PT_ERR_UNSUPPORTED, "ao: a surface without a material makes the reference request its sample array twice and panic (ao.rs:66-69, :78)");
-        for (uint32_t i = 0; i < d->n_materials; i++)
-            if (d->materials[i].tex_bump) return ctx->fail(PT_ERR_UNSUPPORTED, "ao: bump-mapped materials (the bump can flip the frame's normal) are not on the accelerated path");
-    }
+    if (d->n_materials > 0 && !d->materials) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "materials array missing");
     if (d->sampler != PT_SAMPLER_SOBOL && d->sampler != PT_SAMPLER_HALTON)
         return ctx->fail(PT_ERR_UNSUPPORTED, "sampler not on the accelerated path: only the index-addressed samplers (sobol, halton) are reproducible on a wavefront");
     if (d->n_triangles >= 0x7fffffffu) return ctx->fail(PT_ERR_UNSUPPORTED, "too many triangles");
@@ -468,6 +458,18 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             if (m[12] != 0.0f || m[13] != 0.0f || m[14] != 0.0f || m[15] != 1.0f)
                 return ctx->fail(PT_ERR_UNSUPPORTED, "sphere under a projective transform (last matrix row must be 0 0 0 1)");
         }
+    }
+    // integrator-specific refusals come after the index range checks above (they dereference materials[])
+    if (d->integrator == PT_INTEGRATOR_AO) {
+        if (d->ao_samples < 1 || d->ao_samples > 4096) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "ao: nsamples outside [1, 4096]");
+        for (uint32_t i = 0; i < d->n_meshes; i++)
+            if (d->meshes[i].material < 0 || d->materials[d->meshes[i].material].type == PT_MATERIAL_NONE)
+                return ctx->fail(PT_ERR_UNSUPPORTED, "ao: a surface without a material makes the reference request its sample array twice and panic (ao.rs:66-69, :78)");
+        for (uint32_t i = 0; i < d->n_spheres; i++)
+            if (d->spheres[i].material < 0 || d->materials[d->spheres[i].material].type == PT_MATERIAL_NONE)
+                return ctx->fail(PT_ERR_UNSUPPORTED, "ao: a surface without a material makes the reference request its sample array twice and panic (ao.rs:66-69, :78)");
+        for (uint32_t i = 0; i < d->n_materials; i++)
+            if (d->materials[i].tex_bump) return ctx->fail(PT_ERR_UNSUPPORTED, "ao: bump-mapped materials (the bump can flip the frame's normal) are not on the accelerated path");
     }
     if (ctx->sobol_m32.empty() && !load_sobol(ctx)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "cannot read sobol_tables.bin from data dir '" + ctx->data_dir + "'");
 
@@ -967,19 +969,21 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     PT_HIP(ctx->d_spillfilm.alloc(npx * 16));
     PT_HIP(ctx->d_xyzw.alloc(npx * 16));
     PT_HIP(ctx->d_rgb.alloc(npx * 12));
-    PT_HIP(hipMemset(ctx->d_own.p, 0, npx * 16));
-    PT_HIP(hipMemset(ctx->d_spillfilm.p, 0, npx * 16));
-    PT_HIP(hipMemset(ctx->d_xyzw.p, 0, npx * 16));
+    // every kernel runs on ctx->stream (non-blocking: no implicit ordering with the null stream), so do these
+    PT_HIP(hipMemsetAsync(ctx->d_own.p, 0, npx * 16, ctx->stream));
+    PT_HIP(hipMemsetAsync(ctx->d_spillfilm.p, 0, npx * 16, ctx->stream));
+    PT_HIP(hipMemsetAsync(ctx->d_xyzw.p, 0, npx * 16, ctx->stream));
     ctx->xyzw_committed = false;
     if (!ctx->d_counters.p) {
         PT_HIP(ctx->d_counters.alloc(sizeof(PtCounters)));
-        PT_HIP(hipMemset(ctx->d_counters.p, 0, sizeof(PtCounters)));
+        PT_HIP(hipMemsetAsync(ctx->d_counters.p, 0, sizeof(PtCounters), ctx->stream));
         PT_HIP(ctx->d_err.alloc(16));
-        PT_HIP(hipMemset(ctx->d_err.p, 0, 16));
+        PT_HIP(hipMemsetAsync(ctx->d_err.p, 0, 16, ctx->stream));
         PT_HIP(ctx->d_ticket.alloc(16));
         PT_HIP(ctx->d_counts.alloc(PT_COUNTS_WORDS * 4));
-        PT_HIP(hipMemset(ctx->d_counts.p, 0, PT_COUNTS_WORDS * 4));
+        PT_HIP(hipMemsetAsync(ctx->d_counts.p, 0, PT_COUNTS_WORDS * 4, ctx->stream));
     }
+    PT_HIP(hipStreamSynchronize(ctx->stream));
     if ((st = ensure_traversal_scratch(ctx)) != PT_OK) return st;
     double t2 = now_ms();
 
@@ -1034,15 +1038,19 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
         tiles = all.data();
         n_tiles = (uint32_t)all.size();
     }
-    std::vector<uint32_t> pixels;
+    // The pass's pixel list is expanded from the tiles on the device (k_expand_tiles); the host only checks the tiles and
+    // prefix-sums their sizes.
+    std::vector<uint32_t> tile_off(n_tiles);
+    size_t n_pixels_total = 0;
     for (uint32_t i = 0; i < n_tiles; i++) {
         const pt_tile& t = tiles[i];
         if (t.x0 < sbnd[0] || t.y0 < sbnd[1] || t.x1 > sbnd[2] || t.y1 > sbnd[3] || t.x1 < t.x0 || t.y1 < t.y0)
             return ctx->fail(PT_ERR_INVALID_ARGUMENT, "tile outside the sample bounds");
-        for (int32_t y = t.y0; y < t.y1; y++)
-            for (int32_t x = t.x0; x < t.x1; x++) pixels.push_back((uint32_t)(x - sbnd[0]) | ((uint32_t)(y - sbnd[1]) << 16));
+        tile_off[i] = (uint32_t)n_pixels_total;
+        n_pixels_total += (size_t)(t.x1 - t.x0) * (size_t)(t.y1 - t.y0);
+        if (n_pixels_total > (size_t)(sbnd[2] - sbnd[0]) * (size_t)(sbnd[3] - sbnd[1])) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "tiles overlap (more pixels than the sample bounds hold)");
     }
-    if (pixels.empty()) return PT_OK;
+    if (n_pixels_total == 0) return PT_OK;
     const uint32_t spp = sc.sobol.spp;
 
     // Paths in flight per pass.  Every k_trace launch ends with a drain tail (ray lengths are heavy-tailed and a
@@ -1059,7 +1067,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     }
     const bool ao = sc.integrator == PT_INTEGRATOR_AO;
     if (ao) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, ((size_t)128 << 20) / (size_t)sc.ao_samples));      // <= 128 M occlusion rays (4.4 GB) per pass: big launches amortise the drain tail
-    size_t chunk_pix = std::min(pixels.size(), pool_target);
+    size_t chunk_pix = std::min(n_pixels_total, pool_target);
     uint32_t S = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, pool_target / chunk_pix));
     {   // equal passes: 256 spp at 63 spp per pass would leave a 4-spp runt
         const uint32_t passes = (spp + S - 1) / S;
@@ -1067,11 +1075,30 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     }
     pt_status st;
     if ((st = ensure_pool(ctx, chunk_pix * S)) != PT_OK) return st;
-    if (ctx->pixels_cap < pixels.size()) {
-        PT_HIP(ctx->d_pixels.alloc(pixels.size() * 4));
-        ctx->pixels_cap = pixels.size();
+    if (ctx->pixels_cap < n_pixels_total) {
+        PT_HIP(ctx->d_pixels.alloc(n_pixels_total * 4));
+        ctx->pixels_cap = n_pixels_total;
     }
-    PT_HIP(hipMemcpyAsync(ctx->d_pixels.p, pixels.data(), pixels.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const size_t sb_w = (size_t)(sbnd[2] - sbnd[0]), sb_h = (size_t)(sbnd[3] - sbnd[1]);
+        const size_t bm_bytes = ((sb_w * sb_h + 31) / 32) * 4;
+        if (ctx->d_tilebits.bytes < bm_bytes) PT_HIP(ctx->d_tilebits.alloc(bm_bytes));
+        if (ctx->d_tiles.bytes < (size_t)n_tiles * 20) PT_HIP(ctx->d_tiles.alloc((size_t)n_tiles * 20));
+        uint32_t* d_off = reinterpret_cast<uint32_t*>(ctx->d_tiles.as<char>() + (size_t)n_tiles * 16);
+        PT_HIP(hipMemsetAsync(ctx->d_tilebits.p, 0, bm_bytes, ctx->stream));
+        PT_HIP(hipMemcpyAsync(ctx->d_tiles.p, tiles, (size_t)n_tiles * 16, hipMemcpyHostToDevice, ctx->stream));
+        PT_HIP(hipMemcpyAsync(d_off, tile_off.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, ctx->stream));
+        PT_HIP(ptk_expand_tiles(ctx->stream, ctx->d_tiles.as<int4>(), d_off, n_tiles, sbnd[0], sbnd[1], (uint32_t)sb_w, ctx->d_pixels.as<uint32_t>(),
+                                ctx->d_tilebits.as<uint32_t>(), ctx->d_err.as<uint32_t>()));
+        uint32_t herr0 = 0;      // pageable source buffers above: the copies have been staged when the calls return; one sync covers the check
+        PT_HIP(hipMemcpyAsync(&herr0, ctx->d_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP(hipStreamSynchronize(ctx->stream));
+        if (herr0 & 2u) {
+            PT_HIP(hipMemsetAsync(ctx->d_err.p, 0, 4, ctx->stream));
+            PT_HIP(hipStreamSynchronize(ctx->stream));
+            return ctx->fail(PT_ERR_INVALID_ARGUMENT, "tiles overlap: the tiles of one pt_render call must be disjoint");
+        }
+    }
 
     PtQueues Q;
     Q.nee = ctx->d_qnee.as<uint32_t>();
@@ -1088,8 +1115,8 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     hipEvent_t ev_begin = get_event(ctx, ev_i++), ev_end = get_event(ctx, ev_i++);
     PT_HIP(hipEventRecord(ev_begin, ctx->stream));
 
-    for (size_t c0 = 0; c0 < pixels.size(); c0 += chunk_pix) {
-        uint32_t n_pix = (uint32_t)std::min(chunk_pix, pixels.size() - c0);
+    for (size_t c0 = 0; c0 < n_pixels_total; c0 += chunk_pix) {
+        uint32_t n_pix = (uint32_t)std::min(chunk_pix, n_pixels_total - c0);
         const uint32_t* d_pix = ctx->d_pixels.as<uint32_t>() + c0;
         for (uint32_t s0 = 0; s0 < spp; s0 += S) {
             uint32_t ns = std::min(S, spp - s0);
@@ -1182,14 +1209,15 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     uint32_t herr = 0;
     PT_HIP(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
     if (herr) {
-        PT_HIP(hipMemset(err, 0, 4));
+        PT_HIP(hipMemsetAsync(err, 0, 4, ctx->stream));
+        PT_HIP(hipStreamSynchronize(ctx->stream));
         return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow (BVH deeper than the computed bound)");
     }
 #ifdef PT_PROFILE_PHASES
     {   // diagnostic build (tools/tune_trace.sh "prof:-DPT_PROFILE_PHASES:4"): wave-clock split of k_trace's two phases
         unsigned long long pr[10];
         PT_HIP(hipMemcpy(pr, ctx->d_spill.p, sizeof(pr), hipMemcpyDeviceToHost));
-        PT_HIP(hipMemset(ctx->d_spill.p, 0, sizeof(pr)));
+        PT_HIP(hipMemsetAsync(ctx->d_spill.p, 0, sizeof(pr), ctx->stream)); PT_HIP(hipStreamSynchronize(ctx->stream));
         std::fprintf(stderr, "[phases] node: %.3e clk, %llu steps, %.1f lanes/step | leaf: %.3e clk, %llu steps, %.1f lanes/step | wave total %.3e clk | service+begin %.3e clk, iterations with a retire %llu, with a ray start %llu\n",
                      (double)pr[0], pr[1], pr[1] ? (double)pr[2] / pr[1] : 0.0, (double)pr[3], pr[4], pr[4] ? (double)pr[5] / pr[4] : 0.0, (double)pr[6],
                      (double)pr[7], pr[8], pr[9]);
@@ -1290,7 +1318,7 @@ static pt_status trace_batch(pt_context* ctx, uint32_t n, const float* o, const 
     ctx->trace_launches++;
     uint32_t herr = 0;
     PT_HIP(hipMemcpy(&herr, ctx->d_err.p, 4, hipMemcpyDeviceToHost));
-    if (herr) { PT_HIP(hipMemset(ctx->d_err.p, 0, 4)); return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow"); }
+    if (herr) { PT_HIP(hipMemsetAsync(ctx->d_err.p, 0, 4, ctx->stream)); PT_HIP(hipStreamSynchronize(ctx->stream)); return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow"); }
     if (any_hit) PT_HIP(hipMemcpy(occ, d_out.p, n, hipMemcpyDeviceToHost));
     else PT_HIP(hipMemcpy(out, d_out.p, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost));
     return PT_OK;
@@ -1390,11 +1418,12 @@ pt_status pt_radiance_samples(pt_context* ctx, const pt_tile* tile, float* out_r
     size_t fpx = (size_t)ctx->film_w * ctx->film_h;
     DevBuf keep_own, keep_spill;
     PT_HIP(keep_own.alloc(fpx * 16)); PT_HIP(keep_spill.alloc(fpx * 16));
-    PT_HIP(hipMemcpy(keep_own.p, ctx->d_own.p, fpx * 16, hipMemcpyDeviceToDevice));
-    PT_HIP(hipMemcpy(keep_spill.p, ctx->d_spillfilm.p, fpx * 16, hipMemcpyDeviceToDevice));
+    PT_HIP(hipMemcpyAsync(keep_own.p, ctx->d_own.p, fpx * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    PT_HIP(hipMemcpyAsync(keep_spill.p, ctx->d_spillfilm.p, fpx * 16, hipMemcpyDeviceToDevice, ctx->stream));
     pt_status st = render_tiles(ctx, tile, 1, d_rad.as<float>());
-    PT_HIP(hipMemcpy(ctx->d_own.p, keep_own.p, fpx * 16, hipMemcpyDeviceToDevice));
-    PT_HIP(hipMemcpy(ctx->d_spillfilm.p, keep_spill.p, fpx * 16, hipMemcpyDeviceToDevice));
+    PT_HIP(hipMemcpyAsync(ctx->d_own.p, keep_own.p, fpx * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    PT_HIP(hipMemcpyAsync(ctx->d_spillfilm.p, keep_spill.p, fpx * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
     if (st != PT_OK) return st;
     PT_HIP(hipMemcpy(out_rgb, d_rad.p, n * 4, hipMemcpyDeviceToHost));
     return PT_OK;
@@ -1462,7 +1491,10 @@ pt_status pt_get_counters(pt_context* ctx, pt_counters* out) {
 pt_status pt_reset_counters(pt_context* ctx) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(ctx->device);
-    if (ctx->d_counters.p) PT_HIP(hipMemset(ctx->d_counters.p, 0, sizeof(PtCounters)));
+    if (ctx->d_counters.p) {
+        PT_HIP(hipMemsetAsync(ctx->d_counters.p, 0, sizeof(PtCounters), ctx->stream));
+        PT_HIP(hipStreamSynchronize(ctx->stream));
+    }
     ctx->trace_launches = 0;
     ctx->trace_ms = ctx->shade_ms = ctx->render_ms = 0;
     return PT_OK;

@@ -998,6 +998,29 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace_batch_inst(PtScen
     trace_batch_body<true, true>(sc, n, o, d, tmax, out, occ_out, any_hit, ticket, cnt, spill, spill_depth, err);
 }
 
+// ============================================================ tiles -> pixel list
+// One block per tile: writes the tile's pixels (row-major, x | y << 16 relative to the sample bounds) at its offset of the
+// pass's pixel list, and marks them in a bitmap over the sample bounds -- a pixel marked twice means overlapping tiles
+// (k_film folds a pixel's samples with a plain read-modify-write, so the tiles of one call must be disjoint).
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_expand_tiles(const int4* tiles, const uint32_t* tile_off, uint32_t n_tiles, int32_t sb_x0, int32_t sb_y0,
+                                                                     uint32_t sb_w, uint32_t* pixels, uint32_t* bitmap, uint32_t* err) {
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int4 tl = tiles[t];
+        const uint32_t w = (uint32_t)(tl.z - tl.x), n = w * (uint32_t)(tl.w - tl.y), off = tile_off[t];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t x = (uint32_t)(tl.x - sb_x0) + i % w, y = (uint32_t)(tl.y - sb_y0) + i / w;
+            pixels[off + i] = x | (y << 16);
+            const uint32_t bit = y * sb_w + x;
+            if (atomicOr(&bitmap[bit >> 5], 1u << (bit & 31u)) & (1u << (bit & 31u))) atomicOr(err, 2u);
+        }
+    }
+}
+hipError_t ptk_expand_tiles(hipStream_t st, const int4* tiles, const uint32_t* tile_off, uint32_t n_tiles, int32_t sb_x0, int32_t sb_y0, uint32_t sb_w,
+                            uint32_t* pixels, uint32_t* bitmap, uint32_t* err) {
+    hipLaunchKernelGGL(k_expand_tiles, dim3(n_tiles < 4096u ? n_tiles : 4096u), dim3(PT_BLOCK), 0, st, tiles, tile_off, n_tiles, sb_x0, sb_y0, sb_w, pixels, bitmap, err);
+    return hipGetLastError();
+}
+
 // ============================================================ K_GEN: camera samples
 // path i of the pass: pixel = pixels[i % n_pix], sample = s0 + i / n_pix
 // (render_tile, sampler.rs:221-251: start_pixel / get_camera_sample / generate_ray_differential)
