@@ -16,7 +16,7 @@
  *                           (src/core/integrator/sampler.rs:259-325)
  *   pt_film_*            <- Film::merge_film_tile / write_image
  *                           (src/core/film/film.rs:219-241, :440-484)
- *   pt_trace_closest/any <- Scene::intersect / intersect_p
+ *   pt_trace_closest/any, pt_trace_wavefront <- Scene::intersect / intersect_p
  *                           (src/core/scene/scene.rs:44-54)
  *   pt_generate_camera_rays <- Sampler::get_camera_sample +
  *                           PerspectiveCamera::generate_ray_differential
@@ -359,6 +359,11 @@ pt_status pt_film_download_xyzw(pt_context* ctx, float* xyzw_out /* 4*W*H */);
 pt_status pt_film_device_xyzw(pt_context* ctx, void** dev_ptr, size_t* n_floats);
 /* Tell the context the XYZW buffer (possibly reduced in place) is authoritative. */
 pt_status pt_film_commit_xyzw(pt_context* ctx);
+/* Multi-GPU: sum the XYZW film over the ranks of an RCCL communicator the caller created (ncclComm_t passed as void*; one
+ * rank = one context = one GPU) and mark the result authoritative -- the path's only exchange step (each rank has rendered
+ * its share of the tiles into a zero-initialised film).  root < 0: ncclAllReduce; root >= 0: ncclReduce to that rank.
+ * Runs on the library's stream; librccl.so.1 is resolved at run time (the copy already loaded in the process if any). */
+pt_status pt_film_allreduce(pt_context* ctx, void* nccl_comm, int root);
 /* Film::write_image arithmetic: rgb = xyz_to_rgb(xyz)/weight, clamp >=0, *scale. */
 pt_status pt_film_resolve_rgb(pt_context* ctx, float* rgb_out /* 3*W*H */);
 
@@ -368,6 +373,15 @@ pt_status pt_trace_closest(pt_context* ctx, uint32_t n, const float* o, const fl
                            const float* tmax, pt_hit* out);
 pt_status pt_trace_any(pt_context* ctx, uint32_t n, const float* o, const float* d,
                        const float* tmax, uint8_t* occluded_out);
+/* The same queries through the WAVEFRONT's traversal kernel -- the one pt_render spends its time in (persistent lanes,
+ * ray prefetch pipeline, per-XCD queue segments, pooled leaf rounds), not the plain one-ray-per-lane kernel behind
+ * pt_trace_closest/any.  The rays are issued as the three kinds of work items one bounce mixes in a single launch:
+ *   kind[i] = 1  continuation ray: Scene::intersect (scene.rs:44-48)   -> out[i] = {t, prim, b0, b1}
+ *   kind[i] = 2  shadow ray:       Scene::intersect_p (scene.rs:50-54) -> occluded_out[i]
+ *   kind[i] = 3  MIS probe ray:    Scene::intersect, only the primitive is kept (sample_lights.rs:419-447) -> out[i].prim
+ * out and occluded_out hold n entries each (entries of the other kind are zeroed / prim = -1). */
+pt_status pt_trace_wavefront(pt_context* ctx, uint32_t n, const float* o, const float* d, const float* tmax,
+                             const uint8_t* kind, pt_hit* out, uint8_t* occluded_out);
 /* Camera rays for pixel (px,py), sample index s: out_o/out_d 3 floats each per ray,
  * out_pfilm 2 floats per ray. */
 pt_status pt_generate_camera_rays(pt_context* ctx, uint32_t n, const int32_t* pixel_xy,

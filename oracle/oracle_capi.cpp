@@ -3,6 +3,7 @@
 // leg can drive it through ctypes.  Nothing under pbrt-r3_amd/ may link this.
 #include "orc_render.hpp"
 #include <chrono>
+#include <thread>
 
 using namespace orc;
 
@@ -11,6 +12,21 @@ struct orc_scene {
     LightDistribution ld;
     std::string err;
 };
+
+// Rays are independent: large batches are cut into contiguous chunks over host threads (per-chunk stats, summed).
+template <class F>
+static void for_ray_chunks(uint32_t n, QBVH::Stats* total, F body) {
+    unsigned nt = n >= 65536 ? std::min(32u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    std::vector<QBVH::Stats> st(nt);
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; k++) {
+        uint32_t lo = (uint32_t)((uint64_t)n * k / nt), hi = (uint32_t)((uint64_t)n * (k + 1) / nt);
+        if (nt == 1) body(lo, hi, &st[k]);
+        else th.emplace_back([=, &st, &body] { body(lo, hi, &st[k]); });
+    }
+    for (auto& t : th) t.join();
+    for (auto& x : st) { total->nodes += x.nodes; total->tris += x.tris; }
+}
 
 extern "C" {
 
@@ -79,20 +95,24 @@ void orc_radiance_samples(orc_scene* s, const pt_tile* tile, float* out_rgb) {
 
 void orc_trace_closest(const orc_scene* s, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out, pt_counters* counters) {
     QBVH::Stats st;
-    for (uint32_t i = 0; i < n; i++) {
-        Ray r(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
-        SurfHit h;
-        if (s->sc.bvh.intersect(r, &h, &st)) { out[i].t = r.t_max; out[i].prim = h.prim; out[i].b0 = h.b0; out[i].b1 = h.b1; }
-        else { out[i].t = 0.0f; out[i].prim = -1; out[i].b0 = 0.0f; out[i].b1 = 0.0f; }
-    }
+    for_ray_chunks(n, &st, [&](uint32_t lo, uint32_t hi, QBVH::Stats* cs) {
+        for (uint32_t i = lo; i < hi; i++) {
+            Ray r(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+            SurfHit h;
+            if (s->sc.bvh.intersect(r, &h, cs)) { out[i].t = r.t_max; out[i].prim = h.prim; out[i].b0 = h.b0; out[i].b1 = h.b1; }
+            else { out[i].t = 0.0f; out[i].prim = -1; out[i].b0 = 0.0f; out[i].b1 = 0.0f; }
+        }
+    });
     if (counters) { counters->regular_rays += n; counters->nodes_visited += st.nodes; counters->tris_tested += st.tris; }
 }
 void orc_trace_any(const orc_scene* s, uint32_t n, const float* o, const float* d, const float* tmax, uint8_t* out, pt_counters* counters) {
     QBVH::Stats st;
-    for (uint32_t i = 0; i < n; i++) {
-        Ray r(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
-        out[i] = s->sc.bvh.intersect_p(r, &st) ? 1 : 0;
-    }
+    for_ray_chunks(n, &st, [&](uint32_t lo, uint32_t hi, QBVH::Stats* cs) {
+        for (uint32_t i = lo; i < hi; i++) {
+            Ray r(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+            out[i] = s->sc.bvh.intersect_p(r, cs) ? 1 : 0;
+        }
+    });
     if (counters) { counters->shadow_rays += n; counters->nodes_visited += st.nodes; counters->tris_tested += st.tris; }
 }
 // accelerators/exhaustive cross-check: every primitive, no BVH

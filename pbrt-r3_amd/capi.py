@@ -145,7 +145,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<i4"), ("b0", "<f4"), ("b1", "<f4"
 SYMBOLS = [
     "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_abi_version", "pt_set_data_dir",
     "pt_scene_upload", "pt_scene_info_get", "pt_film_clear", "pt_render", "pt_film_download_xyzw",
-    "pt_film_device_xyzw", "pt_film_commit_xyzw", "pt_film_resolve_rgb", "pt_trace_closest", "pt_trace_any",
+    "pt_film_device_xyzw", "pt_film_commit_xyzw", "pt_film_allreduce", "pt_film_resolve_rgb", "pt_trace_closest", "pt_trace_any", "pt_trace_wavefront",
     "pt_generate_camera_rays", "pt_sobol_samples", "pt_radiance_samples", "pt_get_counters", "pt_reset_counters",
     "pt_bvh_leaf_order", "pt_bsdf_eval", "pt_bsdf_sample", "pt_set_bvh_build", "pt_scene_bvh_digest",
 ]
@@ -177,9 +177,11 @@ def load_library(path=None):
     lib.pt_film_download_xyzw.argtypes = [vp, vp]
     lib.pt_film_device_xyzw.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.pt_film_commit_xyzw.argtypes = [vp]
+    lib.pt_film_allreduce.argtypes = [vp, vp, C.c_int]
     lib.pt_film_resolve_rgb.argtypes = [vp, vp]
     lib.pt_trace_closest.argtypes = [vp, u32, vp, vp, vp, vp]
     lib.pt_trace_any.argtypes = [vp, u32, vp, vp, vp, vp]
+    lib.pt_trace_wavefront.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     lib.pt_generate_camera_rays.argtypes = [vp, u32, vp, vp, vp, vp, vp]
     lib.pt_sobol_samples.argtypes = [vp, u32, vp, vp, vp, vp]
     lib.pt_radiance_samples.argtypes = [vp, C.POINTER(pt_tile), vp]
@@ -360,6 +362,10 @@ class Context:
     def film_commit_xyzw(self):
         self._check(self.lib.pt_film_commit_xyzw(self.h))
 
+    def film_allreduce(self, nccl_comm, root=-1):
+        """Sum the XYZW film over an RCCL communicator (ncclComm_t as an integer / c_void_p) inside the library."""
+        self._check(self.lib.pt_film_allreduce(self.h, C.c_void_p(nccl_comm), root))
+
     def film_rgb(self):
         h, w = self.film_shape
         out = np.empty((h, w, 3), np.float32)
@@ -381,6 +387,15 @@ class Context:
         out = np.empty(n, np.uint8)
         self._check(self.lib.pt_trace_any(self.h, n, _ptr(o), _ptr(d), _ptr(tmax), _ptr(out)))
         return out
+
+    def trace_wavefront(self, o, d, tmax, kind):
+        """Rays through the renderer's own traversal kernel; kind: 1 continuation, 2 shadow, 3 probe.  Returns (hits, occluded)."""
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32); kind = np.ascontiguousarray(kind, np.uint8)
+        n = len(tmax)
+        out = np.empty(n, HIT_DTYPE); occ = np.empty(n, np.uint8)
+        self._check(self.lib.pt_trace_wavefront(self.h, n, _ptr(o), _ptr(d), _ptr(tmax), _ptr(kind), _ptr(out), _ptr(occ)))
+        return out, occ
 
     def generate_camera_rays(self, pixel_xy, sample_index):
         pixel_xy = np.ascontiguousarray(pixel_xy, np.int32); sample_index = np.ascontiguousarray(sample_index, np.uint32)

@@ -7,7 +7,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <dlfcn.h>
 
 #include "../../../include/pbrtgpu_host.h"
 
@@ -25,12 +28,80 @@ static void usage() {
                  "      --stats               print the ray counters\n"
                  "      --quiet               only error messages\n"
                  "  -j, --nthreads <n>        accepted for compatibility (the device schedules itself)\n"
-                 "      --device <d>          HIP device index\n");
+                 "      --device <d>          HIP device index\n"
+                 "      --gpus <n>            film tiles dealt round-robin to n GPUs (devices 0..n-1, one host thread and one\n"
+                 "                            library context each), films summed with one RCCL reduce to device 0\n");
+}
+
+// --gpus N: the reference's tile loop (sampler.rs:266-301) sharded over GPUs inside one process.  Every device holds the whole
+// scene and renders tiles r, r+N, r+2N, ...; the only exchange is pt_film_allreduce.  No Python, no torch: RCCL's communicators
+// come from ncclCommInitAll (librccl.so.1, resolved at run time like the library does).
+static int render_multi_gpu(const pt_scene_desc* dsc, int n_gpus, std::vector<float>& rgb, pt_scene_info* info_out, pt_counters* total, double* secs_out) {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    auto init_all = h ? reinterpret_cast<int (*)(void**, int, const int*)>(dlsym(h, "ncclCommInitAll")) : nullptr;
+    auto destroy = h ? reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy")) : nullptr;
+    if (!init_all || !destroy) { std::fprintf(stderr, "pbrt_gpu: --gpus needs librccl.so.1 (ncclCommInitAll)\n"); return 1; }
+    std::vector<void*> comms((size_t)n_gpus, nullptr);
+    std::vector<int> devs((size_t)n_gpus);
+    for (int i = 0; i < n_gpus; i++) devs[(size_t)i] = i;
+    if (init_all(comms.data(), n_gpus, devs.data()) != 0) { std::fprintf(stderr, "pbrt_gpu: ncclCommInitAll failed for %d devices\n", n_gpus); return 1; }
+    std::vector<pt_context*> ctxs((size_t)n_gpus, nullptr);
+    std::vector<int> rc((size_t)n_gpus, 0);
+    std::vector<pt_counters> cnts((size_t)n_gpus);
+    std::vector<std::string> errs((size_t)n_gpus);
+    auto each = [&](auto body) {
+        std::vector<std::thread> th;
+        for (int r = 0; r < n_gpus; r++) th.emplace_back([&, r] { if (rc[(size_t)r] == 0) body(r); });
+        for (auto& t : th) t.join();
+        for (int r = 0; r < n_gpus; r++) if (rc[(size_t)r]) { std::fprintf(stderr, "pbrt_gpu: device %d: %s\n", r, errs[(size_t)r].c_str()); return false; }
+        return true;
+    };
+    auto check = [&](int r, pt_status st, const char* what) {
+        if (st != PT_OK && rc[(size_t)r] == 0) { rc[(size_t)r] = 1; errs[(size_t)r] = std::string(what) + ": " + (ctxs[(size_t)r] ? pt_last_error(ctxs[(size_t)r]) : "no context"); }
+        return st == PT_OK;
+    };
+    bool ok = each([&](int r) {
+        if (!check(r, pt_context_create(r, &ctxs[(size_t)r]), "no usable HIP device")) return;
+        check(r, pt_scene_upload(ctxs[(size_t)r], dsc), "scene upload");
+    });
+    double secs = 0;
+    if (ok) {
+        pt_scene_info_get(ctxs[0], info_out);
+        const int32_t* sb = info_out->sample_bounds;
+        std::vector<std::vector<pt_tile>> mine((size_t)n_gpus);
+        int k = 0;
+        for (int32_t y = sb[1]; y < sb[3]; y += 16)
+            for (int32_t x = sb[0]; x < sb[2]; x += 16, k++) mine[(size_t)(k % n_gpus)].push_back({x, y, std::min(x + 16, sb[2]), std::min(y + 16, sb[3])});
+        auto t0 = std::chrono::steady_clock::now();
+        ok = each([&](int r) {
+            pt_context* c = ctxs[(size_t)r];
+            if (!check(r, pt_film_clear(c), "film clear")) return;
+            if (!mine[(size_t)r].empty() && !check(r, pt_render(c, mine[(size_t)r].data(), (uint32_t)mine[(size_t)r].size()), "render")) { /* still join the collective */ }
+            check(r, pt_film_allreduce(c, comms[(size_t)r], 0), "film reduce");
+            pt_get_counters(c, &cnts[(size_t)r]);
+        });
+        if (ok) {
+            int w = info_out->cropped_bounds[2] - info_out->cropped_bounds[0], hgt = info_out->cropped_bounds[3] - info_out->cropped_bounds[1];
+            rgb.assign((size_t)w * hgt * 3, 0.0f);
+            ok = pt_film_resolve_rgb(ctxs[0], rgb.data()) == PT_OK;
+        }
+        secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    std::memset(total, 0, sizeof(*total));
+    for (int r = 0; r < n_gpus; r++) {
+        total->regular_rays += cnts[(size_t)r].regular_rays; total->shadow_rays += cnts[(size_t)r].shadow_rays;
+        total->camera_rays += cnts[(size_t)r].camera_rays; total->path_vertices += cnts[(size_t)r].path_vertices;
+        if (ctxs[(size_t)r]) pt_context_destroy(ctxs[(size_t)r]);
+        if (comms[(size_t)r]) destroy(comms[(size_t)r]);
+    }
+    *secs_out = secs;
+    return ok ? 0 : 1;
 }
 
 int main(int argc, char** argv) {
     std::string input, outfile;
-    int spp = 0, device = 0;
+    int spp = 0, device = 0, gpus = 0;
     bool quiet = false, cat = false, stats = false;
     pth_options opts;
     std::memset(&opts, 0, sizeof(opts));
@@ -46,6 +117,7 @@ int main(int argc, char** argv) {
         else if (a == "--stats") stats = true;
         else if (a == "--nthreads" || a == "-j") (void)need("--nthreads");
         else if (a == "--device") device = std::atoi(need("--device"));
+        else if (a == "--gpus") gpus = std::max(1, std::atoi(need("--gpus")));
         else if (a == "--quiet") quiet = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] != '-') input = a;
@@ -77,6 +149,24 @@ int main(int argc, char** argv) {
         size_t dot = outfile.find_last_of('.');
         std::string ext = dot == std::string::npos ? std::string() : outfile.substr(dot);
         if (ext != ".exr" && ext != ".png" && ext != ".pfm") outfile = (dot == std::string::npos ? outfile : outfile.substr(0, dot)) + ".pfm";
+    }
+    if (gpus > 0) {
+        std::vector<float> rgb;
+        pt_scene_info info;
+        pt_counters c;
+        double secs = 0;
+        if (render_multi_gpu(pth_scene_get_desc(scene), gpus, rgb, &info, &c, &secs) != 0) { pth_scene_free(scene); return 1; }
+        int w = info.cropped_bounds[2] - info.cropped_bounds[0], h = info.cropped_bounds[3] - info.cropped_bounds[1];
+        const pt_scene_desc* dsc = pth_scene_get_desc(scene);
+        if (pth_write_image(outfile.c_str(), rgb.data(), w, h, info.cropped_bounds[0], info.cropped_bounds[1], dsc->xres, dsc->yres) != PT_OK) { std::fprintf(stderr, "pbrt_gpu: cannot write %s\n", outfile.c_str()); return 1; }
+        if (!quiet)
+            std::fprintf(stderr, "pbrt_gpu: %s  %dx%d, %d spp on %d GPU(s)  rendered + reduced in %.3f s  %.1f Mrays/s  -> %s\n", input.c_str(), w, h, info.spp, gpus, secs,
+                         (double)(c.regular_rays + c.shadow_rays) / secs / 1e6, outfile.c_str());
+        if (stats)
+            std::fprintf(stderr, "  Regular ray intersection tests %llu\n  Shadow ray intersection tests  %llu\n  Camera rays %llu, path vertices %llu\n",
+                         (unsigned long long)c.regular_rays, (unsigned long long)c.shadow_rays, (unsigned long long)c.camera_rays, (unsigned long long)c.path_vertices);
+        pth_scene_free(scene);
+        return 0;
     }
     pt_context* ctx = nullptr;
     st = pt_context_create(device, &ctx);

@@ -1280,6 +1280,51 @@ pt_status pt_film_commit_xyzw(pt_context* ctx) {
     return PT_OK;
 }
 
+// The path's one exchange step, inside the library: sum the per-rank XYZW films over an RCCL communicator the caller owns
+// (Film::merge_film_tile across GPUs, film.rs:219-241).  librccl is looked up at run time -- first the copy already mapped into
+// the process (the communicator must come from that very copy: a torch process carries its own), else the system's.
+}  // extern "C"
+namespace {
+struct RcclApi {
+    int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+    bool tried = false;
+};
+RcclApi& rccl_api() {
+    static RcclApi api;
+    if (api.tried) return api;
+    api.tried = true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return api;
+    api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(dlsym(h, "ncclAllReduce"));
+    api.reduce = reinterpret_cast<decltype(api.reduce)>(dlsym(h, "ncclReduce"));
+    api.error_string = reinterpret_cast<decltype(api.error_string)>(dlsym(h, "ncclGetErrorString"));
+    return api;
+}
+}  // namespace
+extern "C" {
+
+pt_status pt_film_allreduce(pt_context* ctx, void* nccl_comm, int root) {
+    if (!ctx || !nccl_comm) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    (void)hipSetDevice(ctx->device);
+    RcclApi& api = rccl_api();
+    if (!api.all_reduce || !api.reduce) return ctx->fail(PT_ERR_UNSUPPORTED, "librccl.so.1 (ncclAllReduce / ncclReduce) not found");
+    pt_status st = film_to_xyzw(ctx);
+    if (st != PT_OK) return st;
+    const size_t n = (size_t)ctx->film_w * ctx->film_h * 4;
+    const int kFloat = 7, kSum = 0;          // ncclFloat32, ncclSum (rccl.h)
+    int rc = root < 0 ? api.all_reduce(ctx->d_xyzw.p, ctx->d_xyzw.p, n, kFloat, kSum, nccl_comm, ctx->stream)
+                      : api.reduce(ctx->d_xyzw.p, ctx->d_xyzw.p, n, kFloat, kSum, root, nccl_comm, ctx->stream);
+    if (rc != 0) return ctx->fail(PT_ERR_DEVICE, std::string("RCCL: ") + (api.error_string ? api.error_string(rc) : "error"));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->xyzw_committed = true;
+    return PT_OK;
+}
+
 pt_status pt_film_resolve_rgb(pt_context* ctx, float* rgb_out) {
     if (!ctx || !rgb_out) return PT_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
@@ -1329,6 +1374,65 @@ pt_status pt_trace_closest(pt_context* ctx, uint32_t n, const float* o, const fl
 }
 pt_status pt_trace_any(pt_context* ctx, uint32_t n, const float* o, const float* d, const float* tmax, uint8_t* occluded_out) {
     return trace_batch(ctx, n, o, d, tmax, nullptr, occluded_out, 1);
+}
+
+// Caller rays through the kernel the renderer itself traces with (see k_wavefront_results): ray i becomes path slot i; the
+// continuation / shadow / probe queues list the rays of each kind in caller order, exactly the mix one bounce launches.
+pt_status pt_trace_wavefront(pt_context* ctx, uint32_t n, const float* o, const float* d, const float* tmax, const uint8_t* kind, pt_hit* out,
+                             uint8_t* occluded_out) {
+    if (!ctx || !o || !d || !tmax || !kind || !out || !occluded_out) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    std::vector<float> o4((size_t)n * 4), d4((size_t)n * 4);
+    std::vector<uint32_t> ids[3];
+    for (uint32_t i = 0; i < n; i++) {
+        if (kind[i] < 1 || kind[i] > 3) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "ray kind must be 1 (continuation), 2 (shadow) or 3 (probe)");
+        ids[kind[i] - 1].push_back(i);
+        for (int k = 0; k < 3; k++) { o4[4 * (size_t)i + k] = o[3 * (size_t)i + k]; d4[4 * (size_t)i + k] = d[3 * (size_t)i + k]; }
+        o4[4 * (size_t)i + 3] = tmax[i];
+        d4[4 * (size_t)i + 3] = 0.0f;
+    }
+    pt_status st;
+    if ((st = ensure_pool(ctx, std::max<size_t>(n, 65536))) != PT_OK) return st;
+    const PtPaths& P = ctx->paths;
+    float4* const dst_o[3] = {P.ray_o, P.sh_o, P.pr_o};
+    float4* const dst_d[3] = {P.ray_d, P.sh_d, P.pr_d};
+    for (int k = 0; k < 3; k++) {
+        PT_HIP(hipMemcpyAsync(dst_o[k], o4.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        PT_HIP(hipMemcpyAsync(dst_d[k], d4.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    }
+    PtQueues Q;
+    Q.cur = ctx->d_qa.as<uint32_t>(); Q.next = ctx->d_qb.as<uint32_t>();
+    Q.nee = ctx->d_qnee.as<uint32_t>(); Q.counts = ctx->d_counts.as<uint32_t>(); Q.sorted = ctx->d_qsorted.as<uint32_t>();
+    Q.shadow = ctx->d_qshadow.as<uint32_t>(); Q.probe = ctx->d_qprobe.as<uint32_t>();
+    uint32_t* const dst_q[3] = {Q.cur, Q.shadow, Q.probe};
+    for (int k = 0; k < 3; k++)
+        if (!ids[k].empty()) PT_HIP(hipMemcpyAsync(dst_q[k], ids[k].data(), ids[k].size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint32_t> counts(PT_COUNTS_WORDS, 0u);
+    counts[PT_Q_CUR] = (uint32_t)ids[0].size(); counts[PT_Q_SHADOW] = (uint32_t)ids[1].size(); counts[PT_Q_PROBE] = (uint32_t)ids[2].size();
+    PT_HIP(hipMemcpyAsync(Q.counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    DevBuf d_kind, d_out, d_occ;
+    PT_HIP(d_kind.alloc(n)); PT_HIP(d_out.alloc((size_t)n * sizeof(pt_hit))); PT_HIP(d_occ.alloc(n));
+    PT_HIP(hipMemcpyAsync(d_kind.p, kind, n, hipMemcpyHostToDevice, ctx->stream));
+    hipEvent_t a = get_event(ctx, 0), b = get_event(ctx, 1);
+    PT_HIP(hipEventRecord(a, ctx->stream));
+    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->sc, P, Q, ctx->d_counters.as<PtCounters>(), ctx->d_spill.as<uint32_t>(), ctx->spill_depth,
+                     ctx->d_err.as<uint32_t>()));
+    PT_HIP(hipEventRecord(b, ctx->stream));
+    PT_HIP(ptk_wavefront_results(ctx->stream, ctx->grid_wide, ctx->sc, P, n, d_kind.as<uint8_t>(), d_out.as<pt_hit>(), d_occ.as<uint8_t>()));
+    PT_HIP(hipMemsetAsync(Q.counts, 0, PT_COUNTS_WORDS * 4, ctx->stream));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    PT_HIP(hipEventElapsedTime(&ms, a, b));
+    ctx->trace_ms += ms;
+    ctx->trace_launches++;
+    uint32_t herr = 0;
+    PT_HIP(hipMemcpy(&herr, ctx->d_err.p, 4, hipMemcpyDeviceToHost));
+    if (herr) { PT_HIP(hipMemsetAsync(ctx->d_err.p, 0, 4, ctx->stream)); PT_HIP(hipStreamSynchronize(ctx->stream)); return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow"); }
+    PT_HIP(hipMemcpy(out, d_out.p, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(occluded_out, d_occ.p, n, hipMemcpyDeviceToHost));
+    return PT_OK;
 }
 
 pt_status pt_generate_camera_rays(pt_context* ctx, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* out_o, float* out_d,

@@ -998,6 +998,44 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_trace_batch_inst(PtScen
     trace_batch_body<true, true>(sc, n, o, d, tmax, out, occ_out, any_hit, ticket, cnt, spill, spill_depth, err);
 }
 
+// ============================================================ hook: caller rays through the wavefront's own traversal kernel
+// pt_trace_wavefront loads caller rays into the path pool as the three kinds of work items a bounce mixes in one launch and
+// runs ptk_trace (k_trace / k_trace_seq / k_trace_sph_dist / k_trace_sph / k_trace_inst -- whatever the scene renders with).
+// This kernel turns what the traversal stored (hit_t / hit_rec / hit_inst, occluded, probe_rec) into the hook's outputs.
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_wavefront_results(PtScene sc, PtPaths P, uint32_t n, const uint8_t* kind, pt_hit* out, uint8_t* occ) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t k = kind[i];
+        pt_hit h;
+        h.t = 0.0f; h.prim = -1; h.b0 = 0.0f; h.b1 = 0.0f;
+        uint8_t oc = 0;
+        if (k == 2u) oc = P.occluded[i];
+        else {
+            const int32_t rec = k == 1u ? P.hit_rec[i] : P.probe_rec[i];
+            if (rec >= 0) {
+                const uint32_t inst = (k == 1u && sc.n_instances) ? P.hit_inst[i] : 0u;
+                TriVerts tv = load_tri(sc.tris, (uint32_t)rec);
+                h.prim = inst ? (int32_t)sc.instances[inst - 1u].world_prim : (int32_t)tv.prim;
+                if (k == 1u) {
+                    h.t = P.hit_t[i];
+                    if (!inst && !(tv.flags & (PT_TRI_SPHERE | PT_TRI_INSTANCE))) {
+                        RayPre rp;
+                        ray_precompute(rp, f4_3(P.ray_o[i]), f4_3(P.ray_d[i]));
+                        TriHit th;
+                        tri_test(rp, tv.p0, tv.p1, tv.p2, tv.flags, PT_INF, th);   // same arithmetic => same b
+                        h.b0 = th.b0; h.b1 = th.b1;
+                    }
+                }
+            }
+        }
+        out[i] = h;
+        occ[i] = oc;
+    }
+}
+hipError_t ptk_wavefront_results(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n, const uint8_t* kind, pt_hit* out, uint8_t* occ) {
+    hipLaunchKernelGGL(k_wavefront_results, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n, kind, out, occ);
+    return hipGetLastError();
+}
+
 // ============================================================ tiles -> pixel list
 // One block per tile: writes the tile's pixels (row-major, x | y << 16 relative to the sample bounds) at its offset of the
 // pass's pixel list, and marks them in a bitmap over the sample bounds -- a pixel marked twice means overlapping tiles

@@ -1,0 +1,89 @@
+"""GPU side of the multi-GPU path on one device: the zero-copy wrap of the library's film, the staged and in-place RCCL
+reduce of pbrt-r3_amd/dist.py over a world-size-1 "nccl" group, film_commit_xyzw, the library's own pt_film_allreduce over a
+communicator made by ncclCommInitAll, and the C++ `pbrt_gpu --gpus 1` driver (the same code path N GPUs take).
+World size 1 makes the sum the identity, so the film must come back bit for bit."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import bits, scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _rendered(ctx):
+    ctx.upload(scenes.cornell_box(res=64, spp=8))
+    ctx.film_clear(); ctx.render()
+    return ctx.film_xyzw()
+
+
+@pytest.mark.parametrize("staged", [True, False])
+def test_reduce_film_world1_is_identity(gpu_ctx, pkg, nccl_group, staged):
+    want = _rendered(gpu_ctx)
+    assert want[..., 3].sum() > 0
+    film = pkg.dist.reduce_film(gpu_ctx, 0, staged=staged)
+    assert film.numel() == want.size
+    got = gpu_ctx.film_xyzw()
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_commit_makes_the_reduced_buffer_authoritative(gpu_ctx, pkg, nccl_group):
+    want = _rendered(gpu_ctx)
+    ptr, n = gpu_ctx.film_device_xyzw()
+    t = pkg.dist.wrap_device_floats(ptr, n, 0)
+    t.mul_(2.0)                                   # what a reduce over two identical ranks would leave
+    import torch
+    torch.cuda.synchronize(0)
+    assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want))          # not committed: rebuilt from the rank's own sums
+    t.mul_(2.0); torch.cuda.synchronize(0)
+    gpu_ctx.film_commit_xyzw()
+    assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want * np.float32(2.0)))
+    rgb2 = gpu_ctx.film_rgb()                      # weights doubled too: the resolved image is unchanged
+    gpu_ctx.film_clear(); gpu_ctx.render()         # a new render supersedes the committed buffer
+    assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want))
+    assert np.allclose(rgb2, gpu_ctx.film_rgb(), rtol=2e-6, atol=1e-7)
+
+
+def test_library_side_allreduce(gpu_ctx):
+    """pt_film_allreduce with a communicator from ncclCommInitAll -- no torch in the data path."""
+    want = _rendered(gpu_ctx)
+    rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    try:
+        gpu_ctx.film_allreduce(comm.value)              # all-reduce
+        assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want))
+        gpu_ctx.film_clear(); gpu_ctx.render()
+        gpu_ctx.film_allreduce(comm.value, root=0)      # reduce to rank 0
+        assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want))
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
+def test_cpp_driver_gpus_1(tmp_path):
+    """`pbrt_gpu --gpus 1`: threads + ncclCommInitAll + pt_film_allreduce; same image as the single-context run."""
+    exe = os.path.join(ROOT, "pbrt-r3_amd", "csrc", "pbrt_gpu")
+    scene = os.path.join(ROOT, "tests", "scenes", "cornell.pbrt")
+    a, b = str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.check_call([exe, scene, "-o", a, "--pixelsamples", "4", "--quiet"], env=env)
+    subprocess.check_call([exe, scene, "-o", b, "--pixelsamples", "4", "--quiet", "--gpus", "1"], env=env)
+    assert open(a, "rb").read() == open(b, "rb").read()
