@@ -30,6 +30,10 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def gpu_ctx(pkg):
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, same soname as /opt/rocm's).  Whichever copy a process maps
+    # first serves every later library, and a second copy does not find the GPU -- so the tests that hand the film to
+    # torch.distributed (test_gpu_dist.py) need torch's copy in place before libpbrtgpu.so is opened, as bench.py has it.
+    import torch  # noqa: F401
     ctx = pkg.Context(0)
     yield ctx
     ctx.close()
