@@ -74,7 +74,7 @@ struct pt_context {
     // ---- traversal scratch
     DevBuf d_spill, d_err, d_counters, d_ticket;
     uint32_t spill_depth = 0;
-    int grid_trace = 1024, grid_shade = 512, grid_wide = 2048;
+    int grid_trace = 1024, grid_trace_dist = 768, grid_shade = 512, grid_wide = 2048;
 
     // ---- path pool
     size_t pool_paths = 0;
@@ -175,7 +175,8 @@ pt_status ensure_pool(pt_context* ctx, size_t n_paths) {
 }
 
 pt_status ensure_traversal_scratch(pt_context* ctx) {
-    uint32_t need = ctx->max_stack + 1 > PT_LDS_STACK ? ctx->max_stack + 1 - PT_LDS_STACK : 0;     // +1: the top entry is stored too
+    // +1: the top entry is stored too; -1: the pooled-leaf kernels keep a sentinel in LDS slot 0
+    uint32_t need = ctx->max_stack + 1 > PT_FS_SLOTS - 1 ? ctx->max_stack + 1 - (PT_FS_SLOTS - 1) : 0;
     size_t threads = (size_t)std::max(ctx->grid_trace, 2048) * PT_BLOCK;
     if (!ctx->d_spill.p || ctx->spill_depth < need) {
         PT_HIP(ctx->d_spill.alloc((size_t)std::max(need, 1u) * threads * 4));
@@ -215,7 +216,8 @@ pt_status pt_context_create(int device, pt_context** out) {
     std::memset(&ctx->paths, 0, sizeof(ctx->paths));
     // occupancy-sized persistent grids: blocks per CU from register/LDS use x CU count
     ctx->grid_trace = ctx->n_cu * 4;
-    if (const char* e = std::getenv("PBRTGPU_TRACE_BLOCKS_PER_CU")) ctx->grid_trace = ctx->n_cu * std::max(1, std::atoi(e));
+    ctx->grid_trace_dist = ctx->n_cu * 3;
+    if (const char* e = std::getenv("PBRTGPU_TRACE_BLOCKS_PER_CU")) ctx->grid_trace = ctx->grid_trace_dist = ctx->n_cu * std::max(1, std::atoi(e));
     ctx->grid_shade = ctx->n_cu * 2;
     if (const char* e = std::getenv("PBRTGPU_SHADE_BLOCKS_PER_CU")) ctx->grid_shade = ctx->n_cu * std::max(1, std::atoi(e));
     ctx->grid_wide = ctx->n_cu * 8;
@@ -750,6 +752,23 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     PtScene& sc = ctx->sc;
     std::memset(&sc, 0, sizeof(sc));
     pt_status st;
+    // What the lean node visit (pt_kernels.hip node_step_lean) reads beside the builder's output: the per-octant order tables, and
+    // empty child slots as inverted boxes so that they fail the slab test by themselves (the builders leave them all-zero, as the
+    // reference does; the general visit masks them out by the occupied-slot bits either way).
+    if (bvh.nodes.size() >= (1u << 25)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^25 BVH nodes (32-bit node offsets)");
+    ptbvh::parallel_for(bvh.nodes.size(), [&](size_t n0, size_t n1) {
+        for (size_t n = n0; n < n1; n++) {
+            PtNode& nd = bvh.nodes[n];
+            uint32_t lut = 0;
+            for (uint32_t oct = 0; oct < 8; oct++)
+                for (uint32_t k = 0; k < 3; k++)
+                    if ((oct >> ((nd.axes >> (2 * k)) & 3u)) & 1u) lut |= 1u << (8 * k + oct);
+            nd.order_lut = lut;
+            for (int ch = 0; ch < 4; ch++)
+                if (!((nd.axes >> (8 + ch)) & 1u))
+                    for (int a = 0; a < 3; a++) { nd.bmin[a][ch] = INFINITY; nd.bmax[a][ch] = -INFINITY; }
+        }
+    });
     if ((st = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_tris, bvh.tris.data(), bvh.tris.size())) != PT_OK) return st;
     ctx->n_nodes_up = bvh.nodes.size(); ctx->n_tris_up = bvh.tris.size();
@@ -1145,7 +1164,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 PT_HIP(hipMemsetAsync(ctx->d_ticket.p, 0, 16, ctx->stream));
                 PT_HIP(ptk_ao_tag(ctx->stream, ctx->grid_wide, ctx->paths, n_pix, n_paths, s0));
                 PT_HIP(hipEventRecord(a, ctx->stream));
-                PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
                 ctx->trace_launches++;
                 PT_HIP(ptk_ao_rays(ctx->stream, ctx->grid_wide, sc, ctx->paths, n_paths, ao_o, ao_d, ao_t, ao_w, ao_count, cnt));
                 uint32_t n_hit = 0;
@@ -1172,7 +1191,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                         ev_i += 3;
                         PT_HIP(hipEventRecord(a, ctx->stream));
                     }
-                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
                     if (timed) PT_HIP(hipEventRecord(b, ctx->stream));
                     PT_HIP(ptk_nee_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q));
                     ctx->trace_launches++;
@@ -1193,7 +1212,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                     PT_HIP(hipStreamSynchronize(ctx->stream));
                     if (counts[PT_Q_CUR] == 0 && counts[PT_Q_NEE] == 0) break;
                     if (counts[PT_Q_CUR] == 0) {     // only NEE resolves left
-                        PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                        PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
                         PT_HIP(ptk_nee_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q));
                         ctx->trace_launches++;
                         PT_HIP(ptk_prep(ctx->stream, Q, 0));
@@ -1213,6 +1232,18 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
         PT_HIP(hipStreamSynchronize(ctx->stream));
         return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow (BVH deeper than the computed bound)");
     }
+#ifdef PT_STACK_HIST
+    {   // diagnostic build: histogram of the traversal stack depth at node visits (k_trace's lean visit)
+        uint32_t hist[64];
+        PT_HIP(hipMemcpy(hist, ctx->d_spill.as<uint32_t>() + 1024, sizeof(hist), hipMemcpyDeviceToHost));
+        PT_HIP(hipMemsetAsync(ctx->d_spill.as<uint32_t>() + 1024, 0, sizeof(hist), ctx->stream)); PT_HIP(hipStreamSynchronize(ctx->stream));
+        double tot = 0, cum = 0;
+        for (uint32_t v : hist) tot += v;
+        std::fprintf(stderr, "[stack depth at node visits]");
+        for (int k = 0; k < 64; k++) { cum += hist[k]; if (hist[k]) std::fprintf(stderr, " %d:%.4f", k, cum / tot); }
+        std::fprintf(stderr, "\n");
+    }
+#endif
 #ifdef PT_PROFILE_PHASES
     {   // diagnostic build (tools/tune_trace.sh "prof:-DPT_PROFILE_PHASES:4"): wave-clock split of k_trace's two phases
         unsigned long long pr[10];
@@ -1417,7 +1448,7 @@ pt_status pt_trace_wavefront(pt_context* ctx, uint32_t n, const float* o, const 
     PT_HIP(hipMemcpyAsync(d_kind.p, kind, n, hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t a = get_event(ctx, 0), b = get_event(ctx, 1);
     PT_HIP(hipEventRecord(a, ctx->stream));
-    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->sc, P, Q, ctx->d_counters.as<PtCounters>(), ctx->d_spill.as<uint32_t>(), ctx->spill_depth,
+    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, ctx->sc, P, Q, ctx->d_counters.as<PtCounters>(), ctx->d_spill.as<uint32_t>(), ctx->spill_depth,
                      ctx->d_err.as<uint32_t>()));
     PT_HIP(hipEventRecord(b, ctx->stream));
     PT_HIP(ptk_wavefront_results(ctx->stream, ctx->grid_wide, ctx->sc, P, n, d_kind.as<uint8_t>(), d_out.as<pt_hit>(), d_occ.as<uint8_t>()));

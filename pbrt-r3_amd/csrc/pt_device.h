@@ -10,6 +10,9 @@
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 32          // per-lane traversal stack entries kept in LDS
 #endif
+#define PT_SLOT (PT_BLOCK * 4u)    // bytes between two entries of a lane's LDS traversal stack ([entry][lane] layout)
+// LDS stack slots per lane of the pooled-leaf traversal kernels (slot 0 holds a sentinel; deeper entries spill to HBM)
+#define PT_FS_SLOTS (PT_LDS_STACK < 16 ? PT_LDS_STACK : 16)
 #define PT_EMPTY_REF 0xffffffffu
 #define PT_LEAF_BIT 0x80000000u
 #define PT_LEAF_COUNT_SHIFT 28          // bits 28..30 of a leaf reference: min(triangles in the leaf, 8) - 1
@@ -24,7 +27,9 @@ struct PtNode {
     float bmax[3][4];
     uint32_t child[4];
     uint32_t axes;               // axis_top | axis_left << 2 | axis_right << 4 | occupied-slot mask << 8
-    uint32_t pad[3];
+    uint32_t order_lut;          // written at upload (pt_context.cpp finish_nodes): bit o of byte 0 / 1 / 2 = the ray of direction octant o
+                                 // (bit 0 x < 0, bit 1 y < 0, bit 2 z < 0) is negative along axis_top / axis_left / axis_right
+    uint32_t pad[2];
 };
 
 // Triangle record in BVH leaf order (48 bytes = 3 x dwordx4).  The last record of

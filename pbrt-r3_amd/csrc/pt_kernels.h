@@ -4,7 +4,7 @@
 #include "pt_device.h"
 #include "../../include/pbrtgpu.h"
 
-hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
+hipError_t ptk_trace(hipStream_t st, int grid, int grid_dist, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err);
 hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out,
                            uint8_t* occ, int any_hit, uint32_t* ticket, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err);

@@ -345,6 +345,12 @@ struct TravCtx {
     uint32_t spill_depth;
     uint32_t n_nodes, n_tris;
     uint32_t overflow;
+    uint32_t lane_base;      // pooled-leaf kernels: LDS byte address of this lane's slot 0 (see FsStack)
+    // pooled-leaf kernels, staged node fetch (node_round_staged): LDS addresses
+    uint32_t stage_wave;     // this wave's 8 KB staging area (wave-uniform)
+    uint32_t stage_own;      // this lane's staged node: stage_wave + (lane >> 3) * 1024 + (lane & 7) * 128
+    uint32_t idx_pub, idx_ld;// where the lane publishes its node index / reads the eight indices it loads for
+    PT_DEV uint32_t stage_chunk(uint32_t q) const { return stage_own + ((q ^ (threadIdx.x & 7u)) << 4); }
 };
 // The stack lives in LDS (entries 0..PT_LDS_STACK-1, then the HBM spill area); `sp` is its depth and `top` a register
 // copy of entry sp-1 (PT_EMPTY_REF when empty), so a pop has its reference at once and the read that refreshes `top`
@@ -460,6 +466,11 @@ struct LaneRay {
     float tmin, tmax, ray_tmax;
     uint32_t sbits;              // bits 0-2: direction signs, bit 3: needs the EXACT slab form
     uint32_t sp, top;            // top == PT_EMPTY_REF: traversal finished
+    // k_trace / k_trace_sph_dist (the pooled-leaf kernels) keep the stack as an LDS byte address instead of `sp` (see FsStack) and
+    // carry the per-ray constants of the lean node visit
+    uint32_t sa, sa_limit;       // LDS address of the top entry's slot; the lean visit is allowed while sa < sa_limit
+    uint32_t o_nx, o_fx, o_ny, o_fy, o_nz, o_fz;   // byte offsets of the near / far plane rows inside a node (by the direction signs)
+    uint32_t m_t, m_l, m_r;      // this ray's bit in the node's three order tables (PtNode::order_lut)
     int32_t best;
     uint32_t best_inst;          // INST kernels: instance index + 1 of `best` (0 = a world primitive)
 };
@@ -476,6 +487,22 @@ PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max) {
     r.top = PT_EMPTY_REF;
     ray_precompute(r.rp, o, d);
     if (root_test(sc, o, r.idir, r.sbits, t_max, r.tmin, r.tmax)) { r.top = sc.root_ref; r.sp = 1; }
+}
+// The same for the pooled-leaf kernels: `sa` stack (root kept in `top` only: nothing lies above it when it is popped) and the
+// per-ray constants of node_step_lean.
+PT_DEV void ray_begin_fs(const PtScene& sc, LaneRay& r, const TravCtx& c, V3 o, V3 d, float t_max) {
+    ray_begin(sc, r, o, d, t_max);
+    r.sa = c.lane_base + (r.top != PT_EMPTY_REF ? PT_SLOT : 0u);
+    if (r.idir.x == 0.0f || r.idir.y == 0.0f || r.idir.z == 0.0f) r.sbits |= 8u;      // infinite direction component: 0 * inf in the slabs
+    // rows of a node: chunks 0..2 = bmin x / y / z, 3..5 = bmax x / y / z; near / far by the direction signs; as LDS addresses of
+    // this lane's staged node (chunk q sits at q ^ own_i, see node_round_staged)
+    const uint32_t ox = (r.sbits & 1u) ? 3u : 0u, oy = (r.sbits & 2u) ? 3u : 0u, oz = (r.sbits & 4u) ? 3u : 0u;
+    r.o_nx = c.stage_chunk(ox); r.o_fx = c.stage_chunk(3u - ox);
+    r.o_ny = c.stage_chunk(1u + oy); r.o_fy = c.stage_chunk(4u - oy);
+    r.o_nz = c.stage_chunk(2u + oz); r.o_fz = c.stage_chunk(5u - oz);
+    const uint32_t oct = r.sbits & 7u;
+    r.m_t = 1u << oct; r.m_l = 256u << oct; r.m_r = 65536u << oct;
+    r.sa_limit = (r.sbits & 8u) ? 0u : c.lane_base + (PT_FS_SLOTS - 3u) * PT_SLOT;
 }
 PT_DEV bool ray_done(const LaneRay& r) { return r.top == PT_EMPTY_REF; }
 PT_DEV bool ray_wants_tri(const LaneRay& r) { return r.top != PT_EMPTY_REF && (r.top & PT_LEAF_BIT) != 0; }
@@ -610,6 +637,191 @@ PT_DEV void ray_step(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
     else ray_step_node(sc, r, c);
 }
 
+// ============================================================ lean node visit (k_trace, k_trace_sph_dist)
+// The VALU-issue budget decides this kernel (tools/ubench/valu_issue.hip: a two-operand add / sub / mul / and / mov issues in
+// 2.7 SIMD cycles at four waves per SIMD, every three-operand, compare or select form in 4.4-4.8, packed f32 in 4.8 per pair).
+// The first version of the visit spent 177 instructions, two thirds of them on addresses, the order selects and four branch-free
+// pushes.  This one keeps the 48 sub / mul and 16 min / max of the four slab tests -- the parity contract -- and rebuilds the rest:
+//   * stack: `sa` is the LDS byte address of the top entry's slot, slot 0 of every lane holds PT_EMPTY_REF for good, so a pop is
+//     one add and one ds_read (the read that falls on slot 0 empties `top` by itself) and a push one add, one ds_write, one mov;
+//   * pushes are predicated by EXEC, not by selects: the four hit conditions stay in SGPR lane masks as v_cmp leaves them, the
+//     front-to-back order (ORDER_TABLE in closed form, qbvh_x86.rs:187-204) is applied to those masks by the scalar unit, and each
+//     push runs with EXEC = its condition;
+//   * the three order signs of a (node, ray octant) pair come from three 8-bit tables in the node (one AND + compare each);
+//   * the six plane rows are addressed as SGPR base + 32-bit offset with the sign-dependent part hoisted per ray;
+//   * empty child slots hold an inverted box (+inf / -inf) in HBM, so they fail the slab test by themselves.
+// Rays whose reciprocal direction has an infinite, NaN or zero component, and lanes within four slots of the LDS part's end,
+// take the general form (node_step_general) for the whole wave: same results, the first version's cost.
+typedef __attribute__((address_space(3))) uint32_t* pt_lds_u32;
+PT_DEV uint32_t lds_addr_of(const uint32_t* p) { return (uint32_t)(size_t)(pt_lds_u32)p; }
+PT_DEV uint32_t lds_load(uint32_t a) { return *(pt_lds_u32)(size_t)a; }
+PT_DEV void lds_store(uint32_t a, uint32_t v) { *(pt_lds_u32)(size_t)a = v; }
+PT_DEV uint32_t fs_slot(const TravCtx& c, uint32_t sa) { return (sa - c.lane_base) / PT_SLOT; }     // slot of the top entry; 0 = empty stack
+PT_DEV void fs_push(TravCtx& c, uint32_t& sa, uint32_t& top, uint32_t v) {
+    const uint32_t s = fs_slot(c, sa) + 1u;
+    if (s < PT_FS_SLOTS) lds_store(sa + PT_SLOT, v);
+    else if (s - PT_FS_SLOTS < c.spill_depth) c.spill[(size_t)(s - PT_FS_SLOTS) * c.spill_stride] = v;
+    else { c.overflow = 1; return; }
+    sa += PT_SLOT;
+    top = v;
+}
+PT_DEV uint32_t fs_pop(TravCtx& c, uint32_t& sa, uint32_t& top) {      // precondition: top != PT_EMPTY_REF
+    const uint32_t v = top;
+    sa -= PT_SLOT;
+    const uint32_t s = fs_slot(c, sa);
+    if (s >= PT_FS_SLOTS) top = c.spill[(size_t)(s - PT_FS_SLOTS) * c.spill_stride];
+    else top = lds_load(sa);                  // slot 0 hands back PT_EMPTY_REF
+    return v;
+}
+// single-instruction forms: fmaxf / fminf would get a canonicalising v_max in front of every operand the compiler cannot prove quiet
+PT_DEV float v_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PT_DEV float v_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PT_DEV float v_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+PT_DEV float v_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Old-form visit on the `sa` stack (any mix of lanes: NaN-exact slabs, HBM spill).
+template <bool EXACT>
+PT_DEV void visit_node_general(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t sbits, float tmin, float tmax, TravCtx& c, uint32_t& top, uint32_t& sa) {
+    const char* nb = reinterpret_cast<const char*>(nodes) + (size_t)ni * 128u;
+    const uint32_t ox = (sbits & 1u) ? 48u : 0u, oy = (sbits & 2u) ? 48u : 0u, oz = (sbits & 4u) ? 48u : 0u;
+    float4 nx = *reinterpret_cast<const float4*>(nb + ox), fx = *reinterpret_cast<const float4*>(nb + (48u - ox));
+    float4 ny = *reinterpret_cast<const float4*>(nb + 16u + oy), fy = *reinterpret_cast<const float4*>(nb + 16u + (48u - oy));
+    float4 nz = *reinterpret_cast<const float4*>(nb + 32u + oz), fz = *reinterpret_cast<const float4*>(nb + 32u + (48u - oz));
+    uint4 ch = *reinterpret_cast<const uint4*>(nb + 96u);
+    uint32_t axes = *reinterpret_cast<const uint32_t*>(nb + 112u);
+    uint32_t mask = 0;
+#define PT_SLAB(k, C)                                                        \
+    {                                                                        \
+        float a = tmin, b = tmax;                                            \
+        if (EXACT) {                                                         \
+            a = sse_max(a, (nx.C - o.x) * idir.x); b = sse_min(b, (fx.C - o.x) * idir.x); \
+            a = sse_max(a, (ny.C - o.y) * idir.y); b = sse_min(b, (fy.C - o.y) * idir.y); \
+            a = sse_max(a, (nz.C - o.z) * idir.z); b = sse_min(b, (fz.C - o.z) * idir.z); \
+        } else {                                                             \
+            a = fmaxf(a, (nx.C - o.x) * idir.x); b = fminf(b, (fx.C - o.x) * idir.x); \
+            a = fmaxf(a, (ny.C - o.y) * idir.y); b = fminf(b, (fy.C - o.y) * idir.y); \
+            a = fmaxf(a, (nz.C - o.z) * idir.z); b = fminf(b, (fz.C - o.z) * idir.z); \
+        }                                                                    \
+        if (b >= a) mask |= (1u << k);                                       \
+    }
+    PT_SLAB(0, x) PT_SLAB(1, y) PT_SLAB(2, z) PT_SLAB(3, w)
+#undef PT_SLAB
+    mask &= (axes >> 8) & 15u;          // empty slots (inverted boxes here, all-zero in the reference) never count
+    uint32_t s_top = (sbits >> (axes & 3)) & 1, s_left = (sbits >> ((axes >> 2) & 3)) & 1, s_right = (sbits >> ((axes >> 4) & 3)) & 1;
+    uint32_t l0 = s_left ? ch.x : ch.y, l1 = s_left ? ch.y : ch.x;
+    uint32_t l0b = s_left ? 1u : 2u, l1b = s_left ? 2u : 1u;
+    uint32_t r0 = s_right ? ch.z : ch.w, r1 = s_right ? ch.w : ch.z;
+    uint32_t r0b = s_right ? 4u : 8u, r1b = s_right ? 8u : 4u;
+    uint32_t c0 = s_top ? l0 : r0, c1 = s_top ? l1 : r1, c2 = s_top ? r0 : l0, c3 = s_top ? r1 : l1;
+    uint32_t b0 = s_top ? l0b : r0b, b1 = s_top ? l1b : r1b, b2 = s_top ? r0b : l0b, b3 = s_top ? r1b : l1b;
+    if (mask & b0) fs_push(c, sa, top, c0);
+    if (mask & b1) fs_push(c, sa, top, c1);
+    if (mask & b2) fs_push(c, sa, top, c2);
+    if (mask & b3) fs_push(c, sa, top, c3);
+}
+PT_DEV void node_step_general(const PtScene& sc, LaneRay& r, TravCtx& c) {
+    const uint32_t ref = fs_pop(c, r.sa, r.top);
+    c.n_nodes++;
+    if (r.sbits & 8u) visit_node_general<true>(sc.nodes, ref, r.o, r.idir, r.sbits, r.tmin, r.tmax, c, r.top, r.sa);
+    else visit_node_general<false>(sc.nodes, ref, r.o, r.idir, r.sbits, r.tmin, r.tmax, c, r.top, r.sa);
+}
+// Four pushes, each with EXEC = its own condition (lane masks inside the current EXEC).
+PT_DEV void fs_push4_exec(uint32_t& sa, uint32_t& top, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, unsigned long long e0, unsigned long long e1,
+                          unsigned long long e2, unsigned long long e3) {
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[e0]\n\t"
+        "v_add_u32 %[sa], %[slot], %[sa]\n\t"
+        "v_mov_b32 %[top], %[c0]\n\t"
+        "ds_write_b32 %[sa], %[c0]\n\t"
+        "s_mov_b64 exec, %[e1]\n\t"
+        "v_add_u32 %[sa], %[slot], %[sa]\n\t"
+        "v_mov_b32 %[top], %[c1]\n\t"
+        "ds_write_b32 %[sa], %[c1]\n\t"
+        "s_mov_b64 exec, %[e2]\n\t"
+        "v_add_u32 %[sa], %[slot], %[sa]\n\t"
+        "v_mov_b32 %[top], %[c2]\n\t"
+        "ds_write_b32 %[sa], %[c2]\n\t"
+        "s_mov_b64 exec, %[e3]\n\t"
+        "v_add_u32 %[sa], %[slot], %[sa]\n\t"
+        "v_mov_b32 %[top], %[c3]\n\t"
+        "ds_write_b32 %[sa], %[c3]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sa] "+v"(sa), [top] "+v"(top), [sv] "=&s"(sv)
+        : [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [slot] "s"(PT_SLOT)
+        : "memory");
+}
+// One node round of the whole wave.  The kernel is bound by the vector L1's request rate, not by arithmetic: with one ray per lane
+// every lane's 128-byte node is a line of its own, and the eight loads of the first version were 8 x 64 tag look-ups per round
+// (tools/ubench/node_fetch.hip: 77 G node visits/s is all the chip can do that way, k_trace sat at 61 G beside its triangle
+// loads).  Here the wave fetches the up-to-64 nodes TOGETHER: in load j, lane l fetches 16-byte chunk of the node of lane
+// 8 j + (l >> 3) -- eight neighbouring lanes cover one whole line -- straight into LDS (global_load_lds_dwordx4, no VGPR round
+// trip; one instruction lands 1 KiB = 8 nodes), and each owner then reads its rows from LDS.  164-171 G node visits/s in the
+// micro-benchmark.  Chunk c of sub-node i of a piece is stored at position c ^ i (the swizzle is applied to the SOURCE address,
+// the LDS image of an LDS-DMA is lane-linear), so the eight owners of a piece read any one row from eight different bank groups.
+//   w_node  this lane has a node to visit (its reference is r.top)
+typedef __attribute__((address_space(3))) void* pt_lds_void;
+typedef const __attribute__((address_space(1))) void* pt_global_cvoid;
+typedef float pt_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t pt_v4u __attribute__((ext_vector_type(4)));
+PT_DEV float4 lds_load4(uint32_t a) { const pt_v4f v = *(__attribute__((address_space(3))) const pt_v4f*)(size_t)a; return make_float4(v.x, v.y, v.z, v.w); }
+PT_DEV uint4 lds_load4u(uint32_t a) { const pt_v4u v = *(__attribute__((address_space(3))) const pt_v4u*)(size_t)a; return make_uint4(v.x, v.y, v.z, v.w); }
+PT_DEV void node_round_staged(const PtScene& sc, LaneRay& r, TravCtx& c, bool w_node) {
+    // owners: pop, publish the node index (transposed: the eight indices a loader lane needs are contiguous)
+    uint32_t ref = PT_EMPTY_REF, top = PT_EMPTY_REF;
+    if (w_node) {
+#ifdef PT_STACK_HIST
+        atomicAdd(c.spill - ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x) + 1024u + min(fs_slot(c, r.sa), 63u), 1u);   // diagnostic build: stack depth at each node visit
+#endif
+        ref = r.top;
+        r.sa -= PT_SLOT;
+        top = lds_load(r.sa);                 // the entry below (slot 0: PT_EMPTY_REF)
+        c.n_nodes++;
+    }
+    lds_store(c.idx_pub, ref);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {   // loaders
+        const uint4 ia = lds_load4u(c.idx_ld), ib = lds_load4u(c.idx_ld + 16u);
+        const uint32_t ids[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t coff = ((lane & 7u) ^ (lane >> 3)) << 4;
+        const char* nb = reinterpret_cast<const char*>(sc.nodes);
+        const uint32_t piece0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.stage_wave);
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++)
+            if (ids[j] != PT_EMPTY_REF)
+                __builtin_amdgcn_global_load_lds((pt_global_cvoid)(nb + ((ids[j] << 7) + coff)), (pt_lds_void)(size_t)(piece0 + j * 1024u), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA writes have landed (nothing else orders a ds_read behind them)
+    __builtin_amdgcn_wave_barrier();
+    if (w_node) {
+        const float4 nx = lds_load4(r.o_nx), fx = lds_load4(r.o_fx), ny = lds_load4(r.o_ny), fy = lds_load4(r.o_fy), nz = lds_load4(r.o_nz), fz = lds_load4(r.o_fz);
+        const uint4 ch = lds_load4u(c.stage_chunk(6u));
+        const uint32_t lut = lds_load(c.stage_chunk(7u) + 4u);
+        const float ox = r.o.x, oy = r.o.y, oz = r.o.z, ix = r.idir.x, iy = r.idir.y, iz = r.idir.z;
+#define PT_SLAB(C) (v_min3(v_min(r.tmax, (fx.C - ox) * ix), (fy.C - oy) * iy, (fz.C - oz) * iz) >= v_max3(v_max(r.tmin, (nx.C - ox) * ix), (ny.C - oy) * iy, (nz.C - oz) * iz))
+        const bool h0 = PT_SLAB(x), h1 = PT_SLAB(y), h2 = PT_SLAB(z), h3 = PT_SLAB(w);
+#undef PT_SLAB
+        // ORDER_TABLE in closed form: pops visit {0,1} before {2,3} iff the ray is non-negative along axis_top, 0 before 1 iff along
+        // axis_left, 2 before 3 iff along axis_right; pushes run in the reverse of the visit order
+        const bool T = (lut & r.m_t) != 0u, L = (lut & r.m_l) != 0u, R = (lut & r.m_r) != 0u;
+        const uint32_t l0 = L ? ch.x : ch.y, l1 = L ? ch.y : ch.x, r0 = R ? ch.z : ch.w, r1 = R ? ch.w : ch.z;
+        const uint32_t c0 = T ? l0 : r0, c1 = T ? l1 : r1, c2 = T ? r0 : l0, c3 = T ? r1 : l1;
+        // the same selects on the hit conditions, as 64-bit lane masks on the scalar unit (a ? x : y == y ^ (a & (x ^ y))); lanes
+        // outside EXEC are zero in every v_cmp result, so each push condition lies inside EXEC
+        const unsigned long long H0 = __ballot(h0), H1 = __ballot(h1), H2 = __ballot(h2), H3 = __ballot(h3), Tm = __ballot(T), Lm = __ballot(L), Rm = __ballot(R);
+        const unsigned long long yl = Lm & (H0 ^ H1), el0 = H1 ^ yl, el1 = H0 ^ yl;
+        const unsigned long long yr = Rm & (H2 ^ H3), er0 = H3 ^ yr, er1 = H2 ^ yr;
+        const unsigned long long y0 = Tm & (el0 ^ er0), e0 = er0 ^ y0, e2 = el0 ^ y0;
+        const unsigned long long y1 = Tm & (el1 ^ er1), e1 = er1 ^ y1, e3 = el1 ^ y1;
+        fs_push4_exec(r.sa, top, c0, c1, c2, c3, e0, e1, e2, e3);
+        r.top = top;
+    }
+}
+
 // intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
 template <bool SPH, bool INST>
 PT_DEV int32_t trace_closest(const PtScene& sc, V3 o, V3 d, float t_max, TravCtx& c, float* t_out, uint32_t* inst_out) {
@@ -674,7 +886,10 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #define PT_LEAF_MIN 24          // k_trace_seq: leaf phase once this many lanes are parked on a leaf
 #endif
 #ifndef PT_TRACE_WAVES
-#define PT_TRACE_WAVES 4        // waves per SIMD the register allocator must leave room for
+#define PT_TRACE_WAVES 4        // waves per SIMD the register allocator must leave room for (k_trace_seq)
+#endif
+#ifndef PT_TRACE_DIST_WAVES
+#define PT_TRACE_DIST_WAVES 3   // pooled-leaf kernels: 49 KB of LDS per block => three blocks per CU
 #endif
 
 #ifndef PT_LEAF_TRIS_MIN
@@ -684,16 +899,31 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 // triangles of all parked lanes and hand one (ray, triangle) test to each lane of the wave.
 template <bool DIST, bool SPH, bool INST = false>
 PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
-    __shared__ uint32_t s_stack[PT_LDS_STACK * PT_BLOCK];
+    // LDS per block.  Pooled-leaf kernels: 16 stack slots x 1 KB + 8 KB node staging per wave + node-index exchange = 49 KB, three
+    // blocks per CU (RT1M: 99.98 % of node visits find the stack at 13 entries or fewer; deeper lanes spill to HBM); a leaf round's
+    // 64 test results and owner map live in the wave's staging area, which a node round of the same wave never uses at the same time.
+    __shared__ uint32_t s_stack[(DIST ? PT_FS_SLOTS : PT_LDS_STACK) * PT_BLOCK];
     __shared__ unsigned long long s_cnt[4];
-    __shared__ float4 s_res[DIST ? PT_BLOCK : 1];          // per wave: 64 test results (ok, t_scaled, det, t)
-    __shared__ unsigned char s_map[DIST ? PT_BLOCK : 1];   // per wave: work item -> owner lane
+    __shared__ __attribute__((aligned(16))) unsigned char s_stage[DIST ? (PT_BLOCK / 64) * 8192 : 16];
+    __shared__ uint32_t s_idx[DIST ? PT_BLOCK : 1];
+    float4* const s_res = reinterpret_cast<float4*>(s_stage + (threadIdx.x >> 6) * 8192u) - (threadIdx.x & ~63u);            // indexed [wbase + k]
+    unsigned char* const s_map = s_stage + (threadIdx.x >> 6) * 8192u + 1024u - (threadIdx.x & ~63u);
     TravCtx c;
     c.lds = &s_stack[threadIdx.x];
     c.spill_stride = gridDim.x * PT_BLOCK;
     c.spill = spill + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     c.spill_depth = spill_depth;
     c.n_nodes = 0; c.n_tris = 0; c.overflow = 0;
+    c.lane_base = 0; c.stage_wave = 0; c.stage_own = 0; c.idx_pub = 0; c.idx_ld = 0;
+    if constexpr (DIST) {        // slot 0 of the lane's stack: the sentinel a pop of the last entry reads back (see node_step_lean)
+        s_stack[threadIdx.x] = PT_EMPTY_REF;
+        c.lane_base = lds_addr_of(&s_stack[threadIdx.x]);
+        const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        c.stage_wave = lds_addr_of(reinterpret_cast<const uint32_t*>(s_stage + wv * 8192u));
+        c.stage_own = c.stage_wave + (ln >> 3) * 1024u + (ln & 7u) * 128u;
+        c.idx_pub = lds_addr_of(&s_idx[wv * 64u + (ln & 7u) * 8u + (ln >> 3)]);
+        c.idx_ld = lds_addr_of(&s_idx[wv * 64u + (ln >> 3) * 8u]);
+    }
     const uint32_t n_cur = Q.counts[PT_Q_CUR], n_sh = Q.counts[PT_Q_SHADOW], n_pr = Q.counts[PT_Q_PROBE];
     const uint32_t total = n_cur + n_sh + n_pr;
     const uint32_t lane = threadIdx.x & 63;
@@ -707,6 +937,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     uint32_t p = 0;
     LaneRay r;
     r.sp = 0;
+    r.sa = c.lane_base; r.sa_limit = 0;
     r.top = PT_EMPTY_REF;
     bool more = total > 0;
     // prefetch reservation (see the loop): stage, ticket result (lane 0), rays reserved / handed out, one ray per lane
@@ -787,7 +1018,8 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 if (kind == 0 && rank < take) {
                     p = np; kind = nk;
                     if (nk == 2) shadow++; else regular++;
-                    ray_begin(sc, r, f4_3(ro), mk3(rd.x, rd.y, rd.z), ro.w);
+                    if constexpr (DIST) ray_begin_fs(sc, r, c, f4_3(ro), mk3(rd.x, rd.y, rd.z), ro.w);
+                    else ray_begin(sc, r, f4_3(ro), mk3(rd.x, rd.y, rd.z), ro.w);
                 }
                 pf_used += take;
                 if (pf_used == pf_count) pf_stage = 0;
@@ -816,7 +1048,13 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                      c3 = __ballot((tcnt & 8u) != 0);
             const uint32_t n_parked = (uint32_t)(__popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2) + 8 * __popcll(c3));
             if (m_node != 0 && n_parked < PT_LEAF_TRIS_MIN) {
-                if (w_node) ray_step_node(sc, r, c);
+#ifdef PT_FORCE_GENERAL_VISIT
+                const bool lean = false;                                                // experiment: the first version's visit for everyone
+#else
+                const bool lean = __ballot(w_node && r.sa >= r.sa_limit) == 0ull;      // nobody NaN-exact, nobody near the LDS part's end
+#endif
+                if (lean) node_round_staged(sc, r, c, w_node);
+                else if (w_node) node_step_general(sc, r, c);
 #ifdef PT_PROFILE_PHASES
                 prof[0] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[1] += 1; prof[2] += (unsigned long long)__popcll(m_node);
 #endif
@@ -867,7 +1105,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (served) {   // owner side: the leaf's triangles in order, each against the t_max it would have seen
-                    const uint32_t rec0 = stk_pop(c, r.top, r.sp) & PT_LEAF_FIRST_MASK;
+                    const uint32_t rec0 = fs_pop(c, r.sa, r.top) & PT_LEAF_FIRST_MASK;
                     const bool any_hit = kind == 2;
                     bool leaf_hit = false;
                     uint32_t tested = tcnt;
@@ -878,7 +1116,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                         else acc = v.x != 0.0f && tri_accept(v.y, v.z, r.ray_tmax);
                         if (acc) {
                             r.best = (int32_t)(rec0 + k); leaf_hit = true;
-                            if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; tested = k + 1; break; }
+                            if (any_hit) { r.sa = c.lane_base; r.top = PT_EMPTY_REF; tested = k + 1; break; }
                             r.ray_tmax = v.w;
                         }
                     }
@@ -910,7 +1148,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     if (c.overflow) atomicOr(err, 1u);
     flush_counters(cnt, s_cnt, regular, shadow, c.n_nodes, c.n_tris);
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_DIST_WAVES) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                               uint32_t spill_depth, uint32_t* err) {
     trace_body<true, false>(sc, P, Q, cnt, spill, spill_depth, err);
 }
@@ -925,7 +1163,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 2) k_trace_inst(PtScene s
     trace_body<false, true, true>(sc, P, Q, cnt, spill, spill_depth, err);
 }
 // scenes with spheres: a leaf record may stand for a sphere
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace_sph_dist(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_DIST_WAVES) k_trace_sph_dist(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                                            uint32_t spill_depth, uint32_t* err) {
     trace_body<true, true>(sc, P, Q, cnt, spill, spill_depth, err);
 }
@@ -2133,8 +2371,9 @@ extern "C" __global__ void k_bsdf_sample(PtScene sc, uint32_t material, uint32_t
 // ============================================================ launch wrappers (host side of this TU)
 #define PT_LAUNCH_CHECK() hipGetLastError()
 
-hipError_t ptk_trace(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
+hipError_t ptk_trace(hipStream_t st, int grid, int grid_dist, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err) {
+    if (sc.dist_leaves && !sc.n_instances) grid = grid_dist;      // the pooled-leaf kernels fit three blocks per CU, the others four
     if (sc.n_instances) hipLaunchKernelGGL(k_trace_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else if (sc.n_spheres && sc.dist_leaves) hipLaunchKernelGGL(k_trace_sph_dist, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else if (sc.n_spheres) hipLaunchKernelGGL(k_trace_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
