@@ -400,7 +400,7 @@ bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_
     out->nodes.clear(); out->tris.clear(); out->rec_of_prim.clear();
     out->n_leaves = 0; out->max_stack = 1;
     if (n_prims == 0) { out->root_ref = PT_EMPTY_REF; return true; }
-    if (n_prims >= PT_LEAF_FIRST_MASK - 16u) return false;      // a leaf reference keeps 28 bits for the first record
+    if (n_prims >= PT_LEAF_FIRST_MASK - 16u) return false;      // a leaf reference keeps 26 bits for the first record
     std::vector<Item> items, scratch;
     std::vector<uint32_t> order;                                  // order[r] = primitive stored r-th
     const uint32_t n_items = n_prims;

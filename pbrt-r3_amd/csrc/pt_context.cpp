@@ -179,7 +179,8 @@ pt_status ensure_traversal_scratch(pt_context* ctx) {
     uint32_t need = ctx->max_stack + 1 > PT_FS_SLOTS - 1 ? ctx->max_stack + 1 - (PT_FS_SLOTS - 1) : 0;
     size_t threads = (size_t)std::max(ctx->grid_trace, 2048) * PT_BLOCK;
     if (!ctx->d_spill.p || ctx->spill_depth < need) {
-        PT_HIP(ctx->d_spill.alloc((size_t)std::max(need, 1u) * threads * 4));
+        PT_HIP(ctx->d_spill.alloc((size_t)std::max(need, 1u) * threads * 4 + PT_DIAG_WORDS * 4));
+        PT_HIP(hipMemsetAsync(ctx->d_spill.p, 0, PT_DIAG_WORDS * 4, ctx->stream));
         ctx->spill_depth = need;
     }
     return PT_OK;
@@ -216,7 +217,7 @@ pt_status pt_context_create(int device, pt_context** out) {
     std::memset(&ctx->paths, 0, sizeof(ctx->paths));
     // occupancy-sized persistent grids: blocks per CU from register/LDS use x CU count
     ctx->grid_trace = ctx->n_cu * 4;
-    ctx->grid_trace_dist = ctx->n_cu * 3;
+    ctx->grid_trace_dist = ctx->n_cu * ptk_trace_dist_blocks_per_cu();
     if (const char* e = std::getenv("PBRTGPU_TRACE_BLOCKS_PER_CU")) ctx->grid_trace = ctx->grid_trace_dist = ctx->n_cu * std::max(1, std::atoi(e));
     ctx->grid_shade = ctx->n_cu * 2;
     if (const char* e = std::getenv("PBRTGPU_SHADE_BLOCKS_PER_CU")) ctx->grid_shade = ctx->n_cu * std::max(1, std::atoi(e));
@@ -548,7 +549,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     std::vector<PtInstance> dinst(d->n_instances);
     std::vector<Entry> world = make_list(0);
     if (world.empty()) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no world primitives (objects are only rendered through ObjectInstance)");
-    if ((uint64_t)world.size() >= PT_LEAF_FIRST_MASK - 16u) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "more than 2^28 primitives");
+    if ((uint64_t)world.size() >= PT_LEAF_FIRST_MASK - 16u) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "more than 2^26 primitives");
     ptbvh::Result bvh;
     {
         std::vector<ptbvh::Prim> prims(world.size());
@@ -587,7 +588,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         for (uint32_t k = 0; k < n_objects; k++) {
             ObjectBvh& ob = objs[k];
             node_off[k] = (uint32_t)bvh.nodes.size(); rec_off[k] = (uint32_t)bvh.tris.size();
-            if ((uint64_t)rec_off[k] + ob.res.tris.size() >= PT_LEAF_FIRST_MASK - 16u) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "more than 2^28 primitives");
+            if ((uint64_t)rec_off[k] + ob.res.tris.size() >= PT_LEAF_FIRST_MASK - 16u) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "more than 2^26 primitives");
             auto shift = [&](uint32_t ref) {
                 if (ref == PT_EMPTY_REF) return ref;
                 return (ref & PT_LEAF_BIT) ? ((ref & ~PT_LEAF_FIRST_MASK) | ((ref & PT_LEAF_FIRST_MASK) + rec_off[k])) : ref + node_off[k];
@@ -764,6 +765,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                 for (uint32_t k = 0; k < 3; k++)
                     if ((oct >> ((nd.axes >> (2 * k)) & 3u)) & 1u) lut |= 1u << (8 * k + oct);
             nd.order_lut = lut;
+            const uint32_t ax_of[4] = {nd.axes & 3u, (nd.axes >> 2) & 3u, 0u, (nd.axes >> 4) & 3u};     // child 0: axis_top, 1: axis_left, 3: axis_right
+            for (int ch = 0; ch < 4; ch++)
+                if (nd.child[ch] != PT_EMPTY_REF) nd.child[ch] = (nd.child[ch] & ~(3u << PT_REF_AXIS_SHIFT)) | (ax_of[ch] << PT_REF_AXIS_SHIFT);
             for (int ch = 0; ch < 4; ch++)
                 if (!((nd.axes >> (8 + ch)) & 1u))
                     for (int a = 0; a < 3; a++) { nd.bmin[a][ch] = INFINITY; nd.bmax[a][ch] = -INFINITY; }
@@ -1245,13 +1249,15 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     }
 #endif
 #ifdef PT_PROFILE_PHASES
-    {   // diagnostic build (tools/tune_trace.sh "prof:-DPT_PROFILE_PHASES:4"): wave-clock split of k_trace's two phases
-        unsigned long long pr[10];
+    {   // diagnostic build (tools/tune_trace.sh "prof:-DPT_PROFILE_PHASES:3"): where a traversal wave's clocks go
+        unsigned long long pr[16];
         PT_HIP(hipMemcpy(pr, ctx->d_spill.p, sizeof(pr), hipMemcpyDeviceToHost));
         PT_HIP(hipMemsetAsync(ctx->d_spill.p, 0, sizeof(pr), ctx->stream)); PT_HIP(hipStreamSynchronize(ctx->stream));
-        std::fprintf(stderr, "[phases] node: %.3e clk, %llu steps, %.1f lanes/step | leaf: %.3e clk, %llu steps, %.1f lanes/step | wave total %.3e clk | service+begin %.3e clk, iterations with a retire %llu, with a ray start %llu\n",
-                     (double)pr[0], pr[1], pr[1] ? (double)pr[2] / pr[1] : 0.0, (double)pr[3], pr[4], pr[4] ? (double)pr[5] / pr[4] : 0.0, (double)pr[6],
-                     (double)pr[7], pr[8], pr[9]);
+        const double tot = (double)pr[11];
+        std::fprintf(stderr, "[phases] wave clocks %.3e | node rounds %llu (%.1f lanes): issue %.1f%% wait %.1f%% finish %.1f%% = %.0f clk/round | leaf rounds %llu (%.1f items): issue %.1f%% wait %.1f%% finish %.1f%% = %.0f clk/round | general visits %llu: %.1f%% | service %.1f%%\n",
+                     tot, pr[3], pr[3] + pr[13] ? (double)pr[4] / (double)(pr[3] + pr[13]) : 0.0, 100.0 * pr[0] / tot, 100.0 * pr[1] / tot, 100.0 * pr[2] / tot,
+                     pr[3] ? (double)(pr[0] + pr[1] + pr[2]) / (double)pr[3] : 0.0, pr[8], pr[8] ? (double)pr[9] / (double)pr[8] : 0.0, 100.0 * pr[5] / tot, 100.0 * pr[6] / tot,
+                     100.0 * pr[7] / tot, pr[8] ? (double)(pr[5] + pr[6] + pr[7]) / (double)pr[8] : 0.0, pr[13], 100.0 * pr[12] / tot, 100.0 * pr[10] / tot);
     }
 #endif
     float ms = 0;

@@ -11,12 +11,27 @@
 #define PT_LDS_STACK 32          // per-lane traversal stack entries kept in LDS
 #endif
 #define PT_SLOT (PT_BLOCK * 4u)    // bytes between two entries of a lane's LDS traversal stack ([entry][lane] layout)
+// PT_NODE_STAGED 1: the pooled-leaf traversal kernels fetch a round's nodes cooperatively through LDS (global_load_lds_dwordx4;
+// a quarter of the L1 requests, but 49 KB of LDS per block = three blocks per CU and a longer round); 0: every lane loads its
+// own node (four blocks per CU).  Measured on RT1M: 0 is the faster one.
+#ifndef PT_NODE_STAGED
+#define PT_NODE_STAGED 0
+#endif
 // LDS stack slots per lane of the pooled-leaf traversal kernels (slot 0 holds a sentinel; deeper entries spill to HBM)
+#if PT_NODE_STAGED
 #define PT_FS_SLOTS (PT_LDS_STACK < 16 ? PT_LDS_STACK : 16)
+#else
+#define PT_FS_SLOTS PT_LDS_STACK
+#endif
+#define PT_DIAG_WORDS 2048u       // words at the head of the traversal spill buffer reserved for the diagnostic builds (phase clocks, histograms)
 #define PT_EMPTY_REF 0xffffffffu
 #define PT_LEAF_BIT 0x80000000u
 #define PT_LEAF_COUNT_SHIFT 28          // bits 28..30 of a leaf reference: min(triangles in the leaf, 8) - 1
-#define PT_LEAF_FIRST_MASK 0x0fffffffu   // bits 0..27: first triangle record
+#define PT_LEAF_FIRST_MASK 0x03ffffffu   // bits 0..25: first triangle record
+#define PT_REF_INDEX_MASK 0x03ffffffu    // interior reference: bits 0..25 node index
+#define PT_REF_AXIS_SHIFT 26             // bits 26..27 of a CHILD reference stored in a node: one of the node's three split axes, so that the
+                                         // lean visit needs no separate load for them -- child 0 carries axis_top, child 1 axis_left, child 3
+                                         // axis_right (slots 0 and 2 are always occupied; slot 1 / 3 exactly when the left / right pair is one)
 
 // One 4-wide BVH node = one 128-byte line.  Replaces the reference's 144-byte
 // SIMDBVHNode + separate leaf nodes (qbvh_x86.rs:15-24, :93-176): a child that is

@@ -411,7 +411,7 @@ template <bool EXACT>
 PT_DEV void visit_node(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t sbits, float tmin, float tmax, TravCtx& c, uint32_t& top, uint32_t& sp) {
     // near / far planes per axis are picked by address (bmin row at +16*axis, bmax row 48 bytes later)
     // instead of loading both and selecting 24 registers
-    const char* nb = reinterpret_cast<const char*>(nodes) + (size_t)ni * 128u;
+    const char* nb = reinterpret_cast<const char*>(nodes) + (size_t)(ni & PT_REF_INDEX_MASK) * 128u;
     const uint32_t ox = (sbits & 1u) ? 48u : 0u, oy = (sbits & 2u) ? 48u : 0u, oz = (sbits & 4u) ? 48u : 0u;
     float4 nx = *reinterpret_cast<const float4*>(nb + ox), fx = *reinterpret_cast<const float4*>(nb + (48u - ox));
     float4 ny = *reinterpret_cast<const float4*>(nb + 16u + oy), fy = *reinterpret_cast<const float4*>(nb + 16u + (48u - oy));
@@ -497,9 +497,15 @@ PT_DEV void ray_begin_fs(const PtScene& sc, LaneRay& r, const TravCtx& c, V3 o, 
     // rows of a node: chunks 0..2 = bmin x / y / z, 3..5 = bmax x / y / z; near / far by the direction signs; as LDS addresses of
     // this lane's staged node (chunk q sits at q ^ own_i, see node_round_staged)
     const uint32_t ox = (r.sbits & 1u) ? 3u : 0u, oy = (r.sbits & 2u) ? 3u : 0u, oz = (r.sbits & 4u) ? 3u : 0u;
+#if PT_NODE_STAGED
     r.o_nx = c.stage_chunk(ox); r.o_fx = c.stage_chunk(3u - ox);
     r.o_ny = c.stage_chunk(1u + oy); r.o_fy = c.stage_chunk(4u - oy);
     r.o_nz = c.stage_chunk(2u + oz); r.o_fz = c.stage_chunk(5u - oz);
+#else       // byte offsets of the rows inside the node in HBM
+    r.o_nx = ox << 4; r.o_fx = (3u - ox) << 4;
+    r.o_ny = (1u + oy) << 4; r.o_fy = (4u - oy) << 4;
+    r.o_nz = (2u + oz) << 4; r.o_fz = (5u - oz) << 4;
+#endif
     const uint32_t oct = r.sbits & 7u;
     r.m_t = 1u << oct; r.m_l = 256u << oct; r.m_r = 65536u << oct;
     r.sa_limit = (r.sbits & 8u) ? 0u : c.lane_base + (PT_FS_SLOTS - 3u) * PT_SLOT;
@@ -682,7 +688,7 @@ PT_DEV float v_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1
 // Old-form visit on the `sa` stack (any mix of lanes: NaN-exact slabs, HBM spill).
 template <bool EXACT>
 PT_DEV void visit_node_general(const PtNode* nodes, uint32_t ni, V3 o, V3 idir, uint32_t sbits, float tmin, float tmax, TravCtx& c, uint32_t& top, uint32_t& sa) {
-    const char* nb = reinterpret_cast<const char*>(nodes) + (size_t)ni * 128u;
+    const char* nb = reinterpret_cast<const char*>(nodes) + (size_t)(ni & PT_REF_INDEX_MASK) * 128u;
     const uint32_t ox = (sbits & 1u) ? 48u : 0u, oy = (sbits & 2u) ? 48u : 0u, oz = (sbits & 4u) ? 48u : 0u;
     float4 nx = *reinterpret_cast<const float4*>(nb + ox), fx = *reinterpret_cast<const float4*>(nb + (48u - ox));
     float4 ny = *reinterpret_cast<const float4*>(nb + 16u + oy), fy = *reinterpret_cast<const float4*>(nb + 16u + (48u - oy));
@@ -767,12 +773,13 @@ typedef float pt_v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t pt_v4u __attribute__((ext_vector_type(4)));
 PT_DEV float4 lds_load4(uint32_t a) { const pt_v4f v = *(__attribute__((address_space(3))) const pt_v4f*)(size_t)a; return make_float4(v.x, v.y, v.z, v.w); }
 PT_DEV uint4 lds_load4u(uint32_t a) { const pt_v4u v = *(__attribute__((address_space(3))) const pt_v4u*)(size_t)a; return make_uint4(v.x, v.y, v.z, v.w); }
-PT_DEV void node_round_staged(const PtScene& sc, LaneRay& r, TravCtx& c, bool w_node) {
+// issue half: pops, publishes and starts the LDS-DMA fetches; returns the entry below the popped one (the fall-back `top`)
+PT_DEV uint32_t node_round_issue(const PtScene& sc, LaneRay& r, TravCtx& c, bool w_node) {
     // owners: pop, publish the node index (transposed: the eight indices a loader lane needs are contiguous)
     uint32_t ref = PT_EMPTY_REF, top = PT_EMPTY_REF;
     if (w_node) {
 #ifdef PT_STACK_HIST
-        atomicAdd(c.spill - ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x) + 1024u + min(fs_slot(c, r.sa), 63u), 1u);   // diagnostic build: stack depth at each node visit
+        atomicAdd(c.spill - ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x) - PT_DIAG_WORDS + 1024u + min(fs_slot(c, r.sa), 63u), 1u);   // diagnostic build: stack depth at each node visit
 #endif
         ref = r.top;
         r.sa -= PT_SLOT;
@@ -795,8 +802,10 @@ PT_DEV void node_round_staged(const PtScene& sc, LaneRay& r, TravCtx& c, bool w_
             if (ids[j] != PT_EMPTY_REF)
                 __builtin_amdgcn_global_load_lds((pt_global_cvoid)(nb + ((ids[j] << 7) + coff)), (pt_lds_void)(size_t)(piece0 + j * 1024u), 16, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA writes have landed (nothing else orders a ds_read behind them)
-    __builtin_amdgcn_wave_barrier();
+    return top;
+}
+// finish half, after `s_waitcnt vmcnt(0)`: rows from LDS, four slab tests, ordered EXEC-predicated pushes
+PT_DEV void node_round_finish(LaneRay& r, TravCtx& c, bool w_node, uint32_t top) {
     if (w_node) {
         const float4 nx = lds_load4(r.o_nx), fx = lds_load4(r.o_fx), ny = lds_load4(r.o_ny), fy = lds_load4(r.o_fy), nz = lds_load4(r.o_nz), fz = lds_load4(r.o_fz);
         const uint4 ch = lds_load4u(c.stage_chunk(6u));
@@ -820,6 +829,39 @@ PT_DEV void node_round_staged(const PtScene& sc, LaneRay& r, TravCtx& c, bool w_
         fs_push4_exec(r.sa, top, c0, c1, c2, c3, e0, e1, e2, e3);
         r.top = top;
     }
+}
+
+// The lean visit with per-lane loads (PT_NODE_STAGED == 0): every lane fetches its own node, SGPR base + 32-bit offset with the
+// sign-dependent row offsets hoisted per ray.  Keeps the 32-slot LDS stack and four blocks per CU; bound by the vector L1's
+// request rate (eight requests per lane and visit).
+PT_DEV void node_step_lean(const PtScene& sc, LaneRay& r, TravCtx& c) {
+    const uint32_t ref = r.top;
+    r.sa -= PT_SLOT;
+    uint32_t top = lds_load(r.sa);            // the entry below (slot 0: PT_EMPTY_REF); lands while the node is on its way
+    c.n_nodes++;
+    const char* nb = reinterpret_cast<const char*>(sc.nodes);
+    const uint32_t no = ref << 7;             // the shift drops the axis bits a child reference carries above its node index
+    const float4 nx = *reinterpret_cast<const float4*>(nb + (no + r.o_nx)), fx = *reinterpret_cast<const float4*>(nb + (no + r.o_fx));
+    const float4 ny = *reinterpret_cast<const float4*>(nb + (no + r.o_ny)), fy = *reinterpret_cast<const float4*>(nb + (no + r.o_fy));
+    const float4 nz = *reinterpret_cast<const float4*>(nb + (no + r.o_nz)), fz = *reinterpret_cast<const float4*>(nb + (no + r.o_fz));
+    const uint4 ch = *reinterpret_cast<const uint4*>(nb + (no + 96u));
+    const float ox = r.o.x, oy = r.o.y, oz = r.o.z, ix = r.idir.x, iy = r.idir.y, iz = r.idir.z;
+#define PT_SLAB(C) (v_min3(v_min(r.tmax, (fx.C - ox) * ix), (fy.C - oy) * iy, (fz.C - oz) * iz) >= v_max3(v_max(r.tmin, (nx.C - ox) * ix), (ny.C - oy) * iy, (nz.C - oz) * iz))
+    const bool h0 = PT_SLAB(x), h1 = PT_SLAB(y), h2 = PT_SLAB(z), h3 = PT_SLAB(w);
+#undef PT_SLAB
+    // the node's split axes ride in bits 26..27 of child references 0 / 1 / 3 (seven L1 requests per visit instead of eight)
+    const bool T = __builtin_amdgcn_ubfe(r.sbits, __builtin_amdgcn_ubfe(ch.x, PT_REF_AXIS_SHIFT, 2), 1) != 0u;
+    const bool L = __builtin_amdgcn_ubfe(r.sbits, __builtin_amdgcn_ubfe(ch.y, PT_REF_AXIS_SHIFT, 2), 1) != 0u;
+    const bool R = __builtin_amdgcn_ubfe(r.sbits, __builtin_amdgcn_ubfe(ch.w, PT_REF_AXIS_SHIFT, 2), 1) != 0u;
+    const uint32_t l0 = L ? ch.x : ch.y, l1 = L ? ch.y : ch.x, r0 = R ? ch.z : ch.w, r1 = R ? ch.w : ch.z;
+    const uint32_t c0 = T ? l0 : r0, c1 = T ? l1 : r1, c2 = T ? r0 : l0, c3 = T ? r1 : l1;
+    const unsigned long long H0 = __ballot(h0), H1 = __ballot(h1), H2 = __ballot(h2), H3 = __ballot(h3), Tm = __ballot(T), Lm = __ballot(L), Rm = __ballot(R);
+    const unsigned long long yl = Lm & (H0 ^ H1), el0 = H1 ^ yl, el1 = H0 ^ yl;
+    const unsigned long long yr = Rm & (H2 ^ H3), er0 = H3 ^ yr, er1 = H2 ^ yr;
+    const unsigned long long y0 = Tm & (el0 ^ er0), e0 = er0 ^ y0, e2 = el0 ^ y0;
+    const unsigned long long y1 = Tm & (el1 ^ er1), e1 = er1 ^ y1, e3 = el1 ^ y1;
+    fs_push4_exec(r.sa, top, c0, c1, c2, c3, e0, e1, e2, e3);
+    r.top = top;
 }
 
 // intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
@@ -879,6 +921,13 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 // node (4 slab tests, ordered pushes) or a leaf, whose triangle tests are pooled over the wave
 // (DIST) or walked by the owning lane (leaves of more than 8 triangles).  The order of pops,
 // tests and t_max updates per ray is exactly the reference's, whatever the interleaving across lanes.
+#ifdef PT_PROFILE_PHASES
+#define PT_PROF_T(name) const unsigned long long name = (unsigned long long)__builtin_readcyclecounter()
+#define PT_PROF_SET(name) name = (unsigned long long)__builtin_readcyclecounter()
+#else
+#define PT_PROF_T(name) do { } while (0)
+#define PT_PROF_SET(name) do { } while (0)
+#endif
 #ifndef PT_REFILL_MIN
 #define PT_REFILL_MIN 16
 #endif
@@ -889,11 +938,18 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #define PT_TRACE_WAVES 4        // waves per SIMD the register allocator must leave room for (k_trace_seq)
 #endif
 #ifndef PT_TRACE_DIST_WAVES
-#define PT_TRACE_DIST_WAVES 3   // pooled-leaf kernels: 49 KB of LDS per block => three blocks per CU
+#if PT_NODE_STAGED
+#define PT_TRACE_DIST_WAVES 3   // pooled-leaf kernels with staged node fetch: 49 KB of LDS per block => three blocks per CU
+#else
+#define PT_TRACE_DIST_WAVES 4
+#endif
 #endif
 
 #ifndef PT_LEAF_TRIS_MIN
-#define PT_LEAF_TRIS_MIN 56          // distributed leaf phase: run it once this many triangle tests are parked
+#define PT_LEAF_TRIS_MIN 56          // distributed leaf phase on its own (general visit in the wave): once this many triangle tests are parked
+#endif
+#ifndef PT_LEAF_TRIS_FUSED
+#define PT_LEAF_TRIS_FUSED 0         // > 0: a leaf round rides along a staged node round once this many tests are parked (experiment)
 #endif
 // DIST: every leaf holds at most 8 triangles and its reference carries the count, so a leaf phase can pool the
 // triangles of all parked lanes and hand one (ray, triangle) test to each lane of the wave.
@@ -904,25 +960,32 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     // 64 test results and owner map live in the wave's staging area, which a node round of the same wave never uses at the same time.
     __shared__ uint32_t s_stack[(DIST ? PT_FS_SLOTS : PT_LDS_STACK) * PT_BLOCK];
     __shared__ unsigned long long s_cnt[4];
+#if PT_NODE_STAGED
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[DIST ? (PT_BLOCK / 64) * 8192 : 16];
-    __shared__ uint32_t s_idx[DIST ? PT_BLOCK : 1];
+    __shared__ uint32_t s_idx[DIST ? PT_BLOCK + PT_BLOCK / 4 : 1];       // per wave: 64 node indices, then the leaf round's 64-byte owner map
     float4* const s_res = reinterpret_cast<float4*>(s_stage + (threadIdx.x >> 6) * 8192u) - (threadIdx.x & ~63u);            // indexed [wbase + k]
-    unsigned char* const s_map = s_stage + (threadIdx.x >> 6) * 8192u + 1024u - (threadIdx.x & ~63u);
+    unsigned char* const s_map = reinterpret_cast<unsigned char*>(&s_idx[(threadIdx.x >> 6) * 80u + 64u]) - (threadIdx.x & ~63u);
+#else
+    __shared__ float4 s_res[DIST ? PT_BLOCK : 1];          // per wave: 64 test results (ok, t_scaled, det, t)
+    __shared__ unsigned char s_map[DIST ? PT_BLOCK : 1];   // per wave: work item -> owner lane
+#endif
     TravCtx c;
     c.lds = &s_stack[threadIdx.x];
     c.spill_stride = gridDim.x * PT_BLOCK;
-    c.spill = spill + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    c.spill = spill + PT_DIAG_WORDS + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;      // the buffer's first PT_DIAG_WORDS words belong to the diagnostic builds
     c.spill_depth = spill_depth;
     c.n_nodes = 0; c.n_tris = 0; c.overflow = 0;
     c.lane_base = 0; c.stage_wave = 0; c.stage_own = 0; c.idx_pub = 0; c.idx_ld = 0;
     if constexpr (DIST) {        // slot 0 of the lane's stack: the sentinel a pop of the last entry reads back (see node_step_lean)
         s_stack[threadIdx.x] = PT_EMPTY_REF;
         c.lane_base = lds_addr_of(&s_stack[threadIdx.x]);
+#if PT_NODE_STAGED
         const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
         c.stage_wave = lds_addr_of(reinterpret_cast<const uint32_t*>(s_stage + wv * 8192u));
         c.stage_own = c.stage_wave + (ln >> 3) * 1024u + (ln & 7u) * 128u;
-        c.idx_pub = lds_addr_of(&s_idx[wv * 64u + (ln & 7u) * 8u + (ln >> 3)]);
-        c.idx_ld = lds_addr_of(&s_idx[wv * 64u + (ln >> 3) * 8u]);
+        c.idx_pub = lds_addr_of(&s_idx[wv * 80u + (ln & 7u) * 8u + (ln >> 3)]);
+        c.idx_ld = lds_addr_of(&s_idx[wv * 80u + (ln >> 3) * 8u]);
+#endif
     }
     const uint32_t n_cur = Q.counts[PT_Q_CUR], n_sh = Q.counts[PT_Q_SHADOW], n_pr = Q.counts[PT_Q_PROBE];
     const uint32_t total = n_cur + n_sh + n_pr;
@@ -947,7 +1010,9 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     const uint32_t seg_len = (((total + 7u) >> 3) + 63u) & ~63u;
     float4 pf_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf_d = pf_o;
 #ifdef PT_PROFILE_PHASES
-    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0-2 node clk/steps/lanes, 3-5 leaf, 6 total, 7 service+begin clk, 8 retire events, 9 begin events
+    // pooled-leaf kernels: 0 node issue clk, 1 node wait clk, 2 node finish clk, 3 node rounds, 4 node lanes, 5 leaf issue clk, 6 leaf wait clk,
+    // 7 leaf finish clk, 8 leaf rounds, 9 leaf items, 10 service clk, 11 wave total clk, 12 general-visit clk, 13 general-visit rounds
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_t0 = __builtin_readcyclecounter();
 #endif
     for (;;) {
@@ -1039,7 +1104,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         unsigned long long m_tri = __ballot(w_tri), m_node = __ballot(w_node);
 #ifdef PT_PROFILE_PHASES
         long long pt0 = __builtin_readcyclecounter();
-        prof[7] += (unsigned long long)(pt0 - pt_iter);
+        prof[10] += (unsigned long long)(pt0 - pt_iter);
 #endif
         if constexpr (DIST) {
             // triangles parked: the count rides in bits 28..30 of the leaf reference
@@ -1047,70 +1112,67 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             const unsigned long long c0 = __ballot((tcnt & 1u) != 0), c1 = __ballot((tcnt & 2u) != 0), c2 = __ballot((tcnt & 4u) != 0),
                                      c3 = __ballot((tcnt & 8u) != 0);
             const uint32_t n_parked = (uint32_t)(__popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2) + 8 * __popcll(c3));
-            if (m_node != 0 && n_parked < PT_LEAF_TRIS_MIN) {
-#ifdef PT_FORCE_GENERAL_VISIT
-                const bool lean = false;                                                // experiment: the first version's visit for everyone
-#else
-                const bool lean = __ballot(w_node && r.sa >= r.sa_limit) == 0ull;      // nobody NaN-exact, nobody near the LDS part's end
-#endif
-                if (lean) node_round_staged(sc, r, c, w_node);
-                else if (w_node) node_step_general(sc, r, c);
-#ifdef PT_PROFILE_PHASES
-                prof[0] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[1] += 1; prof[2] += (unsigned long long)__popcll(m_node);
-#endif
-            } else if (m_tri != 0) {
-                // ---- distributed leaf phase: one round of up to 64 (ray, triangle) tests.  Owners are served in lane
-                // order while their whole leaf fits; the others stay parked for the next round.
-                const uint32_t wbase = threadIdx.x & ~63u;
-                const uint32_t pre = (uint32_t)(__popcll(c0 & below) + 2 * __popcll(c1 & below) + 4 * __popcll(c2 & below) + 8 * __popcll(c3 & below));
-                const bool served = w_tri && pre + tcnt <= 64u;
-                const unsigned long long m_served = __ballot(served);
+            // ---- distributed leaf round, in two halves so that its triangle loads can fly together with a node round's fetches.
+            // issue: owners are served in lane order while their whole leaf fits (the others stay parked); lane w becomes the helper
+            // of triangle k of owner o, takes the owner's ray constants by ds_bpermute and starts the 48-byte record's load.
+            const uint32_t wbase = threadIdx.x & ~63u;
+            uint32_t lf_pre = 0, lf_items = 0;
+            bool lf_served = false, lf_valid = false;
+            int lf_kk = 0;
+            RayPre lf_rp;
+            TriVerts lf_tv;
+            auto leaf_issue = [&]() {
+                lf_pre = (uint32_t)(__popcll(c0 & below) + 2 * __popcll(c1 & below) + 4 * __popcll(c2 & below) + 8 * __popcll(c3 & below));
+                lf_served = w_tri && lf_pre + tcnt <= 64u;
+                const unsigned long long m_served = __ballot(lf_served);
                 const int last = 63 - __clzll(m_served);                      // m_served != 0: the first parked lane always fits
-                const uint32_t n_items = (uint32_t)__shfl((int)(pre + tcnt), last, 64);
-                if (served)
-                    for (uint32_t k = 0; k < tcnt; k++) s_map[wbase + pre + k] = (unsigned char)lane;
+                lf_items = (uint32_t)__shfl((int)(lf_pre + tcnt), last, 64);
+                if (lf_served)
+                    for (uint32_t k = 0; k < tcnt; k++) s_map[wbase + lf_pre + k] = (unsigned char)lane;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                {   // helper side: lane w tests triangle k of owner o
-                    const bool valid = lane < n_items;
-                    const int o = valid ? (int)s_map[wbase + lane] : 0;
-                    const uint32_t k = lane - (uint32_t)__shfl((int)pre, o, 64);
-                    const uint32_t first = (uint32_t)__shfl((int)(r.top & PT_LEAF_FIRST_MASK), o, 64);
-                    RayPre rp;
-                    rp.o = mk3(__shfl(r.rp.o.x, o, 64), __shfl(r.rp.o.y, o, 64), __shfl(r.rp.o.z, o, 64));
-                    rp.d = mk3(0.0f, 0.0f, 0.0f);        // only the one-sided test (and a sphere) reads the direction
-                    if (SPH || sc.any_one_sided) rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));
-                    const int kk = __shfl(r.rp.kx | (r.rp.ky << 2) | (r.rp.kz << 4) | ((kind == 2 ? 1 : 0) << 6), o, 64);
-                    rp.kx = kk & 3; rp.ky = (kk >> 2) & 3; rp.kz = (kk >> 4) & 3;
-                    rp.sx = __shfl(r.rp.sx, o, 64); rp.sy = __shfl(r.rp.sy, o, 64); rp.sz = __shfl(r.rp.sz, o, 64);
-                    rp.dperm = rp.d;        // not read by tri_core
-                    if (valid) {
-                        TriVerts tv = load_tri(sc.tris, first + k);
-                        bool sphere_rec = false;
-                        if constexpr (SPH) sphere_rec = (tv.flags & PT_TRI_SPHERE) != 0;
-                        if (sphere_rec) {       // Sphere::intersect(_p) against t_max = +inf; the owner applies the t_max tests
-                            SphHit sh;
-                            sh.t = 0.0f; sh.a_hi = 0.0f; sh.b_hi = 0.0f;
-                            bool ok = sph_hit_test(sc.spheres[__float_as_uint(tv.p0.x)], rp.o, rp.d, PT_INF, (kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
-                            s_res[wbase + lane] = make_float4(ok ? 2.0f : 0.0f, sh.a_hi, sh.b_hi, sh.t);
-                        } else {
-                            TriCore tc;
-                            bool ok = tri_core(rp, tv.p0, tv.p1, tv.p2, tv.flags, tc);
-                            s_res[wbase + lane] = make_float4(ok ? 1.0f : 0.0f, tc.t_scaled, tc.det, tc.t);
-                        }
+                lf_valid = lane < lf_items;
+                const int o = lf_valid ? (int)s_map[wbase + lane] : 0;
+                const uint32_t k = lane - (uint32_t)__shfl((int)lf_pre, o, 64);
+                const uint32_t first = (uint32_t)__shfl((int)(r.top & PT_LEAF_FIRST_MASK), o, 64);
+                lf_rp.o = mk3(__shfl(r.rp.o.x, o, 64), __shfl(r.rp.o.y, o, 64), __shfl(r.rp.o.z, o, 64));
+                lf_rp.d = mk3(0.0f, 0.0f, 0.0f);        // only the one-sided test (and a sphere) reads the direction
+                if (SPH || sc.any_one_sided) lf_rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));
+                lf_kk = __shfl(r.rp.kx | (r.rp.ky << 2) | (r.rp.kz << 4) | ((kind == 2 ? 1 : 0) << 6), o, 64);
+                lf_rp.kx = lf_kk & 3; lf_rp.ky = (lf_kk >> 2) & 3; lf_rp.kz = (lf_kk >> 4) & 3;
+                lf_rp.sx = __shfl(r.rp.sx, o, 64); lf_rp.sy = __shfl(r.rp.sy, o, 64); lf_rp.sz = __shfl(r.rp.sz, o, 64);
+                lf_rp.dperm = lf_rp.d;        // not read by tri_core
+                lf_tv.p0 = lf_rp.d; lf_tv.p1 = lf_rp.d; lf_tv.p2 = lf_rp.d; lf_tv.prim = 0; lf_tv.flags = 0;
+                if (lf_valid) lf_tv = load_tri(sc.tris, first + k);
+            };
+            // finish: every helper runs its (ray, triangle) test, results go to LDS, the owner walks its leaf's results in leaf order
+            // and applies the one comparison that depends on the ray's shrinking t_max with the t_max each triangle would have seen
+            auto leaf_finish = [&]() {
+                if (lf_valid) {
+                    bool sphere_rec = false;
+                    if constexpr (SPH) sphere_rec = (lf_tv.flags & PT_TRI_SPHERE) != 0;
+                    if (sphere_rec) {       // Sphere::intersect(_p) against t_max = +inf; the owner applies the t_max tests
+                        SphHit sh;
+                        sh.t = 0.0f; sh.a_hi = 0.0f; sh.b_hi = 0.0f;
+                        bool ok = sph_hit_test(sc.spheres[__float_as_uint(lf_tv.p0.x)], lf_rp.o, lf_rp.d, PT_INF, (lf_kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
+                        s_res[wbase + lane] = make_float4(ok ? 2.0f : 0.0f, sh.a_hi, sh.b_hi, sh.t);
+                    } else {
+                        TriCore tc;
+                        bool ok = tri_core(lf_rp, lf_tv.p0, lf_tv.p1, lf_tv.p2, lf_tv.flags, tc);
+                        s_res[wbase + lane] = make_float4(ok ? 1.0f : 0.0f, tc.t_scaled, tc.det, tc.t);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (served) {   // owner side: the leaf's triangles in order, each against the t_max it would have seen
+                if (lf_served) {
                     const uint32_t rec0 = fs_pop(c, r.sa, r.top) & PT_LEAF_FIRST_MASK;
                     const bool any_hit = kind == 2;
                     bool leaf_hit = false;
                     uint32_t tested = tcnt;
                     for (uint32_t k = 0; k < tcnt; k++) {
-                        const float4 v = s_res[wbase + pre + k];
+                        const float4 v = s_res[wbase + lf_pre + k];
                         bool acc;
                         if (SPH && v.x == 2.0f) acc = !(v.y > r.ray_tmax) && !(v.z > r.ray_tmax);
                         else acc = v.x != 0.0f && tri_accept(v.y, v.z, r.ray_tmax);
@@ -1123,27 +1185,105 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     c.n_tris += tested;
                     if (leaf_hit && !any_hit) r.tmax = r.ray_tmax;
                 }
+            };
+#ifdef PT_FORCE_GENERAL_VISIT
+            const bool lean = false;                                                // experiment: the first version's visit for everyone
+#else
+            const bool lean = __ballot(w_node && r.sa >= r.sa_limit) == 0ull;      // nobody NaN-exact, nobody near the LDS part's end
+#endif
+#if !PT_NODE_STAGED
+            if (lean && m_node != 0 && n_parked < PT_LEAF_TRIS_MIN) {
+                PT_PROF_T(t0);
+                if (w_node) node_step_lean(sc, r, c);
+                PT_PROF_T(t1);
 #ifdef PT_PROFILE_PHASES
-                prof[3] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[4] += 1; prof[5] += (unsigned long long)n_items;
+                prof[2] += t1 - t0; prof[3] += 1; prof[4] += (unsigned long long)__popcll(m_node);
+#endif
+#else
+            if (lean) {
+                // Staged node round and / or leaf round.  With PT_LEAF_TRIS_FUSED > 0 a leaf round rides along a node round once that
+                // many tests are parked, so that the node round's LDS-DMA fetches and the leaf round's record loads fly together
+                // (measured: slower -- the smaller leaf rounds cost more than the shared round trip saves; kept as an experiment switch).
+                const bool do_node = m_node != 0 && (PT_LEAF_TRIS_FUSED > 0 || n_parked < PT_LEAF_TRIS_MIN);
+                const bool do_leaf = m_tri != 0 && (!do_node || (PT_LEAF_TRIS_FUSED > 0 && n_parked >= PT_LEAF_TRIS_FUSED));
+                (void)do_leaf;
+#if PT_LEAF_TRIS_FUSED > 0
+                uint32_t below_top = PT_EMPTY_REF;
+                PT_PROF_T(t0);
+                if (do_node) below_top = node_round_issue(sc, r, c, w_node);
+                PT_PROF_T(t1);
+                if (do_leaf) leaf_issue();
+                PT_PROF_T(t2);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA writes have landed (nothing else orders a ds_read behind them)
+                __builtin_amdgcn_wave_barrier();
+                PT_PROF_T(t3);
+                if (do_node) node_round_finish(r, c, w_node, below_top);
+                PT_PROF_T(t4);
+                if (do_leaf) leaf_finish();
+                PT_PROF_T(t5);
+#else
+                unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+                (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5;
+                PT_PROF_SET(t0);
+                if (do_node) {
+                    const uint32_t below_top = node_round_issue(sc, r, c, w_node);
+                    PT_PROF_SET(t1); PT_PROF_SET(t2);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA writes have landed (nothing else orders a ds_read behind them)
+                    __builtin_amdgcn_wave_barrier();
+                    PT_PROF_SET(t3);
+                    node_round_finish(r, c, w_node, below_top);
+                    PT_PROF_SET(t4); PT_PROF_SET(t5);
+                } else {
+                    PT_PROF_SET(t1);
+                    leaf_issue();
+                    PT_PROF_SET(t2);
+#ifdef PT_PROFILE_PHASES
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                    PT_PROF_SET(t3); PT_PROF_SET(t4);
+                    leaf_finish();
+                    PT_PROF_SET(t5);
+                }
+#endif
+#ifdef PT_PROFILE_PHASES
+                if (do_node) { prof[0] += t1 - t0; prof[2] += t4 - t3; prof[3] += 1; prof[4] += (unsigned long long)__popcll(m_node); }
+                if (do_leaf) { prof[5] += t2 - t1; prof[7] += t5 - t4; prof[8] += 1; prof[9] += (unsigned long long)lf_items; }
+                prof[do_node ? 1 : 6] += t3 - t2;
+#endif
+#endif
+            } else if (m_node != 0 && n_parked < PT_LEAF_TRIS_MIN) {
+                PT_PROF_T(t0);
+                if (w_node) node_step_general(sc, r, c);
+                PT_PROF_T(t1);
+#ifdef PT_PROFILE_PHASES
+                prof[12] += t1 - t0; prof[13] += 1; prof[4] += (unsigned long long)__popcll(m_node);
+#endif
+            } else if (m_tri != 0) {
+                PT_PROF_T(t0);
+                leaf_issue();
+                leaf_finish();
+                PT_PROF_T(t1);
+#ifdef PT_PROFILE_PHASES
+                prof[7] += t1 - t0; prof[8] += 1; prof[9] += (unsigned long long)lf_items;
 #endif
             }
         } else {
         if (m_node != 0 && __popcll(m_tri) < PT_LEAF_MIN) {
             if (w_node) ray_step_node(sc, r, c);
 #ifdef PT_PROFILE_PHASES
-            prof[0] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[1] += 1; prof[2] += (unsigned long long)__popcll(m_node);
+            prof[12] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[13] += 1; prof[4] += (unsigned long long)__popcll(m_node);
 #endif
         } else {
             if (w_tri) ray_step_tri<SPH, INST>(sc, r, kind == 2, c);
 #ifdef PT_PROFILE_PHASES
-            prof[3] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[4] += 1; prof[5] += (unsigned long long)__popcll(m_tri);
+            prof[7] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[8] += 1; prof[9] += (unsigned long long)__popcll(m_tri);
 #endif
         }
         }
     }
 #ifdef PT_PROFILE_PHASES
-    prof[6] = (unsigned long long)(__builtin_readcyclecounter() - prof_t0);
-    if (lane == 0) for (int i = 0; i < 10; i++) atomicAdd(reinterpret_cast<unsigned long long*>(spill) + i, prof[i]);   // diagnostic build only: clobbers spill[0..19]
+    prof[11] = (unsigned long long)(__builtin_readcyclecounter() - prof_t0);
+    if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(reinterpret_cast<unsigned long long*>(spill) + i, prof[i]);   // diagnostic build only: the buffer's diagnostic words
 #endif
     if (c.overflow) atomicOr(err, 1u);
     flush_counters(cnt, s_cnt, regular, shadow, c.n_nodes, c.n_tris);
@@ -1181,7 +1321,7 @@ PT_DEV void trace_batch_body(const PtScene& sc, uint32_t n, const float* o, cons
     TravCtx c;
     c.lds = &s_stack[threadIdx.x];
     c.spill_stride = gridDim.x * PT_BLOCK;
-    c.spill = spill + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    c.spill = spill + PT_DIAG_WORDS + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;      // the buffer's first PT_DIAG_WORDS words belong to the diagnostic builds
     c.spill_depth = spill_depth;
     c.n_nodes = 0; c.n_tris = 0; c.overflow = 0;
     unsigned long long regular = 0, shadow = 0;
@@ -2371,6 +2511,7 @@ extern "C" __global__ void k_bsdf_sample(PtScene sc, uint32_t material, uint32_t
 // ============================================================ launch wrappers (host side of this TU)
 #define PT_LAUNCH_CHECK() hipGetLastError()
 
+int ptk_trace_dist_blocks_per_cu() { return PT_TRACE_DIST_WAVES; }
 hipError_t ptk_trace(hipStream_t st, int grid, int grid_dist, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err) {
     if (sc.dist_leaves && !sc.n_instances) grid = grid_dist;      // the pooled-leaf kernels fit three blocks per CU, the others four

@@ -57,7 +57,8 @@ def test_commit_makes_the_reduced_buffer_authoritative(gpu_ctx, pkg, nccl_group)
     assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want * np.float32(2.0)))
     rgb2 = gpu_ctx.film_rgb()                      # weights doubled too: the resolved image is unchanged
     gpu_ctx.film_clear(); gpu_ctx.render()         # a new render supersedes the committed buffer
-    assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want))
+    again = gpu_ctx.film_xyzw()                    # (edge-split samples go through float atomics: last bits may differ between renders)
+    assert np.array_equal(bits(again[..., 3]), bits(want[..., 3])) and np.allclose(again, want, rtol=2e-6, atol=1e-7)
     assert np.allclose(rgb2, gpu_ctx.film_rgb(), rtol=2e-6, atol=1e-7)
 
 
