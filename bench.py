@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--light", default="quad", choices=["quad", "sphere"], help="quad = the headline; sphere = an analytic sphere light instead (secondary number: k_trace_sph / k_shade_*_sph)")
     ap.add_argument("--integrator", default="path", choices=["path", "ao"], help="path = the headline; ao = Integrator \"ao\" with 64 occlusion rays per camera sample (secondary number: an any-hit workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spp1024", action="store_true", help="skip the secondary 1024-spp frame (N=1 only)")
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU sample (0 = auto, about 15 s)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -204,29 +205,49 @@ def main():
 
     out = None
     if rank == 0:
-        # roofline of the dominant kernel, from rank 0's own launches
+        # roofline of the dominant kernel (k_trace), from rank 0's own launches.  k_trace is bound by the REQUEST RATE of the CU's
+        # vector L1 (TCP): with one ray per lane every lane's node / triangle record is a cache line of its own, and the L1 takes one
+        # 16-byte lane request per clock (tools/ubench/node_fetch.hip: 77 G eight-load node visits/s = 614 G requests/s = 256 CUs x
+        # 2.4 GHz with nothing else running).  achieved = lane requests per launch / launch time.
+        lean = args.integrator == "path"          # k_trace / k_trace_sph_dist: 7 row + child loads per node visit; k_trace_batch (ao's rays): 8
+        per_visit = 7.0 if lean else 8.0
+        n_rays = cnt["regular_rays"] + cnt["shadow_rays"]
+        reqs = per_visit * cnt["nodes_visited"] + 3.0 * cnt["tris_tested"] + 5.0 * n_rays      # per ray: id + 2 x 16 B in, 2 result stores out
         alg_bytes = 48.0 * cnt["regular_rays"] + 36.0 * cnt["shadow_rays"] + 128.0 * cnt["nodes_visited"] + 48.0 * cnt["tris_tested"]
         launches = max(1, cnt["trace_launches"])
         avg_launch_s = cnt["trace_ms"] / 1e3 / launches
-        achieved = (alg_bytes / launches) / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        peak = 8000.0
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tp) and args.materials == "matte" and args.light == "quad" and args.integrator == "path":      # measured on the headline workload only
+        props = torch.cuda.get_device_properties(local_rank)
+        n_cu = int(props.multi_processor_count)
+        peak = n_cu * 2.4                          # G requests/s: one per clock per CU at the 2.4 GHz nominal clock (MI355X_MICROARCH.md)
+        achieved = (reqs / launches) / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        scene_bytes = 128.0 * info.n_nodes + 48.0 * sd.desc.n_triangles
+        compulsory = (48.0 * cnt["regular_rays"] + 36.0 * cnt["shadow_rays"]) / launches + scene_bytes
+        traffic, traffic_note = None, "no PMC measurement for this workload"
+        tp = os.path.join(ROOT, "profiles", "traffic_r02.json")
+        key = {"triangles": args.triangles, "res": args.res, "spp": args.spp, "max_depth": args.max_depth, "materials": args.materials,
+               "sampler": args.sampler, "light": args.light, "integrator": args.integrator}
+        if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                if tj.get("workload") == key:      # measured on exactly this workload (passes of the same size), else null
+                    traffic, traffic_note = tj.get("fabric_bytes_per_launch"), tj.get("note", "")
             except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_trace_sph" if args.light == "sphere" else "k_trace", "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
-                    "frac": round(achieved / peak, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1),
-                    "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
-                    "nodes_per_ray": round(cnt["nodes_visited"] / max(1.0, cnt["regular_rays"] + cnt["shadow_rays"]), 2),
-                    "tris_per_ray": round(cnt["tris_tested"] / max(1.0, cnt["regular_rays"] + cnt["shadow_rays"]), 2),
+                pass
+        roofline = {"bound": "l1_req", "kernel": "k_trace_sph_dist" if args.light == "sphere" else "k_trace", "achieved": round(achieved, 2), "peak": round(peak, 1),
+                    "unit": "Greq/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "requests_per_launch": round(reqs / launches, 1), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
+                    "nodes_per_ray": round(cnt["nodes_visited"] / max(1.0, n_rays), 2), "tris_per_ray": round(cnt["tris_tested"] / max(1.0, n_rays), 2),
                     "trace_share_of_render": round(cnt["trace_ms"] / max(1e-9, cnt["render_ms"]), 3),
-                    "note": "achieved counts ALGORITHMIC bytes (128 B per node visit, 48 B per triangle test, ray records); the upper BVH "
-                            "levels are re-read from L2 / Infinity Cache, so it can exceed the HBM peak -- traffic is the measured HBM side"}
-        cpu = None
+                    # informational: SURVEY.md section 8d's algorithmic bytes (cache-served, can exceed the HBM peak), what HBM must move at least,
+                    # and the measured L2-miss (fabric) traffic where profiles/ holds it for this workload
+                    "algorithmic_gbps": round((alg_bytes / launches) / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else 0.0,
+                    "hbm_compulsory_bytes_per_launch": round(compulsory, 1),
+                    "hbm_compulsory_frac_of_8TBps": round(compulsory / avg_launch_s / 8e12, 5) if avg_launch_s > 0 else 0.0,
+                    "fabric_frac_of_8TBps": round(traffic / avg_launch_s / 8e12, 4) if (traffic and avg_launch_s > 0) else None,
+                    "note": "bound = lane requests to the CU's vector L1 (one 16-byte request per clock per CU): "
+                            "%g per node visit, 3 per triangle test, 5 per ray; traffic = FETCH_SIZE/WRITE_SIZE-derived bytes leaving L2 "
+                            "(Infinity Cache hits included) per launch: %s" % (per_visit, traffic_note)}
+        cpu, parity, spp1024 = None, None, None
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only (rank 0 would keep the other ranks waiting)
             import oracle_lib
             osc = oracle_lib.load().scene(sd)
@@ -243,13 +264,48 @@ def main():
             stride = max(1, len(tiles) // ntile)
             sample = tiles[::stride][:ntile]
             log("cpu baseline: rendering %d tiles on %d threads" % (len(sample), cores))
-            _, ccnt, secs = osc.render(sample, threads=cores, want_image=False)
+            oxyzw, ccnt, secs = osc.render(sample, threads=cores, want_image=True)
             log("cpu baseline: done in %.1f s" % secs)
+            # parity of the benchmarked frame: the GPU film of the last timed step against the oracle on the sampled tiles
+            # (linear RGB after the division by the filter weight; north_star tolerance: 1e-3 relative L2)
+            g_rgb = ctx.film_rgb().astype(np.float64)
+            o_rgb = osc.resolve_rgb(oxyzw).astype(np.float64)
+            cb = list(info.cropped_bounds)
+            mask = np.zeros(g_rgb.shape[:2], bool)
+            for (x0, y0, x1, y1) in sample:
+                # interior pixels of the tile only: a border pixel also receives the edge-split samples of the neighbouring tiles
+                # (normalised footprints, quirk Q1), which the full GPU frame has and the oracle's partial film has not
+                mask[max(y0 + 1, cb[1]) - cb[1]: max(min(y1 - 1, cb[3]) - cb[1], 0), max(x0 + 1, cb[0]) - cb[0]: max(min(x1 - 1, cb[2]) - cb[0], 0)] = True
+            gd, od = g_rgb[mask], o_rgb[mask]
+            den = np.maximum(np.abs(od), 1e-6)
+            parity = {"rel_l2": float(np.sqrt(((gd - od) ** 2).sum()) / max(np.sqrt((od ** 2).sum()), 1e-30)),
+                      "max_rel": float((np.abs(gd - od) / den).max()) if gd.size else 0.0,
+                      "pixels_over_1pct": int(((np.abs(gd - od) / den).max(axis=-1) > 0.01).sum()) if gd.size else 0,
+                      "n_pixels": int(mask.sum()), "tolerance_rel_l2": 1e-3,
+                      "reference": "oracle (CPU restatement), interior pixels of the %d sampled tiles at all %d spp" % (len(sample), info.spp)}
+            log("parity: rel-L2 %.3e over %d pixels" % (parity["rel_l2"], parity["n_pixels"]))
             crays = ccnt["regular_rays"] + ccnt["shadow_rays"]
             cpu = {"value": round(crays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                    "sample": "%d of %d 16x16 tiles (every %dth), all %d spp, %.1f s" % (len(sample), len(tiles), stride, info.spp, secs),
                    "note": "C++ restatement of the reference (oracle/), not the Rust binary"}
             osc.close()
+        if world == 1 and not args.no_spp1024 and args.spp != 1024:
+            # north_star's target sentence quotes 1024 spp for the same scene (BASELINE config 2 says 256; Mrays/s is spp-independent,
+            # wall-clock scales): one extra frame at 1024 spp, wall-clock reported beside the headline
+            sd4 = pkg.scenes.rt1m(args.triangles, res=args.res, spp=1024, max_depth=args.max_depth, materials=args.materials, sampler=args.sampler, light=args.light)
+            if args.integrator == "ao":
+                sd4.desc.integrator, sd4.desc.ao_samples, sd4.desc.ao_cos_sample = pkg.capi.PT_INTEGRATOR_AO, 64, 1
+            i4 = ctx.upload(sd4)
+            ctx.film_clear(); ctx.reset_counters()
+            torch.cuda.synchronize()
+            t4 = time.time()
+            ctx.render()
+            torch.cuda.synchronize()
+            s4 = time.time() - t4
+            c4 = ctx.counters()
+            spp1024 = {"spp": int(i4.spp), "wall_s": round(s4, 3), "mrays_s": round((c4["regular_rays"] + c4["shadow_rays"]) / s4 / 1e6, 1),
+                       "rays": int(c4["regular_rays"] + c4["shadow_rays"])}
+            log("1024 spp: %.2f s wall, %.1f Mrays/s" % (s4, spp1024["mrays_s"]))
         out = {
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
@@ -261,7 +317,7 @@ def main():
                        "rays_per_step": int(rays / max(1, args.steps)), "camera_samples_per_step": int(tot[8] / max(1, args.steps)),
                        "bvh_build_ms": round(info.bvh_build_ms, 1), "upload_ms": round(info.upload_ms, 1),
                        "scene_gen_s": round(t_scene, 2)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "spp1024": spp1024,
         }
         if args.integrator == "ao":
             out["config"]["workload"] = out["config"]["workload"].replace("path maxdepth %d" % args.max_depth, "ao nsamples 64 cossample")

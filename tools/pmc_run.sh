@@ -11,7 +11,7 @@ for set in ${PMC_SETS_OVERRIDE:+} "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAI
   i=$((i+1))
   out="gpurun_out/pmc_$tag/p$i"
   mkdir -p "$out"
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$out" -- python3 bench.py --spp ${SPP:-16} --steps 1 --warmup 0 --no-cpu-baseline > "$out/bench.json" 2> "$out/bench.err"
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$out" -- python3 bench.py --spp ${SPP:-16} --steps 1 --warmup 0 --no-cpu-baseline --no-spp1024 > "$out/bench.json" 2> "$out/bench.err"
   echo "pass $i ($set): exit $?"
 done
 python3 tools/pmc_summarize.py "gpurun_out/pmc_$tag" | tee "gpurun_out/pmc_$tag/summary.txt"

@@ -12,7 +12,7 @@ i=0
 for set in "$@"; do
   out="gpurun_out/pmc_$tag/pass$i"
   mkdir -p "$out"
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$out" -- python3 bench.py --spp ${SPP:-32} --steps 1 --warmup 0 --no-cpu-baseline > "$out/bench.json" 2> "$out/bench.err" || { echo "pass $i failed"; tail -5 "$out/bench.err"; }
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$out" -- python3 bench.py --spp ${SPP:-32} --steps 1 --warmup 0 --no-cpu-baseline --no-spp1024 > "$out/bench.json" 2> "$out/bench.err" || { echo "pass $i failed"; tail -5 "$out/bench.err"; }
   echo "pass $i done: $(cut -c1-60 $out/bench.json)"
   i=$((i+1))
 done

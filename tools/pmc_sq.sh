@@ -10,7 +10,7 @@ i=0
 for set in "${sets[@]}"; do
   out="gpurun_out/sq_$tag/pass$i"
   mkdir -p "$out"
-  timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d "$out" -- python3 bench.py --spp ${SPP:-52} --steps 1 --warmup 0 --no-cpu-baseline > "$out/bench.json" 2> "$out/bench.err" || { echo "pass $i failed"; tail -5 "$out/bench.err"; }
+  timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d "$out" -- python3 bench.py --spp ${SPP:-52} --steps 1 --warmup 0 --no-cpu-baseline --no-spp1024 > "$out/bench.json" 2> "$out/bench.err" || { echo "pass $i failed"; tail -5 "$out/bench.err"; }
   echo "pass $i done"
   i=$((i+1))
 done

@@ -8,7 +8,7 @@ for pass in fetch write; do
   if [ $pass = fetch ]; then set="FETCH_SIZE"; else set="WRITE_SIZE"; fi
   out="gpurun_out/pmc_$tag/$pass"
   mkdir -p "$out"
-  timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d "$out" -- python3 bench.py --spp ${SPP:-16} --steps 1 --warmup 0 --no-cpu-baseline > "$out/bench.json" 2> "$out/bench.err" || { echo "pass $pass failed"; tail -5 "$out/bench.err"; exit 1; }
+  timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d "$out" -- python3 bench.py --spp ${SPP:-16} --steps 1 --warmup 0 --no-cpu-baseline --no-spp1024 > "$out/bench.json" 2> "$out/bench.err" || { echo "pass $pass failed"; tail -5 "$out/bench.err"; exit 1; }
   echo "pass $pass done"
 done
 python3 tools/pmc_summarize.py "gpurun_out/pmc_$tag" > "gpurun_out/pmc_$tag/summary.txt"
