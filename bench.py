@@ -209,8 +209,7 @@ def main():
         # vector L1 (TCP): with one ray per lane every lane's node / triangle record is a cache line of its own, and the L1 takes one
         # 16-byte lane request per clock (tools/ubench/node_fetch.hip: 77 G eight-load node visits/s = 614 G requests/s = 256 CUs x
         # 2.4 GHz with nothing else running).  achieved = lane requests per launch / launch time.
-        lean = args.integrator == "path"          # k_trace / k_trace_sph_dist: 7 row + child loads per node visit; k_trace_batch (ao's rays): 8
-        per_visit = 7.0 if lean else 8.0
+        per_visit = 7.0                           # k_trace / k_trace_sph_dist (path and ao alike): six plane rows + the child references per node visit
         n_rays = cnt["regular_rays"] + cnt["shadow_rays"]
         reqs = per_visit * cnt["nodes_visited"] + 3.0 * cnt["tris_tested"] + 5.0 * n_rays      # per ray: id + 2 x 16 B in, 2 result stores out
         alg_bytes = 48.0 * cnt["regular_rays"] + 36.0 * cnt["shadow_rays"] + 128.0 * cnt["nodes_visited"] + 48.0 * cnt["tris_tested"]
@@ -322,7 +321,7 @@ def main():
         if args.integrator == "ao":
             out["config"]["workload"] = out["config"]["workload"].replace("path maxdepth %d" % args.max_depth, "ao nsamples 64 cossample")
             if roofline:
-                roofline["kernel"] = "k_trace + k_trace_batch (any hit)"
+                roofline["kernel"] = "k_trace (camera rays, then the occlusion rays as shadow work items)"
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -1151,15 +1151,16 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 // camera rays -> closest hits -> ao_samples occlusion rays per hit (compacted) -> any-hit -> ordered sum
                 const uint32_t n_paths = n_pix * ns;
                 const size_t cap = (size_t)n_paths * (size_t)sc.ao_samples;
-                if (ctx->ao_rays_cap < cap) {
-                    PT_HIP(ctx->d_ao.alloc(cap * 33 + 256));
+                if (ctx->ao_rays_cap < cap) {      // per ray: origin + t_max, direction (the record of a shadow work item), weight, item id, occlusion flag
+                    PT_HIP(ctx->d_ao.alloc(cap * 41 + 256));
                     ctx->ao_rays_cap = cap;
+                    PT_HIP(ptk_iota(ctx->stream, ctx->grid_wide, reinterpret_cast<uint32_t*>(ctx->d_ao.as<char>() + ctx->ao_rays_cap * 36), (uint32_t)cap));
                 }
-                float* ao_o = ctx->d_ao.as<float>();
-                float* ao_d = ao_o + 3 * ctx->ao_rays_cap;
-                float* ao_t = ao_d + 3 * ctx->ao_rays_cap;
-                float* ao_w = ao_t + ctx->ao_rays_cap;
-                uint8_t* ao_occ = reinterpret_cast<uint8_t*>(ao_w + ctx->ao_rays_cap);
+                float4* ao_o = ctx->d_ao.as<float4>();
+                float4* ao_d = ao_o + ctx->ao_rays_cap;
+                float* ao_w = reinterpret_cast<float*>(ao_d + ctx->ao_rays_cap);
+                uint32_t* ao_ids = reinterpret_cast<uint32_t*>(ao_w + ctx->ao_rays_cap);
+                uint8_t* ao_occ = reinterpret_cast<uint8_t*>(ao_ids + ctx->ao_rays_cap);
                 uint32_t* ao_count = ctx->d_ticket.as<uint32_t>() + 2;
                 hipEvent_t a = get_event(ctx, ev_i), b = get_event(ctx, ev_i + 1), c = get_event(ctx, ev_i + 2);
                 if (!a || !b || !c) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
@@ -1170,15 +1171,15 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 PT_HIP(hipEventRecord(a, ctx->stream));
                 PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
                 ctx->trace_launches++;
-                PT_HIP(ptk_ao_rays(ctx->stream, ctx->grid_wide, sc, ctx->paths, n_paths, ao_o, ao_d, ao_t, ao_w, ao_count, cnt));
-                uint32_t n_hit = 0;
-                PT_HIP(hipMemcpyAsync(&n_hit, ao_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-                PT_HIP(hipStreamSynchronize(ctx->stream));
-                const uint32_t n_rays = n_hit * (uint32_t)sc.ao_samples;
-                if (n_rays) {
-                    PT_HIP(hipMemsetAsync(ctx->d_ticket.p, 0, 8, ctx->stream));
-                    PT_HIP(ptk_trace_batch(ctx->stream, ctx->grid_trace, sc, n_rays, ao_o, ao_d, ao_t, nullptr, ao_occ, 1, ctx->d_ticket.as<uint32_t>(), cnt,
-                                           ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                PT_HIP(ptk_ao_rays(ctx->stream, ctx->grid_wide, sc, ctx->paths, n_paths, ao_o, ao_d, ao_w, ao_count, cnt));
+                {   // the occlusion rays as shadow work items of the wavefront traversal kernel itself (any hit -> occlusion flag);
+                    // the item count is read on the device, so the pass never waits for the host
+                    PtPaths AP = ctx->paths;
+                    AP.sh_o = ao_o; AP.sh_d = ao_d; AP.occluded = ao_occ;
+                    PtQueues AQ = Q;
+                    AQ.shadow = ao_ids;
+                    PT_HIP(ptk_ao_queue(ctx->stream, AQ, ao_count, (uint32_t)sc.ao_samples));
+                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, AP, AQ, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
                     ctx->trace_launches++;
                 }
                 PT_HIP(hipEventRecord(b, ctx->stream));

@@ -27,8 +27,10 @@ hipError_t ptk_bsdf_sample(hipStream_t st, const PtScene& sc, uint32_t material,
 hipError_t ptk_sobol_samples(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim,
                              float* out);
 hipError_t ptk_ao_tag(hipStream_t st, int grid, const PtPaths& P, uint32_t n_pix, uint32_t n_paths, uint32_t s0);
-hipError_t ptk_ao_rays(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+hipError_t ptk_ao_rays(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, float4* ao_o, float4* ao_d, float* ao_w,
                        uint32_t* counter, PtCounters* cnt);
+hipError_t ptk_ao_queue(hipStream_t st, const PtQueues& Q, const uint32_t* counter, uint32_t n_s);
+hipError_t ptk_iota(hipStream_t st, int grid, uint32_t* out, uint32_t n);
 hipError_t ptk_ao_resolve(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, const float* ao_w, const uint8_t* occ);
 hipError_t ptk_expand_tiles(hipStream_t st, const int4* tiles, const uint32_t* tile_off, uint32_t n_tiles, int32_t sb_x0, int32_t sb_y0, uint32_t sb_w,
                             uint32_t* pixels, uint32_t* bitmap, uint32_t* err);

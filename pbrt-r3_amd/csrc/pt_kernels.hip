@@ -2539,7 +2539,7 @@ hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t
 // sample order -- the reference's summation order, so the radiance is bit-identical.
 //   counter[0] = hit paths so far; P.nee[path] = batch slot + 1 (0 = the camera ray escaped)
 template <bool SPH, bool INST>
-PT_DEV void ao_rays_body(const PtScene& sc, const PtPaths& P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w, uint32_t* counter,
+PT_DEV void ao_rays_body(const PtScene& sc, const PtPaths& P, uint32_t n_paths, float4* ao_o, float4* ao_d, float* ao_w, uint32_t* counter,
                          PtCounters* cnt) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_s = (uint32_t)sc.ao_samples;
@@ -2588,24 +2588,23 @@ PT_DEV void ao_rays_body(const PtScene& sc, const PtPaths& P, uint32_t n_paths, 
             wi = mk3(wi.x * ss.x + wi.y * tt.x + wi.z * n.x, wi.x * ss.y + wi.y * tt.y + wi.z * n.y, wi.x * ss.z + wi.y * tt.z + wi.z * n.z);
             const V3 o = offset_ray_origin(s.p, s.p_error, s.n, wi);
             const size_t r = r0 + k;
-            ao_o[3 * r] = o.x; ao_o[3 * r + 1] = o.y; ao_o[3 * r + 2] = o.z;
-            ao_d[3 * r] = wi.x; ao_d[3 * r + 1] = wi.y; ao_d[3 * r + 2] = wi.z;
-            ao_tmax[r] = PT_INF;
+            ao_o[r] = make_float4(o.x, o.y, o.z, PT_INF);          // the record layout of a shadow work item (origin, t_max | direction)
+            ao_d[r] = make_float4(wi.x, wi.y, wi.z, 0.0f);
             ao_w[r] = dot(wi, n) / (pdf * (float)n_s);
         }
     }
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_rays(PtScene sc, PtPaths P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_rays(PtScene sc, PtPaths P, uint32_t n_paths, float4* ao_o, float4* ao_d, float* ao_w,
                                                                 uint32_t* counter, PtCounters* cnt) {
-    ao_rays_body<false, false>(sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+    ao_rays_body<false, false>(sc, P, n_paths, ao_o, ao_d, ao_w, counter, cnt);
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_rays_sph(PtScene sc, PtPaths P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_rays_sph(PtScene sc, PtPaths P, uint32_t n_paths, float4* ao_o, float4* ao_d, float* ao_w,
                                                                     uint32_t* counter, PtCounters* cnt) {
-    ao_rays_body<true, false>(sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+    ao_rays_body<true, false>(sc, P, n_paths, ao_o, ao_d, ao_w, counter, cnt);
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_rays_inst(PtScene sc, PtPaths P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_rays_inst(PtScene sc, PtPaths P, uint32_t n_paths, float4* ao_o, float4* ao_d, float* ao_w,
                                                                      uint32_t* counter, PtCounters* cnt) {
-    ao_rays_body<true, true>(sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+    ao_rays_body<true, true>(sc, P, n_paths, ao_o, ao_d, ao_w, counter, cnt);
 }
 // path i of the pass took pixel-sample number s0 + i / n_pix (k_gen); the array slice of get_2d_array starts at n_s times that
 extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_ao_tag(PtPaths P, uint32_t n_pix, uint32_t n_paths, uint32_t s0) {
@@ -2629,11 +2628,30 @@ hipError_t ptk_ao_tag(hipStream_t st, int grid, const PtPaths& P, uint32_t n_pix
     hipLaunchKernelGGL(k_ao_tag, dim3(grid), dim3(PT_BLOCK), 0, st, P, n_pix, n_paths, s0);
     return PT_LAUNCH_CHECK();
 }
-hipError_t ptk_ao_rays(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, float* ao_o, float* ao_d, float* ao_tmax, float* ao_w,
+hipError_t ptk_ao_rays(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, float4* ao_o, float4* ao_d, float* ao_w,
                        uint32_t* counter, PtCounters* cnt) {
-    if (sc.n_instances) hipLaunchKernelGGL(k_ao_rays_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
-    else if (sc.n_spheres) hipLaunchKernelGGL(k_ao_rays_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
-    else hipLaunchKernelGGL(k_ao_rays, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_o, ao_d, ao_tmax, ao_w, counter, cnt);
+    if (sc.n_instances) hipLaunchKernelGGL(k_ao_rays_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_o, ao_d, ao_w, counter, cnt);
+    else if (sc.n_spheres) hipLaunchKernelGGL(k_ao_rays_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_o, ao_d, ao_w, counter, cnt);
+    else hipLaunchKernelGGL(k_ao_rays, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, n_paths, ao_o, ao_d, ao_w, counter, cnt);
+    return PT_LAUNCH_CHECK();
+}
+// The occlusion rays become the shadow work items of one wavefront traversal launch: item i is ray i (identity list), the count
+// comes from the device-side hit counter -- no host round trip between the two traversals of a pass.
+extern "C" __global__ void k_ao_queue(PtQueues Q, const uint32_t* counter, uint32_t n_s) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        Q.counts[PT_Q_CUR] = 0; Q.counts[PT_Q_SHADOW] = counter[0] * n_s; Q.counts[PT_Q_PROBE] = 0; Q.counts[PT_Q_NEE] = 0;
+        for (uint32_t k = 0; k < 8u; k++) Q.counts[PT_Q_SEG_TICKET0 + 32u * k] = 0;
+    }
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_iota(uint32_t* out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = i;
+}
+hipError_t ptk_ao_queue(hipStream_t st, const PtQueues& Q, const uint32_t* counter, uint32_t n_s) {
+    hipLaunchKernelGGL(k_ao_queue, dim3(1), dim3(64), 0, st, Q, counter, n_s);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_iota(hipStream_t st, int grid, uint32_t* out, uint32_t n) {
+    hipLaunchKernelGGL(k_iota, dim3(grid), dim3(PT_BLOCK), 0, st, out, n);
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_ao_resolve(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n_paths, const float* ao_w, const uint8_t* occ) {
