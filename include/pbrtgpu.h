@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 5
+#define PT_ABI_VERSION 6
 
 typedef enum {
     PT_OK = 0,
@@ -116,7 +116,9 @@ typedef struct {
 } pt_texture;
 
 /* Material::compute_scattering_functions variants (src/materials/).  Colour parameters and Matte's sigma may be
- * textures (tex_* below) and a procedural bump map is applied (tex_bump); roughness and eta textures must fold to constants. */
+ * textures (tex_* below), a procedural bump map is applied (tex_bump), and (ABI 6) the float parameters "roughness" /
+ * "uroughness" / "vroughness" / "eta" may be textures too: they are evaluated at every hit and the roughness goes through
+ * TrowbridgeReitzDistribution::roughness_to_alpha (`ln`, core/distribution/trowbridge_reitz.rs:113-121) on the device. */
 typedef enum {
     PT_MATERIAL_NONE = 0,      /* GeometricPrimitive.material == None: ray passes through (path.rs:108-111) */
     PT_MATERIAL_MATTE = 1,     /* materials/matte.rs:25-53      Kd, sigma */
@@ -131,7 +133,7 @@ typedef enum {
 #define PT_ROUGHNESS_UNSET (-1.0f)   /* "uroughness"/"vroughness" not given: Metal and Uber fall back to "roughness" */
 
 /* Field defaults are the reference's create_*_material defaults; a field a material type does not
- * read is ignored.  156 bytes. */
+ * read is ignored.  164 bytes. */
 typedef struct {
     int32_t type;           /* pt_material_type */
     float kd[3];            /* "Kd": matte 0.5, plastic/uber 0.25, substrate 0.5 */
@@ -151,7 +153,10 @@ typedef struct {
      * above.  Zero-initialised materials are therefore constant. */
     uint32_t tex_kd, tex_ks, tex_kr, tex_kt, tex_opacity, tex_sigma, tex_metal_eta, tex_metal_k;
     uint32_t tex_bump;      /* "bumpmap" (core/material.rs:31-72): index + 1 of the displacement (float) texture, 0 = none */
-    float reserved[2];
+    /* ABI 6: float textures (index + 1, 0 = the constant above) behind "roughness", "uroughness", "vroughness" and "eta" / "index"
+     * (plastic.rs:57-62, glass.rs:57-81, metal.rs:58-69, uber.rs:66,96-104, substrate.rs:45-54).  A Metal / Uber material whose
+     * "uroughness" ("vroughness") is neither a number nor a texture falls back to "roughness" -- constant or textured. */
+    uint32_t tex_roughness, tex_uroughness, tex_vroughness, tex_eta;
 } pt_material;
 
 /* DiffuseAreaLight parameters shared by every triangle of one emissive shape

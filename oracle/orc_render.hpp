@@ -489,7 +489,8 @@ inline bool make_bsdf(const Scene& sc, SurfHit& si, BSDF* b, const RayDiff& rd =
     if (mid < 0) return false;
     const pt_material& m0 = sc.materials[mid];
     if (m0.type == PT_MATERIAL_NONE ||
-        !(m0.tex_kd | m0.tex_ks | m0.tex_kr | m0.tex_kt | m0.tex_opacity | m0.tex_sigma | m0.tex_metal_eta | m0.tex_metal_k | m0.tex_bump))
+        !(m0.tex_kd | m0.tex_ks | m0.tex_kr | m0.tex_kt | m0.tex_opacity | m0.tex_sigma | m0.tex_metal_eta | m0.tex_metal_k | m0.tex_bump |
+          m0.tex_roughness | m0.tex_uroughness | m0.tex_vroughness | m0.tex_eta))
         return make_bsdf_from_material(m0, si, b);
     pt_material m = m0;
     TexHit th = compute_differentials(si, rd);                  // SurfaceInteraction::compute_scattering_functions :284-295
@@ -501,7 +502,11 @@ inline bool make_bsdf(const Scene& sc, SurfHit& si, BSDF* b, const RayDiff& rd =
     };
     spec(m.tex_kd, m.kd); spec(m.tex_ks, m.ks); spec(m.tex_kr, m.kr); spec(m.tex_kt, m.kt); spec(m.tex_opacity, m.opacity);
     spec(m.tex_metal_eta, m.metal_eta); spec(m.tex_metal_k, m.metal_k);
-    if (m.tex_sigma) m.sigma = texture_eval(sc.textures.data(), (int32_t)m.tex_sigma - 1, th, sc.images.data()).c[0];
+    // float textures: Matte's sigma, and the roughness / eta parameters (plastic.rs:57-62, glass.rs:57-81, metal.rs:58-69,
+    // uber.rs:66,96-104, substrate.rs:45-54): evaluated at the hit, then roughness_to_alpha (`ln`) inside the constant code
+    auto flt = [&](uint32_t t, float* out) { if (t) *out = texture_eval(sc.textures.data(), (int32_t)t - 1, th, sc.images.data()).c[0]; };
+    flt(m.tex_sigma, &m.sigma); flt(m.tex_roughness, &m.roughness); flt(m.tex_uroughness, &m.uroughness); flt(m.tex_vroughness, &m.vroughness);
+    flt(m.tex_eta, &m.eta);
     return make_bsdf_from_material(m, si, b);
 }
 
@@ -879,7 +884,8 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
         for (int k = 0; k < 3; k++)
             if (textures[i].tex[k] >= (int32_t)i) { if (err) *err = "texture child index must be smaller than the texture's own"; return false; }
     for (const pt_material& m : materials) {
-        const uint32_t refs[9] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k, m.tex_bump};
+        const uint32_t refs[13] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k, m.tex_bump,
+                                   m.tex_roughness, m.tex_uroughness, m.tex_vroughness, m.tex_eta};
         for (uint32_t r : refs) if (r > d.n_textures) { if (err) *err = "material texture index out of range"; return false; }
     }
     // spheres and object instances, spliced into the primitive lists at before_triangle (ties: creation order)

@@ -37,7 +37,7 @@ class pt_material(C.Structure):
                 ("metal_eta", C.c_float * 3), ("metal_k", C.c_float * 3),
                 ("tex_kd", C.c_uint32), ("tex_ks", C.c_uint32), ("tex_kr", C.c_uint32), ("tex_kt", C.c_uint32),
                 ("tex_opacity", C.c_uint32), ("tex_sigma", C.c_uint32), ("tex_metal_eta", C.c_uint32), ("tex_metal_k", C.c_uint32),
-                ("tex_bump", C.c_uint32), ("reserved", C.c_float * 2)]
+                ("tex_bump", C.c_uint32), ("tex_roughness", C.c_uint32), ("tex_uroughness", C.c_uint32), ("tex_vroughness", C.c_uint32), ("tex_eta", C.c_uint32)]
 
 
 class pt_texture(C.Structure):

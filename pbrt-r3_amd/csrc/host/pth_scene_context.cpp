@@ -505,7 +505,7 @@ public:
         if (const std::string* tex = bound_texture(geom, mat, n)) {
             auto nd = node_float_textures.find(*tex);
             if (nd != node_float_textures.end()) {
-                if (!tex_out) { fail("parameter \"" + n + "\" uses texture \"" + *tex + "\", which varies over the surface: only colour parameters and Matte's sigma may (roughness / eta textures must be constant)"); return false; }
+                if (!tex_out) { fail("parameter \"" + n + "\" uses texture \"" + *tex + "\", which varies over the surface: not supported for this parameter"); return false; }
                 *tex_out = nd->second + 1;
                 return true;
             }
@@ -534,7 +534,7 @@ public:
         m.uroughness = m.vroughness = PT_ROUGHNESS_UNSET;
         m.remap_roughness = geom.find_one_bool("remaproughness", mp.find_one_bool("remaproughness", true)) ? 1 : 0;
         auto eta_or_index = [&]() {                              // get_float_texture_helper(&["eta", "index"], 1.5)
-            if (!lookup_float(geom, mp, "eta", &m.eta)) lookup_float(geom, mp, "index", &m.eta);
+            if (!lookup_float(geom, mp, "eta", &m.eta, &m.tex_eta)) lookup_float(geom, mp, "index", &m.eta, &m.tex_eta);
         };
         if (mi.name == "matte") {                                   // matte.rs:56-61
             m.type = PT_MATERIAL_MATTE;
@@ -545,7 +545,7 @@ public:
             m.type = PT_MATERIAL_PLASTIC;
             set3(m.kd, 0.25f); set3(m.ks, 0.25f); m.roughness = 0.1f;
             lookup_rgb(geom, mp, "Kd", m.kd, &m.tex_kd); lookup_rgb(geom, mp, "Ks", m.ks, &m.tex_ks);
-            lookup_float(geom, mp, "roughness", &m.roughness);
+            lookup_float(geom, mp, "roughness", &m.roughness, &m.tex_roughness);
         } else if (mi.name == "mirror") {                           // mirror.rs:43-47
             m.type = PT_MATERIAL_MIRROR;
             set3(m.kr, 0.9f);
@@ -554,7 +554,7 @@ public:
             m.type = PT_MATERIAL_GLASS;
             set3(m.kr, 1.0f); set3(m.kt, 1.0f); m.uroughness = m.vroughness = 0.0f;
             lookup_rgb(geom, mp, "Kr", m.kr, &m.tex_kr); lookup_rgb(geom, mp, "Kt", m.kt, &m.tex_kt);
-            lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
+            lookup_float(geom, mp, "uroughness", &m.uroughness, &m.tex_uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness, &m.tex_vroughness);
             eta_or_index();
         } else if (mi.name == "metal") {                            // metal.rs:127-149
             m.type = PT_MATERIAL_METAL;
@@ -567,22 +567,22 @@ public:
                 if (!have_eta) rgb_from_sampled(*T, T->cu_lambda, T->cu_n, m.metal_eta);
                 if (!have_k) rgb_from_sampled(*T, T->cu_lambda, T->cu_k, m.metal_k);
             }
-            lookup_float(geom, mp, "roughness", &m.roughness);
-            lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
+            lookup_float(geom, mp, "roughness", &m.roughness, &m.tex_roughness);
+            lookup_float(geom, mp, "uroughness", &m.uroughness, &m.tex_uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness, &m.tex_vroughness);
         } else if (mi.name == "uber") {                             // uber.rs:142-168
             m.type = PT_MATERIAL_UBER;
             set3(m.kd, 0.25f); set3(m.ks, 0.25f); m.roughness = 0.1f;
             lookup_rgb(geom, mp, "Kd", m.kd, &m.tex_kd); lookup_rgb(geom, mp, "Ks", m.ks, &m.tex_ks);
             lookup_rgb(geom, mp, "Kr", m.kr, &m.tex_kr); lookup_rgb(geom, mp, "Kt", m.kt, &m.tex_kt);
             lookup_rgb(geom, mp, "opacity", m.opacity, &m.tex_opacity);
-            lookup_float(geom, mp, "roughness", &m.roughness);
-            lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
+            lookup_float(geom, mp, "roughness", &m.roughness, &m.tex_roughness);
+            lookup_float(geom, mp, "uroughness", &m.uroughness, &m.tex_uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness, &m.tex_vroughness);
             eta_or_index();
         } else if (mi.name == "substrate") {                        // substrate.rs:70-86
             m.type = PT_MATERIAL_SUBSTRATE;
             set3(m.kd, 0.5f); set3(m.ks, 0.5f); m.uroughness = m.vroughness = 0.1f;
             lookup_rgb(geom, mp, "Kd", m.kd, &m.tex_kd); lookup_rgb(geom, mp, "Ks", m.ks, &m.tex_ks);
-            lookup_float(geom, mp, "uroughness", &m.uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness);
+            lookup_float(geom, mp, "uroughness", &m.uroughness, &m.tex_uroughness); lookup_float(geom, mp, "vroughness", &m.vroughness, &m.tex_vroughness);
         } else {
             fail("Material \"" + mi.name + "\": outside the accelerated path (matte, plastic, mirror, glass, metal, uber, substrate are supported)");
             return -1;

@@ -425,7 +425,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const pt_material& m = d->materials[i];
-        const uint32_t refs[9] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k, m.tex_bump};
+        const uint32_t refs[13] = {m.tex_kd, m.tex_ks, m.tex_kr, m.tex_kt, m.tex_opacity, m.tex_sigma, m.tex_metal_eta, m.tex_metal_k, m.tex_bump,
+                                   m.tex_roughness, m.tex_uroughness, m.tex_vroughness, m.tex_eta};
         for (uint32_t r : refs)
             if (r > d->n_textures || (r && !d->textures)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "material texture index out of range");
     }
@@ -727,11 +728,12 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         build_lobes(d->materials[i], mats[i]);
         {
             const pt_material& in = d->materials[i];
-            const uint32_t refs[9] = {in.tex_kd, in.tex_ks, in.tex_kr, in.tex_kt, in.tex_opacity, in.tex_sigma, in.tex_metal_eta, in.tex_metal_k, in.tex_bump};
+            const uint32_t refs[13] = {in.tex_kd, in.tex_ks, in.tex_kr, in.tex_kt, in.tex_opacity, in.tex_sigma, in.tex_metal_eta, in.tex_metal_k, in.tex_bump,
+                                       in.tex_roughness, in.tex_uroughness, in.tex_vroughness, in.tex_eta};
             PtMatParams& mp = mparams[i];
             mp.m = in;
             material_alphas(in, &mp.a_r, &mp.a_u, &mp.a_v);
-            for (int k = 0; k < 9; k++) {
+            for (int k = 0; k < 13; k++) {
                 if (!refs[k] || in.type == PT_MATERIAL_NONE) continue;
                 mp.prog[k] = add_program(refs[k] - 1);
                 if (!mp.prog[k]) return ctx->fail(PT_ERR_UNSUPPORTED, "a material parameter's texture graph needs more than 12 nodes");

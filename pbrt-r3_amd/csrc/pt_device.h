@@ -123,11 +123,11 @@ struct PtImage {
 #define PT_TEX_CHILD_CONST 15u      // texture program entry, child slot: the node's own constant (pt_texture.h)
 // A material with texture-driven parameters: the caller's parameter block, the roughness values after the optional
 // roughness_to_alpha remap (host-side: logf), and per parameter the offset of its texture program in PtScene::tex_prog
-// (0 = constant).  Parameter order: Kd Ks Kr Kt opacity sigma metal-eta metal-k bump.
+// (0 = constant).  Parameter order: Kd Ks Kr Kt opacity sigma metal-eta metal-k bump roughness uroughness vroughness eta.
 struct PtMatParams {
     pt_material m;
     float a_r, a_u, a_v;
-    uint32_t prog[9];            // [8] = the bump map's displacement texture
+    uint32_t prog[13];           // [8] = the bump map's displacement texture, [9..12] = roughness, uroughness, vroughness, eta
 };
 
 // One DiffuseAreaLight (one emissive triangle).

@@ -1997,7 +1997,14 @@ __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material,
         if (k == 5) mp.m.sigma = v.x;
         else { dst[k][0] = v.x; dst[k][1] = v.y; dst[k][2] = v.z; }
     }
-    build_lobes(mp.m, mp.a_r, mp.a_u, mp.a_v, *out);
+    // float parameters behind textures: "roughness" / "uroughness" / "vroughness" (then roughness_to_alpha, unless "remaproughness"
+    // is off) and "eta"; the constant ones keep the values the host remapped at upload
+    float a_r = mp.a_r, a_u = mp.a_u, a_v = mp.a_v;
+    if (mp.prog[9]) { mp.m.roughness = tex_eval(sc.textures, sc.tex_prog + mp.prog[9], th, sc.images).x; a_r = mp.m.remap_roughness ? pt_roughness_to_alpha(mp.m.roughness) : mp.m.roughness; }
+    if (mp.prog[10]) { mp.m.uroughness = tex_eval(sc.textures, sc.tex_prog + mp.prog[10], th, sc.images).x; a_u = mp.m.remap_roughness ? pt_roughness_to_alpha(mp.m.uroughness) : mp.m.uroughness; }
+    if (mp.prog[11]) { mp.m.vroughness = tex_eval(sc.textures, sc.tex_prog + mp.prog[11], th, sc.images).x; a_v = mp.m.remap_roughness ? pt_roughness_to_alpha(mp.m.vroughness) : mp.m.vroughness; }
+    if (mp.prog[12]) mp.m.eta = tex_eval(sc.textures, sc.tex_prog + mp.prog[12], th, sc.images).x;
+    build_lobes(mp.m, a_r, a_u, a_v, *out);
 }
 template <bool GENERAL, bool SPH, bool TEX = false, bool INST = false>
 PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, const uint32_t* list, uint32_t begin, uint32_t end,

@@ -473,9 +473,18 @@ class SceneBuilder:
         self.cur_material = self._add_material(capi.PT_MATERIAL_MATTE, Kd, sigma, bump=bumpmap)
 
     # defaults below are the reference's create_*_material defaults
+    @staticmethod
+    def _ft(v, unset=False):
+        """A float parameter: a number, a Tex handle (float texture evaluated per hit), or None = not given."""
+        if isinstance(v, Tex):
+            return v
+        if v is None and unset:
+            return capi.PT_ROUGHNESS_UNSET
+        return float(v)
+
     def material_plastic(self, Kd=(0.25,) * 3, Ks=(0.25,) * 3, roughness=0.1, remaproughness=True, bumpmap=None):
         """materials/plastic.rs:73-86."""
-        self.cur_material = self._add_material(capi.PT_MATERIAL_PLASTIC, Kd, ks=Ks, roughness=float(roughness), remap_roughness=int(remaproughness), bump=bumpmap)
+        self.cur_material = self._add_material(capi.PT_MATERIAL_PLASTIC, Kd, ks=Ks, roughness=self._ft(roughness), remap_roughness=int(remaproughness), bump=bumpmap)
 
     def material_mirror(self, Kr=(0.9,) * 3, bumpmap=None):
         """materials/mirror.rs:43-47."""
@@ -483,29 +492,26 @@ class SceneBuilder:
 
     def material_glass(self, Kr=(1.0,) * 3, Kt=(1.0,) * 3, eta=1.5, uroughness=0.0, vroughness=0.0, remaproughness=True):
         """materials/glass.rs:124-143."""
-        self.cur_material = self._add_material(capi.PT_MATERIAL_GLASS, kr=Kr, kt=Kt, eta=float(eta), uroughness=float(uroughness),
-                                               vroughness=float(vroughness), remap_roughness=int(remaproughness))
+        self.cur_material = self._add_material(capi.PT_MATERIAL_GLASS, kr=Kr, kt=Kt, eta=self._ft(eta), uroughness=self._ft(uroughness),
+                                               vroughness=self._ft(vroughness), remap_roughness=int(remaproughness))
 
     def material_metal(self, eta, k, roughness=0.01, uroughness=None, vroughness=None, remaproughness=True):
         """materials/metal.rs:127-149; eta and k as RGB (the reference's default is the copper SPD converted to RGB)."""
         self.cur_material = self._add_material(
-            capi.PT_MATERIAL_METAL, metal_eta=eta, metal_k=k, roughness=float(roughness), remap_roughness=int(remaproughness),
-            uroughness=capi.PT_ROUGHNESS_UNSET if uroughness is None else float(uroughness),
-            vroughness=capi.PT_ROUGHNESS_UNSET if vroughness is None else float(vroughness))
+            capi.PT_MATERIAL_METAL, metal_eta=eta, metal_k=k, roughness=self._ft(roughness), remap_roughness=int(remaproughness),
+            uroughness=self._ft(uroughness, True), vroughness=self._ft(vroughness, True))
 
     def material_uber(self, Kd=(0.25,) * 3, Ks=(0.25,) * 3, Kr=(0.0,) * 3, Kt=(0.0,) * 3, opacity=(1.0,) * 3, eta=1.5, roughness=0.1,
                       uroughness=None, vroughness=None, remaproughness=True):
         """materials/uber.rs:142-168."""
         self.cur_material = self._add_material(
-            capi.PT_MATERIAL_UBER, Kd, ks=Ks, kr=Kr, kt=Kt, opacity=opacity, eta=float(eta), roughness=float(roughness),
-            remap_roughness=int(remaproughness),
-            uroughness=capi.PT_ROUGHNESS_UNSET if uroughness is None else float(uroughness),
-            vroughness=capi.PT_ROUGHNESS_UNSET if vroughness is None else float(vroughness))
+            capi.PT_MATERIAL_UBER, Kd, ks=Ks, kr=Kr, kt=Kt, opacity=opacity, eta=self._ft(eta), roughness=self._ft(roughness),
+            remap_roughness=int(remaproughness), uroughness=self._ft(uroughness, True), vroughness=self._ft(vroughness, True))
 
     def material_substrate(self, Kd=(0.5,) * 3, Ks=(0.5,) * 3, uroughness=0.1, vroughness=0.1, remaproughness=True):
         """materials/substrate.rs:70-86."""
-        self.cur_material = self._add_material(capi.PT_MATERIAL_SUBSTRATE, Kd, ks=Ks, uroughness=float(uroughness),
-                                               vroughness=float(vroughness), remap_roughness=int(remaproughness))
+        self.cur_material = self._add_material(capi.PT_MATERIAL_SUBSTRATE, Kd, ks=Ks, uroughness=self._ft(uroughness),
+                                               vroughness=self._ft(vroughness), remap_roughness=int(remaproughness))
 
     def material_none(self):
         self.cur_material = -1

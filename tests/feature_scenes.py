@@ -283,6 +283,49 @@ def scene_textures(res=48, spp=8, depth=5, sampler="sobol", aamode="closedform",
     return b.build()
 
 
+def scene_roughness_textures(res=48, spp=8, depth=6, sampler="sobol"):
+    """Float textures behind "roughness" / "uroughness" / "vroughness" / "eta" (ABI 6): evaluated at every hit, roughness through
+    roughness_to_alpha's `ln` on the device (plastic.rs:57-62, glass.rs:57-81, metal.rs:58-69, uber.rs:66,96-104,
+    substrate.rs:45-54, trowbridge_reitz.rs:113-121).  A plastic wall whose roughness is a checkerboard, a rough-glass sphere with
+    bilerp u/v roughness and a checkerboard index (its smooth checks make the glass specular there), a metal sphere whose only
+    "roughness" is a texture (uroughness / vroughness fall back to it) with remapping off, an uber mesh with a textured vroughness
+    beside a constant uroughness, and a substrate floor with fbm roughness."""
+    b = base(res=res, spp=spp, depth=depth)
+    if sampler == "halton":
+        b.sampler_halton(spp)
+    T = scenes
+    s = 2.0
+    b.material_substrate(Kd=(0.4, 0.3, 0.2), Ks=(0.3, 0.3, 0.3), uroughness=b.texture_scale(b.texture_fbm(octaves=4, roughness=0.6), 0.4),
+                         vroughness=b.texture_bilerp(0.02, 0.3, 0.3, 0.02))
+    scenes._quad(b, (s, -s, -s), (-s, -s, -s), (-s, -s, s), (s, -s, s))
+    b.material_matte((0.7, 0.7, 0.7))
+    scenes._quad(b, (s, s, -s), (s, s, s), (-s, s, s), (-s, s, -s))
+    b.material_plastic(Kd=(0.3, 0.4, 0.7), Ks=(0.5, 0.5, 0.5), roughness=b.texture_checkerboard(0.02, 0.4, uscale=5.0, vscale=5.0, aamode="none"))
+    scenes._quad(b, (s, -s, s), (-s, -s, s), (-s, s, s), (s, s, s))
+    b.material_matte((0.2, 0.6, 0.3))
+    scenes._quad(b, (-s, -s, s), (-s, -s, -s), (-s, s, -s), (-s, s, s))
+    b.material_matte((0.7, 0.2, 0.2))
+    scenes._quad(b, (s, -s, -s), (s, -s, s), (s, s, s), (s, s, -s))
+    b.material_matte((0.5, 0.5, 0.5))
+    b.area_light_source_diffuse(L=(10, 9, 8))
+    h = 0.999 * s
+    scenes._quad(b, (0.5, h, -0.5), (0.5, h, 0.5), (-0.5, h, 0.5), (-0.5, h, -0.5))
+    b.no_area_light()
+    tg = T.transform_translate(0.9, -1.3, -0.2)
+    b.material_glass(eta=b.texture_checkerboard(1.3, 1.7, uscale=3.0, vscale=3.0, aamode="none"),
+                     uroughness=b.texture_checkerboard(0.0, 0.15, uscale=2.0, vscale=4.0, aamode="none"),
+                     vroughness=b.texture_checkerboard(0.0, 0.05, uscale=2.0, vscale=4.0, aamode="none"))
+    b.shape_sphere(radius=0.65, object_to_world=tg[0], world_to_object=tg[1])
+    tm = T.transform_translate(0.1, 0.2, 1.2)
+    b.material_metal(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=b.texture_bilerp(0.01, 0.2, 0.08, 0.3), remaproughness=False)
+    b.shape_sphere(radius=0.5, object_to_world=tm[0], world_to_object=tm[1])
+    b.material_uber(Kd=(0.3, 0.3, 0.1), Ks=(0.4, 0.4, 0.4), Kr=(0.1, 0.1, 0.1), uroughness=0.05, vroughness=b.texture_checkerboard(0.02, 0.3, uscale=6.0, vscale=6.0),
+                    eta=b.texture_bilerp(1.2, 1.6, 1.4, 1.8))
+    P, N, UV, idx = uv_sphere((-1.0, -1.2, 0.4), 0.7)
+    b.shape_trianglemesh(P, idx, N=N, uv=UV)
+    return b.build()
+
+
 # The scene of test_host_frontend.py::test_texture_directives_equal_programmatic_scene as .pbrt text (also rendered on the
 # device by test_gpu_features.py): every texture class on the path, bound through shape and material parameter lists.
 TEXTURED_PBRT = '''

@@ -69,6 +69,8 @@ def _compare(ctx, osc, exact_film, frac_limit=0.0):
     ("textures_closedform", lambda: fs.scene_textures(), True),
     ("textures_point_halton", lambda: fs.scene_textures(sampler="halton", aamode="none"), True),
     ("textures_thin_lens", lambda: fs.scene_textures(lens=True), True),
+    ("roughness_textures", lambda: fs.scene_roughness_textures(), True),
+    ("roughness_textures_halton", lambda: fs.scene_roughness_textures(sampler="halton", spp=6), True),
     ("textures_noise", lambda: fs.scene_noise_textures(), True),
     ("textures_noise_halton", lambda: fs.scene_noise_textures(sampler="halton"), True),
     # object instancing: TransformedPrimitive over per-object accelerators

@@ -675,11 +675,12 @@ def test_constant_folding_textures():
     d2 = ps2.desc
     m3 = d2.materials[d2.meshes[2].material]
     assert d2.n_textures == 1 and m3.tex_kd == 1 and d2.textures[0].type == capi.PT_TEX_CHECKERBOARD_2D
-    # ... which roughness cannot be; an image map whose file is missing is reported
-    with pytest.raises(capi.PtError) as e:
-        capi.ParsedScene(text=text.replace('Texture "chk" "spectrum" "checkerboard"', 'Texture "fchk" "float" "checkerboard"')
-                         .replace('"texture roughness" "rough"', '"texture roughness" "fchk"'))
-    assert e.value.status == 4 and "varies over the surface" in str(e.value)
+    # ... and so does a roughness (ABI 6: roughness_to_alpha runs on the device at every hit); an image map whose file is missing is reported
+    ps3 = capi.ParsedScene(text=text.replace('Texture "chk" "spectrum" "checkerboard"', 'Texture "fchk" "float" "checkerboard"')
+                           .replace('"texture roughness" "rough"', '"texture roughness" "fchk"'))
+    d3 = ps3.desc
+    m4 = d3.materials[d3.meshes[1].material]
+    assert m4.tex_roughness == 1 and m4.tex_uroughness == 0 and d3.textures[0].type == capi.PT_TEX_CHECKERBOARD_2D and m4.remap_roughness == 1
     with pytest.raises(capi.PtError) as e:
         capi.ParsedScene(text=text.replace('"spectrum" "checkerboard"', '"spectrum" "imagemap" "string filename" "x.png"')
                          .replace('"texture Kd" "blend"', '"texture Kd" "chk"'))
