@@ -70,7 +70,8 @@ def main():
                     help="matte = BASELINE config 2 (the headline); mixed = killeroo-class stand-in for config 4 (secondary number)")
     ap.add_argument("--sampler", default="sobol", choices=["sobol", "halton"], help="sobol = the headline; halton = the reference's default sampler (secondary number)")
     ap.add_argument("--light", default="quad", choices=["quad", "sphere"], help="quad = the headline; sphere = an analytic sphere light instead (secondary number: k_trace_sph / k_shade_*_sph)")
-    ap.add_argument("--integrator", default="path", choices=["path", "ao"], help="path = the headline; ao = Integrator \"ao\" with 64 occlusion rays per camera sample (secondary number: an any-hit workload)")
+    ap.add_argument("--integrator", default="path", choices=["path", "ao", "directlighting", "whitted"],
+                    help="path = the headline; ao = Integrator \"ao\" with 64 occlusion rays per camera sample; directlighting / whitted = the recursive integrators (secondary numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spp1024", action="store_true", help="skip the secondary 1024-spp frame (N=1 only)")
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU sample (0 = auto, about 15 s)")
@@ -134,6 +135,9 @@ def main():
     sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, materials=args.materials, sampler=args.sampler, light=args.light)
     if args.integrator == "ao":
         sd.desc.integrator, sd.desc.ao_samples, sd.desc.ao_cos_sample = pkg.capi.PT_INTEGRATOR_AO, 64, 1
+    elif args.integrator in ("directlighting", "whitted"):
+        sd.desc.integrator = pkg.capi.PT_INTEGRATOR_DIRECTLIGHTING if args.integrator == "directlighting" else pkg.capi.PT_INTEGRATOR_WHITTED
+        sd.desc.direct_strategy, sd.desc.max_depth = pkg.capi.PT_DIRECT_ALL, 5
     t_scene = time.time() - t0
     ctx = pkg.Context(local_rank)
     info = ctx.upload(sd)
@@ -292,8 +296,10 @@ def main():
             # north_star's target sentence quotes 1024 spp for the same scene (BASELINE config 2 says 256; Mrays/s is spp-independent,
             # wall-clock scales): one extra frame at 1024 spp, wall-clock reported beside the headline
             sd4 = pkg.scenes.rt1m(args.triangles, res=args.res, spp=1024, max_depth=args.max_depth, materials=args.materials, sampler=args.sampler, light=args.light)
-            if args.integrator == "ao":
-                sd4.desc.integrator, sd4.desc.ao_samples, sd4.desc.ao_cos_sample = pkg.capi.PT_INTEGRATOR_AO, 64, 1
+            sd4.desc.integrator, sd4.desc.ao_samples, sd4.desc.ao_cos_sample = sd.desc.integrator, sd.desc.ao_samples, sd.desc.ao_cos_sample
+            sd4.desc.direct_strategy = sd.desc.direct_strategy
+            if args.integrator in ("directlighting", "whitted"):
+                sd4.desc.max_depth = 5
             i4 = ctx.upload(sd4)
             ctx.film_clear(); ctx.reset_counters()
             torch.cuda.synchronize()
@@ -318,6 +324,8 @@ def main():
                        "scene_gen_s": round(t_scene, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "spp1024": spp1024,
         }
+        if args.integrator in ("directlighting", "whitted"):
+            out["config"]["workload"] = out["config"]["workload"].replace("path maxdepth %d" % args.max_depth, args.integrator + " maxdepth 5")
         if args.integrator == "ao":
             out["config"]["workload"] = out["config"]["workload"].replace("path maxdepth %d" % args.max_depth, "ao nsamples 64 cossample")
             if roofline:

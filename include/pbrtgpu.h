@@ -227,7 +227,15 @@ typedef enum {
  * hemisphere of the geometric normal, directions from the sampler's 2-D sample array (dimensions 5, 6 of sample number
  * camera_sample * ao_samples + k; core/sampler/global_sampler.rs, samplers/sobol.rs:43-75).  Lights and materials play no part, except
  * that the reference panics on a surface without a material and lets a bump map flip the frame: both are refused at upload. */
-typedef enum { PT_INTEGRATOR_PATH = 0, PT_INTEGRATOR_AO = 1 } pt_integrator_type;
+/* PT_INTEGRATOR_DIRECTLIGHTING: DirectLightingIntegrator::li (integrators/directlighting.rs:66-135): emitted + direct light at the
+ * hit ("strategy" all: every light, its u_light / u_scattering from the sampler's 2-D arrays while they last -- two arrays per light
+ * and depth, area lights request one sample each; "one": uniform_sample_one_light with a uniform pick), then the trees of
+ * specular_reflect / specular_transmit (core/integrator/sampler.rs:37-150) down to "maxdepth" (pt_scene_desc.max_depth, default 5),
+ * ray differentials carried through the specular bounces.  PT_INTEGRATOR_WHITTED: WhittedIntegrator::li (integrators/whitted.rs:38-110):
+ * one light sample per light and hit without MIS, weighted by the shading normal as it was before bump mapping, the same trees.
+ * The sampler is consumed depth first (reflect subtree, then transmit), as the reference's recursion does. */
+typedef enum { PT_INTEGRATOR_PATH = 0, PT_INTEGRATOR_AO = 1, PT_INTEGRATOR_DIRECTLIGHTING = 2, PT_INTEGRATOR_WHITTED = 3 } pt_integrator_type;
+typedef enum { PT_DIRECT_ALL = 0, PT_DIRECT_ONE = 1 } pt_direct_strategy;      /* directlighting "strategy" (default "all") */
 typedef enum { PT_LIGHTS_UNIFORM = 0, PT_LIGHTS_POWER = 1, PT_LIGHTS_SPATIAL = 2 } pt_light_strategy;
 
 typedef struct {
@@ -293,7 +301,7 @@ typedef struct {
     int32_t integrator;         /* pt_integrator_type; 0 (zero-initialised descriptors) = path */
     int32_t ao_samples;         /* ao "nsamples", default 64: one 2-D sample array of this size per camera sample (ao.rs:14-36) */
     int32_t ao_cos_sample;      /* ao "cossample", default true */
-    int32_t reserved;
+    int32_t direct_strategy;    /* ABI 6: directlighting "strategy", a pt_direct_strategy */
 } pt_scene_desc;
 
 /* Axis-aligned block of film *sample* pixels, half-open: the unit the reference

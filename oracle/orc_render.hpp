@@ -149,7 +149,7 @@ struct Scene {
     // sampler / integrator
     SobolTables sobol;
     int32_t spp = 1, max_depth = 5, light_strategy = PT_LIGHTS_SPATIAL;
-    int32_t integrator = PT_INTEGRATOR_PATH, ao_samples = 64;
+    int32_t integrator = PT_INTEGRATOR_PATH, ao_samples = 64, direct_strategy = PT_DIRECT_ALL;
     bool ao_cos_sample = true;
     int32_t sampler_kind = PT_SAMPLER_SOBOL;
     bool halton_at_center = false;
@@ -157,6 +157,7 @@ struct Scene {
         if (sampler_kind == PT_SAMPLER_HALTON) sm.init_halton((uint32_t)spp, sample_bounds, halton_at_center);
         else sm.init(&sobol, (uint32_t)spp, sample_bounds);
         sm.array2d_n = integrator == PT_INTEGRATOR_AO ? (uint32_t)ao_samples : 0u;
+        sm.n_arrays1 = (integrator == PT_INTEGRATOR_DIRECTLIGHTING && direct_strategy == PT_DIRECT_ALL) ? 2u * (uint32_t)lights.size() * (uint32_t)std::max(max_depth, 0) : 0u;
     }
     Float rr_threshold = 1.0f;
 
@@ -519,15 +520,8 @@ inline RGB surf_le(const Scene& sc, const SurfHit& si, V3 w) {
 
 // estimate_direct_surface + uniform_sample_one_light_surface
 // (core/integrator/sample_lights.rs:129-176, :330-453), handle_media = false, specular = false
-inline RGB uniform_sample_one_light(const Scene& sc, const SurfHit& it, const BSDF& bsdf, SobolSampler& sampler,
-                                    const Distribution1D* distrib, RayCounters& rc) {
-    size_t n_lights = sc.lights.size();
-    if (n_lights == 0) return RGB();
-    Float light_pdf;
-    size_t light_num = distrib->sample_discrete(sampler.get_1d(), &light_pdf, nullptr);
-    if (light_pdf <= 0.0f) return RGB();
-    V2 u_light = sampler.get_2d();
-    V2 u_scattering = sampler.get_2d();
+// estimate_direct / estimate_direct_surface (sample_lights.rs:178-328, :330-453: the same arithmetic), handle_media = false, specular = false
+inline RGB estimate_direct(const Scene& sc, const SurfHit& it, const BSDF& bsdf, size_t light_num, V2 u_light, V2 u_scattering, RayCounters& rc) {
     const AreaLight& light = sc.lights[light_num];
     const uint32_t bsdf_flags = BSDF_ALL & ~BSDF_SPECULAR;
     RGB ld;
@@ -591,7 +585,19 @@ inline RGB uniform_sample_one_light(const Scene& sc, const SurfHit& it, const BS
             }
         }
     }
-    return ld / light_pdf;
+    return ld;
+}
+// uniform_sample_one_light_surface (sample_lights.rs:129-176) with the integrator's light distribution
+inline RGB uniform_sample_one_light(const Scene& sc, const SurfHit& it, const BSDF& bsdf, SobolSampler& sampler,
+                                    const Distribution1D* distrib, RayCounters& rc) {
+    size_t n_lights = sc.lights.size();
+    if (n_lights == 0) return RGB();
+    Float light_pdf;
+    size_t light_num = distrib->sample_discrete(sampler.get_1d(), &light_pdf, nullptr);
+    if (light_pdf <= 0.0f) return RGB();
+    V2 u_light = sampler.get_2d();
+    V2 u_scattering = sampler.get_2d();
+    return estimate_direct(sc, it, bsdf, light_num, u_light, u_scattering, rc) / light_pdf;
 }
 
 // PathIntegrator::li (integrators/path.rs:61-241)
@@ -675,6 +681,151 @@ inline RGB ao_li(const Scene& sc, Ray ray, SobolSampler& sampler, RayCounters& r
         bool occluded = sc.bvh.intersect_p(sh, &st2);
         rc.nodes += st2.nodes; rc.tris += st2.tris;
         if (!occluded) l = l + RGB(dot(wi, n) / (pdf * (Float)n_samples));
+    }
+    return l;
+}
+
+// ---- DirectLightingIntegrator::li (integrators/directlighting.rs:66-135) and WhittedIntegrator::li (integrators/whitted.rs:38-110)
+// with SamplerIntegrator::specular_reflect / specular_transmit (core/integrator/sampler.rs:37-150).  Recursive like the reference,
+// so the sampler is consumed depth first.
+inline RGB rec_li(const Scene& sc, Ray ray, RayDiff rd, SobolSampler& sampler, RayCounters& rc, int depth) {
+    const bool whitted = sc.integrator == PT_INTEGRATOR_WHITTED;
+    SurfHit isect;
+    rc.regular++;
+    QBVH::Stats st;
+    bool found = sc.bvh.intersect(ray, &isect, &st);
+    rc.nodes += st.nodes; rc.tris += st.tris;
+    if (!found) return RGB();                       // sum of light.le(ray): zero for area lights (light.rs:33-35)
+    const V3 n_before = isect.sh_n;                 // whitted.rs:52: the shading normal before compute_scattering_functions (bump mapping)
+    const V3 wo = isect.wo;
+    const TexHit th = compute_differentials(isect, rd);      // what compute_scattering_functions leaves in isect.dpdx / dudx .. (surface_interaction.rs:284-295)
+    BSDF bsdf;
+    if (!make_bsdf(sc, isect, &bsdf, rd)) {
+        if (whitted) return RGB();
+        // directlighting.rs:113-116: through the surface with a plain ray, same depth
+        return rec_li(sc, Ray(offset_ray_origin(isect.p, isect.p_error, isect.n, ray.d), ray.d, kInfinity), RayDiff(), sampler, rc, depth);
+    }
+    rc.vertices++;
+    RGB l;
+    const size_t n_lights = sc.lights.size();
+    if (whitted) {
+        for (size_t j = 0; j < n_lights; j++) {
+            const AreaLight& light = sc.lights[j];
+            const V2 u = sampler.get_2d();
+            RGB li; V3 wi, lp, lperr, ln; Float pdf;
+            RGB term;
+            if (light_sample_li(sc, light, isect.p, isect.p_error, isect.n, u, &li, &wi, &pdf, &lp, &lperr, &ln) && !(pdf <= 0.0f || li.is_black())) {
+                RGB f = bsdf.f(wo, wi, BSDF_ALL);
+                if (!f.is_black()) {
+                    V3 origin = offset_ray_origin(isect.p, isect.p_error, isect.n, lp - isect.p);
+                    V3 target = offset_ray_origin(lp, lperr, ln, origin - lp);
+                    Ray sr(origin, target - origin, 1.0f - kShadowEpsilon);
+                    rc.shadow++;
+                    QBVH::Stats st2;
+                    bool occluded = sc.bvh.intersect_p(sr, &st2);
+                    rc.nodes += st2.nodes; rc.tris += st2.tris;
+                    if (!occluded) term = f * li * (abs_dot(wi, n_before) / pdf);
+                }
+            }
+            l += term;
+        }
+    } else {
+        l = surf_le(sc, isect, wo);
+        if (n_lights > 0) {
+            RGB ld_all;
+            if (sc.direct_strategy == PT_DIRECT_ALL) {              // uniform_sample_all_lights (sample_lights.rs:24-82), one sample per light
+                for (size_t j = 0; j < n_lights; j++) {
+                    V2 u_light, u_scattering;
+                    const bool a = sampler.get_2d_array1(&u_light), b = sampler.get_2d_array1(&u_scattering);
+                    if (a && b) {
+                        RGB ld;
+                        ld += estimate_direct(sc, isect, bsdf, j, u_light, u_scattering, rc);
+                        ld_all += ld / 1.0f;
+                    } else {
+                        u_light = sampler.get_2d();
+                        u_scattering = sampler.get_2d();
+                        ld_all += estimate_direct(sc, isect, bsdf, j, u_light, u_scattering, rc);
+                    }
+                }
+            } else {                                                 // uniform_sample_one_light (sample_lights.rs:84-127), no distribution
+                Float fl = sampler.get_1d() * (Float)n_lights;
+                size_t light_num = std::min((size_t)fl, n_lights - 1);
+                Float light_pdf = 1.0f / (Float)n_lights;
+                V2 u_light = sampler.get_2d();
+                V2 u_scattering = sampler.get_2d();
+                ld_all = estimate_direct(sc, isect, bsdf, light_num, u_light, u_scattering, rc) / light_pdf;
+            }
+            l += ld_all;
+        }
+    }
+    if (depth + 1 < sc.max_depth) {
+        const V3 ns0 = isect.sh_n;
+        {   // specular_reflect (sampler.rs:37-82)
+            const V2 u = sampler.get_2d();
+            RGB f; V3 wi; Float pdf; uint32_t ty;
+            RGB term;
+            if (bsdf.sample_f(wo, u, BSDF_REFLECTION | BSDF_SPECULAR, &f, &wi, &pdf, &ty)) {
+                const V3 ns = ns0;
+                const Float wi_ns = abs_dot(wi, ns);
+                if (pdf > 0.0f && !f.is_black() && wi_ns != 0.0f) {
+                    Ray r2(offset_ray_origin(isect.p, isect.p_error, isect.n, wi), wi, kInfinity);
+                    RayDiff d2;
+                    if (rd.has) {
+                        d2.has = true;
+                        d2.rx_o = isect.p + th.dpdx;
+                        d2.ry_o = isect.p + th.dpdy;
+                        const V3 dndx = isect.sh_dndu * th.dudx + isect.sh_dndv * th.dvdx;
+                        const V3 dndy = isect.sh_dndu * th.dudy + isect.sh_dndv * th.dvdy;
+                        const V3 dwodx = -rd.rx_d - wo, dwody = -rd.ry_d - wo;
+                        const Float d_dndx = dot(dwodx, ns) + dot(wo, dndx);
+                        const Float d_dndy = dot(dwody, ns) + dot(wo, dndy);
+                        const Float wo_ns = dot(wo, ns);
+                        d2.rx_d = wi - dwodx + 2.0f * (wo_ns * dndx + d_dndx * ns);
+                        d2.ry_d = wi - dwody + 2.0f * (wo_ns * dndy + d_dndy * ns);
+                    }
+                    term = f * rec_li(sc, r2, d2, sampler, rc, depth + 1) * (wi_ns / pdf);
+                }
+            }
+            l += term;
+        }
+        {   // specular_transmit (sampler.rs:84-143)
+            const V2 u = sampler.get_2d();
+            RGB f; V3 wi; Float pdf; uint32_t ty;
+            RGB term;
+            if (bsdf.sample_f(wo, u, BSDF_TRANSMISSION | BSDF_SPECULAR, &f, &wi, &pdf, &ty)) {
+                V3 ns = ns0;
+                Float wi_ns = abs_dot(wi, ns);
+                Float wo_ns = dot(wo, ns);
+                if (pdf > 0.0f && !f.is_black() && wi_ns != 0.0f) {
+                    Ray r2(offset_ray_origin(isect.p, isect.p_error, isect.n, wi), wi, kInfinity);
+                    RayDiff d2;
+                    if (rd.has) {
+                        d2.has = true;
+                        d2.rx_o = isect.p + th.dpdx;
+                        d2.ry_o = isect.p + th.dpdy;
+                        V3 dndx = isect.sh_dndu * th.dudx + isect.sh_dndv * th.dvdx;
+                        V3 dndy = isect.sh_dndu * th.dudy + isect.sh_dndv * th.dvdy;
+                        Float eta = 1.0f / bsdf.eta;
+                        if (dot(wo, ns) < 0.0f) {
+                            eta = 1.0f / eta;
+                            ns = -ns; dndx = -dndx; dndy = -dndy;
+                            wi_ns = abs_dot(wi, ns);
+                            wo_ns = dot(wo, ns);
+                        }
+                        const V3 dwodx = -rd.rx_d - wo, dwody = -rd.ry_d - wo;
+                        const Float d_dndx = dot(dwodx, ns) + dot(wo, dndx);
+                        const Float d_dndy = dot(dwody, ns) + dot(wo, dndy);
+                        const Float mu = eta * wo_ns - wi_ns;
+                        const Float dmudx = (eta - (eta * eta * wo_ns) / wi_ns) * d_dndx;
+                        const Float dmudy = (eta - (eta * eta * wo_ns) / wi_ns) * d_dndy;
+                        d2.rx_d = wi - eta * dwodx + (mu * dndx + dmudx * ns);
+                        d2.ry_d = wi - eta * dwody + (mu * dndy + dmudy * ns);
+                    }
+                    term = f * rec_li(sc, r2, d2, sampler, rc, depth + 1) * (wi_ns / pdf);
+                }
+            }
+            l += term;
+        }
     }
     return l;
 }
@@ -807,7 +958,11 @@ inline void render_tile(const Scene& sc, LightDistribution& ldist, const int32_t
                 RayDiff rdiff;
                 Ray ray = generate_ray(sc, cs, &rdiff);
                 rc.camera++;
-                RGB l = validate_radiance(sc.integrator == PT_INTEGRATOR_AO ? ao_li(sc, ray, sampler, rc) : path_li(sc, ldist, ray, sampler, rc, rdiff));
+                RGB l;
+                if (sc.integrator == PT_INTEGRATOR_AO) l = ao_li(sc, ray, sampler, rc);
+                else if (sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING || sc.integrator == PT_INTEGRATOR_WHITTED) l = rec_li(sc, ray, rdiff, sampler, rc, 0);
+                else l = path_li(sc, ldist, ray, sampler, rc, rdiff);
+                l = validate_radiance(l);
                 if (radiance_out) { radiance_out[3 * k] = l.c[0]; radiance_out[3 * k + 1] = l.c[1]; radiance_out[3 * k + 2] = l.c[2]; k++; }
                 tile.add_sample(cs.p_film, l, 1.0f);
             } while (sampler.start_next_sample());
@@ -990,6 +1145,7 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
     spp = sampler_kind == PT_SAMPLER_HALTON ? std::max(1, d.spp) : (int32_t)round_up_pow2((uint32_t)std::max(1, d.spp));
     max_depth = d.max_depth; rr_threshold = d.rr_threshold; light_strategy = d.light_strategy;
     integrator = d.integrator; ao_samples = d.ao_samples > 0 ? d.ao_samples : 64; ao_cos_sample = d.ao_cos_sample != 0;
+    direct_strategy = d.direct_strategy;
     return true;
 }
 

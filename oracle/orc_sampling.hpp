@@ -223,6 +223,11 @@ struct SobolSampler {
     static const uint32_t array_start_dim = 5;
     uint32_t array_end_dim = 5;
     uint32_t array2d_n = 0;          // size of the one requested 2-D sample array (AOIntegrator::new, ao.rs:24-31); 0 = none
+    // DirectLightingIntegrator::preprocess ("all" strategy, directlighting.rs:50-65): 2 * lights * maxdepth arrays of ONE sample each
+    // (area lights report one sample, round_count is the identity).  Array i of the current pixel sample is that sample's own
+    // value at dimensions (5 + 2 i, 6 + 2 i) (sobol.rs:60-75, base_sampler.rs:59-70); get_2d_array hands them out in request order
+    // and returns None once they are used up (then the caller falls back to get_2d).
+    uint32_t n_arrays1 = 0, array_next = 0;
 
     void init_halton(uint32_t samples_per_pixel, const int32_t sb[4], bool at_center) {   // halton.rs:57-112
         kind = 1;
@@ -287,7 +292,15 @@ struct SobolSampler {
         current_sample = 0;
         dimension = 0;
         interval_sample_index = get_index_for_sample(0);
-        array_end_dim = array_start_dim + (array2d_n ? 2u : 0u);      // sobol.rs:43-45, halton.rs:176-178
+        array_end_dim = array_start_dim + (array2d_n ? 2u : 0u) + 2u * n_arrays1;      // sobol.rs:43-45, halton.rs:176-178
+        array_next = 0;
+    }
+    bool get_2d_array1(V2* out) {
+        if (array_next >= n_arrays1) return false;
+        const uint32_t d = array_start_dim + 2u * array_next;
+        array_next++;
+        *out = V2(sample_dimension(interval_sample_index, d), sample_dimension(interval_sample_index, d + 1));
+        return true;
     }
     // Element k of get_2d_array(n) for the current pixel sample: start_pixel fills sample_array2d[0][j] from sample number j at
     // dimensions (5, 6) for j < n * spp (sobol.rs:60-75), get_2d_array slices [n * current, n * current + n) (base_sampler.rs:59-70).
@@ -297,12 +310,14 @@ struct SobolSampler {
     }
     bool start_next_sample() {
         dimension = 0;
+        array_next = 0;
         interval_sample_index = get_index_for_sample((int64_t)current_sample + 1);
         current_sample += 1;
         return current_sample < spp;
     }
     bool set_sample_number(uint32_t n) {
         dimension = 0;
+        array_next = 0;
         interval_sample_index = get_index_for_sample(n);
         current_sample = n;
         return current_sample < spp;

@@ -106,7 +106,7 @@ class pt_scene_desc(C.Structure):
         ("n_spheres", C.c_uint32), ("spheres", C.POINTER(pt_sphere)),
         ("n_textures", C.c_uint32), ("textures", C.POINTER(pt_texture)),
         ("n_images", C.c_uint32), ("images", C.POINTER(pt_image)),
-        ("n_instances", C.c_uint32), ("instances", C.POINTER(pt_instance)), ("integrator", C.c_int32), ("ao_samples", C.c_int32), ("ao_cos_sample", C.c_int32), ("reserved", C.c_int32),
+        ("n_instances", C.c_uint32), ("instances", C.POINTER(pt_instance)), ("integrator", C.c_int32), ("ao_samples", C.c_int32), ("ao_cos_sample", C.c_int32), ("direct_strategy", C.c_int32),
     ]
 
 
@@ -136,7 +136,8 @@ class pt_scene_info(C.Structure):
 
 
 BVH_BUILD_AUTO, BVH_BUILD_HOST, BVH_BUILD_DEVICE = 0, 1, 2
-PT_INTEGRATOR_PATH, PT_INTEGRATOR_AO = 0, 1
+PT_INTEGRATOR_PATH, PT_INTEGRATOR_AO, PT_INTEGRATOR_DIRECTLIGHTING, PT_INTEGRATOR_WHITTED = 0, 1, 2, 3
+PT_DIRECT_ALL, PT_DIRECT_ONE = 0, 1
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<i4"), ("b0", "<f4"), ("b1", "<f4")])

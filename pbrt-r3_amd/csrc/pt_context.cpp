@@ -81,6 +81,9 @@ struct pt_context {
     DevBuf d_pool;          // one slab carved into the SoA arrays of PtPaths
     PtPaths paths;
     DevBuf d_qa, d_qb, d_qnee, d_qshadow, d_qprobe, d_qsorted, d_counts, d_pixels, d_tiles, d_tilebits;
+    DevBuf d_rec, d_counts2; // recursive integrators (directlighting, whitted): frames, differentials, next-event entries and lists; the second counter block
+    size_t rec_paths = 0;
+    uint32_t rec_epp = 0, rec_depth = 0;
     DevBuf d_ao;             // AO integrator: occlusion-ray batch (o, d, tmax, weight, occluded) for ao_rays_cap rays
     size_t ao_rays_cap = 0;
     size_t pixels_cap = 0;
@@ -405,7 +408,11 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (d->n_triangles > 0 && (!d->P || !d->indices || !d->tri_mesh || !d->meshes)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "triangle arrays missing");
     if (d->n_spheres > 0 && !d->spheres) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "spheres array missing");
     if (d->xres <= 0 || d->yres <= 0 || d->spp <= 0 || d->max_depth < 0 || d->max_depth > 250) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "bad film / sampler / integrator parameters");
-    if (d->integrator != PT_INTEGRATOR_PATH && d->integrator != PT_INTEGRATOR_AO) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown integrator");
+    if (d->integrator < PT_INTEGRATOR_PATH || d->integrator > PT_INTEGRATOR_WHITTED) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown integrator");
+    if (d->integrator == PT_INTEGRATOR_DIRECTLIGHTING && d->direct_strategy != PT_DIRECT_ALL && d->direct_strategy != PT_DIRECT_ONE)
+        return ctx->fail(PT_ERR_INVALID_ARGUMENT, "unknown directlighting strategy");
+    if ((d->integrator == PT_INTEGRATOR_DIRECTLIGHTING || d->integrator == PT_INTEGRATOR_WHITTED) && d->max_depth > 16)
+        return ctx->fail(PT_ERR_UNSUPPORTED, "directlighting / whitted: maxdepth above 16 (one frame per level is kept per camera sample)");
     if (d->n_materials > 0 && !d->materials) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "materials array missing");
     if (d->sampler != PT_SAMPLER_SOBOL && d->sampler != PT_SAMPLER_HALTON)
         return ctx->fail(PT_ERR_UNSUPPORTED, "sampler not on the accelerated path: only the index-addressed samplers (sobol, halton) are reproducible on a wavefront");
@@ -855,6 +862,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     std::memcpy(sc.wb_max, bvh.root_hi, 12);
     sc.max_depth = d->max_depth;
     sc.integrator = d->integrator;
+    sc.direct_strategy = d->direct_strategy;
     sc.ao_samples = d->ao_samples > 0 ? d->ao_samples : 64;
     sc.ao_cos_sample = d->ao_cos_sample != 0;
     sc.rr_threshold = d->rr_threshold;
@@ -1091,6 +1099,11 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
         }
     }
     const bool ao = sc.integrator == PT_INTEGRATOR_AO;
+    const bool rec = sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING || sc.integrator == PT_INTEGRATOR_WHITTED;
+    const uint32_t rec_epp = rec ? ((sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING && sc.direct_strategy == PT_DIRECT_ONE) ? 1u : std::max(1u, sc.n_lights)) : 0u;
+    const uint32_t rec_depth = (uint32_t)std::max(1, sc.max_depth);
+    const size_t rec_per_path = 64 + (size_t)rec_depth * PT_REC_FRAME_F4 * 16 + (size_t)rec_epp * (6 * 16 + 1 + 4 + 4 + 8);
+    if (rec) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, ((size_t)6 << 30) / rec_per_path));
     if (ao) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, ((size_t)128 << 20) / (size_t)sc.ao_samples));      // <= 128 M occlusion rays (4.4 GB) per pass: big launches amortise the drain tail
     size_t chunk_pix = std::min(n_pixels_total, pool_target);
     uint32_t S = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, pool_target / chunk_pix));
@@ -1187,6 +1200,56 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 PT_HIP(hipEventRecord(b, ctx->stream));
                 PT_HIP(ptk_ao_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, n_paths, ao_w, ao_occ));
                 PT_HIP(hipEventRecord(c, ctx->stream));
+            } else if (rec) {
+                // DirectLighting / Whitted: depth-first walk over the specular trees, two traversal launches per tree level
+                const uint32_t n_paths = n_pix * ns;
+                if (ctx->rec_paths < ctx->pool_paths || ctx->rec_epp != rec_epp || ctx->rec_depth != rec_depth || !ctx->d_rec.p) {
+                    PT_HIP(ctx->d_rec.alloc(ctx->pool_paths * rec_per_path + 65536));
+                    ctx->rec_paths = ctx->pool_paths; ctx->rec_epp = rec_epp; ctx->rec_depth = rec_depth;
+                    if (!ctx->d_counts2.p) PT_HIP(ctx->d_counts2.alloc(PT_COUNTS_WORDS * 4));
+                }
+                PT_HIP(hipMemsetAsync(ctx->d_counts2.p, 0, PT_COUNTS_WORDS * 4, ctx->stream));
+                const size_t np = ctx->rec_paths, ne = np * rec_epp;
+                PtRec R;
+                char* rb = ctx->d_rec.as<char>();
+                auto take = [&](size_t bytes) { char* q = rb; rb += (bytes + 255) & ~(size_t)255; return q; };
+                R.diff = (float4*)take(np * 64);
+                R.frames = (float4*)take(np * (size_t)rec_depth * PT_REC_FRAME_F4 * 16);
+                R.sh_o = (float4*)take(ne * 16); R.sh_d = (float4*)take(ne * 16); R.pr_o = (float4*)take(ne * 16); R.pr_d = (float4*)take(ne * 16);
+                R.A = (float4*)take(ne * 16); R.B = (float4*)take(ne * 16);
+                R.prec = (int32_t*)take(ne * 4); R.flags = (uint32_t*)take(ne * 4);
+                uint32_t* nl_shadow = (uint32_t*)take(ne * 4);
+                uint32_t* nl_probe = (uint32_t*)take(ne * 4);
+                R.occ = (uint8_t*)take(ne);
+                R.n_paths = (uint32_t)np; R.max_depth = rec_depth; R.epp = rec_epp;
+                R.n_arrays1 = (sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING && sc.direct_strategy == PT_DIRECT_ALL) ? 2u * sc.n_lights * (uint32_t)std::max(sc.max_depth, 0) : 0u;
+                if (5u + 2u * R.n_arrays1 > 60000u) return ctx->fail(PT_ERR_UNSUPPORTED, "directlighting \"all\": too many lights x maxdepth for the sampler's array dimensions");
+                PtPaths NP = ctx->paths;             // the node's next-event rays as shadow / probe work items
+                NP.sh_o = R.sh_o; NP.sh_d = R.sh_d; NP.pr_o = R.pr_o; NP.pr_d = R.pr_d; NP.occluded = R.occ; NP.probe_rec = R.prec;
+                PtQueues Qn = Q;
+                Qn.counts = ctx->d_counts2.as<uint32_t>(); Qn.shadow = nl_shadow; Qn.probe = nl_probe;
+                PT_HIP(ptk_rec_init(ctx->stream, ctx->grid_wide, sc, ctx->paths, R, n_paths));
+                for (uint32_t iter = 0; iter < 100000u; iter++) {
+                    hipEvent_t a = get_event(ctx, ev_i), b = get_event(ctx, ev_i + 1), c = get_event(ctx, ev_i + 2);
+                    if (!a || !b || !c) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
+                    if (ev_i < 3000) { spans.push_back({ev_i, 0}); ev_i += 3; }
+                    Qn.cur = Q.cur;
+                    PT_HIP(hipEventRecord(a, ctx->stream));
+                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                    PT_HIP(ptk_prep(ctx->stream, Qn, 0));
+                    PT_HIP(ptk_rec_enter(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, Qn, R, cnt, rec_epp));
+                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, NP, Qn, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                    ctx->trace_launches += 2;
+                    PT_HIP(hipEventRecord(b, ctx->stream));
+                    PT_HIP(ptk_rec_next(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, R));
+                    PT_HIP(ptk_prep(ctx->stream, Q, 1));
+                    PT_HIP(hipEventRecord(c, ctx->stream));
+                    std::swap(Q.cur, Q.next);
+                    uint32_t n_live = 0;
+                    PT_HIP(hipMemcpyAsync(&n_live, Q.counts + PT_Q_CUR, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    PT_HIP(hipStreamSynchronize(ctx->stream));
+                    if (n_live == 0) break;
+                }
             } else if (sc.n_lights > 0) {          // no lights: li() returns zero immediately (path.rs:71-74)
                 auto bounce = [&]() -> pt_status {
                     const bool timed = !no_events;

@@ -248,6 +248,7 @@ struct PtScene {
     int32_t max_depth;
     float rr_threshold;
     int32_t integrator;          // pt_integrator_type
+    int32_t direct_strategy;     // pt_direct_strategy (directlighting)
     int32_t ao_samples, ao_cos_sample;
     PtCamera cam;
     PtFilm film;
@@ -279,6 +280,25 @@ struct PtPaths {
     int32_t* probe_rec;
     uint32_t* hit_inst;  // instance index + 1 of the closest hit (0 = a world primitive); allocated for scenes with instances only
 };
+
+// ---- DirectLightingIntegrator / WhittedIntegrator on the wavefront (pt_kernels.hip, "recursive integrators"): the per-camera-sample
+// state of the depth-first walk over the specular_reflect / specular_transmit tree
+#define PT_REC_FRAME_F4 8u       // float4 per frame
+struct PtRec {
+    float4* diff;            // [4][n_paths]: the current ray's offset rays rx_o, ry_o, rx_d, ry_d (valid when PT_ST_DIFF is set)
+    float4* frames;          // [max_depth][PT_REC_FRAME_F4][n_paths]: ray o | hit record, ray d | instance, rx_o | phase, ry_o, rx_d | pending scale,
+                             //                                        ry_d, l, pending f
+    // next-event entries, entry e = path * epp + j (j: the light, or 0 for "one"): shadow ray, MIS probe ray, the two pending terms
+    float4 *sh_o, *sh_d, *pr_o, *pr_d, *A, *B;       // A.w = selection pdf of the light ("one"), B.w unused
+    uint8_t* occ;            // shadow ray result
+    int32_t* prec;           // probe ray result (closest record)
+    uint32_t* flags;         // per entry: PT_NEE_SHADOW | PT_NEE_PROBE | light << 8
+    uint32_t n_paths, max_depth, epp, n_arrays1;     // n_arrays1: one-sample 2-D arrays requested per camera sample ("all" strategy)
+};
+#define PT_REC_OUT_FRAME 0u      // k_rec_enter outcomes (bits 2..3 of the state's flag byte): a frame was pushed, next-event rays may be pending
+#define PT_REC_OUT_RETURN0 1u    // the ray left the scene (or Whitted met a surface without BSDF): the node returns zero
+#define PT_REC_OUT_RETRACE 2u    // DirectLighting passed through a surface without BSDF: the new ray is traced at the same depth
+#define PT_ST_DIFF 1u            // recursive integrators: the current ray carries differentials
 
 #define PT_ST_SPECULAR 1u
 #define PT_ST_CAMERA 2u         // the ray is still the camera ray: it has differentials (textures filter with them)

@@ -36,3 +36,7 @@ hipError_t ptk_expand_tiles(hipStream_t st, const int4* tiles, const uint32_t* t
                             uint32_t* pixels, uint32_t* bitmap, uint32_t* err);
 hipError_t ptk_wavefront_results(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n, const uint8_t* kind, pt_hit* out, uint8_t* occ);
 int ptk_trace_dist_blocks_per_cu();      // blocks per CU the pooled-leaf traversal kernels were built for (LDS budget)
+hipError_t ptk_rec_init(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t n);
+hipError_t ptk_rec_enter(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtQueues& Qn, const PtRec& R, PtCounters* cnt,
+                         uint32_t lights_per_node);
+hipError_t ptk_rec_next(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtRec& R);

@@ -2515,6 +2515,477 @@ extern "C" __global__ void k_bsdf_sample(PtScene sc, uint32_t material, uint32_t
     }
 }
 
+// ============================================================ recursive integrators (directlighting, whitted)
+// DirectLightingIntegrator::li (integrators/directlighting.rs:66-135) and WhittedIntegrator::li (integrators/whitted.rs:38-110) with
+// SamplerIntegrator::specular_reflect / specular_transmit (core/integrator/sampler.rs:37-143).  The reference recurses, and its sampler
+// is consumed in that order (the reflect subtree first, then the transmit branch), so every camera sample walks its tree depth first:
+// a stack of frames in HBM (PtRec::frames), one k_trace launch per tree level for the child rays and one for the node's next-event
+// rays.  Per iteration of the host loop:
+//   k_trace        the current ray of every live camera sample (continuation items)
+//   k_rec_enter    the node at its hit: emitted light, BSDF, the next-event rays of the node (entries in PtRec), a new frame
+//   k_trace        those shadow / MIS probe rays
+//   k_rec_next     resolves the node's direct light in the reference's order of additions, then runs the walk -- sample specular_reflect,
+//                  else specular_transmit, else return to the parent frame and continue there -- until a child ray has to be traced or
+//                  the root has returned
+// The interaction of a frame is rebuilt from its ray and hit record whenever it is needed again (after the reflect subtree, for the
+// transmit sample): the same arithmetic, so the same values.  One kernel variant (spheres, textures, instances all compiled in).
+struct RecNode {
+    Surf s;
+    GBsdf gb;
+    PtMaterial tm;
+    TexHit th;
+    V3 n_before;
+    float bsdf_eta;
+    bool found, has_bsdf;
+};
+PT_DEV void rec_build(const PtScene& sc, V3 ro, V3 rd, int32_t rec, uint32_t inst, bool has_diff, const RayDiffs& rdf, RecNode& nd) {
+    float thit;
+    nd.found = rec >= 0 && make_surf_inst<true>(sc, ro, rd, (uint32_t)rec, inst, nd.s, &thit);
+    nd.has_bsdf = false;
+    nd.bsdf_eta = 1.0f;
+    if (!nd.found) return;
+    nd.n_before = nd.s.sh_n;
+    nd.th.p = nd.s.p; nd.th.uv = nd.s.uv;
+    compute_differentials(nd.th, nd.s.p, nd.s.n, nd.s.dpdu, nd.s.dpdv, has_diff, rdf);
+    if (nd.s.material < 0) return;
+    const PtMaterial* m = &sc.materials[nd.s.material];
+    if (m->textured) {
+        textured_lobes(sc, nd.s.material, nd.th, &nd.tm, nd.s.n, nd.s.uv, &nd.s.sh_n, &nd.s.sh_dpdu, nd.s.sh_dpdv, nd.s.sh_dndu, nd.s.sh_dndv);
+        m = &nd.tm;
+    }
+    if (!m->has_bsdf) return;
+    nd.has_bsdf = true;
+    nd.gb.ns = nd.s.sh_n; nd.gb.ng = nd.s.n;
+    nd.gb.ss = normalize(nd.s.sh_dpdu);
+    nd.gb.ts = normalize(cross(nd.gb.ns, nd.gb.ss));
+    nd.gb.lobes = m->lobes; nd.gb.n_lobes = m->n_lobes;
+    nd.bsdf_eta = m->bsdf_eta;
+}
+PT_DEV float4* rec_frame(const PtRec& R, uint32_t depth, uint32_t k, uint32_t p) { return R.frames + ((size_t)depth * PT_REC_FRAME_F4 + k) * R.n_paths + p; }
+// estimate_direct (sample_lights.rs:178-328) for light `light_num`: the two MIS terms and their rays go to entry e, the rays' results
+// are combined by k_rec_next.  Returns the PT_NEE_* flags of the entry.
+PT_DEV uint32_t rec_estimate_direct(const PtScene& sc, const PtRec& R, const RecNode& nd, uint32_t light_num, V2 u_light, V2 u_scat, uint32_t e) {
+    const Surf& s = nd.s;
+    const PtLight& lt = sc.lights[light_num];
+    const uint32_t kNoSpec = PT_BSDF_ALL & ~PT_BSDF_SPECULAR;
+    uint32_t nee = light_num << 8;
+    V3 A = mk3(0.0f, 0.0f, 0.0f), B = A;
+    V3 li, wi, lp, lperr, ln;
+    float lpdf;
+    if (light_sample_any<true>(sc, lt, s.p, s.p_error, s.n, u_light, &li, &wi, &lpdf, &lp, &lperr, &ln)) {
+        if (lpdf > 0.0f && !is_black(li)) {
+            V3 f = gbsdf_f(nd.gb, s.wo, wi, kNoSpec) * abs_dot(wi, s.sh_n);
+            float spdf = gbsdf_pdf(nd.gb, s.wo, wi, kNoSpec);
+            if (!is_black(f)) {
+                V3 origin = offset_ray_origin(s.p, s.p_error, s.n, lp - s.p);
+                V3 target = offset_ray_origin(lp, lperr, ln, origin - lp);
+                V3 sd = target - origin;
+                R.sh_o[e] = make_float4(origin.x, origin.y, origin.z, 1.0f - PT_SHADOW_EPS);
+                R.sh_d[e] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+                float weight = power_heuristic(lpdf, spdf);
+                A = f * li * (weight / lpdf);
+                nee |= PT_NEE_SHADOW;
+            }
+        }
+    }
+    V3 f2, wi2;
+    float spdf2;
+    uint32_t type2;
+    if (gbsdf_sample_f(nd.gb, s.wo, u_scat, kNoSpec, &f2, &wi2, &spdf2, &type2)) {
+        V3 f = f2 * abs_dot(wi2, s.sh_n);
+        if (!is_black(f) && spdf2 > 0.0f) {
+            V3 po = offset_ray_origin(s.p, s.p_error, s.n, wi2);
+            Surf ls;
+            float lt_t;
+            if (make_surf_any<true>(sc, po, wi2, lt.tri_rec, ls, &lt_t)) {          // light.pdf_li -> Shape::pdf_from (shape.rs:40-54)
+                float lp2 = distance_squared(s.p, ls.p) / (abs_dot(ls.n, -wi2) * lt.area);
+                if (isinf(lp2)) lp2 = 0.0f;
+                if (lp2 != 0.0f) {
+                    float weight = power_heuristic(spdf2, lp2);
+                    V3 le = light_L(lt, ls.n, -wi2);
+                    B = f * le * 1.0f * (weight / spdf2);
+                    R.pr_o[e] = make_float4(po.x, po.y, po.z, PT_INF);
+                    R.pr_d[e] = make_float4(wi2.x, wi2.y, wi2.z, 0.0f);
+                    nee |= PT_NEE_PROBE;
+                }
+            }
+        }
+    }
+    R.A[e] = make_float4(A.x, A.y, A.z, 1.0f);
+    R.B[e] = make_float4(B.x, B.y, B.z, 0.0f);
+    R.flags[e] = nee;
+    return nee;
+}
+// camera rays carry differentials: the offset rays of every camera sample (k_gen made the main ray), the sampler past its arrays
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_init(PtScene sc, PtPaths P, PtRec R, uint32_t n) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        Sampler sl;
+        sl.index = P.sobol_index[p];
+        sl.dim = 2;
+        const uint32_t pk = P.pixel[p];
+        sl.px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0];
+        sl.py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
+        V2 u_lens = mk2(0.0f, 0.0f);
+        if (sc.cam.lens_radius > 0.0f) u_lens = sl.get_2d(sc);
+        const float2 pf = P.p_film[p];
+        RayDiffs rdf;
+        camera_differentials(sc, mk2(pf.x, pf.y), u_lens, f4_3(P.ray_o[p]), f4_3(P.ray_d[p]), rdf);
+        R.diff[p] = make_float4(rdf.rx_o.x, rdf.rx_o.y, rdf.rx_o.z, 0.0f);
+        R.diff[(size_t)R.n_paths + p] = make_float4(rdf.ry_o.x, rdf.ry_o.y, rdf.ry_o.z, 0.0f);
+        R.diff[2 * (size_t)R.n_paths + p] = make_float4(rdf.rx_d.x, rdf.rx_d.y, rdf.rx_d.z, 0.0f);
+        R.diff[3 * (size_t)R.n_paths + p] = make_float4(rdf.ry_d.x, rdf.ry_d.y, rdf.ry_d.z, 0.0f);
+        // get_2d right after the camera sample jumps over the array dimensions (sobol.rs:118-141): dimension 5 + 2 * arrays
+        P.state[p] = (5u + 2u * R.n_arrays1) | (0u << 16) | (PT_ST_DIFF << 24);
+        P.nee[p] = 0;                        // arrays handed out so far
+    }
+}
+PT_DEV RayDiffs rec_load_diff(const PtRec& R, uint32_t p) {
+    RayDiffs d;
+    d.rx_o = f4_3(R.diff[p]); d.ry_o = f4_3(R.diff[(size_t)R.n_paths + p]);
+    d.rx_d = f4_3(R.diff[2 * (size_t)R.n_paths + p]); d.ry_d = f4_3(R.diff[3 * (size_t)R.n_paths + p]);
+    return d;
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_enter(PtScene sc, PtPaths P, PtQueues Q, PtRec R, PtCounters* cnt) {
+    const uint32_t n = Q.counts[PT_Q_CUR];
+    const uint32_t lane = threadIdx.x & 63;
+    const bool whitted = sc.integrator == PT_INTEGRATOR_WHITTED;
+    uint32_t n_vert = 0;
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + lane;
+        if (i >= n) continue;
+        const uint32_t p = Q.cur[i];
+        const V3 ro = f4_3(P.ray_o[p]), rd = f4_3(P.ray_d[p]);
+        const int32_t rec = P.hit_rec[p];
+        const uint32_t inst = sc.n_instances ? P.hit_inst[p] : 0u;
+        uint32_t st = P.state[p];
+        uint32_t dim = st & 0xffffu, depth = (st >> 16) & 0xffu, flags = (st >> 24) & 3u;
+        const bool has_diff = (flags & PT_ST_DIFF) != 0;
+        RayDiffs rdf;
+        rdf.rx_o = rdf.ry_o = rdf.rx_d = rdf.ry_d = mk3(0.0f, 0.0f, 0.0f);
+        if (has_diff) rdf = rec_load_diff(R, p);
+        RecNode nd;
+        rec_build(sc, ro, rd, rec, inst, has_diff, rdf, nd);
+        uint32_t outcome = PT_REC_OUT_FRAME;
+        if (!nd.found) outcome = PT_REC_OUT_RETURN0;              // the lights' le(ray) sum: zero for area lights
+        else if (!nd.has_bsdf) {
+            if (whitted) outcome = PT_REC_OUT_RETURN0;
+            else {                                                  // directlighting.rs:113-116: a plain ray through the surface, same depth
+                const V3 no = offset_ray_origin(nd.s.p, nd.s.p_error, nd.s.n, rd);
+                P.ray_o[p] = make_float4(no.x, no.y, no.z, PT_INF);
+                flags &= ~PT_ST_DIFF;
+                outcome = PT_REC_OUT_RETRACE;
+            }
+        }
+        if (outcome == PT_REC_OUT_FRAME) {
+            n_vert++;
+            Sampler sm;
+            sm.index = P.sobol_index[p];
+            sm.dim = dim;
+            const uint32_t pk = P.pixel[p];
+            sm.px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0];
+            sm.py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
+            V3 l = mk3(0.0f, 0.0f, 0.0f);
+            const uint32_t e0 = p * R.epp;
+            if (whitted) {
+                // one light sample per light, no MIS, weighted by the shading normal from before the bump map (whitted.rs:52-78)
+                for (uint32_t j = 0; j < sc.n_lights; j++) {
+                    const V2 u = sm.get_2d(sc);
+                    const PtLight& lt = sc.lights[j];
+                    uint32_t nee = j << 8;
+                    V3 A = mk3(0.0f, 0.0f, 0.0f);
+                    V3 li, wi, lp, lperr, ln;
+                    float lpdf;
+                    if (light_sample_any<true>(sc, lt, nd.s.p, nd.s.p_error, nd.s.n, u, &li, &wi, &lpdf, &lp, &lperr, &ln) && !(lpdf <= 0.0f || is_black(li))) {
+                        V3 f = gbsdf_f(nd.gb, nd.s.wo, wi, PT_BSDF_ALL);
+                        if (!is_black(f)) {
+                            V3 origin = offset_ray_origin(nd.s.p, nd.s.p_error, nd.s.n, lp - nd.s.p);
+                            V3 target = offset_ray_origin(lp, lperr, ln, origin - lp);
+                            V3 sd = target - origin;
+                            R.sh_o[e0 + j] = make_float4(origin.x, origin.y, origin.z, 1.0f - PT_SHADOW_EPS);
+                            R.sh_d[e0 + j] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+                            A = f * li * (abs_dot(wi, nd.n_before) / lpdf);
+                            nee |= PT_NEE_SHADOW;
+                        }
+                    }
+                    R.A[e0 + j] = make_float4(A.x, A.y, A.z, 1.0f);
+                    R.flags[e0 + j] = nee;
+                }
+            } else {
+                if (nd.s.light >= 0) l = light_L(sc.lights[nd.s.light], nd.s.n, nd.s.wo);          // isect.le(wo)
+                if (sc.n_lights > 0) {
+                    if (sc.direct_strategy == PT_DIRECT_ALL) {        // uniform_sample_all_lights: one sample per light, from the arrays while they last
+                        uint32_t arr = P.nee[p];
+                        for (uint32_t j = 0; j < sc.n_lights; j++) {
+                            V2 u_light, u_scat;
+                            if (arr + 2u <= R.n_arrays1) {
+                                u_light = mk2(sample_dimension(sc, sm.index, 5u + 2u * arr, sm.px, sm.py), sample_dimension(sc, sm.index, 6u + 2u * arr, sm.px, sm.py));
+                                u_scat = mk2(sample_dimension(sc, sm.index, 7u + 2u * arr, sm.px, sm.py), sample_dimension(sc, sm.index, 8u + 2u * arr, sm.px, sm.py));
+                                arr += 2u;
+                            } else {
+                                arr = R.n_arrays1;
+                                u_light = sm.get_2d(sc);
+                                u_scat = sm.get_2d(sc);
+                            }
+                            rec_estimate_direct(sc, R, nd, j, u_light, u_scat, e0 + j);
+                        }
+                        P.nee[p] = arr;
+                    } else {                                          // uniform_sample_one_light without a distribution (sample_lights.rs:105-127)
+                        const float fl = sm.get_1d(sc) * (float)sc.n_lights;
+                        uint32_t light_num = fl > 0.0f ? (fl >= 4294967296.0f ? 0xffffffffu : (uint32_t)fl) : 0u;      // `as usize` saturates
+                        if (light_num > sc.n_lights - 1u) light_num = sc.n_lights - 1u;
+                        const float light_pdf = 1.0f / (float)sc.n_lights;
+                        const V2 u_light = sm.get_2d(sc);
+                        const V2 u_scat = sm.get_2d(sc);
+                        rec_estimate_direct(sc, R, nd, light_num, u_light, u_scat, e0);
+                        float4 a = R.A[e0];
+                        a.w = light_pdf;
+                        R.A[e0] = a;
+                    }
+                }
+            }
+            dim = sm.dim;
+            // the frame: what a later visit needs to rebuild this interaction, and the node's radiance so far
+            *rec_frame(R, depth, 0, p) = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)rec));
+            *rec_frame(R, depth, 1, p) = make_float4(rd.x, rd.y, rd.z, __uint_as_float(inst | (has_diff ? 0x80000000u : 0u)));
+            *rec_frame(R, depth, 2, p) = make_float4(rdf.rx_o.x, rdf.rx_o.y, rdf.rx_o.z, 0.0f);
+            *rec_frame(R, depth, 3, p) = make_float4(rdf.ry_o.x, rdf.ry_o.y, rdf.ry_o.z, 0.0f);
+            *rec_frame(R, depth, 4, p) = make_float4(rdf.rx_d.x, rdf.rx_d.y, rdf.rx_d.z, 0.0f);
+            *rec_frame(R, depth, 5, p) = make_float4(rdf.ry_d.x, rdf.ry_d.y, rdf.ry_d.z, 0.0f);
+            *rec_frame(R, depth, 6, p) = make_float4(l.x, l.y, l.z, 0.0f);
+        }
+        P.state[p] = (dim & 0xffffu) | (depth << 16) | ((flags | (outcome << 2)) << 24);
+    }
+    // the next-event rays of this launch: entries with a live shadow / probe ray, in entry order
+    __shared__ unsigned long long s_vert;
+    if (threadIdx.x == 0) s_vert = 0;
+    __syncthreads();
+    if (n_vert) atomicAdd(&s_vert, (unsigned long long)n_vert);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_vert) atomicAdd(&cnt->vertices, s_vert);
+}
+// compaction of the entries with live rays into the shadow / probe work lists of the next traversal launch
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_nee_lists(PtPaths P, PtQueues Q, PtQueues Qn, PtRec R, uint32_t n_lights_per_node) {
+    const uint32_t n = Q.counts[PT_Q_CUR];
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t total = n * n_lights_per_node;
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < total; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + lane;
+        bool want_sh = false, want_pr = false;
+        uint32_t e = 0;
+        if (i < total) {
+            const uint32_t p = Q.cur[i / n_lights_per_node];
+            if (((P.state[p] >> 26) & 3u) == PT_REC_OUT_FRAME) {
+                e = p * R.epp + i % n_lights_per_node;
+                const uint32_t fl = R.flags[e];
+                want_sh = (fl & PT_NEE_SHADOW) != 0; want_pr = (fl & PT_NEE_PROBE) != 0;
+            }
+        }
+        const unsigned long long ms = __ballot(want_sh), mp = __ballot(want_pr);
+        uint32_t bs = 0, bp = 0;
+        if (lane == 0) {
+            if (ms) bs = atomicAdd(&Qn.counts[PT_Q_SHADOW], (uint32_t)__popcll(ms));
+            if (mp) bp = atomicAdd(&Qn.counts[PT_Q_PROBE], (uint32_t)__popcll(mp));
+        }
+        bs = __shfl(bs, 0, 64); bp = __shfl(bp, 0, 64);
+        if (want_sh) Qn.shadow[bs + (uint32_t)__popcll(ms & below)] = e;
+        if (want_pr) Qn.probe[bp + (uint32_t)__popcll(mp & below)] = e;
+    }
+}
+// specular_reflect / specular_transmit at the frame `depth` (sampler.rs:37-143): true = a child ray was set up (cur ray, differentials, pending f / scale)
+PT_DEV bool rec_sample_child(const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t p, uint32_t depth, bool transmit, Sampler& sm, V3* pend_f, float* pend_scale, uint32_t* child_flags) {
+    const float4 f0 = *rec_frame(R, depth, 0, p), f1 = *rec_frame(R, depth, 1, p);
+    const V3 ro = f4_3(f0), rd = f4_3(f1);
+    const int32_t rec = (int32_t)__float_as_uint(f0.w);
+    const uint32_t iw = __float_as_uint(f1.w);
+    const bool has_diff = (iw & 0x80000000u) != 0;
+    RayDiffs rdf;
+    rdf.rx_o = f4_3(*rec_frame(R, depth, 2, p)); rdf.ry_o = f4_3(*rec_frame(R, depth, 3, p));
+    rdf.rx_d = f4_3(*rec_frame(R, depth, 4, p)); rdf.ry_d = f4_3(*rec_frame(R, depth, 5, p));
+    RecNode nd;
+    rec_build(sc, ro, rd, rec, iw & 0x7fffffffu, has_diff, rdf, nd);
+    const V2 u = sm.get_2d(sc);
+    V3 f, wi;
+    float pdf;
+    uint32_t ty;
+    if (!gbsdf_sample_f(nd.gb, nd.s.wo, u, (transmit ? PT_BSDF_TRANSMISSION : PT_BSDF_REFLECTION) | PT_BSDF_SPECULAR, &f, &wi, &pdf, &ty)) return false;
+    const Surf& s = nd.s;
+    const V3 wo = s.wo;
+    V3 ns = s.sh_n;
+    float wi_ns = abs_dot(wi, ns);
+    float wo_ns = dot(wo, ns);
+    if (!(pdf > 0.0f && !is_black(f) && wi_ns != 0.0f)) return false;
+    const V3 no = offset_ray_origin(s.p, s.p_error, s.n, wi);
+    P.ray_o[p] = make_float4(no.x, no.y, no.z, PT_INF);
+    P.ray_d[p] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+    *child_flags = 0;
+    if (has_diff) {
+        const V3 rx_o = s.p + nd.th.dpdx, ry_o = s.p + nd.th.dpdy;
+        V3 dndx = s.sh_dndu * nd.th.dudx + s.sh_dndv * nd.th.dvdx;
+        V3 dndy = s.sh_dndu * nd.th.dudy + s.sh_dndv * nd.th.dvdy;
+        V3 rx_d, ry_d;
+        if (!transmit) {
+            const V3 dwodx = -rdf.rx_d - wo, dwody = -rdf.ry_d - wo;
+            const float d_dndx = dot(dwodx, ns) + dot(wo, dndx);
+            const float d_dndy = dot(dwody, ns) + dot(wo, dndy);
+            rx_d = wi - dwodx + 2.0f * (wo_ns * dndx + d_dndx * ns);
+            ry_d = wi - dwody + 2.0f * (wo_ns * dndy + d_dndy * ns);
+        } else {
+            float eta = 1.0f / nd.bsdf_eta;
+            if (dot(wo, ns) < 0.0f) {
+                eta = 1.0f / eta;
+                ns = -ns; dndx = -dndx; dndy = -dndy;
+                wi_ns = abs_dot(wi, ns);
+                wo_ns = dot(wo, ns);
+            }
+            const V3 dwodx = -rdf.rx_d - wo, dwody = -rdf.ry_d - wo;
+            const float d_dndx = dot(dwodx, ns) + dot(wo, dndx);
+            const float d_dndy = dot(dwody, ns) + dot(wo, dndy);
+            const float mu = eta * wo_ns - wi_ns;
+            const float dmudx = (eta - (eta * eta * wo_ns) / wi_ns) * d_dndx;
+            const float dmudy = (eta - (eta * eta * wo_ns) / wi_ns) * d_dndy;
+            rx_d = wi - eta * dwodx + (mu * dndx + dmudx * ns);
+            ry_d = wi - eta * dwody + (mu * dndy + dmudy * ns);
+        }
+        R.diff[p] = make_float4(rx_o.x, rx_o.y, rx_o.z, 0.0f);
+        R.diff[(size_t)R.n_paths + p] = make_float4(ry_o.x, ry_o.y, ry_o.z, 0.0f);
+        R.diff[2 * (size_t)R.n_paths + p] = make_float4(rx_d.x, rx_d.y, rx_d.z, 0.0f);
+        R.diff[3 * (size_t)R.n_paths + p] = make_float4(ry_d.x, ry_d.y, ry_d.z, 0.0f);
+        *child_flags = PT_ST_DIFF;
+    }
+    *pend_f = f;
+    *pend_scale = wi_ns / pdf;
+    return true;
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_next(PtScene sc, PtPaths P, PtQueues Q, PtRec R) {
+    const uint32_t n = Q.counts[PT_Q_CUR];
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const bool whitted = sc.integrator == PT_INTEGRATOR_WHITTED;
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + lane;
+        bool cont = false;
+        uint32_t p = 0;
+        if (i < n) {
+            p = Q.cur[i];
+            uint32_t st = P.state[p];
+            uint32_t dim = st & 0xffffu, depth = (st >> 16) & 0xffu, flags = (st >> 24) & 3u;
+            const uint32_t outcome = (st >> 26) & 3u;
+            if (outcome == PT_REC_OUT_RETRACE) cont = true;
+            else {
+                Sampler sm;
+                sm.index = P.sobol_index[p];
+                sm.dim = dim;
+                const uint32_t pk = P.pixel[p];
+                sm.px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0];
+                sm.py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
+                V3 v = mk3(0.0f, 0.0f, 0.0f);       // the value a finished node hands to its parent
+                bool returning = outcome == PT_REC_OUT_RETURN0;
+                int32_t d = returning ? (int32_t)depth - 1 : (int32_t)depth;
+                uint32_t phase = 0;                  // of the frame d when not returning: 0 = sample reflect next, 1 = sample transmit next
+                V3 l = mk3(0.0f, 0.0f, 0.0f);
+                if (!returning) {
+                    // the node's direct light, in the reference's order of additions
+                    l = f4_3(*rec_frame(R, depth, 6, p));
+                    const uint32_t e0 = p * R.epp;
+                    if (whitted) {
+                        for (uint32_t j = 0; j < sc.n_lights; j++) {
+                            const uint32_t fl = R.flags[e0 + j];
+                            V3 term = mk3(0.0f, 0.0f, 0.0f);
+                            if ((fl & PT_NEE_SHADOW) && R.occ[e0 + j] == 0) term = f4_3(R.A[e0 + j]);
+                            l = l + term;
+                        }
+                    } else if (sc.n_lights > 0) {
+                        V3 ld_all = mk3(0.0f, 0.0f, 0.0f);
+                        const uint32_t cnt_e = sc.direct_strategy == PT_DIRECT_ALL ? sc.n_lights : 1u;
+                        for (uint32_t j = 0; j < cnt_e; j++) {
+                            const uint32_t fl = R.flags[e0 + j];
+                            const float4 A = R.A[e0 + j];
+                            V3 ld = mk3(0.0f, 0.0f, 0.0f);
+                            if ((fl & PT_NEE_SHADOW) && R.occ[e0 + j] == 0) ld = ld + f4_3(A);
+                            if (fl & PT_NEE_PROBE) {
+                                const int32_t best = R.prec[e0 + j];
+                                if (best >= 0 && (uint32_t)best == sc.lights[fl >> 8].tri_rec) ld = ld + f4_3(R.B[e0 + j]);
+                            }
+                            if (sc.direct_strategy == PT_DIRECT_ALL) ld_all = ld_all + ld / 1.0f;
+                            else ld_all = ld / A.w;
+                        }
+                        l = l + ld_all;
+                    }
+                }
+                for (;;) {
+                    if (returning) {
+                        if (d < 0) { P.L[p] = make_float4(v.x, v.y, v.z, 0.0f); break; }
+                        // back in frame d: add the finished child's term, move on to the next phase
+                        const float4 fr2 = *rec_frame(R, (uint32_t)d, 2, p);
+                        const uint32_t ph = __float_as_uint(fr2.w);              // 1 = the reflect child was pending, 2 = the transmit child
+                        const float4 pf = *rec_frame(R, (uint32_t)d, 7, p);
+                        const float scale = rec_frame(R, (uint32_t)d, 4, p)->w;
+                        l = f4_3(*rec_frame(R, (uint32_t)d, 6, p));
+                        l = l + (f4_3(pf) * v) * scale;
+                        returning = false;
+                        if (ph == 2u) { v = l; returning = true; d--; continue; }     // both children done: this node returns
+                        phase = 1;
+                    }
+                    if ((uint32_t)d + 1u < (uint32_t)sc.max_depth) {
+                        V3 pend_f;
+                        float pend_scale;
+                        uint32_t cflags;
+                        bool child = false;
+                        if (phase == 0) {
+                            child = rec_sample_child(sc, P, R, p, (uint32_t)d, false, sm, &pend_f, &pend_scale, &cflags);
+                            if (!child) { l = l + mk3(0.0f, 0.0f, 0.0f); phase = 1; }
+                        }
+                        if (!child && phase == 1) {
+                            child = rec_sample_child(sc, P, R, p, (uint32_t)d, true, sm, &pend_f, &pend_scale, &cflags);
+                            if (child) phase = 2;
+                            else l = l + mk3(0.0f, 0.0f, 0.0f);
+                        } else if (child) phase = 1;
+                        if (child) {
+                            // park this frame: radiance so far, which child is pending, its factor; the child becomes the current ray
+                            *rec_frame(R, (uint32_t)d, 6, p) = make_float4(l.x, l.y, l.z, 0.0f);
+                            *rec_frame(R, (uint32_t)d, 7, p) = make_float4(pend_f.x, pend_f.y, pend_f.z, 0.0f);
+                            float4 fr2 = *rec_frame(R, (uint32_t)d, 2, p);
+                            fr2.w = __uint_as_float(phase);
+                            *rec_frame(R, (uint32_t)d, 2, p) = fr2;
+                            float4 fr4 = *rec_frame(R, (uint32_t)d, 4, p);
+                            fr4.w = pend_scale;
+                            *rec_frame(R, (uint32_t)d, 4, p) = fr4;
+                            depth = (uint32_t)d + 1u;
+                            flags = cflags;
+                            cont = true;
+                            break;
+                        }
+                    }
+                    v = l; returning = true; d--;      // no (further) child: the node returns its radiance
+                }
+                dim = sm.dim;
+                P.state[p] = (dim & 0xffffu) | (depth << 16) | (flags << 24);
+            }
+            if (outcome == PT_REC_OUT_RETRACE) P.state[p] = st & ~(3u << 26);
+        }
+        const unsigned long long mc = __ballot(cont);
+        uint32_t bc = 0;
+        if (lane == 0 && mc) bc = atomicAdd(&Q.counts[PT_Q_NEXT], (uint32_t)__popcll(mc));
+        bc = __shfl(bc, 0, 64);
+        if (cont) Q.next[bc + (uint32_t)__popcll(mc & below)] = p;
+    }
+}
+hipError_t ptk_rec_init(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t n) {
+    hipLaunchKernelGGL(k_rec_init, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, R, n);
+    return hipGetLastError();
+}
+hipError_t ptk_rec_enter(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtQueues& Qn, const PtRec& R, PtCounters* cnt,
+                         uint32_t lights_per_node) {
+    hipLaunchKernelGGL(k_rec_enter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R, cnt);
+    hipLaunchKernelGGL(k_rec_nee_lists, dim3(grid), dim3(PT_BLOCK), 0, st, P, Q, Qn, R, lights_per_node);
+    return hipGetLastError();
+}
+hipError_t ptk_rec_next(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtRec& R) {
+    hipLaunchKernelGGL(k_rec_next, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R);
+    return hipGetLastError();
+}
+
 // ============================================================ launch wrappers (host side of this TU)
 #define PT_LAUNCH_CHECK() hipGetLastError()
 

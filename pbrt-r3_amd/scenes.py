@@ -251,6 +251,7 @@ class SceneBuilder:
         self.film_scale, self.max_sample_luminance = 1.0, float("inf")
         self.spp, self.max_depth, self.rr_threshold = 16, 5, 1.0
         self.integrator, self.ao_samples, self.ao_cos_sample = capi.PT_INTEGRATOR_PATH, 64, True
+        self.direct_strategy = capi.PT_DIRECT_ALL
         self.light_strategy = capi.PT_LIGHTS_SPATIAL
         self.split_method, self.max_node_prims = capi.PT_SPLIT_SAH, 4
 
@@ -341,6 +342,15 @@ class SceneBuilder:
     def integrator_ao(self, nsamples=64, cossample=True):
         """Integrator "ao" (integrators/ao.rs:118-138)."""
         self.integrator, self.ao_samples, self.ao_cos_sample = capi.PT_INTEGRATOR_AO, int(nsamples), bool(cossample)
+
+    def integrator_directlighting(self, maxdepth=5, strategy="all"):
+        """Integrator "directlighting" (integrators/directlighting.rs:137-158)."""
+        self.integrator, self.max_depth = capi.PT_INTEGRATOR_DIRECTLIGHTING, int(maxdepth)
+        self.direct_strategy = capi.PT_DIRECT_ONE if strategy == "one" else capi.PT_DIRECT_ALL
+
+    def integrator_whitted(self, maxdepth=5):
+        """Integrator "whitted" (integrators/whitted.rs:112-135)."""
+        self.integrator, self.max_depth = capi.PT_INTEGRATOR_WHITTED, int(maxdepth)
 
     def accelerator_bvh(self, splitmethod="sah", maxnodeprims=4):
         self.split_method = {"sah": 0, "hlbvh": 1, "middle": 2, "equal": 3}.get(splitmethod, 0)
@@ -710,6 +720,7 @@ class SceneBuilder:
         d.halton_sample_at_center = 1 if getattr(self, "halton_center", False) else 0
         d.max_depth, d.rr_threshold, d.light_strategy = self.max_depth, self.rr_threshold, self.light_strategy
         d.integrator, d.ao_samples, d.ao_cos_sample = self.integrator, self.ao_samples, int(self.ao_cos_sample)
+        d.direct_strategy = self.direct_strategy
         return sd
 
 

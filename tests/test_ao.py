@@ -60,8 +60,8 @@ def test_front_end_ao_integrator(tmp_path):
     ps2 = capi.ParsedScene(text=text.replace('"integer nsamples" 24 "bool cossample" "false"', ""), work_dir=str(tmp_path))
     assert (ps2.desc.integrator, ps2.desc.ao_samples, ps2.desc.ao_cos_sample) == (capi.PT_INTEGRATOR_AO, 64, 1)
     with pytest.raises(capi.PtError) as e:
-        capi.ParsedScene(text=text.replace('"ao"', '"whitted"'), work_dir=str(tmp_path))
-    assert "only path and ao" in str(e.value)
+        capi.ParsedScene(text=text.replace('"ao"', '"bdpt"'), work_dir=str(tmp_path))
+    assert "only path, ao, directlighting and whitted" in str(e.value)
 
 
 @pytest.mark.gpu
