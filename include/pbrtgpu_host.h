@@ -76,6 +76,20 @@ pt_status pth_write_pfm(const char* path, const float* rgb, int width, int heigh
  * PT_ERR_UNSUPPORTED. */
 pt_status pth_write_image(const char* path, const float* rgb, int width, int height, int x0, int y0, int full_w, int full_h);
 
+/* ---- live display: the reference's `--display-server host:port` (TevDisplay, src/displays/tev/; Film::render_start /
+ * update_display / render_end, src/core/film/film.rs:278-360, :424-438).  The packets are tev's IPC CreateImage / UpdateImage as
+ * IPCGen writes them (src/displays/tev/display.rs:147-235); an update is cut into 128 x 128 tiles (display.rs:266-345). */
+typedef struct pth_display pth_display;
+pt_status pth_display_connect(const char* host_port, pth_display** out, char* err, size_t err_cap);
+/* Film::render_start: create the image (the film's full resolution, channels R G B) under `title` (the film's filename). */
+pt_status pth_display_start(pth_display* d, const char* title, uint32_t full_width, uint32_t full_height);
+/* Film::update_display: a width x height block of linear RGB (3 floats per pixel, rows first) whose top-left pixel is (x, y). */
+pt_status pth_display_update(pth_display* d, uint32_t x, uint32_t y, uint32_t width, uint32_t height, const float* rgb);
+void pth_display_close(pth_display* d);
+/* The two packets by themselves (tests): return the packet size, write it when cap suffices. */
+size_t pth_tev_create_packet(const char* name, uint32_t width, uint32_t height, unsigned char* out, size_t cap);
+size_t pth_tev_update_packet(const char* name, uint32_t x, uint32_t y, uint32_t width, uint32_t height, const float* rgb, unsigned char* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

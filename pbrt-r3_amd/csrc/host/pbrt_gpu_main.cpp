@@ -29,6 +29,7 @@ static void usage() {
                  "      --quiet               only error messages\n"
                  "  -j, --nthreads <n>        accepted for compatibility (the device schedules itself)\n"
                  "      --device <d>          HIP device index\n"
+                 "      --display-server <host:port>   stream the image to a tev viewer while it renders (bands of tile rows)\n"
                  "      --gpus <n>            film tiles dealt round-robin to n GPUs (devices 0..n-1, one host thread and one\n"
                  "                            library context each), films summed with one RCCL reduce to device 0\n");
 }
@@ -100,7 +101,7 @@ static int render_multi_gpu(const pt_scene_desc* dsc, int n_gpus, std::vector<fl
 }
 
 int main(int argc, char** argv) {
-    std::string input, outfile;
+    std::string input, outfile, display_server;
     int spp = 0, device = 0, gpus = 0;
     bool quiet = false, cat = false, stats = false;
     pth_options opts;
@@ -118,6 +119,7 @@ int main(int argc, char** argv) {
         else if (a == "--nthreads" || a == "-j") (void)need("--nthreads");
         else if (a == "--device") device = std::atoi(need("--device"));
         else if (a == "--gpus") gpus = std::max(1, std::atoi(need("--gpus")));
+        else if (a == "--display-server") display_server = need("--display-server");
         else if (a == "--quiet") quiet = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] != '-') input = a;
@@ -177,8 +179,30 @@ int main(int argc, char** argv) {
     pt_scene_info_get(ctx, &info);
     int w = info.cropped_bounds[2] - info.cropped_bounds[0], h = info.cropped_bounds[3] - info.cropped_bounds[1];
     auto t0 = std::chrono::steady_clock::now();
-    if (pt_film_clear(ctx) != PT_OK || pt_render(ctx, nullptr, 0) != PT_OK) return fail("render");
     std::vector<float> rgb((size_t)w * h * 3);
+    if (!display_server.empty()) {
+        // --display-server (bin/pbrt.rs:297-309): Film::render_start creates the image at the full resolution, every finished band of
+        // tile rows is pushed as Film::update_display pushes a merged tile (film.rs:278-360)
+        pth_display* disp = nullptr;
+        char derr[256] = {0};
+        if (pth_display_connect(display_server.c_str(), &disp, derr, sizeof(derr)) != PT_OK) { std::fprintf(stderr, "pbrt_gpu: %s\n", derr); pt_context_destroy(ctx); pth_scene_free(scene); return 1; }
+        const pt_scene_desc* dd = pth_scene_get_desc(scene);
+        pth_display_start(disp, pth_scene_output_filename(scene), (uint32_t)dd->xres, (uint32_t)dd->yres);
+        if (pt_film_clear(ctx) != PT_OK) return fail("film clear");
+        const int32_t* sb = info.sample_bounds;
+        const int32_t band = 128;
+        for (int32_t y0 = sb[1]; y0 < sb[3]; y0 += band) {
+            std::vector<pt_tile> tiles;
+            for (int32_t y = y0; y < std::min(y0 + band, sb[3]); y += 16)
+                for (int32_t x = sb[0]; x < sb[2]; x += 16) tiles.push_back({x, y, std::min(x + 16, sb[2]), std::min(y + 16, std::min(y0 + band, sb[3]))});
+            if (pt_render(ctx, tiles.data(), (uint32_t)tiles.size()) != PT_OK) return fail("render");
+            if (pt_film_resolve_rgb(ctx, rgb.data()) != PT_OK) return fail("film resolve");
+            const int32_t cy0 = std::max(y0, info.cropped_bounds[1]), cy1 = std::min(std::min(y0 + band, sb[3]), info.cropped_bounds[3]);
+            if (cy1 > cy0)
+                pth_display_update(disp, (uint32_t)info.cropped_bounds[0], (uint32_t)cy0, (uint32_t)w, (uint32_t)(cy1 - cy0), &rgb[(size_t)(cy0 - info.cropped_bounds[1]) * w * 3]);
+        }
+        pth_display_close(disp);
+    } else if (pt_film_clear(ctx) != PT_OK || pt_render(ctx, nullptr, 0) != PT_OK) return fail("render");
     if (pt_film_resolve_rgb(ctx, rgb.data()) != PT_OK) return fail("film resolve");
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     pt_counters c;
