@@ -448,6 +448,19 @@ bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_
             tree.clear();
         }
     }
+    if (split_method == PT_SPLIT_SAH && dev && dev->mode != PT_BVH_BUILD_HOST && n_items >= 2 && bld.max_prims >= 2 &&
+        (dev->mode == PT_BVH_BUILD_DEVICE || n_items >= kDeviceMinPrims)) {
+        std::unique_ptr<float[]> raw(new float[(size_t)n_items * 6]);
+        parallel_for(n_items, [&](size_t p0, size_t p1) {
+            for (size_t pi = p0; pi < p1; pi++) { std::memcpy(&raw[pi * 6], prims[pi].lo, 12); std::memcpy(&raw[pi * 6 + 3], prims[pi].hi, 12); }
+        });
+        tt[1] = now();
+        const int rc = device_sah(dev->stream, raw.get(), n_items, bld.max_prims, &order, &tree, &dev->err);
+        tt[2] = now();
+        if (rc < 0) return false;
+        if (rc == 0) { on_device = true; dev->used = true; root = 0; }
+        else { tree.clear(); order.clear(); }
+    }
     if (!on_device) {
         init_items();
         bld.items = items.data();

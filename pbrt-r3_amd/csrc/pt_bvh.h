@@ -56,6 +56,9 @@ struct LbvhNode {
 // when the host has to build instead (a range needs the centroid-median fallback, non-finite bounds, no memory), -1 on a HIP error.
 int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, std::vector<uint32_t>* order, std::vector<LbvhNode>* nodes,
                 uint32_t* n_treelets, hipError_t* err);
+// pt_sah.hip: the SAH binary build on the GPU, level by level.  Same conventions: 0 = order / nodes filled (nodes[0] is the root), 1 = the
+// host has to build (a split needs the equal-counts fallback, non-finite bounds, maxnodeprims < 2), -1 = HIP error.
+int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, std::vector<uint32_t>* order, std::vector<LbvhNode>* nodes, hipError_t* err);
 // Where the lower half of an HLBVH build runs: PT_BVH_BUILD_AUTO picks the device from kDeviceMinPrims primitives up.
 struct DeviceBuild { hipStream_t stream; int mode; bool used; hipError_t err; };
 const uint32_t kDeviceMinPrims = 1u << 16;

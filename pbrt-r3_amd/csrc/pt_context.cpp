@@ -774,6 +774,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                 for (uint32_t k = 0; k < 3; k++)
                     if ((oct >> ((nd.axes >> (2 * k)) & 3u)) & 1u) lut |= 1u << (8 * k + oct);
             nd.order_lut = lut;
+            // -0.0 and +0.0 bounds: the host builders keep whichever came first, the device builders order them; one spelling for both
+            for (int a = 0; a < 3; a++)
+                for (int ch = 0; ch < 4; ch++) { if (nd.bmin[a][ch] == 0.0f) nd.bmin[a][ch] = 0.0f; if (nd.bmax[a][ch] == 0.0f) nd.bmax[a][ch] = 0.0f; }
             const uint32_t ax_of[4] = {nd.axes & 3u, (nd.axes >> 2) & 3u, 0u, (nd.axes >> 4) & 3u};     // child 0: axis_top, 1: axis_left, 3: axis_right
             for (int ch = 0; ch < 4; ch++)
                 if (nd.child[ch] != PT_EMPTY_REF) nd.child[ch] = (nd.child[ch] & ~(3u << PT_REF_AXIS_SHIFT)) | (ax_of[ch] << PT_REF_AXIS_SHIFT);

@@ -124,7 +124,12 @@ PT_DEV uint64_t sampler_index(const PtScene& sc, uint64_t sample_num, int32_t px
     return sobol_interval_to_index(sc.sobol, sample_num, px - sc.film.sample_bounds[0], py - sc.film.sample_bounds[1]);
 }
 // SobolSampler::sample_dimension (samplers/sobol.rs:167-185)
-PT_DEV float sample_dimension(const PtScene& sc, uint64_t index, uint32_t dim, int32_t px, int32_t py) {
+#ifdef PT_SAMPLER_NOINLINE
+__device__ __noinline__ float sample_dimension(
+#else
+PT_DEV float sample_dimension(
+#endif
+const PtScene& sc, uint64_t index, uint32_t dim, int32_t px, int32_t py) {
     if (sc.sobol.kind == PT_SAMPLER_HALTON) return halton_sample_dimension(sc.sobol, index, dim);
     float s = sobol_sample_float(sc.sobol, index, dim);
     if (dim == 0 || dim == 1) {

@@ -1,0 +1,414 @@
+// pt_sah.hip -- the SAH binary build on the GPU (src/accelerators/bvh/build/sah.rs:31-170 via build/node.rs; the host version is
+// Builder::build in pt_bvh.cpp).
+//
+// The reference recurses over ranges of one primitive array; a range's split depends only on the range, so all ranges of one tree
+// level can be split at once.  One level = seven small kernels over the item array:
+//   k_sah_bounds     every item of a new node adds its box and centroid to the node's bounds (ordered-uint atomicMin / Max; waves whose
+//                    64 items belong to one node reduce in registers first, so the root costs 16 K atomics per word, not 1 M)
+//   k_sah_decide     per new node: leaf (n <= maxnodeprims, or no centroid extent), else the split axis = widest centroid axis
+//   k_sah_buckets    every item of a splitting node: its bucket (12 buckets over the centroid bounds: one subtract, one IEEE divide,
+//                    floor), bucket counts and bucket boxes by atomics
+//   k_sah_split      per splitting node: the 11 candidate costs with the reference's own loops and f32 order, the cheapest bucket, the two
+//                    children's ranges (left count = the counts of the buckets up to it); new node numbers from one atomic counter
+//   k_sah_flags + exclusive scan + k_sah_scatter   the stable partition of every splitting range at once: an item's new place is the
+//                    range's start plus its rank among the range's left items (or the split point plus its rank among the right ones)
+// Everything is integer work, exact min / max, or the same f32 expressions as the host's (-ffp-contract=off on both sides), and a stable
+// partition has one result -- so the binary tree and the item order equal the host builder's.  Node NUMBERING differs (level order
+// here); it is only ever link-walked.  What is not done here: the equal-counts fallback of a split that leaves one side empty (it
+// needs a stable sort of the range by centroid) and non-finite bounds -- both raise `fallback` and the caller builds on the host.
+// -0.0 and +0.0 bounds compare equal on the host (first come, first kept) and ordered here (-0 < +0): pt_context.cpp writes zeros of
+// node boxes as +0 for both builders.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "pt_bvh.h"
+
+namespace ptbvh {
+
+namespace {
+
+constexpr int kB = 12;                   // SAH buckets (sah.rs)
+constexpr uint32_t ST_NEW = 0, ST_SPLIT = 1, ST_LEAF = 2;
+
+__device__ inline uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ inline float ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+__device__ inline float fmin_le(float a, float b) { return a <= b ? a : b; }
+__device__ inline float fmax_ge(float a, float b) { return a >= b ? a : b; }
+
+struct SItem { float lo[3], hi[3], c[3]; uint32_t prim; };      // 40 bytes, as the host's Item
+struct SNodes {                           // binary nodes, SoA over node id
+    uint32_t *lo, *hi;                    // item range
+    uint32_t* nb;                         // [12][cap]: ordered-uint bounds of the items (lo xyz, hi xyz), then of their centroids
+    uint32_t* state;
+    uint32_t *axis, *left, *right, *mid, *minb, *slot;
+    uint32_t cap;
+};
+
+__global__ __launch_bounds__(256) void k_sah_items(const float* __restrict__ raw, uint32_t n, SItem* items, uint32_t* node_of, uint32_t* flags) {
+    const float eps = 1.1920929e-7f * 2.0f;          // BOUND_EPS (build/node.rs:13)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        SItem it;
+        bool bad = false;
+        for (int a = 0; a < 3; a++) {
+            it.lo[a] = raw[(size_t)i * 6 + a] - eps;
+            it.hi[a] = raw[(size_t)i * 6 + 3 + a] + eps;
+            it.c[a] = (it.lo[a] + it.hi[a]) * 0.5f;
+            bad |= !(fabsf(it.lo[a]) <= 3.4028235e38f) || !(fabsf(it.hi[a]) <= 3.4028235e38f);
+        }
+        it.prim = i;
+        items[i] = it;
+        node_of[i] = 0;
+        if (bad) atomicOr(flags, 1u);
+    }
+}
+__global__ void k_sah_root(SNodes N, uint32_t n, uint32_t* counters) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        N.lo[0] = 0; N.hi[0] = n; N.state[0] = ST_NEW;
+        for (int q = 0; q < 12; q++) N.nb[(size_t)q * N.cap] = (q % 6) < 3 ? 0xffffffffu : 0u;
+        counters[0] = 1;      // nodes allocated
+    }
+}
+// bounds of the new nodes
+__global__ __launch_bounds__(256) void k_sah_bounds(const SItem* __restrict__ items, const uint32_t* __restrict__ node_of, uint32_t n, SNodes N) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n;
+    const uint32_t nd = in ? node_of[i] : 0xffffffffu;
+    const bool act = in && N.state[nd] == ST_NEW;
+    uint32_t v[12];
+    if (act) {
+        const SItem it = items[i];
+        for (int a = 0; a < 3; a++) { v[a] = f2ord(it.lo[a]); v[3 + a] = f2ord(it.hi[a]); v[6 + a] = f2ord(it.c[a]); v[9 + a] = v[6 + a]; }
+    } else {
+        for (int a = 0; a < 3; a++) { v[a] = 0xffffffffu; v[3 + a] = 0u; v[6 + a] = 0xffffffffu; v[9 + a] = 0u; }
+    }
+    if (__ballot(act) == 0ull) return;
+    // Items of one node are consecutive, so a wave holds a few runs of equal node ids: a segmented scan (min / max are exact in any
+    // order) leaves each run's reduction in its last lane, which alone goes to memory -- 12 atomics per run and wave, not per item.
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t key = act ? nd : 0xffffffffu;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t ko = (uint32_t)__shfl_up((int)key, off, 64);
+        const bool take = lane >= (uint32_t)off && ko == key;
+        for (int k = 0; k < 12; k++) {
+            const uint32_t o = (uint32_t)__shfl_up((int)v[k], off, 64);
+            if (take) v[k] = (k % 6) < 3 ? min(v[k], o) : max(v[k], o);
+        }
+    }
+    const uint32_t kn = (uint32_t)__shfl_down((int)key, 1, 64);
+    if (act && (lane == 63 || kn != key)) {
+        for (int k = 0; k < 12; k++) {
+            if ((k % 6) < 3) atomicMin(&N.nb[(size_t)k * N.cap + nd], v[k]);
+            else atomicMax(&N.nb[(size_t)k * N.cap + nd], v[k]);
+        }
+    }
+}
+__device__ inline int max_extent(const float* lo, const float* hi) {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx > dy && dx > dz) return 0;
+    if (dy > dz) return 1;
+    return 2;
+}
+// per new node: leaf or split axis; splitting nodes get a slot of the bucket arrays
+__global__ __launch_bounds__(256) void k_sah_decide(SNodes N, const uint32_t* act, uint32_t n_act, uint32_t max_prims, uint32_t* bcnt, uint32_t* bbox, uint32_t* counters) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_act) return;
+    const uint32_t nd = act[k];
+    const uint32_t n = N.hi[nd] - N.lo[nd];
+    float clo[3], chi[3];
+    for (int a = 0; a < 3; a++) { clo[a] = ord2f(N.nb[(size_t)(6 + a) * N.cap + nd]); chi[a] = ord2f(N.nb[(size_t)(9 + a) * N.cap + nd]); }
+    const int dim = max_extent(clo, chi);
+    if (n <= max_prims || clo[dim] == chi[dim]) { N.state[nd] = ST_LEAF; atomicAdd(&counters[3], 1u); return; }
+    N.state[nd] = ST_SPLIT;
+    N.axis[nd] = (uint32_t)dim;
+    const uint32_t s = atomicAdd(&counters[1], 1u);      // slot among this level's splitting nodes
+    N.slot[nd] = s;
+    for (int b = 0; b < kB; b++) {
+        bcnt[(size_t)s * kB + b] = 0;
+        for (int a = 0; a < 3; a++) { bbox[((size_t)s * kB + b) * 6 + a] = 0xffffffffu; bbox[((size_t)s * kB + b) * 6 + 3 + a] = 0u; }
+    }
+}
+__device__ inline int bucket_of(const float* clo, const float* chi, const float* c, int dim) {      // sah.rs bucket index (pt_bvh.cpp bucket_index)
+    float o = c[dim] - clo[dim];
+    if (chi[dim] > clo[dim]) o = o / (chi[dim] - clo[dim]);
+    int b = (int)floorf((float)kB * o);
+    if (b > kB - 1) b = kB - 1;
+    if (b < 0) b = 0;
+    return b;
+}
+// Bucket counts and boxes.  At the top of the tree a million items would queue on 84 words; a workgroup therefore gathers the items of
+// ITS FIRST node (near the root: all of them) in LDS and sends one atomic per used word, the others go straight to memory (deep in
+// the tree the nodes are small and the words many).
+__global__ __launch_bounds__(256) void k_sah_buckets(const SItem* __restrict__ items, const uint32_t* __restrict__ node_of, uint32_t n, SNodes N, uint32_t* bcnt, uint32_t* bbox,
+                                                    uint8_t* bucket) {
+    __shared__ uint32_t s_cnt[kB];
+    __shared__ uint32_t s_box[kB * 6];
+    __shared__ uint32_t s_node;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < kB) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < kB * 6) s_box[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
+    if (threadIdx.x == 0) s_node = node_of[blockIdx.x * blockDim.x];
+    __syncthreads();
+    const uint32_t first = s_node;
+    const bool first_splits = N.state[first] == ST_SPLIT;
+    if (i < n) {
+        const uint32_t nd = node_of[i];
+        if (N.state[nd] == ST_SPLIT) {
+            const SItem it = items[i];
+            const int dim = (int)N.axis[nd];
+            float clo[3], chi[3];
+            for (int a = 0; a < 3; a++) { clo[a] = ord2f(N.nb[(size_t)(6 + a) * N.cap + nd]); chi[a] = ord2f(N.nb[(size_t)(9 + a) * N.cap + nd]); }
+            const int b = bucket_of(clo, chi, it.c, dim);
+            bucket[i] = (uint8_t)b;
+            if (nd == first) {
+                atomicAdd(&s_cnt[b], 1u);
+                for (int a = 0; a < 3; a++) { atomicMin(&s_box[b * 6 + a], f2ord(it.lo[a])); atomicMax(&s_box[b * 6 + 3 + a], f2ord(it.hi[a])); }
+            } else {
+                const size_t s = (size_t)N.slot[nd] * kB + b;
+                atomicAdd(&bcnt[s], 1u);
+                for (int a = 0; a < 3; a++) { atomicMin(&bbox[s * 6 + a], f2ord(it.lo[a])); atomicMax(&bbox[s * 6 + 3 + a], f2ord(it.hi[a])); }
+            }
+        }
+    }
+    __syncthreads();
+    if (first_splits) {
+        const size_t s0 = (size_t)N.slot[first] * kB;
+        if (threadIdx.x < kB && s_cnt[threadIdx.x]) atomicAdd(&bcnt[s0 + threadIdx.x], s_cnt[threadIdx.x]);
+        if (threadIdx.x < kB * 6 && s_cnt[threadIdx.x / 6]) {
+            if ((threadIdx.x % 6) < 3) atomicMin(&bbox[s0 * 6 + threadIdx.x], s_box[threadIdx.x]);
+            else atomicMax(&bbox[s0 * 6 + threadIdx.x], s_box[threadIdx.x]);
+        }
+    }
+}
+struct Box { float lo[3], hi[3]; };
+__device__ inline void box_grow(Box& b, const Box& o) { for (int i = 0; i < 3; i++) { b.lo[i] = fmin_le(b.lo[i], o.lo[i]); b.hi[i] = fmax_ge(b.hi[i], o.hi[i]); } }
+__device__ inline float box_area(const Box& b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return 2.0f * (dx * dy + dx * dz + dy * dz);
+}
+// per splitting node: the SAH costs in the host's order of operations, the split, the children
+__global__ __launch_bounds__(64) void k_sah_split(SNodes N, const uint32_t* act, uint32_t n_act, const uint32_t* bcnt, const uint32_t* bbox, uint32_t* next_act, uint32_t* counters,
+                                                 uint32_t* flags) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_act) return;
+    const uint32_t nd = act[k];
+    if (N.state[nd] != ST_SPLIT) return;
+    const size_t s = (size_t)N.slot[nd] * kB;
+    int count[kB];
+    Box bb[kB];
+    for (int b = 0; b < kB; b++) {
+        count[b] = (int)bcnt[s + b];
+        for (int a = 0; a < 3; a++) {
+            // an empty bucket keeps box_empty()'s +max / lowest (the atomics started from the ordered images of +inf-ish extremes: map back)
+            const uint32_t lo = bbox[(s + b) * 6 + a], hi = bbox[(s + b) * 6 + 3 + a];
+            bb[b].lo[a] = count[b] ? ord2f(lo) : 3.4028235e38f;
+            bb[b].hi[a] = count[b] ? ord2f(hi) : -3.4028235e38f;
+        }
+    }
+    Box bounds;
+    for (int a = 0; a < 3; a++) { bounds.lo[a] = ord2f(N.nb[(size_t)a * N.cap + nd]); bounds.hi[a] = ord2f(N.nb[(size_t)(3 + a) * N.cap + nd]); }
+    const float total_area = box_area(bounds);
+    float cost[kB - 1];
+    for (int i = 0; i < kB - 1; i++) {
+        Box b0 = bb[i], b1 = bb[i + 1];
+        int c0 = 0, c1 = 0;
+        for (int j = 0; j <= i; j++) { box_grow(b0, bb[j]); c0 += count[j]; }
+        for (int j = i + 1; j < kB; j++) { box_grow(b1, bb[j]); c1 += count[j]; }
+        cost[i] = 1.0f + ((float)c0 * box_area(b0) + (float)c1 * box_area(b1)) / total_area;
+    }
+    float min_cost = cost[0];
+    int min_bucket = 0;
+    for (int i = 1; i < kB - 1; i++)
+        if (cost[i] < min_cost) { min_cost = cost[i]; min_bucket = i; }
+    uint32_t nl = 0;
+    for (int b = 0; b <= min_bucket; b++) nl += (uint32_t)count[b];
+    const uint32_t lo = N.lo[nd], hi = N.hi[nd];
+    if (nl == 0 || nl == hi - lo) { atomicOr(flags, 2u); N.state[nd] = ST_LEAF; return; }      // equal-counts fallback: the host builds
+    const uint32_t c = atomicAdd(&counters[0], 2u);
+    if (c + 2u > N.cap) { atomicOr(flags, 4u); N.state[nd] = ST_LEAF; return; }
+    N.minb[nd] = (uint32_t)min_bucket;
+    N.mid[nd] = lo + nl;
+    N.left[nd] = c; N.right[nd] = c + 1u;
+    for (uint32_t ch = 0; ch < 2; ch++) {
+        const uint32_t id = c + ch;
+        N.lo[id] = ch ? lo + nl : lo;
+        N.hi[id] = ch ? hi : lo + nl;
+        N.state[id] = ST_NEW;
+        for (int q = 0; q < 12; q++) N.nb[(size_t)q * N.cap + id] = (q % 6) < 3 ? 0xffffffffu : 0u;
+    }
+    const uint32_t a = atomicAdd(&counters[2], 2u);
+    next_act[a] = c; next_act[a + 1] = c + 1u;
+}
+__global__ __launch_bounds__(256) void k_sah_flags(const uint32_t* __restrict__ node_of, const uint8_t* __restrict__ bucket, uint32_t n, SNodes N, uint32_t* flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nd = node_of[i];
+    flag[i] = (N.state[nd] == ST_SPLIT && (uint32_t)bucket[i] <= N.minb[nd]) ? 1u : 0u;
+}
+// exclusive prefix sum of flag[] in three steps: 1024-item blocks, the block totals by one workgroup, add back
+__global__ __launch_bounds__(256) void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t n, uint32_t* out, uint32_t* totals) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
+    uint32_t v[4], sum = 0;
+    for (int k = 0; k < 4; k++) { v[k] = base + k < n ? in[base + k] : 0u; sum += v[k]; }
+    uint32_t inc = sum;
+    const uint32_t lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= (uint32_t)off) inc += o; }
+    if (lane == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += s_w[w];
+    uint32_t run = wbase + inc - sum;
+    for (int k = 0; k < 4; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 255) totals[blockIdx.x] = wbase + inc;
+}
+__global__ __launch_bounds__(1024) void k_scan_totals(uint32_t* totals, uint32_t n_blocks) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? totals[i] : 0u;
+        uint32_t inc = v;
+        const uint32_t lane = threadIdx.x & 63;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= (uint32_t)off) inc += o; }
+        if (lane == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += s_w[w];
+        const uint32_t carry = s_carry;
+        if (i < n_blocks) totals[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wbase + inc;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_sah_scatter(const SItem* __restrict__ src, const uint32_t* __restrict__ node_of, const uint32_t* __restrict__ flag,
+                                                    const uint32_t* __restrict__ pre, const uint32_t* __restrict__ totals, uint32_t n, SNodes N, SItem* dst, uint32_t* node_of_dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nd = node_of[i];
+    uint32_t to = i, child = nd;
+    if (N.state[nd] == ST_SPLIT) {
+        const uint32_t lo = N.lo[nd];
+        const uint32_t rank_l = (pre[i] + totals[i >> 10]) - (pre[lo] + totals[lo >> 10]);        // left items of the range before this one
+        if (flag[i]) { to = lo + rank_l; child = N.left[nd]; }
+        else { to = N.mid[nd] + (i - lo - rank_l); child = N.right[nd]; }
+    }
+    dst[to] = src[i];
+    node_of_dst[to] = child;
+}
+__global__ __launch_bounds__(256) void k_sah_export(SNodes N, uint32_t n_nodes, LbvhNode* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_nodes) return;
+    LbvhNode o;
+    for (int a = 0; a < 3; a++) { o.lo[a] = ord2f(N.nb[(size_t)a * N.cap + k]); o.hi[a] = ord2f(N.nb[(size_t)(3 + a) * N.cap + k]); }
+    if (N.state[k] == ST_LEAF) { o.left = -1; o.right = -1; o.first = N.lo[k]; o.count = N.hi[k] - N.lo[k]; o.axis = 0; }
+    else { o.left = (int32_t)N.left[k]; o.right = (int32_t)N.right[k]; o.first = 0; o.count = 0; o.axis = (uint8_t)N.axis[k]; }
+    out[k] = o;
+}
+__global__ __launch_bounds__(256) void k_sah_order(const SItem* __restrict__ items, uint32_t n, uint32_t* order) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[i] = items[i].prim;
+}
+
+struct Scratch {
+    void* p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+#define SAH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { if (err) *err = e_; return -1; } } while (0)
+
+}  // namespace
+
+// SAH binary build on the device.  raw_bounds = n x {lo[3], hi[3]} (host memory, not yet inflated).  On success (0): order[k] = primitive
+// stored k-th, nodes[0] the root.  1: the host has to build instead (equal-counts fallback needed, non-finite bounds, too few items);
+// -1: HIP error.
+int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, std::vector<uint32_t>* order, std::vector<LbvhNode>* nodes, hipError_t* err) {
+    const bool trace = std::getenv("PBRTGPU_BUILD_TRACE") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    if (err) *err = hipSuccess;
+    if (n < 2 || n > (1u << 26) || max_prims < 2) return 1;
+    const uint32_t cap = 2u * n + 2u;
+    const uint32_t max_split = n / (max_prims + 1u) + 2u;          // nodes splitting in one level hold more than max_prims items each
+    Scratch d_raw, d_items[2], d_nodeof[2], d_nodes, d_bcnt, d_bbox, d_bucket, d_flag, d_pre, d_tot, d_act[2], d_small, d_export, d_order;
+    SAH_TRY(d_raw.alloc((size_t)n * 24));
+    for (int i = 0; i < 2; i++) { SAH_TRY(d_items[i].alloc((size_t)n * sizeof(SItem))); SAH_TRY(d_nodeof[i].alloc((size_t)n * 4)); SAH_TRY(d_act[i].alloc((size_t)cap * 4)); }
+    SAH_TRY(d_nodes.alloc((size_t)cap * 4 * 21));
+    SAH_TRY(d_bcnt.alloc((size_t)max_split * kB * 4));
+    SAH_TRY(d_bbox.alloc((size_t)max_split * kB * 6 * 4));
+    SAH_TRY(d_bucket.alloc(n));
+    SAH_TRY(d_flag.alloc((size_t)n * 4));
+    SAH_TRY(d_pre.alloc((size_t)n * 4));
+    const uint32_t n_sblocks = (n + 1023u) / 1024u;
+    SAH_TRY(d_tot.alloc((size_t)n_sblocks * 4));
+    SAH_TRY(d_small.alloc(64));
+    SNodes N;
+    {
+        uint32_t* b = d_nodes.as<uint32_t>();
+        N.cap = cap;
+        N.lo = b; N.hi = b + cap; N.nb = b + 2 * (size_t)cap;
+        uint32_t* r = b + 14 * (size_t)cap;
+        N.state = r; N.axis = r + cap; N.left = r + 2 * (size_t)cap; N.right = r + 3 * (size_t)cap; N.mid = r + 4 * (size_t)cap; N.minb = r + 5 * (size_t)cap; N.slot = r + 6 * (size_t)cap;
+    }
+    uint32_t* counters = d_small.as<uint32_t>();       // [0] nodes, [1] splitting this level, [2] next active, [3] leaves
+    uint32_t* flags = counters + 8;
+    SAH_TRY(hipMemsetAsync(d_small.p, 0, 64, st));
+    SAH_TRY(hipMemcpyAsync(d_raw.p, raw_bounds, (size_t)n * 24, hipMemcpyHostToDevice, st));
+    const uint32_t blocks = (n + 255u) / 256u;
+    k_sah_items<<<blocks < 4096u ? blocks : 4096u, 256, 0, st>>>(d_raw.as<float>(), n, d_items[0].as<SItem>(), d_nodeof[0].as<uint32_t>(), flags);
+    k_sah_root<<<1, 64, 0, st>>>(N, n, counters);
+    const uint32_t root_act = 0;
+    SAH_TRY(hipMemcpyAsync(d_act[0].p, &root_act, 4, hipMemcpyHostToDevice, st));
+    const double t1 = now();
+    int cur = 0, acur = 0;
+    uint32_t n_act = 1, levels = 0;
+    uint32_t host_small[12];
+    while (n_act > 0) {
+        if (++levels > 512u) return 1;
+        SItem* items = d_items[cur].as<SItem>();
+        uint32_t* node_of = d_nodeof[cur].as<uint32_t>();
+        const uint32_t* act = d_act[acur].as<uint32_t>();
+        uint32_t* next_act = d_act[acur ^ 1].as<uint32_t>();
+        SAH_TRY(hipMemsetAsync(counters + 1, 0, 8, st));         // splitting / next-active counts of this level
+        k_sah_bounds<<<blocks, 256, 0, st>>>(items, node_of, n, N);
+        k_sah_decide<<<(n_act + 255u) / 256u, 256, 0, st>>>(N, act, n_act, max_prims, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), counters);
+        k_sah_buckets<<<blocks, 256, 0, st>>>(items, node_of, n, N, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), d_bucket.as<uint8_t>());
+        k_sah_split<<<(n_act + 63u) / 64u, 64, 0, st>>>(N, act, n_act, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), next_act, counters, flags);
+        k_sah_flags<<<blocks, 256, 0, st>>>(node_of, d_bucket.as<uint8_t>(), n, N, d_flag.as<uint32_t>());
+        k_scan_blocks<<<n_sblocks, 256, 0, st>>>(d_flag.as<uint32_t>(), n, d_pre.as<uint32_t>(), d_tot.as<uint32_t>());
+        k_scan_totals<<<1, 1024, 0, st>>>(d_tot.as<uint32_t>(), n_sblocks);
+        k_sah_scatter<<<blocks, 256, 0, st>>>(items, node_of, d_flag.as<uint32_t>(), d_pre.as<uint32_t>(), d_tot.as<uint32_t>(), n, N, d_items[cur ^ 1].as<SItem>(),
+                                              d_nodeof[cur ^ 1].as<uint32_t>());
+        SAH_TRY(hipGetLastError());
+        SAH_TRY(hipMemcpyAsync(host_small, counters, 48, hipMemcpyDeviceToHost, st));
+        SAH_TRY(hipStreamSynchronize(st));
+        if (host_small[8] != 0) {
+            if (trace) std::fprintf(stderr, "[bvh] device SAH gives up at level %u: flags %u (1 non-finite bounds, 2 a split left one side empty, 4 node capacity)\n", levels, host_small[8]);
+            return 1;
+        }
+        n_act = host_small[2];
+        cur ^= 1; acur ^= 1;
+    }
+    const double t2 = now();
+    const uint32_t n_nodes = host_small[0];
+    SAH_TRY(d_export.alloc((size_t)n_nodes * sizeof(LbvhNode)));
+    SAH_TRY(d_order.alloc((size_t)n * 4));
+    k_sah_export<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(N, n_nodes, d_export.as<LbvhNode>());
+    k_sah_order<<<blocks, 256, 0, st>>>(d_items[cur].as<SItem>(), n, d_order.as<uint32_t>());
+    SAH_TRY(hipGetLastError());
+    nodes->resize(n_nodes);
+    order->resize(n);
+    SAH_TRY(hipMemcpyAsync(nodes->data(), d_export.p, (size_t)n_nodes * sizeof(LbvhNode), hipMemcpyDeviceToHost, st));
+    SAH_TRY(hipMemcpyAsync(order->data(), d_order.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    SAH_TRY(hipStreamSynchronize(st));
+    if (trace) std::fprintf(stderr, "[bvh] device SAH: %u items, %u nodes, %u levels: setup %.2f levels %.2f read-back %.2f ms\n", n, n_nodes, levels, t1 - t0, t2 - t1, now() - t2);
+    return 0;
+}
+
+}  // namespace ptbvh

@@ -73,7 +73,7 @@ def test_auto_picks_device_from_64k_primitives():
             sd = scenes.rt1m(n, res=16, spp=1, max_depth=1)
             sd.desc.split_method = 1
             assert ctx.upload(sd).bvh_on_device == want
-        sd.desc.split_method = 0           # SAH always builds on the host
+        sd.desc.split_method = 2           # "middle" (and "equal") always build on the host
         ctx.set_bvh_build(DEVICE)
         assert ctx.upload(sd).bvh_on_device == 0
         with pytest.raises(pkg.PtError):
@@ -98,3 +98,61 @@ def test_instanced_scene_with_device_built_object_trees(oracle):
         osc.close()
     finally:
         ctx.close()
+
+
+# ---- the SAH build on the GPU (pt_sah.hip)
+@pytest.mark.parametrize("n,leaf", [(12, 4), (13, 2), (65, 4), (1024, 4), (1025, 3), (4000, 4), (70001, 4), (300000, 8), (300000, 2), (1000000, 4)])
+def test_device_sah_matches_host_sah(n, leaf, oracle):
+    """Level-by-level SAH on the device against the host's recursive builder: byte-identical node and record arrays, and the leaf
+    order the oracle's restatement of sah.rs produces."""
+    sd = scenes.rt1m(n, res=16, spp=1, max_depth=1)
+    sd.desc.split_method = 0
+    sd.desc.max_node_prims = leaf
+    host, dev = _digests(sd)
+    assert host == dev
+    if n <= 300000:
+        ctx = pkg.Context(0)
+        try:
+            ctx.set_bvh_build(DEVICE)
+            info = ctx.upload(sd)
+            assert info.bvh_on_device == 1
+            osc = oracle.scene(sd)
+            assert (osc.info.n_nodes, osc.info.n_leaves) == (info.n_nodes, info.n_leaves)
+            o, d, tmax = random_rays(info, 20000, 9)
+            g = ctx.trace_closest(o, d, tmax)
+            r, _ = osc.trace_closest(o, d, tmax)
+            assert np.array_equal(g["prim"], r["prim"]) and np.array_equal(bits(g["t"]), bits(r["t"]))
+            osc.close()
+        finally:
+            ctx.close()
+
+
+def test_device_sah_clustered_and_feature_scenes(oracle):
+    """Clustered geometry (deep, lopsided levels), a scene with spheres and one with instances (every primitive list goes through the
+    device builder)."""
+    rng = np.random.default_rng(12)
+    b = scenes.SceneBuilder()
+    b.look_at((0, 0, -5), (0, 0, 0), (0, 1, 0)); b.camera_perspective(fov=40.0)
+    b.film(xresolution=16, yresolution=16); b.pixel_filter_box(); b.sampler_sobol(1); b.integrator_path(maxdepth=1)
+    b.accelerator_bvh("sah", 4)
+    b.material_matte((0.5, 0.5, 0.5))
+    centers = np.concatenate([rng.normal((0.5, 0.2, -0.3), 0.1, (60000, 3)), rng.normal((-0.7, -0.6, 0.6), 0.05, (30000, 3)),
+                              rng.uniform(-2, 2, (500, 3))]).astype(np.float32)
+    off = rng.uniform(-0.002, 0.002, (len(centers), 3, 3)).astype(np.float32)
+    verts = (centers[:, None, :] + off).reshape(-1, 3)
+    b.shape_trianglemesh_fast(verts, np.arange(len(verts)), twosided=True)
+    host, dev = _digests(b.build())
+    assert host == dev
+    for sd in (fs.scene_spheres(), fs.scene_instances(split="sah")):
+        ctx = pkg.Context(0)
+        try:
+            ctx.set_bvh_build(DEVICE)
+            info = ctx.upload(sd)
+            osc = oracle.scene(sd)
+            sb = list(info.sample_bounds)
+            cx, cy = (sb[0] + sb[2]) // 2, (sb[1] + sb[3]) // 2
+            tile = (cx - 8, cy - 8, cx + 8, cy + 8)
+            assert np.array_equal(bits(ctx.radiance_samples(tile)), bits(osc.radiance_samples(tile)))
+            osc.close()
+        finally:
+            ctx.close()
