@@ -88,4 +88,11 @@ def test_cpp_driver_gpus_1(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     subprocess.check_call([exe, scene, "-o", a, "--pixelsamples", "4", "--quiet"], env=env)
     subprocess.check_call([exe, scene, "-o", b, "--pixelsamples", "4", "--quiet", "--gpus", "1"], env=env)
-    assert open(a, "rb").read() == open(b, "rb").read()
+    def pfm(path):
+        with open(path, "rb") as f:
+            assert f.readline().strip() == b"PF"
+            w, h = map(int, f.readline().split())
+            f.readline()
+            return np.frombuffer(f.read(), "<f4").reshape(h, w, 3)
+    ia, ib = pfm(a), pfm(b)        # two renders: pixels with edge-split samples (float atomics) may differ in the last bits
+    assert ia.shape == ib.shape and np.allclose(ia, ib, rtol=2e-6, atol=1e-7) and (ia.view(np.uint32) == ib.view(np.uint32)).mean() > 0.95
