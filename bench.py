@@ -241,6 +241,7 @@ def main():
                     "requests_per_launch": round(reqs / launches, 1), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
                     "nodes_per_ray": round(cnt["nodes_visited"] / max(1.0, n_rays), 2), "tris_per_ray": round(cnt["tris_tested"] / max(1.0, n_rays), 2),
                     "trace_share_of_render": round(cnt["trace_ms"] / max(1e-9, cnt["render_ms"]), 3),
+                    "shade_share_of_render": round(cnt["shade_ms"] / max(1e-9, cnt["render_ms"]), 3),
                     # informational: SURVEY.md section 8d's algorithmic bytes (cache-served, can exceed the HBM peak), what HBM must move at least,
                     # and the measured L2-miss (fabric) traffic where profiles/ holds it for this workload
                     "algorithmic_gbps": round((alg_bytes / launches) / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else 0.0,

@@ -64,6 +64,13 @@ uint32_t orc_bvh_ordered_prims(const orc_scene* s, uint32_t* out, uint32_t cap) 
     return n;
 }
 
+// diagnostic: node visits by tree depth (tools/depth_hist.py).  enable = 1 computes the world tree's depths and starts counting.
+void orc_depth_hist(orc_scene* s, int enable, uint64_t* out32) {
+    if (enable) { s->sc.bvh.compute_depths(); for (auto& h : g_depth_hist) h = 0; g_depth_hist_on = true; return; }
+    g_depth_hist_on = false;
+    for (int i = 0; i < 32; i++) out32[i] = g_depth_hist[i];
+}
+
 static void fill_counters(const RayCounters& rc, pt_counters* c) {
     if (!c) return;
     c->camera_rays += rc.camera; c->regular_rays += rc.regular; c->shadow_rays += rc.shadow;

@@ -9,6 +9,7 @@
 #include "orc_sampling.hpp"
 #include <algorithm>
 #include <memory>
+#include <atomic>
 #include <vector>
 
 namespace orc {
@@ -603,8 +604,26 @@ inline uint32_t order_entry(uint32_t hit_mask, uint32_t node_idx) {
     return order;
 }
 
+// diagnostic (tools/depth_hist.py): node visits by 4-wide tree depth, summed over every traversal while enabled
+static std::atomic<uint64_t> g_depth_hist[32];
+static std::atomic<bool> g_depth_hist_on{false};
+
 struct QBVH {
     const Geometry* geom = nullptr;
+    mutable std::vector<uint8_t> depth_of_node;      // filled by compute_depths() for the diagnostic above
+    void compute_depths() const {
+        depth_of_node.assign(nodes.size(), 0);
+        std::vector<size_t> cur{0}, nxt;
+        for (uint8_t d = 0; !cur.empty(); d = d < 31 ? d + 1 : d) {
+            nxt.clear();
+            for (size_t n : cur) {
+                depth_of_node[n] = d;
+                if (nodes[n].is_leaf) continue;
+                for (int k = 0; k < 4; k++) if (nodes[n].children[k] != kEmpty && !nodes[nodes[n].children[k]].is_leaf) nxt.push_back(nodes[n].children[k]);
+            }
+            cur.swap(nxt);
+        }
+    }
     std::vector<size_t> prims;     // ordered primitive numbers
     std::vector<QNode> nodes;
     Bounds3 bounds;
@@ -742,6 +761,7 @@ struct QBVH {
             const QNode& nd = nodes[cur];
             if (nd.is_leaf == 0) {
                 if (st) st->nodes++;
+                if (g_depth_hist_on.load(std::memory_order_relaxed) && !depth_of_node.empty()) g_depth_hist[depth_of_node[cur]].fetch_add(1, std::memory_order_relaxed);
                 if (step_log) step_log->push_back(0);
                 uint32_t hit_mask = test_aabb(nd, org, idir, sign, tmin, tmax);
                 if (hit_mask != 0) {
@@ -790,6 +810,7 @@ struct QBVH {
             const QNode& nd = nodes[cur];
             if (nd.is_leaf == 0) {
                 if (st) st->nodes++;
+                if (g_depth_hist_on.load(std::memory_order_relaxed) && !depth_of_node.empty()) g_depth_hist[depth_of_node[cur]].fetch_add(1, std::memory_order_relaxed);
                 if (step_log) step_log->push_back(0);
                 uint32_t hit_mask = test_aabb(nd, org, idir, sign, tmin, tmax);
                 if (hit_mask != 0) {

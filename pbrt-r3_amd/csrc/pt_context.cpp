@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/pbrtgpu.h"
@@ -1094,6 +1095,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     // RT1M.  64 M slots are ~14.4 GB of path state + 1.5 GB of queues -- HBM3E is 288 GB.
     size_t pool_target = (size_t)64 << 20;
     if (const char* e = std::getenv("PBRTGPU_POOL_PATHS")) pool_target = std::max<size_t>(65536, std::strtoull(e, nullptr, 10));
+    pool_target = std::min<size_t>(pool_target, (size_t)1 << 28);      // k_shade keeps (path id | queue bits) in one word
     {   // never more than half of what the device has free
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ctx->pool_paths < pool_target) {
@@ -1151,6 +1153,8 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     uint32_t* err = ctx->d_err.as<uint32_t>();
     size_t ev_i = 0;
     std::vector<std::pair<size_t, int>> spans;   // (event index, kind) kind 0 = trace, 1 = shade
+    const bool bounce_log = std::getenv("PBRTGPU_BOUNCE_LOG") != nullptr;
+    std::vector<std::array<uint32_t, 3>> bounce_counts;
     const bool no_events = std::getenv("PBRTGPU_NO_EVENTS") != nullptr;   // experiment: cost of the per-bounce event records
 
     hipEvent_t ev_begin = get_event(ctx, ev_i++), ev_end = get_event(ctx, ev_i++);
@@ -1257,6 +1261,12 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 auto bounce = [&]() -> pt_status {
                     const bool timed = !no_events;
                     hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+                    if (bounce_log) {          // diagnostic (PBRTGPU_BOUNCE_LOG): queue sizes going into this bounce; costs a sync per bounce
+                        uint32_t qc[PT_Q_PROBE + 1];
+                        PT_HIP(hipMemcpyAsync(qc, Q.counts, sizeof(qc), hipMemcpyDeviceToHost, ctx->stream));
+                        PT_HIP(hipStreamSynchronize(ctx->stream));
+                        bounce_counts.push_back({qc[PT_Q_CUR], qc[PT_Q_SHADOW], qc[PT_Q_PROBE]});
+                    }
                     if (timed) {
                         a = get_event(ctx, ev_i); b = get_event(ctx, ev_i + 1); c = get_event(ctx, ev_i + 2);
                         if (!a || !b || !c) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
@@ -1329,15 +1339,34 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                      100.0 * pr[7] / tot, pr[8] ? (double)(pr[5] + pr[6] + pr[7]) / (double)pr[8] : 0.0, pr[13], 100.0 * pr[12] / tot, 100.0 * pr[10] / tot);
     }
 #endif
+    {   // diagnostic build -DPT_PROFILE_SHADE: where a shading wave's clocks go
+        unsigned long long sp[16];
+        if (ptk_shade_prof_read(sp)) {
+            double tot = 0;
+            for (int k = 0; k < 16; k++) if (k != 12) tot += (double)sp[k];
+            static const char* names[16] = {"surface", "emit+bsdf setup", "grid+pick light", "u_light,u_scat", "light sample+f", "bsdf MIS+probe", "pend stores",
+                                            "u continuation", "continuation", "compaction", "sample tables", "ticket", "", "wait list[item]", "wait path state", "wait record+index"};
+            std::fprintf(stderr, "[shade phases] %llu iterations of 64 paths, %.0f clocks each:", sp[12], sp[12] ? tot / (double)sp[12] : 0.0);
+            for (int k = 0; k < 16; k++) if (k != 12 && sp[k]) std::fprintf(stderr, " %s %.1f%%", names[k], 100.0 * (double)sp[k] / tot);
+            std::fprintf(stderr, "\n");
+        }
+    }
     float ms = 0;
     PT_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
     ctx->render_ms += ms;
+    size_t span_i = 0;
     for (auto& sp : spans) {
         float t_ms = 0, s_ms = 0;
         PT_HIP(hipEventElapsedTime(&t_ms, ctx->ev[sp.first], ctx->ev[sp.first + 1]));
         PT_HIP(hipEventElapsedTime(&s_ms, ctx->ev[sp.first + 1], ctx->ev[sp.first + 2]));
         ctx->trace_ms += t_ms;
         ctx->shade_ms += s_ms;
+        if (bounce_log && span_i < bounce_counts.size()) {
+            const auto& q = bounce_counts[span_i];
+            std::fprintf(stderr, "[bounce %zu] rays: %u continuation + %u shadow + %u probe | trace %.3f ms (%.1f Mrays/s) | resolve + shade %.3f ms (%.2f ns per shaded path)\n", span_i, q[0],
+                         q[1], q[2], t_ms, ((double)q[0] + q[1] + q[2]) / (t_ms * 1e3), s_ms, q[0] ? s_ms * 1e6 / q[0] : 0.0);
+        }
+        span_i++;
     }
     ctx->xyzw_committed = false;
     return PT_OK;

@@ -35,6 +35,7 @@ hipError_t ptk_ao_resolve(hipStream_t st, int grid, const PtScene& sc, const PtP
 hipError_t ptk_expand_tiles(hipStream_t st, const int4* tiles, const uint32_t* tile_off, uint32_t n_tiles, int32_t sb_x0, int32_t sb_y0, uint32_t sb_w,
                             uint32_t* pixels, uint32_t* bitmap, uint32_t* err);
 hipError_t ptk_wavefront_results(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n, const uint8_t* kind, pt_hit* out, uint8_t* occ);
+int ptk_shade_prof_read(unsigned long long* out16);
 int ptk_trace_dist_blocks_per_cu();      // blocks per CU the pooled-leaf traversal kernels were built for (LDS budget)
 hipError_t ptk_rec_init(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t n);
 hipError_t ptk_rec_enter(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtQueues& Qn, const PtRec& R, PtCounters* cnt,

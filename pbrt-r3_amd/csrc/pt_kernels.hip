@@ -155,6 +155,60 @@ struct Sampler {
         return mk2(x, y);
     }
 };
+// A path vertex draws at most eight dimensions (light choice, u_light, u_scattering, the continuation's u, Russian roulette), each a
+// pure function of (index, dimension).  k_shade evaluates all eight as soon as it knows the path's index -- their table loads then
+// overlap the reconstruction of the hit instead of stalling the wave five times -- and the sampler hands them out by position.
+#define PT_PRE_DIMS 8
+struct SamplerPre {
+    Sampler s;
+    float q0, q1, q2, q3, q4, q5, q6, q7;      // scalars, not an array: a select chain over an array becomes an indexed scratch access
+    uint32_t dim0;
+    bool have;               // false: every draw is evaluated where it is made (Halton: a digit loop per dimension, no loads to overlap)
+    PT_DEV void begin(const PtScene& sc) {
+        dim0 = s.dim;
+        q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = 0.0f;
+        const PtSobol& sb = sc.sobol;
+        // the byte-table form of sobol_bits for eight consecutive dimensions at once: every load is issued before the first is used
+        have = sb.kind != PT_SAMPLER_HALTON && dim0 >= 2u && dim0 + PT_PRE_DIMS <= sb.n_tab_dims && (s.index >> 56) == 0;
+        if (have) {
+            const uint32_t lo = (uint32_t)s.index, hi = (uint32_t)(s.index >> 32);
+            const uint32_t* T = sb.bytetab + (size_t)dim0 * (7u * 256u);
+            const uint32_t i0 = lo & 255u, i1 = 256u + ((lo >> 8) & 255u), i2 = 512u + ((lo >> 16) & 255u), i3 = 768u + (lo >> 24);
+#define PT_PRE_LOAD(k) const uint32_t a##k = T[k * 1792u + i0], b##k = T[k * 1792u + i1], c##k = T[k * 1792u + i2], d##k = T[k * 1792u + i3];
+            PT_PRE_LOAD(0) PT_PRE_LOAD(1) PT_PRE_LOAD(2) PT_PRE_LOAD(3) PT_PRE_LOAD(4) PT_PRE_LOAD(5) PT_PRE_LOAD(6) PT_PRE_LOAD(7)
+#undef PT_PRE_LOAD
+            uint32_t v0 = a0 ^ b0 ^ c0 ^ d0, v1 = a1 ^ b1 ^ c1 ^ d1, v2 = a2 ^ b2 ^ c2 ^ d2, v3 = a3 ^ b3 ^ c3 ^ d3, v4 = a4 ^ b4 ^ c4 ^ d4, v5 = a5 ^ b5 ^ c5 ^ d5,
+                     v6 = a6 ^ b6 ^ c6 ^ d6, v7 = a7 ^ b7 ^ c7 ^ d7;
+            if (__ballot(hi != 0u)) {        // indices of 2^32 and more (a byte of zero selects no column: its table entry is 0)
+                const uint32_t j0 = 1024u + (hi & 255u), j1 = 1280u + ((hi >> 8) & 255u), j2 = 1536u + ((hi >> 16) & 255u);
+#define PT_PRE_HI(k) v##k ^= T[k * 1792u + j0] ^ T[k * 1792u + j1] ^ T[k * 1792u + j2];
+                PT_PRE_HI(0) PT_PRE_HI(1) PT_PRE_HI(2) PT_PRE_HI(3) PT_PRE_HI(4) PT_PRE_HI(5) PT_PRE_HI(6) PT_PRE_HI(7)
+#undef PT_PRE_HI
+            }
+#define PT_PRE_F(v) fminf((float)((double)(v) * 2.3283064365386963e-10), PT_ONE_MINUS_EPS)
+            q0 = PT_PRE_F(v0); q1 = PT_PRE_F(v1); q2 = PT_PRE_F(v2); q3 = PT_PRE_F(v3); q4 = PT_PRE_F(v4); q5 = PT_PRE_F(v5); q6 = PT_PRE_F(v6); q7 = PT_PRE_F(v7);
+#undef PT_PRE_F
+        }
+    }
+    static PT_DEV float pick8(uint32_t k, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {     // by value: nothing to index
+        float r = a0;
+        r = k == 1u ? a1 : r; r = k == 2u ? a2 : r; r = k == 3u ? a3 : r; r = k == 4u ? a4 : r; r = k == 5u ? a5 : r; r = k == 6u ? a6 : r; r = k == 7u ? a7 : r;
+        return r;
+    }
+    PT_DEV float pick(uint32_t k) const { return pick8(k, q0, q1, q2, q3, q4, q5, q6, q7); }
+    PT_DEV float get_1d(const PtScene& sc) {
+        if (!have || s.dim - dim0 >= PT_PRE_DIMS) return s.get_1d(sc);
+        float x = pick(s.dim - dim0);
+        s.dim += 1;
+        return x;
+    }
+    PT_DEV V2 get_2d(const PtScene& sc) {
+        if (!have || s.dim - dim0 + 1u >= PT_PRE_DIMS) return s.get_2d(sc);
+        V2 r = mk2(pick(s.dim - dim0), pick(s.dim - dim0 + 1u));
+        s.dim += 2;
+        return r;
+    }
+};
 
 // ============================================================ camera
 PT_DEV V3 xform_point(const float* m, V3 p) {
@@ -1601,23 +1655,24 @@ PT_DEV bool make_surf_tv(const PtScene& sc, V3 ro, V3 rd, const TriVerts& tv, ui
     *t_out = h.t;
     return true;
 }
-PT_DEV bool make_surf(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, float* t_out) {
-    const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)rec * 3;
-    float4 a = q[0], b = q[1], c = q[2];
+// (a, b, c): the three 16-byte rows of leaf record `rec`, loaded by the caller (k_shade starts that load before anything else)
+PT_DEV bool make_surf_rec(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, float4 a, float4 b, float4 c, Surf& s, float* t_out) {
     TriVerts tv;
     tv.p0 = mk3(a.x, a.y, a.z); tv.prim = __float_as_uint(a.w);
     tv.p1 = mk3(b.x, b.y, b.z); tv.flags = __float_as_uint(b.w);
     tv.p2 = mk3(c.x, c.y, c.z);
     return make_surf_tv(sc, ro, rd, tv, __float_as_uint(c.w), s, t_out, rec);
 }
+PT_DEV bool make_surf(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, float* t_out) {
+    const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)rec * 3;
+    return make_surf_rec(sc, ro, rd, rec, q[0], q[1], q[2], s, t_out);
+}
 
 // A record of a sphere-capable scene: Sphere::intersect again on the same ray (deterministic, and t_max only ever
 // rejected candidates, so the unbounded re-test finds the hit the traversal found) and its world-space interaction.
 template <bool SPH>
-PT_DEV bool make_surf_any(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, float* t_out) {
+PT_DEV bool make_surf_any_rec(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, float4 a, float4 b, float4 c, Surf& s, float* t_out) {
     if constexpr (SPH) {
-        const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)rec * 3;
-        const float4 a = q[0], b = q[1];
         const uint32_t flags = __float_as_uint(b.w);
         if (flags & PT_TRI_SPHERE) {
             SphHit sh;
@@ -1627,12 +1682,17 @@ PT_DEV bool make_surf_any(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s
             s.dpdu = s.sh_dpdu; s.sh_dpdv = s.dpdv;
             s.prim = __float_as_uint(a.w);
             s.material = (int32_t)(flags >> PT_TRI_MATERIAL_SHIFT) - 1;
-            s.light = (int32_t)__float_as_uint(q[2].w) - 1;
+            s.light = (int32_t)__float_as_uint(c.w) - 1;
             *t_out = sh.t;
             return true;
         }
     }
-    return make_surf(sc, ro, rd, rec, s, t_out);
+    return make_surf_rec(sc, ro, rd, rec, a, b, c, s, t_out);
+}
+template <bool SPH>
+PT_DEV bool make_surf_any(const PtScene& sc, V3 ro, V3 rd, uint32_t rec, Surf& s, float* t_out) {
+    const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)rec * 3;
+    return make_surf_any_rec<SPH>(sc, ro, rd, rec, q[0], q[1], q[2], s, t_out);
 }
 
 // A hit inside an object instance: Shape::intersect again in instance space, then Transform::transform_surface_interaction
@@ -1964,6 +2024,9 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 
 // ============================================================ K_SHADE
 // One bounce of PathIntegrator::li for every path in Q.cur (path.rs:85-234).
+#ifndef PT_SHADE_FLUSH
+#define PT_SHADE_FLUSH 4         // k_shade: iterations (of 64 paths) per queue reservation
+#endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
 #endif
@@ -2011,16 +2074,74 @@ __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material,
     if (mp.prog[12]) mp.m.eta = tex_eval(sc.textures, sc.tex_prog + mp.prog[12], th, sc.images).x;
     build_lobes(mp.m, a_r, a_u, a_v, *out);
 }
+// Diagnostic build -DPT_PROFILE_SHADE: wave clocks of shade_body by section (tools/tune_shade.sh "prof:-DPT_PROFILE_SHADE")
+#ifdef PT_PROFILE_SHADE
+__device__ unsigned long long g_shade_prof[16];
+#define PT_SHP(k) do { const unsigned long long t_now_ = (unsigned long long)__builtin_readcyclecounter(); shp_acc[k] += t_now_ - shp_last; shp_last = t_now_; } while (0)
+#define PT_SHP_SYNC(k) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PT_SHP(k); } while (0)      // section ends once every load issued so far is back
+#else
+#define PT_SHP(k) do { } while (0)
+#define PT_SHP_SYNC(k) do { } while (0)
+#endif
 template <bool GENERAL, bool SPH, bool TEX = false, bool INST = false>
 PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, const uint32_t* list, uint32_t begin, uint32_t end,
                        uint32_t* ticket) {
     __shared__ unsigned long long s_vert;
+    // A vertex's next-event outputs wait here (28 KB per block) until every load of the iteration has come back: on this ISA loads and
+    // stores share one in-order counter (vmcnt), so a store issued in the middle of the dependent chain grid -> light table -> light
+    // makes each later wait sit out the store's round trip as well.
+    __shared__ float4 s_stage[7][PT_BLOCK];
+    __shared__ uint32_t s_pend[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: path id (28 bits) | queue bits of the iterations not yet queued
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
     uint32_t n_vert = 0;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t chunk_left = 0, next_base = 0;
+#ifdef PT_PROFILE_SHADE
+    unsigned long long shp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long shp_last = (unsigned long long)__builtin_readcyclecounter();
+#endif
+    // Queue entries are handed out in batches of PT_SHADE_FLUSH iterations.  A returning atomic on one address is served every 11.3 ns
+    // (tools/ubench/atomic_rate.hip: 88 M/s however many waves ask), so one reservation per queue and 64 paths -- 540 k of them
+    // for a 34 M-path bounce -- made the queue counter, not the shading, set this kernel's duration.
+    uint32_t n_batch = 0;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    auto flush_batch = [&]() {
+        if (n_batch == 0) return;
+        uint32_t tc = 0, tn = 0, ts = 0, tp = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++) {
+            if (j < n_batch) {
+                const uint32_t e = s_pend[j][threadIdx.x];
+                tc += (uint32_t)__popcll(__ballot((e & (1u << 28)) != 0)); tn += (uint32_t)__popcll(__ballot((e & (2u << 28)) != 0));
+                ts += (uint32_t)__popcll(__ballot((e & (4u << 28)) != 0)); tp += (uint32_t)__popcll(__ballot((e & (8u << 28)) != 0));
+            }
+        }
+        uint32_t bc = 0, bn = 0, bs = 0, bp = 0;
+        if (lane == 0) {
+            if (tc) bc = atomicAdd(&Q.counts[PT_Q_NEXT], tc);
+            if (tn) bn = atomicAdd(&Q.counts[PT_Q_NEE], tn);
+            if (ts) bs = atomicAdd(&Q.counts[PT_Q_SHADOW], ts);
+            if (tp) bp = atomicAdd(&Q.counts[PT_Q_PROBE], tp);
+        }
+        bc = __shfl(bc, 0, 64); bn = __shfl(bn, 0, 64); bs = __shfl(bs, 0, 64); bp = __shfl(bp, 0, 64);
+#pragma unroll
+        for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++) {
+            if (j < n_batch) {
+                const uint32_t e = s_pend[j][threadIdx.x], ep = e & 0x0fffffffu;
+                const unsigned long long mc = __ballot((e & (1u << 28)) != 0), mn = __ballot((e & (2u << 28)) != 0), ms = __ballot((e & (4u << 28)) != 0),
+                                         mp = __ballot((e & (8u << 28)) != 0);
+                if (e & (1u << 28)) Q.next[bc + (uint32_t)__popcll(mc & below)] = ep;
+                if (e & (2u << 28)) Q.nee[bn + (uint32_t)__popcll(mn & below)] = ep;
+                if (e & (4u << 28)) Q.shadow[bs + (uint32_t)__popcll(ms & below)] = ep;
+                if (e & (8u << 28)) Q.probe[bp + (uint32_t)__popcll(mp & below)] = ep;
+                bc += (uint32_t)__popcll(mc); bn += (uint32_t)__popcll(mn); bs += (uint32_t)__popcll(ms); bp += (uint32_t)__popcll(mp);
+            }
+        }
+        n_batch = 0;
+    };
     for (;;) {
+        PT_SHP(11);
         if (chunk_left == 0) {                 // one ticket atomic per 4 x 64 items
             uint32_t t0 = 0;
             if (lane == 0) t0 = atomicAdd(ticket, 256u);
@@ -2030,12 +2151,31 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         uint32_t base = next_base;
         next_base += 64u; chunk_left--;
         if (base >= end) break;
+#ifdef PT_PROFILE_SHADE
+        shp_acc[12]++;           // iterations
+#endif
         uint32_t item = base + lane;
         bool active = item < end;
         bool cont = false, want_nee = false, want_sh = false, want_pr = false;
         uint32_t p = 0;
+        uint32_t wr = 0, o_nee = 0, o_state = 0;     // outputs held back to the end of the iteration: 1 ray_o, 2 ray_d + beta, 4 shadow ray, 8 probe ray, 16 pending NEE, 32 state
+        float4 o_ray_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), o_ray_d = o_ray_o, o_beta = o_ray_o;
+        auto commit = [&]() {
+            if (wr & 4u) { P.sh_o[p] = s_stage[0][threadIdx.x]; P.sh_d[p] = s_stage[1][threadIdx.x]; }
+            if (wr & 8u) { P.pr_o[p] = s_stage[2][threadIdx.x]; P.pr_d[p] = s_stage[3][threadIdx.x]; }
+            if (wr & 16u) { P.pendA[p] = s_stage[4][threadIdx.x]; P.pendB[p] = s_stage[5][threadIdx.x]; P.pbeta[p] = s_stage[6][threadIdx.x]; P.nee[p] = o_nee; }
+            if (wr & 1u) P.ray_o[p] = o_ray_o;
+            if (wr & 2u) { P.ray_d[p] = o_ray_d; P.beta[p] = o_beta; }
+            if (wr & 32u) P.state[p] = o_state;
+            wr = 0;
+        };
+        // The textured / instanced kernels (425 registers and still spilling) store where the value is made, as they always did: held back
+        // to the end of the iteration, the continuation ray came out wrong for about 1 % of the samples of seven feature scenes (bisected
+        // to exactly that deferral; the kernels that do not spill are bit-exact either way).
+#define PT_COMMIT_NOW() do { if constexpr (TEX || INST) commit(); } while (0)
         if (active) {
             p = list[item];
+            PT_SHP_SYNC(13);
             float4 ro4 = P.ray_o[p], rd4 = P.ray_d[p];
             V3 ro = f4_3(ro4), rd = f4_3(rd4);
             int32_t rec = P.hit_rec[p];
@@ -2044,11 +2184,31 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             float4 beta4 = P.beta[p];
             V3 beta = f4_3(beta4);
             float eta_scale = beta4.w;
+            PT_SHP_SYNC(14);
+            // the hit's leaf record: asked for first, so that it travels while the sample tables are read
+            float4 rec_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rec_b = rec_a, rec_c = rec_a;
+            if (rec >= 0) {
+                const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)(uint32_t)rec * 3;
+                rec_a = q[0]; rec_b = q[1]; rec_c = q[2];
+            }
+            // this vertex's sample dimensions, started before the hit is reconstructed (see SamplerPre)
+            SamplerPre sm;
+            sm.s.index = 0; sm.s.dim = dim; sm.s.px = 0; sm.s.py = 0; sm.dim0 = dim; sm.have = false;
+            if (rec >= 0 && (int32_t)bounces < sc.max_depth) {
+                sm.s.index = P.sobol_index[p];
+                const uint32_t pk = P.pixel[p];
+                sm.s.px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0];
+                sm.s.py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
+                PT_SHP_SYNC(15);
+                sm.begin(sc);
+                PT_SHP_SYNC(10);
+            }
             Surf s;
             float thit;
             bool found;
             if constexpr (INST) found = rec >= 0 && make_surf_inst<SPH>(sc, ro, rd, (uint32_t)rec, P.hit_inst[p], s, &thit);
-            else found = rec >= 0 && make_surf_any<SPH>(sc, ro, rd, (uint32_t)rec, s, &thit);
+            else found = rec >= 0 && make_surf_any_rec<SPH>(sc, ro, rd, (uint32_t)rec, rec_a, rec_b, rec_c, s, &thit);
+            PT_SHP(0);
             // emitted radiance at the first vertex / after a specular bounce (path.rs:87-98)
             if (found && (bounces == 0 || (flags & PT_ST_SPECULAR))) {
                 int32_t li = s.light;
@@ -2092,8 +2252,8 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 if (no_bsdf) {
                     // no BSDF: continue through the surface, same bounce count (path.rs:108-111)
                     V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
-                    P.ray_o[p] = make_float4(no.x, no.y, no.z, PT_INF);
-                    cont = true;
+                    o_ray_o = make_float4(no.x, no.y, no.z, PT_INF); wr |= 1u;
+                    cont = true; PT_COMMIT_NOW();
                 } else {
                     n_vert++;
                     Bsdf b;
@@ -2130,20 +2290,17 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                         if constexpr (GENERAL) return gbsdf_sample_f(gb, wo_w, uu, fl, f_o, wi_o, pdf_o, type_o);
                         else { *type_o = PT_BSDF_REFLECTION | PT_BSDF_DIFFUSE; return bsdf_sample_f(b, wo_w, uu, f_o, wi_o, pdf_o); }
                     };
-                    Sampler sm;
-                    sm.index = P.sobol_index[p];
-                    sm.dim = dim;
-                    uint32_t pk = P.pixel[p];
-                    sm.px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0];
-                    sm.py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
+                    PT_SHP(1);
                     // ---- next-event estimation (uniform_sample_one_light_surface, sample_lights.rs:129-176)
                     if (nonspecular && sc.n_lights > 0) {
                         const float* tab = grid_lookup(sc.grid, s.p);
                         float light_pdf;
                         uint32_t light_num = sample_discrete(tab, sc.n_lights, sm.get_1d(sc), &light_pdf);
+                        PT_SHP(2);
                         if (light_pdf > 0.0f) {
                             V2 u_light = sm.get_2d(sc);
                             V2 u_scat = sm.get_2d(sc);
+                            PT_SHP(3);
                             const PtLight& lt = sc.lights[light_num];
                             uint32_t nee = light_num << 8;
                             V3 A = mk3(0.0f, 0.0f, 0.0f), B = mk3(0.0f, 0.0f, 0.0f);
@@ -2158,14 +2315,16 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                         V3 origin = offset_ray_origin(s.p, s.p_error, s.n, lp - s.p);
                                         V3 target = offset_ray_origin(lp, lperr, ln, origin - lp);
                                         V3 sd = target - origin;
-                                        P.sh_o[p] = make_float4(origin.x, origin.y, origin.z, 1.0f - PT_SHADOW_EPS);
-                                        P.sh_d[p] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+                                        s_stage[0][threadIdx.x] = make_float4(origin.x, origin.y, origin.z, 1.0f - PT_SHADOW_EPS);
+                                        s_stage[1][threadIdx.x] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+                                        wr |= 4u; PT_COMMIT_NOW();
                                         float weight = power_heuristic(lpdf, spdf);
                                         A = f * li * (weight / lpdf);
                                         nee |= PT_NEE_SHADOW;
                                     }
                                 }
                             }
+                            PT_SHP(4);
                             // BSDF sampling half of MIS (sample_lights.rs:393-451)
                             V3 f2, wi2;
                             float spdf2;
@@ -2196,26 +2355,30 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                             // if the probe lands on this triangle its interaction is `ls` again
                                             V3 le = light_L(lt, ls.n, -wi2);
                                             B = f * le * 1.0f * (weight / spdf2);
-                                            P.pr_o[p] = make_float4(po.x, po.y, po.z, PT_INF);
-                                            P.pr_d[p] = make_float4(wi2.x, wi2.y, wi2.z, 0.0f);
+                                            s_stage[2][threadIdx.x] = make_float4(po.x, po.y, po.z, PT_INF);
+                                            s_stage[3][threadIdx.x] = make_float4(wi2.x, wi2.y, wi2.z, 0.0f);
+                                            wr |= 8u; PT_COMMIT_NOW();
                                             nee |= PT_NEE_PROBE;
                                         }
                                     }
                                 }
                             }
+                            PT_SHP(5);
                             if (nee & (PT_NEE_SHADOW | PT_NEE_PROBE)) {
-                                P.pendA[p] = make_float4(A.x, A.y, A.z, light_pdf);
-                                P.pendB[p] = make_float4(B.x, B.y, B.z, 0.0f);
-                                P.pbeta[p] = make_float4(beta.x, beta.y, beta.z, 0.0f);
-                                P.nee[p] = nee;
+                                s_stage[4][threadIdx.x] = make_float4(A.x, A.y, A.z, light_pdf);
+                                s_stage[5][threadIdx.x] = make_float4(B.x, B.y, B.z, 0.0f);
+                                s_stage[6][threadIdx.x] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                                o_nee = nee; wr |= 16u; PT_COMMIT_NOW();
                                 want_nee = true;
                                 want_sh = (nee & PT_NEE_SHADOW) != 0;
                                 want_pr = (nee & PT_NEE_PROBE) != 0;
                             }
                         }
                     }
+                    PT_SHP(6);
                     // ---- continuation (path.rs:139-233)
                     V2 u = sm.get_2d(sc);
+                    PT_SHP(7);
                     V3 f, wi;
                     float pdf;
                     uint32_t stype;
@@ -2235,34 +2398,33 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                             else beta = beta / (1.0f - q);
                         }
                         if (alive) {
-                            P.ray_o[p] = make_float4(no.x, no.y, no.z, PT_INF);
-                            P.ray_d[p] = make_float4(wi.x, wi.y, wi.z, 0.0f);
-                            P.beta[p] = make_float4(beta.x, beta.y, beta.z, eta_scale);
+                            o_ray_o = make_float4(no.x, no.y, no.z, PT_INF);
+                            o_ray_d = make_float4(wi.x, wi.y, wi.z, 0.0f);
+                            o_beta = make_float4(beta.x, beta.y, beta.z, eta_scale);
+                            wr |= 3u; PT_COMMIT_NOW();
                             bounces++;
                             cont = true;
                         }
                     }
-                    dim = sm.dim;
+                    dim = sm.s.dim;
                 }
-                if (cont) P.state[p] = (dim & 0xffffu) | ((bounces & 0xffu) << 16) | ((flags & ~PT_ST_CAMERA) << 24);     // later rays are plain Rays
+                if (cont) { o_state = (dim & 0xffffu) | ((bounces & 0xffu) << 16) | ((flags & ~PT_ST_CAMERA) << 24); wr |= 32u; } PT_COMMIT_NOW();     // later rays are plain Rays
             }
         }
-        // ---- order-preserving wave compaction into the next / nee queues
-        unsigned long long mc = __ballot(cont), mn = __ballot(want_nee), ms = __ballot(want_sh), mp = __ballot(want_pr);
-        uint32_t bc = 0, bn = 0, bs = 0, bp = 0;
-        if (lane == 0) {
-            if (mc) bc = atomicAdd(&Q.counts[PT_Q_NEXT], (uint32_t)__popcll(mc));
-            if (mn) bn = atomicAdd(&Q.counts[PT_Q_NEE], (uint32_t)__popcll(mn));
-            if (ms) bs = atomicAdd(&Q.counts[PT_Q_SHADOW], (uint32_t)__popcll(ms));
-            if (mp) bp = atomicAdd(&Q.counts[PT_Q_PROBE], (uint32_t)__popcll(mp));
-        }
-        bc = __shfl(bc, 0, 64); bn = __shfl(bn, 0, 64); bs = __shfl(bs, 0, 64); bp = __shfl(bp, 0, 64);
-        unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        if (cont) Q.next[bc + (uint32_t)__popcll(mc & below)] = p;
-        if (want_nee) Q.nee[bn + (uint32_t)__popcll(mn & below)] = p;
-        if (want_sh) Q.shadow[bs + (uint32_t)__popcll(ms & below)] = p;
-        if (want_pr) Q.probe[bp + (uint32_t)__popcll(mp & below)] = p;
+        PT_SHP(8);
+        // ---- order-preserving wave compaction into the next / nee queues, one iteration behind: the four reservations of this
+        // iteration are asked for here and used after the next iteration's work, so that nobody waits for the atomics' round trip
+        // ---- everything this vertex writes in one burst, after the last load of the iteration
+        commit();
+        // ---- where it goes next: remembered (path | queue bits), queued with the batch
+        s_pend[n_batch][threadIdx.x] = p | ((cont ? 1u : 0u) | (want_nee ? 2u : 0u) | (want_sh ? 4u : 0u) | (want_pr ? 8u : 0u)) << 28;
+        if (++n_batch == PT_SHADE_FLUSH) flush_batch();
+        PT_SHP(9);
     }
+    flush_batch();
+#ifdef PT_PROFILE_SHADE
+    if (lane == 0) { for (int k = 0; k < 16; k++) atomicAdd(&g_shade_prof[k], shp_acc[k]); }
+#endif
     if (n_vert) atomicAdd(&s_vert, (unsigned long long)n_vert);
     __syncthreads();
     if (threadIdx.x == 0 && s_vert) atomicAdd(&cnt->vertices, s_vert);
@@ -2995,6 +3157,17 @@ hipError_t ptk_rec_next(hipStream_t st, int grid, const PtScene& sc, const PtPat
 #define PT_LAUNCH_CHECK() hipGetLastError()
 
 int ptk_trace_dist_blocks_per_cu() { return PT_TRACE_DIST_WAVES; }
+int ptk_shade_prof_read(unsigned long long* out16) {       // 1 when the library is the -DPT_PROFILE_SHADE diagnostic build (reads and clears)
+#ifdef PT_PROFILE_SHADE
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_shade_prof), sizeof(z)) != hipSuccess) return 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, sizeof(z));
+    return 1;
+#else
+    (void)out16;
+    return 0;
+#endif
+}
 hipError_t ptk_trace(hipStream_t st, int grid, int grid_dist, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err) {
     if (sc.dist_leaves && !sc.n_instances) grid = grid_dist;      // the pooled-leaf kernels fit three blocks per CU, the others four

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time of the BVH build inside pt_scene_upload (pt_scene_info.bvh_build_ms) for the RT1M geometry with
-splitmethod hlbvh: threaded host builder against the GPU lower half (pt_hlbvh.hip).  Run on the GPU box:
+splitmethod sah and hlbvh: threaded host builder against the GPU builders (pt_sah.hip, pt_hlbvh.hip).  Run on the GPU box:
     python3 tools/bvh_build_time.py [n_triangles ...]"""
 import importlib
 import json
@@ -17,17 +17,16 @@ def main():
     for n in sizes:
         sd = pkg.scenes.rt1m(n, res=64, spp=1, max_depth=1)
         row = {"n_triangles": n}
-        sd.desc.split_method = 0
-        row["sah_host_ms"] = round(ctx.upload(sd).bvh_build_ms, 2)
-        sd.desc.split_method = 1
-        for name, where in (("hlbvh_host_ms", pkg.capi.BVH_BUILD_HOST), ("hlbvh_device_ms", pkg.capi.BVH_BUILD_DEVICE)):
-            ctx.set_bvh_build(where)
-            best = None
-            for _ in range(3):
-                info = ctx.upload(sd)
-                best = info.bvh_build_ms if best is None else min(best, info.bvh_build_ms)
-            row[name] = round(best, 2)
-            row[name.replace("_ms", "_digest")] = "%016x" % ctx.bvh_digest()[0]
+        for method, tag in ((0, "sah"), (1, "hlbvh")):
+            sd.desc.split_method = method
+            for where_name, where in (("host", pkg.capi.BVH_BUILD_HOST), ("device", pkg.capi.BVH_BUILD_DEVICE)):
+                ctx.set_bvh_build(where)
+                best = None
+                for _ in range(3):
+                    info = ctx.upload(sd)
+                    best = info.bvh_build_ms if best is None else min(best, info.bvh_build_ms)
+                row["%s_%s_ms" % (tag, where_name)] = round(best, 2)
+                row["%s_%s_digest" % (tag, where_name)] = "%016x" % ctx.bvh_digest()[0]
         print(json.dumps(row), flush=True)
     ctx.close()
 

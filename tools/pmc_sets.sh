@@ -25,7 +25,7 @@ for f in glob.glob("gpurun_out/pmc_%s/pass*/**/*counter_collection.csv" % tag, r
         k = r["Kernel_Name"].split("(")[0]
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
 for k in sorted(tot):
-    if not k.startswith("k_trace"): continue
+    if not (k.startswith("k_trace") or k.startswith("k_shade")): continue
     print("==", k)
     for c in sorted(tot[k]): print("  %-36s %18.0f  over %d launches  (%.4g per launch)" % (c, tot[k][c], calls[k][c], tot[k][c] / max(1, calls[k][c])))
 PY
