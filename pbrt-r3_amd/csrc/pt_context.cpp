@@ -586,6 +586,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (!ptbvh::build_prims(prims.data(), (uint32_t)prims.size(), d->split_method, max_node_prims, &bvh, &dev_build))
             return dev_build.err != hipSuccess ? ctx->hip_fail(dev_build.err, "HLBVH build on the device") : ctx->fail(PT_ERR_INVALID_ARGUMENT, hlbvh_msg);
     }
+    const size_t n_world_nodes = bvh.nodes.size();          // the objects' trees are appended behind these
     for (size_t prim = 0; prim < world.size(); prim++) if (world[prim].kind == 2) dinst[world[prim].idx].world_prim = (uint32_t)prim;
     // one node array and one record array: the world first, then each object with its references shifted
     std::vector<Entry> rec_entry(bvh.tris.size() - 1);        // record -> what it stands for (shading records below)
@@ -767,6 +768,36 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     // empty child slots as inverted boxes so that they fail the slab test by themselves (the builders leave them all-zero, as the
     // reference does; the general visit masks them out by the occupied-slot bits either way).
     if (bvh.nodes.size() >= (1u << 25)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^25 BVH nodes (32-bit node offsets)");
+    // The builders emit nodes depth-first.  The top of the WORLD tree is renumbered breadth-first (the first PT_TOP_BFS_NODES nodes in
+    // level order, everything else behind them in the old order), so that "node index < n" means "one of the top levels": k_trace keeps
+    // those in LDS (PT_TOP_NODES).  Traversal order, boxes and references are untouched -- only where a node lives.
+    uint32_t n_top = 0;
+    if (n_world_nodes > 0 && !(bvh.root_ref & PT_LEAF_BIT) && bvh.root_ref != PT_EMPTY_REF) {
+        std::vector<uint32_t> bfs;
+        bfs.reserve(PT_TOP_BFS_NODES);
+        bfs.push_back(bvh.root_ref & PT_REF_INDEX_MASK);
+        for (size_t head = 0; head < bfs.size() && bfs.size() < PT_TOP_BFS_NODES; head++)
+            for (int ch = 0; ch < 4 && bfs.size() < PT_TOP_BFS_NODES; ch++) {
+                const uint32_t r = bvh.nodes[bfs[head]].child[ch];
+                if (r != PT_EMPTY_REF && !(r & PT_LEAF_BIT)) bfs.push_back(r & PT_REF_INDEX_MASK);
+            }
+        n_top = (uint32_t)bfs.size();
+        std::vector<uint32_t> new_of(n_world_nodes, 0xffffffffu);
+        for (uint32_t k = 0; k < n_top; k++) new_of[bfs[k]] = k;
+        uint32_t next = n_top;
+        for (size_t n = 0; n < n_world_nodes; n++) if (new_of[n] == 0xffffffffu) new_of[n] = next++;
+        std::vector<PtNode> moved(n_world_nodes);
+        ptbvh::parallel_for(n_world_nodes, [&](size_t n0, size_t n1) {
+            for (size_t n = n0; n < n1; n++) {
+                PtNode nd = bvh.nodes[n];
+                for (int ch = 0; ch < 4; ch++)
+                    if (nd.child[ch] != PT_EMPTY_REF && !(nd.child[ch] & PT_LEAF_BIT)) nd.child[ch] = (nd.child[ch] & ~PT_REF_INDEX_MASK) | new_of[nd.child[ch] & PT_REF_INDEX_MASK];
+                moved[new_of[n]] = nd;
+            }
+        });
+        std::copy(moved.begin(), moved.end(), bvh.nodes.begin());
+        bvh.root_ref = (bvh.root_ref & ~PT_REF_INDEX_MASK) | new_of[bvh.root_ref & PT_REF_INDEX_MASK];
+    }
     ptbvh::parallel_for(bvh.nodes.size(), [&](size_t n0, size_t n1) {
         for (size_t n = n0; n < n1; n++) {
             PtNode& nd = bvh.nodes[n];
@@ -862,6 +893,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (d->n_spheres) sc.general_materials = 1;     // sphere scenes run the sphere-capable kernel instantiations (sorted shade queue)
     if (d->n_instances) { sc.general_materials = 1; sc.dist_leaves = 0; }      // k_trace_inst walks leaves per lane; one shade kernel handles everything
     sc.root_ref = bvh.root_ref;
+    sc.n_top = n_top;
     std::memcpy(sc.wb_min, bvh.root_lo, 12);
     std::memcpy(sc.wb_max, bvh.root_hi, 12);
     sc.max_depth = d->max_depth;

@@ -17,9 +17,18 @@
 #ifndef PT_NODE_STAGED
 #define PT_NODE_STAGED 0
 #endif
+// PT_TOP_NODES > 0: the pooled-leaf traversal kernels keep the first PT_TOP_NODES nodes of the world tree (the upload numbers the top
+// of the tree breadth-first, so these are its top levels: 85 = levels 0..3) in LDS, 112 bytes each, and visits to them read LDS instead
+// of going through the vector L1, whose request rate bounds the kernel.  Paid for with 8 of the 32 stack slots.
+#ifndef PT_TOP_NODES
+#define PT_TOP_NODES 85
+#endif
+#define PT_TOP_BFS_NODES 1365u   // what the upload renumbers breadth-first (levels 0..5), whatever PT_TOP_NODES the kernels were built with
 // LDS stack slots per lane of the pooled-leaf traversal kernels (slot 0 holds a sentinel; deeper entries spill to HBM)
 #if PT_NODE_STAGED
 #define PT_FS_SLOTS (PT_LDS_STACK < 16 ? PT_LDS_STACK : 16)
+#elif PT_TOP_NODES > 0
+#define PT_FS_SLOTS (PT_LDS_STACK < 24 ? PT_LDS_STACK : 24)
 #else
 #define PT_FS_SLOTS PT_LDS_STACK
 #endif
@@ -244,6 +253,7 @@ struct PtScene {
     uint32_t n_spheres;          // > 0: the sphere-capable kernel instantiations run
     uint32_t n_lights;
     uint32_t root_ref;           // node 0, or a leaf reference when the whole scene is one leaf
+    uint32_t n_top;              // nodes 0 .. n_top-1 are the top of the world tree in breadth-first order (at most PT_TOP_BFS_NODES)
     float wb_min[3], wb_max[3];  // BVH root bounds (Scene::world_bound)
     int32_t max_depth;
     float rr_threshold;

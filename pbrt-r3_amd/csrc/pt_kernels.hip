@@ -405,6 +405,7 @@ struct TravCtx {
     uint32_t n_nodes, n_tris;
     uint32_t overflow;
     uint32_t lane_base;      // pooled-leaf kernels: LDS byte address of this lane's slot 0 (see FsStack)
+    uint32_t top_lds, top_bytes;   // pooled-leaf kernels: LDS byte address of the cached top of the tree; 128 x the number of nodes cached
     // pooled-leaf kernels, staged node fetch (node_round_staged): LDS addresses
     uint32_t stage_wave;     // this wave's 8 KB staging area (wave-uniform)
     uint32_t stage_own;      // this lane's staged node: stage_wave + (lane >> 3) * 1024 + (lane & 7) * 128
@@ -900,10 +901,26 @@ PT_DEV void node_step_lean(const PtScene& sc, LaneRay& r, TravCtx& c) {
     c.n_nodes++;
     const char* nb = reinterpret_cast<const char*>(sc.nodes);
     const uint32_t no = ref << 7;             // the shift drops the axis bits a child reference carries above its node index
-    const float4 nx = *reinterpret_cast<const float4*>(nb + (no + r.o_nx)), fx = *reinterpret_cast<const float4*>(nb + (no + r.o_fx));
-    const float4 ny = *reinterpret_cast<const float4*>(nb + (no + r.o_ny)), fy = *reinterpret_cast<const float4*>(nb + (no + r.o_fy));
-    const float4 nz = *reinterpret_cast<const float4*>(nb + (no + r.o_nz)), fz = *reinterpret_cast<const float4*>(nb + (no + r.o_fz));
-    const uint4 ch = *reinterpret_cast<const uint4*>(nb + (no + 96u));
+    float4 nx, fx, ny, fy, nz, fz;
+    uint4 ch;
+#if PT_TOP_NODES > 0
+    // two ifs, LDS first: the two paths fill the same registers, and the wait the compiler puts between them (it tracks registers, not
+    // lanes) is then the short LDS one, not the global loads' round trip
+    const bool in_lds = no < c.top_bytes;
+    if (in_lds) {                             // one of the top nodes: its seven rows sit in LDS, 112 bytes apart (no - no / 8 = 112 x index)
+        const uint32_t la = c.top_lds + no - (no >> 3);
+        nx = lds_load4(la + r.o_nx); fx = lds_load4(la + r.o_fx); ny = lds_load4(la + r.o_ny); fy = lds_load4(la + r.o_fy);
+        nz = lds_load4(la + r.o_nz); fz = lds_load4(la + r.o_fz);
+        ch = lds_load4u(la + 96u);
+    }
+    if (!in_lds)
+#endif
+    {
+        nx = *reinterpret_cast<const float4*>(nb + (no + r.o_nx)); fx = *reinterpret_cast<const float4*>(nb + (no + r.o_fx));
+        ny = *reinterpret_cast<const float4*>(nb + (no + r.o_ny)); fy = *reinterpret_cast<const float4*>(nb + (no + r.o_fy));
+        nz = *reinterpret_cast<const float4*>(nb + (no + r.o_nz)); fz = *reinterpret_cast<const float4*>(nb + (no + r.o_fz));
+        ch = *reinterpret_cast<const uint4*>(nb + (no + 96u));
+    }
     const float ox = r.o.x, oy = r.o.y, oz = r.o.z, ix = r.idir.x, iy = r.idir.y, iz = r.idir.z;
 #define PT_SLAB(C) (v_min3(v_min(r.tmax, (fx.C - ox) * ix), (fy.C - oy) * iy, (fz.C - oz) * iz) >= v_max3(v_max(r.tmin, (nx.C - ox) * ix), (ny.C - oy) * iy, (nz.C - oz) * iz))
     const bool h0 = PT_SLAB(x), h1 = PT_SLAB(y), h2 = PT_SLAB(z), h3 = PT_SLAB(w);
@@ -1028,8 +1045,12 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     __shared__ float4 s_res[DIST ? PT_BLOCK : 1];          // per wave: 64 test results (ok, t_scaled, det, t)
     __shared__ unsigned char s_map[DIST ? PT_BLOCK : 1];   // per wave: work item -> owner lane
 #endif
+#if PT_TOP_NODES > 0 && !PT_NODE_STAGED
+    __shared__ float4 s_top[DIST ? PT_TOP_NODES * 7 : 1];      // rows 0..6 (six plane rows, child references) of the first nodes of the tree
+#endif
     TravCtx c;
     c.lds = &s_stack[threadIdx.x];
+    c.top_lds = 0; c.top_bytes = 0;
     c.spill_stride = gridDim.x * PT_BLOCK;
     c.spill = spill + PT_DIAG_WORDS + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;      // the buffer's first PT_DIAG_WORDS words belong to the diagnostic builds
     c.spill_depth = spill_depth;
@@ -1046,6 +1067,16 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         c.idx_ld = lds_addr_of(&s_idx[wv * 80u + (ln >> 3) * 8u]);
 #endif
     }
+#if PT_TOP_NODES > 0 && !PT_NODE_STAGED
+    if constexpr (DIST) {
+        const uint32_t n_top = min(sc.n_top, (uint32_t)PT_TOP_NODES);
+        const float4* src = reinterpret_cast<const float4*>(sc.nodes);
+        for (uint32_t k = threadIdx.x; k < n_top * 7u; k += PT_BLOCK) { const uint32_t nd = k / 7u; s_top[k] = src[nd * 8u + (k - nd * 7u)]; }
+        c.top_lds = lds_addr_of(reinterpret_cast<const uint32_t*>(s_top));
+        c.top_bytes = n_top << 7;
+        __syncthreads();
+    }
+#endif
     const uint32_t n_cur = Q.counts[PT_Q_CUR], n_sh = Q.counts[PT_Q_SHADOW], n_pr = Q.counts[PT_Q_PROBE];
     const uint32_t total = n_cur + n_sh + n_pr;
     const uint32_t lane = threadIdx.x & 63;
