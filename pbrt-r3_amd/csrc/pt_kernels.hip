@@ -2963,10 +2963,36 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_enter(PtScene sc
 }
 // compaction of the entries with live rays into the shadow / probe work lists of the next traversal launch
 extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_nee_lists(PtPaths P, PtQueues Q, PtQueues Qn, PtRec R, uint32_t n_lights_per_node) {
+    __shared__ uint32_t s_e[PT_SHADE_FLUSH][PT_BLOCK];       // entries of the iterations not yet queued (one reservation per PT_SHADE_FLUSH iterations, see shade_body)
     const uint32_t n = Q.counts[PT_Q_CUR];
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const uint32_t total = n * n_lights_per_node;
+    uint32_t n_batch = 0, want = 0;                           // want: bits 2 j / 2 j + 1 = entry j goes to the shadow / probe list
+    auto flush = [&]() {
+        if (n_batch == 0) return;
+        uint32_t ts = 0, tp = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++)
+            if (j < n_batch) { ts += (uint32_t)__popcll(__ballot(((want >> (2u * j)) & 1u) != 0)); tp += (uint32_t)__popcll(__ballot(((want >> (2u * j)) & 2u) != 0)); }
+        uint32_t bs = 0, bp = 0;
+        if (lane == 0) {
+            if (ts) bs = atomicAdd(&Qn.counts[PT_Q_SHADOW], ts);
+            if (tp) bp = atomicAdd(&Qn.counts[PT_Q_PROBE], tp);
+        }
+        bs = __shfl(bs, 0, 64); bp = __shfl(bp, 0, 64);
+#pragma unroll
+        for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++)
+            if (j < n_batch) {
+                const bool ws = ((want >> (2u * j)) & 1u) != 0, wp = ((want >> (2u * j)) & 2u) != 0;
+                const unsigned long long ms = __ballot(ws), mp = __ballot(wp);
+                const uint32_t e = s_e[j][threadIdx.x];
+                if (ws) Qn.shadow[bs + (uint32_t)__popcll(ms & below)] = e;
+                if (wp) Qn.probe[bp + (uint32_t)__popcll(mp & below)] = e;
+                bs += (uint32_t)__popcll(ms); bp += (uint32_t)__popcll(mp);
+            }
+        n_batch = 0; want = 0;
+    };
     for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < total; base += gridDim.x * blockDim.x) {
         const uint32_t i = base + lane;
         bool want_sh = false, want_pr = false;
@@ -2979,16 +3005,11 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_nee_lists(PtPaths P
                 want_sh = (fl & PT_NEE_SHADOW) != 0; want_pr = (fl & PT_NEE_PROBE) != 0;
             }
         }
-        const unsigned long long ms = __ballot(want_sh), mp = __ballot(want_pr);
-        uint32_t bs = 0, bp = 0;
-        if (lane == 0) {
-            if (ms) bs = atomicAdd(&Qn.counts[PT_Q_SHADOW], (uint32_t)__popcll(ms));
-            if (mp) bp = atomicAdd(&Qn.counts[PT_Q_PROBE], (uint32_t)__popcll(mp));
-        }
-        bs = __shfl(bs, 0, 64); bp = __shfl(bp, 0, 64);
-        if (want_sh) Qn.shadow[bs + (uint32_t)__popcll(ms & below)] = e;
-        if (want_pr) Qn.probe[bp + (uint32_t)__popcll(mp & below)] = e;
+        s_e[n_batch][threadIdx.x] = e;
+        want |= ((want_sh ? 1u : 0u) | (want_pr ? 2u : 0u)) << (2u * n_batch);
+        if (++n_batch == PT_SHADE_FLUSH) flush();
     }
+    flush();
 }
 // specular_reflect / specular_transmit at the frame `depth` (sampler.rs:37-143): true = a child ray was set up (cur ray, differentials, pending f / scale)
 PT_DEV bool rec_sample_child(const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t p, uint32_t depth, bool transmit, Sampler& sm, V3* pend_f, float* pend_scale, uint32_t* child_flags) {
@@ -3060,6 +3081,27 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_next(PtScene sc,
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool whitted = sc.integrator == PT_INTEGRATOR_WHITTED;
+    __shared__ uint32_t s_e[PT_SHADE_FLUSH][PT_BLOCK];       // paths of the iterations not yet queued (one reservation per PT_SHADE_FLUSH iterations, see shade_body)
+    uint32_t n_batch = 0, want = 0;
+    auto flush = [&]() {
+        if (n_batch == 0) return;
+        uint32_t tc = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++)
+            if (j < n_batch) tc += (uint32_t)__popcll(__ballot(((want >> j) & 1u) != 0));
+        uint32_t bc = 0;
+        if (lane == 0 && tc) bc = atomicAdd(&Q.counts[PT_Q_NEXT], tc);
+        bc = __shfl(bc, 0, 64);
+#pragma unroll
+        for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++)
+            if (j < n_batch) {
+                const bool w = ((want >> j) & 1u) != 0;
+                const unsigned long long mc = __ballot(w);
+                if (w) Q.next[bc + (uint32_t)__popcll(mc & below)] = s_e[j][threadIdx.x];
+                bc += (uint32_t)__popcll(mc);
+            }
+        n_batch = 0; want = 0;
+    };
     for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += gridDim.x * blockDim.x) {
         const uint32_t i = base + lane;
         bool cont = false;
@@ -3162,12 +3204,11 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_next(PtScene sc,
             }
             if (outcome == PT_REC_OUT_RETRACE) P.state[p] = st & ~(3u << 26);
         }
-        const unsigned long long mc = __ballot(cont);
-        uint32_t bc = 0;
-        if (lane == 0 && mc) bc = atomicAdd(&Q.counts[PT_Q_NEXT], (uint32_t)__popcll(mc));
-        bc = __shfl(bc, 0, 64);
-        if (cont) Q.next[bc + (uint32_t)__popcll(mc & below)] = p;
+        s_e[n_batch][threadIdx.x] = p;
+        want |= (cont ? 1u : 0u) << n_batch;
+        if (++n_batch == PT_SHADE_FLUSH) flush();
     }
+    flush();
 }
 hipError_t ptk_rec_init(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t n) {
     hipLaunchKernelGGL(k_rec_init, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, R, n);
