@@ -215,7 +215,8 @@ def main():
         # 2.4 GHz with nothing else running).  achieved = lane requests per launch / launch time.
         per_visit = 7.0                           # k_trace / k_trace_sph_dist (path and ao alike): six plane rows + the child references per node visit
         n_rays = cnt["regular_rays"] + cnt["shadow_rays"]
-        reqs = per_visit * cnt["nodes_visited"] + 3.0 * cnt["tris_tested"] + 5.0 * n_rays      # per ray: id + 2 x 16 B in, 2 result stores out
+        l1_visits = cnt["nodes_visited"] - cnt.get("nodes_from_lds", 0)       # visits to the top levels of the tree read the kernel's LDS copy, not L1
+        reqs = per_visit * l1_visits + 3.0 * cnt["tris_tested"] + 5.0 * n_rays      # per ray: id + 2 x 16 B in, 2 result stores out
         alg_bytes = 48.0 * cnt["regular_rays"] + 36.0 * cnt["shadow_rays"] + 128.0 * cnt["nodes_visited"] + 48.0 * cnt["tris_tested"]
         launches = max(1, cnt["trace_launches"])
         avg_launch_s = cnt["trace_ms"] / 1e3 / launches
@@ -240,6 +241,7 @@ def main():
                     "unit": "Greq/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "requests_per_launch": round(reqs / launches, 1), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
                     "nodes_per_ray": round(cnt["nodes_visited"] / max(1.0, n_rays), 2), "tris_per_ray": round(cnt["tris_tested"] / max(1.0, n_rays), 2),
+                    "node_visits_from_lds": round(cnt.get("nodes_from_lds", 0) / max(1.0, cnt["nodes_visited"]), 4),
                     "trace_share_of_render": round(cnt["trace_ms"] / max(1e-9, cnt["render_ms"]), 3),
                     "shade_share_of_render": round(cnt["shade_ms"] / max(1e-9, cnt["render_ms"]), 3),
                     # informational: SURVEY.md section 8d's algorithmic bytes (cache-served, can exceed the HBM peak), what HBM must move at least,
@@ -249,7 +251,7 @@ def main():
                     "hbm_compulsory_frac_of_8TBps": round(compulsory / avg_launch_s / 8e12, 5) if avg_launch_s > 0 else 0.0,
                     "fabric_frac_of_8TBps": round(traffic / avg_launch_s / 8e12, 4) if (traffic and avg_launch_s > 0) else None,
                     "note": "bound = lane requests to the CU's vector L1 (one 16-byte request per clock per CU): "
-                            "%g per node visit, 3 per triangle test, 5 per ray; traffic = FETCH_SIZE/WRITE_SIZE-derived bytes leaving L2 "
+                            "%g per node visit that is not served from the LDS copy of the top of the tree, 3 per triangle test, 5 per ray; traffic = FETCH_SIZE/WRITE_SIZE-derived bytes leaving L2 "
                             "(Infinity Cache hits included) per launch: %s" % (per_visit, traffic_note)}
         cpu, parity, spp1024 = None, None, None
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only (rank 0 would keep the other ranks waiting)

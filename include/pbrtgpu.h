@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 6
+#define PT_ABI_VERSION 7
 
 typedef enum {
     PT_OK = 0,
@@ -326,6 +326,7 @@ typedef struct {
     double   trace_ms;          /* device time in the traversal kernel (HIP events) */
     double   shade_ms;
     double   render_ms;         /* first ray-gen launch -> film ready on device */
+    uint64_t nodes_from_lds;    /* of nodes_visited: visits the traversal kernel served from its LDS copy of the top of the tree */
 } pt_counters;
 
 typedef struct {

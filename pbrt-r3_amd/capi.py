@@ -122,7 +122,7 @@ class pt_counters(C.Structure):
     _fields_ = [("camera_rays", C.c_uint64), ("regular_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("path_vertices", C.c_uint64),
                 ("trace_launches", C.c_uint64), ("trace_ms", C.c_double), ("shade_ms", C.c_double),
-                ("render_ms", C.c_double)]
+                ("render_ms", C.c_double), ("nodes_from_lds", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

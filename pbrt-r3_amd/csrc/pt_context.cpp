@@ -486,6 +486,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (ctx->sobol_m32.empty() && !load_sobol(ctx)) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "cannot read sobol_tables.bin from data dir '" + ctx->data_dir + "'");
 
     double t0 = now_ms();
+    const bool build_trace = std::getenv("PBRTGPU_BUILD_TRACE") != nullptr;
+    double tm_last = t0;
+    auto mark = [&](const char* what) { if (build_trace) { const double t = now_ms(); std::fprintf(stderr, "[upload] %s %.1f ms\n", what, t - tm_last); tm_last = t; } };
     // ---- BVH (host) ---------------------------------------------------------
     std::vector<uint32_t> tri_flags(d->n_triangles);
     ptbvh::parallel_for(d->n_triangles, [&](size_t t0_, size_t t1_) {
@@ -499,6 +502,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         tri_flags[t] = f;
     }
     });
+    mark("triangle flags");
     std::vector<PtSphere> sph;
     std::vector<ptbvh::SpherePrim> sprims;
     build_spheres(d, sph, sprims);
@@ -556,7 +560,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     for (uint32_t i = 0; i < d->n_instances; i++)
         if (d->instances[i].object >= n_objects || objs[d->instances[i].object].list.empty()) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "instance of an unknown or empty object");
     std::vector<PtInstance> dinst(d->n_instances);
+    mark("object trees");
     std::vector<Entry> world = make_list(0);
+    mark("world primitive list");
     if (world.empty()) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no world primitives (objects are only rendered through ObjectInstance)");
     if ((uint64_t)world.size() >= PT_LEAF_FIRST_MASK - 16u) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "more than 2^26 primitives");
     ptbvh::Result bvh;
@@ -583,9 +589,12 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             }
             ptbvh::instance_record(en.idx, &prims[i].rec);
         }
+        mark("world primitives (bounds + records)");
         if (!ptbvh::build_prims(prims.data(), (uint32_t)prims.size(), d->split_method, max_node_prims, &bvh, &dev_build))
             return dev_build.err != hipSuccess ? ctx->hip_fail(dev_build.err, "HLBVH build on the device") : ctx->fail(PT_ERR_INVALID_ARGUMENT, hlbvh_msg);
+        mark("build_prims");
     }
+    mark("free primitive list");
     const size_t n_world_nodes = bvh.nodes.size();          // the objects' trees are appended behind these
     for (size_t prim = 0; prim < world.size(); prim++) if (world[prim].kind == 2) dinst[world[prim].idx].world_prim = (uint32_t)prim;
     // one node array and one record array: the world first, then each object with its references shifted
@@ -628,6 +637,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             std::memcpy(o.root_lo, ob.lo, 12); std::memcpy(o.root_hi, ob.hi, 12);
         }
     }
+    mark("record map + objects");
     double t1 = now_ms();
     ctx->max_stack = bvh.max_stack + max_inner_stack;
 
@@ -1753,6 +1763,7 @@ pt_status pt_get_counters(pt_context* ctx, pt_counters* out) {
         PT_HIP(hipMemcpy(&c, ctx->d_counters.p, sizeof(c), hipMemcpyDeviceToHost));
         out->camera_rays = c.camera_rays; out->regular_rays = c.regular_rays; out->shadow_rays = c.shadow_rays;
         out->nodes_visited = c.nodes; out->tris_tested = c.tris; out->path_vertices = c.vertices;
+        out->nodes_from_lds = c.nodes_lds;
     }
     out->trace_launches = ctx->trace_launches;
     out->trace_ms = ctx->trace_ms; out->shade_ms = ctx->shade_ms; out->render_ms = ctx->render_ms;

@@ -229,6 +229,7 @@ struct PtLightGrid {
 
 struct PtCounters {
     unsigned long long regular_rays, shadow_rays, nodes, tris, vertices, camera_rays;
+    unsigned long long nodes_lds;       // of `nodes`: visits k_trace served from its LDS copy of the top of the tree (no L1 request)
 };
 
 struct PtScene {

@@ -406,6 +406,7 @@ struct TravCtx {
     uint32_t overflow;
     uint32_t lane_base;      // pooled-leaf kernels: LDS byte address of this lane's slot 0 (see FsStack)
     uint32_t top_lds, top_bytes;   // pooled-leaf kernels: LDS byte address of the cached top of the tree; 128 x the number of nodes cached
+    uint32_t n_nodes_lds;          // node visits served from that copy
     // pooled-leaf kernels, staged node fetch (node_round_staged): LDS addresses
     uint32_t stage_wave;     // this wave's 8 KB staging area (wave-uniform)
     uint32_t stage_own;      // this lane's staged node: stage_wave + (lane >> 3) * 1024 + (lane & 7) * 128
@@ -907,6 +908,7 @@ PT_DEV void node_step_lean(const PtScene& sc, LaneRay& r, TravCtx& c) {
     // two ifs, LDS first: the two paths fill the same registers, and the wait the compiler puts between them (it tracks registers, not
     // lanes) is then the short LDS one, not the global loads' round trip
     const bool in_lds = no < c.top_bytes;
+    c.n_nodes_lds += in_lds ? 1u : 0u;
     if (in_lds) {                             // one of the top nodes: its seven rows sit in LDS, 112 bytes apart (no - no / 8 = 112 x index)
         const uint32_t la = c.top_lds + no - (no >> 3);
         nx = lds_load4(la + r.o_nx); fx = lds_load4(la + r.o_fx); ny = lds_load4(la + r.o_ny); fy = lds_load4(la + r.o_fy);
@@ -1050,7 +1052,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #endif
     TravCtx c;
     c.lds = &s_stack[threadIdx.x];
-    c.top_lds = 0; c.top_bytes = 0;
+    c.top_lds = 0; c.top_bytes = 0; c.n_nodes_lds = 0;
     c.spill_stride = gridDim.x * PT_BLOCK;
     c.spill = spill + PT_DIAG_WORDS + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;      // the buffer's first PT_DIAG_WORDS words belong to the diagnostic builds
     c.spill_depth = spill_depth;
@@ -1377,6 +1379,11 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #endif
     if (c.overflow) atomicOr(err, 1u);
     flush_counters(cnt, s_cnt, regular, shadow, c.n_nodes, c.n_tris);
+    {   // LDS-served node visits: one add per wave
+        unsigned long long v = c.n_nodes_lds;
+        for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((int)(v >> 32), o, 64) << 32 | (unsigned int)__shfl_xor((int)(unsigned int)v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt->nodes_lds, v);
+    }
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_DIST_WAVES) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                               uint32_t spill_depth, uint32_t* err) {
@@ -2055,6 +2062,9 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 
 // ============================================================ K_SHADE
 // One bounce of PathIntegrator::li for every path in Q.cur (path.rs:85-234).
+#ifndef PT_SHADE_TICKET
+#define PT_SHADE_TICKET 4        // k_shade: iterations (of 64 paths) per work ticket
+#endif
 #ifndef PT_SHADE_FLUSH
 #define PT_SHADE_FLUSH 4         // k_shade: iterations (of 64 paths) per queue reservation
 #endif
@@ -2173,11 +2183,11 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     };
     for (;;) {
         PT_SHP(11);
-        if (chunk_left == 0) {                 // one ticket atomic per 4 x 64 items
+        if (chunk_left == 0) {                 // one ticket atomic per PT_SHADE_TICKET x 64 items
             uint32_t t0 = 0;
-            if (lane == 0) t0 = atomicAdd(ticket, 256u);
+            if (lane == 0) t0 = atomicAdd(ticket, 64u * PT_SHADE_TICKET);
             next_base = begin + (uint32_t)__shfl((int)t0, 0, 64);
-            chunk_left = 4;
+            chunk_left = PT_SHADE_TICKET;
         }
         uint32_t base = next_base;
         next_base += 64u; chunk_left--;

@@ -122,3 +122,22 @@ def test_wavefront_rt1m_2m_rays(gpu_ctx, oracle):
     n_hit, n_occ = _check(gpu_ctx, osc, o, d, t, kind)
     assert n_hit > 100000 and n_occ > 100000
     osc.close()
+
+
+def test_top_of_tree_is_served_from_lds(gpu_ctx, oracle):
+    """The upload numbers the top of the world tree breadth-first and k_trace keeps its first nodes in LDS: the visits counted as
+    served from there are a real share of all node visits (every ray starts at the root), never more than all of them, and the
+    owner-walks-the-leaf kernel (leaves of more than 8 triangles), which has no such copy, reports none.  What the rays hit is
+    covered by the parity tests above -- the renumbering moves nodes, it does not change a reference's meaning."""
+    for make, expect in ((SCENES["rt20k"], True), (SCENES["rt4k_leaf12"], False)):
+        sd = make()
+        osc = oracle.scene(sd)
+        gpu_ctx.upload(sd)
+        o, d, t, kind = _rays(gpu_ctx, osc, 30011, 77)
+        _check(gpu_ctx, osc, o, d, t, kind)
+        c = gpu_ctx.counters()
+        if expect:
+            assert 0.05 * c["nodes_visited"] < c["nodes_from_lds"] <= c["nodes_visited"]
+        else:
+            assert c["nodes_from_lds"] == 0
+        osc.close()
