@@ -11,6 +11,7 @@
 #include "pt_bvh.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <future>
@@ -74,7 +75,7 @@ struct Builder {
     int method;
     size_t par_threshold;
 
-    typedef std::vector<BNode> Tree;
+    typedef NoInitVec<BNode> Tree;
 
     // Append a finished subtree (root at sub[0], links relative to sub) to dst; returns its new root index.
     static int32_t splice(Tree& dst, const Tree& sub) {
@@ -88,7 +89,7 @@ struct Builder {
         return base;
     }
     static int32_t push_leaf(Tree& t, size_t lo, size_t hi, const Box& b) {
-        BNode n;
+        BNode n = BNode::blank();
         std::memcpy(n.lo, b.lo, 12); std::memcpy(n.hi, b.hi, 12);
         n.first = (uint32_t)lo; n.count = (uint32_t)(hi - lo);
         t.push_back(n);
@@ -169,7 +170,7 @@ struct Builder {
         }
         int32_t me = (int32_t)t.size();
         {
-            BNode nd;
+            BNode nd = BNode::blank();
             nd.axis = (uint8_t)dim;
             t.push_back(nd);
         }
@@ -207,7 +208,7 @@ struct Hlbvh {
     Item* items;
     const uint32_t* code;      // Morton code of items[i] (valid until a median fallback reorders a range)
     uint32_t max_prims;
-    std::vector<BNode>& t;
+    NoInitVec<BNode>& t;
     bool failed = false;
 
     static uint32_t spread3(uint32_t x) {          // left_shift3 (hlbvh.rs:23-40); 1024 is clamped to 1023
@@ -230,7 +231,7 @@ struct Hlbvh {
         return Builder::push_leaf(t, lo, hi, b);
     }
     int32_t join(int axis, int32_t l, int32_t r) {
-        BNode nd;
+        BNode nd = BNode::blank();
         nd.axis = (uint8_t)axis; nd.left = l; nd.right = r;
         for (int i = 0; i < 3; i++) { nd.lo[i] = fmin_le(t[l].lo[i], t[r].lo[i]); nd.hi[i] = fmax_ge(t[l].hi[i], t[r].hi[i]); }
         t.push_back(nd);
@@ -352,34 +353,49 @@ inline uint32_t leaf_reference(uint32_t first, uint32_t count) {
 }
 
 struct Collapser {
-    const std::vector<BNode>& b;
+    const NoInitVec<BNode>& b;
     Result& out;
     uint32_t max_depth4 = 0;
 
     uint32_t leaf_ref(const BNode& n) const { return leaf_reference(n.first, n.count); }
 
-    // One 4-wide node from a binary node and its two children (a leaf child fills slot 0/2 and
-    // leaves slot 1/3 empty, exactly like flatten_qbvh_tree).  Returns the node index.
-    uint32_t emit(int32_t bi, uint32_t depth) {
-        if (depth > max_depth4) max_depth4 = depth;
+    // the (up to four) binary nodes that fill the slots of the 4-wide node made from binary node bi (a leaf child fills slot 0 / 2 and
+    // leaves slot 1 / 3 empty, exactly like flatten_qbvh_tree)
+    void slots_of(int32_t bi, int32_t slot_idx[4]) const {
         const BNode& n = b[bi];
-        uint32_t me = (uint32_t)out.nodes.size();
-        out.nodes.push_back(PtNode());
+        const BNode& c0 = b[n.left];
+        const BNode& c1 = b[n.right];
+        slot_idx[0] = slot_idx[1] = slot_idx[2] = slot_idx[3] = -1;
+        if (c0.count > 0) slot_idx[0] = n.left; else { slot_idx[0] = c0.left; slot_idx[1] = c0.right; }
+        if (c1.count > 0) slot_idx[2] = n.right; else { slot_idx[2] = c1.left; slot_idx[3] = c1.right; }
+    }
+    // 4-wide nodes in the subtree of binary node bi (itself included)
+    uint32_t count4(int32_t bi) const {
+        int32_t si[4];
+        slots_of(bi, si);
+        uint32_t c = 1;
+        for (int k = 0; k < 4; k++) if (si[k] >= 0 && b[si[k]].count == 0) c += count4(si[k]);
+        return c;
+    }
+    // One 4-wide node from a binary node and its two children, numbered depth-first: the node takes index `next`, its subtrees follow.
+    // Subtrees listed in `cut` (binary node -> first index, in depth-first order) are skipped: somebody else emits them.
+    uint32_t emit(int32_t bi, uint32_t depth, uint32_t& next, uint32_t& deepest, const std::vector<std::pair<int32_t, uint32_t>>* cut, size_t* cut_pos) {
+        if (depth > deepest) deepest = depth;
+        const BNode& n = b[bi];
+        const uint32_t me = next++;
         PtNode nd;
         std::memset(&nd, 0, sizeof(nd));
         const BNode& c0 = b[n.left];
         const BNode& c1 = b[n.right];
-        const BNode* slot[4] = {nullptr, nullptr, nullptr, nullptr};
-        int32_t slot_idx[4] = {-1, -1, -1, -1};
-        if (c0.count > 0) { slot[0] = &c0; slot_idx[0] = n.left; }
-        else { slot[0] = &b[c0.left]; slot_idx[0] = c0.left; slot[1] = &b[c0.right]; slot_idx[1] = c0.right; }
-        if (c1.count > 0) { slot[2] = &c1; slot_idx[2] = n.right; }
-        else { slot[2] = &b[c1.left]; slot_idx[2] = c1.left; slot[3] = &b[c1.right]; slot_idx[3] = c1.right; }
+        int32_t slot_idx[4];
+        slots_of(bi, slot_idx);
         for (int k = 0; k < 4; k++) {
-            if (!slot[k]) { nd.child[k] = PT_EMPTY_REF; continue; }   // box stays all-zero as in the reference
-            for (int a = 0; a < 3; a++) { nd.bmin[a][k] = slot[k]->lo[a]; nd.bmax[a][k] = slot[k]->hi[a]; }
-            if (slot[k]->count > 0) nd.child[k] = leaf_ref(*slot[k]);
-            else nd.child[k] = emit(slot_idx[k], depth + 1);
+            if (slot_idx[k] < 0) { nd.child[k] = PT_EMPTY_REF; continue; }   // box stays all-zero as in the reference
+            const BNode& sl = b[slot_idx[k]];
+            for (int a = 0; a < 3; a++) { nd.bmin[a][k] = sl.lo[a]; nd.bmax[a][k] = sl.hi[a]; }
+            if (sl.count > 0) nd.child[k] = leaf_ref(sl);
+            else if (cut && *cut_pos < cut->size() && (*cut)[*cut_pos].first == slot_idx[k]) { nd.child[k] = (*cut)[*cut_pos].second; next = (*cut)[*cut_pos].second + cut_size[*cut_pos]; (*cut_pos)++; }
+            else nd.child[k] = emit(slot_idx[k], depth + 1, next, deepest, cut, cut_pos);
         }
         nd.axes = (uint32_t)n.axis | ((uint32_t)c0.axis << 2) | ((uint32_t)c1.axis << 4);
         for (int k = 0; k < 4; k++)
@@ -387,9 +403,77 @@ struct Collapser {
         out.nodes[me] = nd;
         return me;
     }
+    std::vector<uint32_t> cut_size;      // 4-wide nodes under each entry of the cut
+
+    // The whole tree.  The top levels are walked on this thread; the subtrees hanging below 4-wide depth kCutDepth are counted and then
+    // emitted by the host's threads, each into the index range the depth-first numbering gives it.
+    uint32_t run(int32_t root) {
+        const uint32_t kCutDepth = 5;
+        struct Sub { int32_t bi; uint32_t depth; };
+        std::vector<Sub> subs;
+        {   // the cut, in depth-first order
+            struct It { int32_t bi; uint32_t depth; };
+            std::vector<It> stack{{root, 1}};
+            while (!stack.empty()) {
+                const It it = stack.back();
+                stack.pop_back();
+                if (it.depth > kCutDepth) { subs.push_back({it.bi, it.depth}); continue; }
+                int32_t si[4];
+                slots_of(it.bi, si);
+                for (int k = 3; k >= 0; k--) if (si[k] >= 0 && b[si[k]].count == 0) stack.push_back({si[k], it.depth + 1});
+            }
+        }
+        cut_size.assign(subs.size(), 0);
+        parallel_tasks(subs.size(), [&](size_t i) { cut_size[i] = count4(subs[i].bi); });
+        // first indices: walk the top again, counting; then the real emission of the top with the cut in place
+        std::vector<std::pair<int32_t, uint32_t>> cut(subs.size());
+        {
+            uint32_t next = 0;
+            size_t pos = 0;
+            struct It { int32_t bi; uint32_t depth; };
+            std::vector<It> stack{{root, 1}};
+            while (!stack.empty()) {
+                const It it = stack.back();
+                stack.pop_back();
+                if (it.depth > kCutDepth) { cut[pos] = {it.bi, next}; next += cut_size[pos]; pos++; continue; }
+                next++;
+                int32_t si[4];
+                slots_of(it.bi, si);
+                for (int k = 3; k >= 0; k--) if (si[k] >= 0 && b[si[k]].count == 0) stack.push_back({si[k], it.depth + 1});
+            }
+            out.nodes.resize(next);
+        }
+        uint32_t next = 0, deepest = 0;
+        size_t pos = 0;
+        const uint32_t root_index = emit(root, 1, next, deepest, &cut, &pos);
+        std::atomic<uint32_t> deep{deepest};
+        parallel_tasks(subs.size(), [&](size_t i) {
+            uint32_t nx = cut[i].second, dp = 0;
+            emit(subs[i].bi, subs[i].depth, nx, dp, nullptr, nullptr);
+            uint32_t cur = deep.load();
+            while (dp > cur && !deep.compare_exchange_weak(cur, dp)) {}
+        });
+        max_depth4 = deep.load();
+        return root_index;
+    }
 };
 
 }  // namespace
+
+// Page-locked staging for the bounds a device build uploads (24 bytes per primitive): from pageable memory that copy is staged by
+// the runtime at 2-3 GB/s -- 10 ms per million triangles, more than the build itself.  One buffer per calling thread, kept and regrown.
+static float* pinned_floats(size_t n) {
+    static thread_local float* buf = nullptr;
+    static thread_local size_t cap = 0;
+    if (n > cap) {
+        if (buf) (void)hipHostFree(buf);
+        buf = nullptr; cap = 0;
+        void* q = nullptr;
+        if (hipHostMalloc(&q, n * sizeof(float), hipHostMallocDefault) != hipSuccess) return nullptr;
+        buf = (float*)q; cap = n;
+    }
+    return buf;
+}
 
 // Generic entry: any mix of primitives, each with its world bound and its ready-made 48-byte leaf record.
 bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_node_prims, Result* out, DeviceBuild* dev) {
@@ -402,7 +486,13 @@ bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_
     if (n_prims == 0) { out->root_ref = PT_EMPTY_REF; return true; }
     if (n_prims >= PT_LEAF_FIRST_MASK - 16u) return false;      // a leaf reference keeps 26 bits for the first record
     std::vector<Item> items, scratch;
-    std::vector<uint32_t> order;                                  // order[r] = primitive stored r-th
+    // order[r] = primitive stored r-th; the binary tree.  Kept by the calling thread between builds (cleared, capacity retained) while they
+    // stay below 256 MB: mapping and unmapping 60 MB per million primitives on every build cost more than reading the tree back.
+    static thread_local NoInitVec<uint32_t> order_keep;
+    static thread_local NoInitVec<BNode> tree_keep;
+    struct Trim { ~Trim() { if (tree_keep.capacity() * sizeof(BNode) > ((size_t)256 << 20)) { NoInitVec<BNode>().swap(tree_keep); NoInitVec<uint32_t>().swap(order_keep); } } } trim;
+    NoInitVec<uint32_t>& order = order_keep;
+    order.clear();
     const uint32_t n_items = n_prims;
     auto init_items = [&]() {
         items.resize(n_prims); scratch.resize(n_prims);
@@ -421,19 +511,21 @@ bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_
     bld.max_prims = (uint32_t)std::min(std::max(max_node_prims, 0), 255);
     bld.method = split_method;
     bld.par_threshold = 32768;
-    std::vector<BNode> tree;
+    NoInitVec<BNode>& tree = tree_keep;
+    tree.clear();
     tree.reserve((size_t)n_items);
     int32_t root = 0;
     bool on_device = false;
     if (split_method == PT_SPLIT_HLBVH && dev && dev->mode != PT_BVH_BUILD_HOST && n_items >= 2 &&
         (dev->mode == PT_BVH_BUILD_DEVICE || n_items >= kDeviceMinPrims)) {
-        std::unique_ptr<float[]> raw(new float[(size_t)n_items * 6]);      // uninitialised: first touched by the threads that fill it
+        float* raw = pinned_floats((size_t)n_items * 6);
+        if (!raw) return false;
         parallel_for(n_items, [&](size_t p0, size_t p1) {
             for (size_t pi = p0; pi < p1; pi++) { std::memcpy(&raw[pi * 6], prims[pi].lo, 12); std::memcpy(&raw[pi * 6 + 3], prims[pi].hi, 12); }
         });
         uint32_t n_treelets = 0;
         tt[1] = now();
-        const int rc = device_lbvh(dev->stream, raw.get(), n_items, bld.max_prims, &order, &tree, &n_treelets, &dev->err);
+        const int rc = device_lbvh(dev->stream, raw, n_items, bld.max_prims, &order, &tree, &n_treelets, &dev->err);
         tt[2] = now();
         if (rc < 0) return false;
         if (rc == 0) {
@@ -450,12 +542,13 @@ bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_
     }
     if (split_method == PT_SPLIT_SAH && dev && dev->mode != PT_BVH_BUILD_HOST && n_items >= 2 && bld.max_prims >= 2 &&
         (dev->mode == PT_BVH_BUILD_DEVICE || n_items >= kDeviceMinPrims)) {
-        std::unique_ptr<float[]> raw(new float[(size_t)n_items * 6]);
+        float* raw = pinned_floats((size_t)n_items * 6);
+        if (!raw) return false;
         parallel_for(n_items, [&](size_t p0, size_t p1) {
             for (size_t pi = p0; pi < p1; pi++) { std::memcpy(&raw[pi * 6], prims[pi].lo, 12); std::memcpy(&raw[pi * 6 + 3], prims[pi].hi, 12); }
         });
         tt[1] = now();
-        const int rc = device_sah(dev->stream, raw.get(), n_items, bld.max_prims, &order, &tree, &dev->err);
+        const int rc = device_sah(dev->stream, raw, n_items, bld.max_prims, &order, &tree, &dev->err);
         tt[2] = now();
         if (rc < 0) return false;
         if (rc == 0) { on_device = true; dev->used = true; root = 0; }
@@ -513,10 +606,21 @@ bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_
         pad.flags = PT_TRI_LAST;
         out->tris.push_back(pad);
     }
-    out->n_leaves = 0;
-    out->max_leaf = 0;
-    for (const BNode& n : tree)
-        if (n.count > 0) { out->tris[n.first + n.count - 1].flags |= PT_TRI_LAST; out->n_leaves++; out->max_leaf = std::max(out->max_leaf, n.count); }
+    {
+        std::atomic<uint32_t> n_leaves{0}, max_leaf{0};
+        parallel_for(tree.size(), [&](size_t k0, size_t k1) {
+            uint32_t nl = 0, ml = 0;
+            for (size_t k = k0; k < k1; k++) {
+                const BNode& n = tree[k];
+                if (n.count > 0) { out->tris[n.first + n.count - 1].flags |= PT_TRI_LAST; nl++; ml = std::max(ml, n.count); }
+            }
+            n_leaves += nl;
+            uint32_t cur = max_leaf.load();
+            while (ml > cur && !max_leaf.compare_exchange_weak(cur, ml)) {}
+        });
+        out->n_leaves = n_leaves.load();
+        out->max_leaf = max_leaf.load();
+    }
     if (tree[root].count > 0) {           // the whole scene is one leaf
         out->root_ref = leaf_reference(tree[root].first, tree[root].count);
         out->max_stack = 1;
@@ -524,7 +628,7 @@ bool build_prims(const Prim* prims, uint32_t n_prims, int split_method, int max_
     }
     tt[4] = now();
     Collapser col{tree, *out};
-    out->root_ref = col.emit(root, 1);
+    out->root_ref = col.run(root);
     out->max_stack = 3 * col.max_depth4 + 2;
     tt[5] = now();
     if (trace) std::fprintf(stderr, "[bvh] n=%u device=%d pack %.1f lbvh %.1f tree(host)/upper %.1f records %.1f collapse %.1f ms\n", n_items, (int)on_device,

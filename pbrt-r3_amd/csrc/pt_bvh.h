@@ -2,7 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <memory>
 #include <thread>
+#include <utility>
 #include <vector>
 #include "pt_device.h"
 #include "../../include/pbrtgpu.h"
@@ -21,10 +24,35 @@ template <class F> inline void parallel_for(size_t n, F fn) {
     for (std::thread& t : th) t.join();
 }
 
+// std::vector that leaves new elements uninitialised (resize() of a 50 MB array would otherwise zero it on one thread -- and fault every page
+// in on that thread -- before the parallel fill or the device copy overwrites it)
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U> void construct(U* p) { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <class T> using NoInitVec = std::vector<T, NoInitAlloc<T>>;
+
+// fn(i) for i in [0, n) on up to 16 host threads, indices handed out one at a time (uneven tasks: subtrees)
+template <class F> inline void parallel_tasks(size_t n, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw ? (hw < 16 ? hw : 16) : 4;
+    if (nt > n) nt = n;
+    if (nt < 2) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (std::thread& t : th) t.join();
+}
+
 struct Result {
-    std::vector<PtNode> nodes;          // 4-wide interior nodes, root first
-    std::vector<PtTri> tris;            // triangle records in leaf order + one zero pad record
-    std::vector<uint32_t> rec_of_prim;  // primitive index -> record index
+    NoInitVec<PtNode> nodes;            // 4-wide interior nodes, root first
+    NoInitVec<PtTri> tris;              // triangle records in leaf order + one zero pad record
+    NoInitVec<uint32_t> rec_of_prim;    // primitive index -> record index
     uint32_t root_ref = PT_EMPTY_REF;
     uint32_t max_leaf = 0;             // most triangles in one leaf
     uint32_t n_leaves = 0;
@@ -45,20 +73,22 @@ void triangle_prim(const float* P, const uint32_t* indices, uint32_t t, uint32_t
 void sphere_record(uint32_t sphere_index, uint32_t flags, PtTri* rec);
 void instance_record(uint32_t instance_index, PtTri* rec);
 // Binary build node (BVHBuildNode, build/node.rs:20-60): a leaf covers items [first, first + count), an interior node has count 0.
-struct LbvhNode {
+struct LbvhNode {                       // plain data (no initialisers): arrays of it are filled by a device copy or by the threads that own a range
     float lo[3], hi[3];
-    int32_t left = -1, right = -1;     // children (indices into the same array) or -1
-    uint32_t first = 0, count = 0;
-    uint8_t axis = 0;
+    int32_t left, right;               // children (indices into the same array) or -1
+    uint32_t first, count;
+    uint8_t axis;
+    static LbvhNode blank() { LbvhNode n; for (int i = 0; i < 3; i++) n.lo[i] = n.hi[i] = 0.0f; n.left = n.right = -1; n.first = n.count = 0; n.axis = 0; return n; }
 };
+
 // pt_hlbvh.hip: Morton codes, radix sort, treelets and emit_lbvh on the GPU.  raw_bounds = n x {lo[3], hi[3]} (host memory, not yet
 // inflated).  On success (0) order[k] = primitive stored k-th, nodes[0 .. n_treelets) are the treelet roots in Morton order.  Returns 1
 // when the host has to build instead (a range needs the centroid-median fallback, non-finite bounds, no memory), -1 on a HIP error.
-int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, std::vector<uint32_t>* order, std::vector<LbvhNode>* nodes,
+int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes,
                 uint32_t* n_treelets, hipError_t* err);
 // pt_sah.hip: the SAH binary build on the GPU, level by level.  Same conventions: 0 = order / nodes filled (nodes[0] is the root), 1 = the
 // host has to build (a split needs the equal-counts fallback, non-finite bounds, maxnodeprims < 2), -1 = HIP error.
-int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, std::vector<uint32_t>* order, std::vector<LbvhNode>* nodes, hipError_t* err);
+int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes, hipError_t* err);
 // Where the lower half of an HLBVH build runs: PT_BVH_BUILD_AUTO picks the device from kDeviceMinPrims primitives up.
 struct DeviceBuild { hipStream_t stream; int mode; bool used; hipError_t err; };
 const uint32_t kDeviceMinPrims = 1u << 16;

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <string>
 #include <array>
+#include <memory>
 #include <vector>
 
 #include "../../include/pbrtgpu.h"
@@ -82,6 +83,9 @@ struct pt_context {
     DevBuf d_pool;          // one slab carved into the SoA arrays of PtPaths
     PtPaths paths;
     DevBuf d_qa, d_qb, d_qnee, d_qshadow, d_qprobe, d_qsorted, d_counts, d_pixels, d_tiles, d_tilebits;
+    ptbvh::Result host_bvh;                       // upload scratch: the world tree's arrays
+    std::unique_ptr<ptbvh::Prim[]> host_prims;    // upload scratch (see pt_scene_upload); released when it exceeds 4 M primitives
+    size_t host_prims_cap = 0;
     DevBuf d_rec, d_counts2; // recursive integrators (directlighting, whitted): frames, differentials, next-event entries and lists; the second counter block
     size_t rec_paths = 0;
     uint32_t rec_epp = 0, rec_depth = 0;
@@ -519,6 +523,11 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (tag == 0) for (uint32_t i = 0; i < d->n_instances; i++) extra.push_back({d->instances[i].before_triangle, d->instances[i].order, 2u, i});
         std::stable_sort(extra.begin(), extra.end(), [](const Extra& x, const Extra& y) { return x.before != y.before ? x.before < y.before : x.order < y.order; });
         std::vector<Entry> out;
+        if (extra.empty() && n_objects == 0) {            // triangles only, all in the world: the list is the triangle array
+            out.resize(d->n_triangles);
+            ptbvh::parallel_for(d->n_triangles, [&](size_t a, size_t b) { for (size_t t = a; t < b; t++) out[t] = {0u, (uint32_t)t}; });
+            return out;
+        }
         size_t e = 0;
         for (uint32_t t = 0; t <= d->n_triangles; t++) {
             while (e < extra.size() && extra[e].before <= t) { out.push_back({extra[e].kind, extra[e].idx}); e++; }
@@ -565,13 +574,23 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     mark("world primitive list");
     if (world.empty()) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no world primitives (objects are only rendered through ObjectInstance)");
     if ((uint64_t)world.size() >= PT_LEAF_FIRST_MASK - 16u) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "more than 2^26 primitives");
-    ptbvh::Result bvh;
+    // the build's output arrays live in the context between uploads (cleared, capacity retained) while they stay below 1 GB
+    ptbvh::Result& bvh = ctx->host_bvh;
+    struct TrimBvh { pt_context* c; ~TrimBvh() { if (c->host_bvh.nodes.capacity() * sizeof(PtNode) > ((size_t)1 << 30)) c->host_bvh = ptbvh::Result(); } } trim_bvh{ctx};
     {
-        std::vector<ptbvh::Prim> prims(world.size());
+        // the world's primitive list: uninitialised storage, first touched by the threads that fill it, kept by the context for the next
+        // upload (allocating and returning 72 MB per million triangles costs more than the device-side build)
+        if (ctx->host_prims_cap < world.size()) {
+            ctx->host_prims.reset();
+            ctx->host_prims.reset(new ptbvh::Prim[world.size()]);
+            ctx->host_prims_cap = world.size();
+        }
+        struct PrimsView { ptbvh::Prim* p; size_t n; ptbvh::Prim* data() const { return p; } size_t size() const { return n; } ptbvh::Prim& operator[](size_t i) const { return p[i]; } };
+        PrimsView prims{ctx->host_prims.get(), world.size()};
         ptbvh::parallel_for(world.size(), [&](size_t i0, size_t i1) {
             for (size_t i = i0; i < i1; i++) if (world[i].kind != 2) fill_prim(world[i], &prims[i]);
         });
-        for (size_t i = 0; i < world.size(); i++) {
+        for (size_t i = 0; d->n_instances && i < world.size(); i++) {
             const Entry& en = world[i];
             if (en.kind != 2) continue;
             const pt_instance& in = d->instances[en.idx];
@@ -594,12 +613,13 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             return dev_build.err != hipSuccess ? ctx->hip_fail(dev_build.err, "HLBVH build on the device") : ctx->fail(PT_ERR_INVALID_ARGUMENT, hlbvh_msg);
         mark("build_prims");
     }
+    if (ctx->host_prims_cap > ((size_t)4 << 20)) { ctx->host_prims.reset(); ctx->host_prims_cap = 0; }
     mark("free primitive list");
     const size_t n_world_nodes = bvh.nodes.size();          // the objects' trees are appended behind these
-    for (size_t prim = 0; prim < world.size(); prim++) if (world[prim].kind == 2) dinst[world[prim].idx].world_prim = (uint32_t)prim;
+    if (d->n_instances) for (size_t prim = 0; prim < world.size(); prim++) if (world[prim].kind == 2) dinst[world[prim].idx].world_prim = (uint32_t)prim;
     // one node array and one record array: the world first, then each object with its references shifted
     std::vector<Entry> rec_entry(bvh.tris.size() - 1);        // record -> what it stands for (shading records below)
-    for (size_t prim = 0; prim < world.size(); prim++) rec_entry[bvh.rec_of_prim[prim]] = world[prim];
+    ptbvh::parallel_for(world.size(), [&](size_t a, size_t b) { for (size_t prim = a; prim < b; prim++) rec_entry[bvh.rec_of_prim[prim]] = world[prim]; });
     uint32_t max_inner_stack = 0;
     if (n_objects) {
         bvh.tris.pop_back();

@@ -254,19 +254,51 @@ __global__ __launch_bounds__(256) void k_hl_up(const Work* __restrict__ work, ui
     for (int i = 0; i < 3; i++) { nd.lo[i] = fmin_le(l.lo[i], r.lo[i]); nd.hi[i] = fmax_ge(l.hi[i], r.hi[i]); }
 }
 
+// Device scratch for one build.  The blocks come out of an arena the calling thread keeps per device (one hipMalloc, reused by every
+// later build: the 14 hipMalloc / hipFree pairs cost 7 ms per build, more than the build's kernels); what does not fit -- the first
+// build, or a bigger scene -- is allocated the slow way and the arena is regrown to the high-water mark afterwards.
+struct ScratchArena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0, wanted = 0;
+    int dev = -1;
+    void begin() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        if (d != dev) { base = nullptr; cap = 0; dev = d; }      // another device: its own arena (the old block stays with its device)
+        used = 0; wanted = 0;
+    }
+    void end() {                                                   // every block handed out has been returned (Scratch destructors ran)
+        if (wanted > cap && wanted <= ((size_t)4 << 30)) {
+            if (base) (void)hipFree(base);
+            base = nullptr; cap = 0;
+            void* q = nullptr;
+            if (hipMalloc(&q, wanted) == hipSuccess) { base = (char*)q; cap = wanted; }
+        }
+    }
+};
+static thread_local ScratchArena t_arena;
 struct Scratch {
     void* p = nullptr;
-    ~Scratch() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    bool own = false;
+    ~Scratch() { if (p && own) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) {
+        bytes = (bytes ? bytes : 16) + 255 & ~(size_t)255;
+        t_arena.wanted += bytes;
+        if (t_arena.used + bytes <= t_arena.cap) { p = t_arena.base + t_arena.used; t_arena.used += bytes; own = false; return hipSuccess; }
+        own = true;
+        return hipMalloc(&p, bytes);
+    }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
+struct ArenaScope { ArenaScope() { t_arena.begin(); } ~ArenaScope() { t_arena.end(); } };
 
 }  // namespace
 
 #define HL_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { if (err) *err = e_; return e_ == hipErrorOutOfMemory ? 1 : -1; } } while (0)
 
-int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, std::vector<uint32_t>* order, std::vector<LbvhNode>* nodes,
+int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes,
                 uint32_t* n_treelets, hipError_t* err) {
+    ArenaScope arena_scope;          // declared before every Scratch: destroyed after them
     const bool trace = std::getenv("PBRTGPU_BUILD_TRACE") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();

@@ -315,12 +315,43 @@ __global__ __launch_bounds__(256) void k_sah_order(const SItem* __restrict__ ite
     if (i < n) order[i] = items[i].prim;
 }
 
+// Device scratch for one build.  The blocks come out of an arena the calling thread keeps per device (one hipMalloc, reused by every
+// later build: the 14 hipMalloc / hipFree pairs cost 7 ms per build, more than the build's kernels); what does not fit -- the first
+// build, or a bigger scene -- is allocated the slow way and the arena is regrown to the high-water mark afterwards.
+struct ScratchArena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0, wanted = 0;
+    int dev = -1;
+    void begin() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        if (d != dev) { base = nullptr; cap = 0; dev = d; }      // another device: its own arena (the old block stays with its device)
+        used = 0; wanted = 0;
+    }
+    void end() {                                                   // every block handed out has been returned (Scratch destructors ran)
+        if (wanted > cap && wanted <= ((size_t)4 << 30)) {
+            if (base) (void)hipFree(base);
+            base = nullptr; cap = 0;
+            void* q = nullptr;
+            if (hipMalloc(&q, wanted) == hipSuccess) { base = (char*)q; cap = wanted; }
+        }
+    }
+};
+static thread_local ScratchArena t_arena;
 struct Scratch {
     void* p = nullptr;
-    ~Scratch() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    bool own = false;
+    ~Scratch() { if (p && own) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) {
+        bytes = (bytes ? bytes : 16) + 255 & ~(size_t)255;
+        t_arena.wanted += bytes;
+        if (t_arena.used + bytes <= t_arena.cap) { p = t_arena.base + t_arena.used; t_arena.used += bytes; own = false; return hipSuccess; }
+        own = true;
+        return hipMalloc(&p, bytes);
+    }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
+struct ArenaScope { ArenaScope() { t_arena.begin(); } ~ArenaScope() { t_arena.end(); } };
 #define SAH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { if (err) *err = e_; return -1; } } while (0)
 
 }  // namespace
@@ -328,7 +359,8 @@ struct Scratch {
 // SAH binary build on the device.  raw_bounds = n x {lo[3], hi[3]} (host memory, not yet inflated).  On success (0): order[k] = primitive
 // stored k-th, nodes[0] the root.  1: the host has to build instead (equal-counts fallback needed, non-finite bounds, too few items);
 // -1: HIP error.
-int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, std::vector<uint32_t>* order, std::vector<LbvhNode>* nodes, hipError_t* err) {
+int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes, hipError_t* err) {
+    ArenaScope arena_scope;          // declared before every Scratch: destroyed after them
     const bool trace = std::getenv("PBRTGPU_BUILD_TRACE") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
@@ -360,6 +392,7 @@ int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max
     uint32_t* flags = counters + 8;
     SAH_TRY(hipMemsetAsync(d_small.p, 0, 64, st));
     SAH_TRY(hipMemcpyAsync(d_raw.p, raw_bounds, (size_t)n * 24, hipMemcpyHostToDevice, st));
+    if (trace) { const double ta = now(); (void)hipStreamSynchronize(st); std::fprintf(stderr, "[bvh] device SAH: bounds upload %.2f ms (%.1f MB)\n", now() - ta, n * 24e-6); }
     const uint32_t blocks = (n + 255u) / 256u;
     k_sah_items<<<blocks < 4096u ? blocks : 4096u, 256, 0, st>>>(d_raw.as<float>(), n, d_items[0].as<SItem>(), d_nodeof[0].as<uint32_t>(), flags);
     k_sah_root<<<1, 64, 0, st>>>(N, n, counters);
