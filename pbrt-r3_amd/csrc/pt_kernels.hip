@@ -2146,6 +2146,9 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     // (tools/ubench/atomic_rate.hip: 88 M/s however many waves ask), so one reservation per queue and 64 paths -- 540 k of them
     // for a 34 M-path bounce -- made the queue counter, not the shading, set this kernel's duration.
     uint32_t n_batch = 0;
+    uint32_t pf_p = 0;                  // prefetched for the next iteration: path id, its hit record
+    int32_t pf_rec = -1;
+    bool pf_valid = false;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     auto flush_batch = [&]() {
         if (n_batch == 0) return;
@@ -2214,12 +2217,20 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         // to the end of the iteration, the continuation ray came out wrong for about 1 % of the samples of seven feature scenes (bisected
         // to exactly that deferral; the kernels that do not spill are bit-exact either way).
 #define PT_COMMIT_NOW() do { if constexpr (TEX || INST) commit(); } while (0)
+        // the next iteration's path id and hit record are asked for one iteration ahead (within a work ticket): two of the three
+        // dependent round trips at the head of an iteration -- list -> path state -> leaf record -- then overlap this iteration's work
+        const bool had_pf = pf_valid;
+        const uint32_t pf_p_now = pf_p;
+        const int32_t pf_rec_now = pf_rec;
+        pf_valid = chunk_left > 0;
+        const bool pf_lane = pf_valid && next_base + lane < end;
+        if (pf_lane) pf_p = list[next_base + lane];
         if (active) {
-            p = list[item];
+            p = had_pf ? pf_p_now : list[item];
             PT_SHP_SYNC(13);
             float4 ro4 = P.ray_o[p], rd4 = P.ray_d[p];
             V3 ro = f4_3(ro4), rd = f4_3(rd4);
-            int32_t rec = P.hit_rec[p];
+            int32_t rec = had_pf ? pf_rec_now : P.hit_rec[p];
             uint32_t st = P.state[p];
             uint32_t dim = st & 0xffffu, bounces = (st >> 16) & 0xffu, flags = st >> 24;
             float4 beta4 = P.beta[p];
@@ -2250,6 +2261,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             if constexpr (INST) found = rec >= 0 && make_surf_inst<SPH>(sc, ro, rd, (uint32_t)rec, P.hit_inst[p], s, &thit);
             else found = rec >= 0 && make_surf_any_rec<SPH>(sc, ro, rd, (uint32_t)rec, rec_a, rec_b, rec_c, s, &thit);
             PT_SHP(0);
+            if (pf_lane) pf_rec = P.hit_rec[pf_p];          // pf_p has long arrived
             // emitted radiance at the first vertex / after a specular bounce (path.rs:87-98)
             if (found && (bounces == 0 || (flags & PT_ST_SPECULAR))) {
                 int32_t li = s.light;
