@@ -86,6 +86,9 @@ struct pt_context {
     ptbvh::Result host_bvh;                       // upload scratch: the world tree's arrays
     std::unique_ptr<ptbvh::Prim[]> host_prims;    // upload scratch (see pt_scene_upload); released when it exceeds 4 M primitives
     size_t host_prims_cap = 0;
+    DevBuf d_sort_ids, d_sort_keys[2], d_sort_temp;   // pt_raysort.hip: the second id list, the key lists and rocprim's scratch
+    size_t sort_cap = 0;
+    int sort_shadow_min = 1 << 20;                     // shadow rays of a launch are ordered by origin cell from this many up (0: never)
     DevBuf d_rec, d_counts2; // recursive integrators (directlighting, whitted): frames, differentials, next-event entries and lists; the second counter block
     size_t rec_paths = 0;
     uint32_t rec_epp = 0, rec_depth = 0;
@@ -229,6 +232,7 @@ pt_status pt_context_create(int device, pt_context** out) {
     if (const char* e = std::getenv("PBRTGPU_TRACE_BLOCKS_PER_CU")) ctx->grid_trace = ctx->grid_trace_dist = ctx->n_cu * std::max(1, std::atoi(e));
     ctx->grid_shade = ctx->n_cu * 2;
     if (const char* e = std::getenv("PBRTGPU_SHADE_BLOCKS_PER_CU")) ctx->grid_shade = ctx->n_cu * std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("PBRTGPU_SORT_SHADOW_MIN")) ctx->sort_shadow_min = std::max(0, std::atoi(e));
     ctx->grid_wide = ctx->n_cu * 8;
     // Sobol' tables: $PBRTGPU_DATA_DIR, else <directory of this shared library>/../data
     const char* dd = std::getenv("PBRTGPU_DATA_DIR");
@@ -924,6 +928,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (d->n_instances) { sc.general_materials = 1; sc.dist_leaves = 0; }      // k_trace_inst walks leaves per lane; one shade kernel handles everything
     sc.root_ref = bvh.root_ref;
     sc.n_top = n_top;
+    for (int a = 0; a < 3; a++) { const float ext = bvh.root_hi[a] - bvh.root_lo[a]; sc.cell_scale[a] = ext > 0.0f ? 128.0f / ext : 0.0f; }
     std::memcpy(sc.wb_min, bvh.root_lo, 12);
     std::memcpy(sc.wb_max, bvh.root_hi, 12);
     sc.max_depth = d->max_depth;
@@ -1211,6 +1216,19 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     Q.sorted = ctx->d_qsorted.as<uint32_t>();
     Q.shadow = ctx->d_qshadow.as<uint32_t>();
     Q.probe = ctx->d_qprobe.as<uint32_t>();
+    Q.shadow_key = nullptr;
+    if (ctx->sort_shadow_min > 0 && sc.integrator == PT_INTEGRATOR_PATH) {       // pt_raysort.hip: k_shade writes a key per shadow ray, each bounce's list is sorted by it
+        if (ctx->sort_cap < ctx->pool_paths) {
+            const size_t tb = ptk_sort_rays_temp_bytes((uint32_t)ctx->pool_paths);
+            if (tb == 0) return ctx->fail(PT_ERR_DEVICE, "radix sort scratch size query failed");
+            PT_HIP(ctx->d_sort_ids.alloc(ctx->pool_paths * 4));
+            PT_HIP(ctx->d_sort_keys[0].alloc(ctx->pool_paths * 4));
+            PT_HIP(ctx->d_sort_keys[1].alloc(ctx->pool_paths * 4));
+            PT_HIP(ctx->d_sort_temp.alloc(tb));
+            ctx->sort_cap = ctx->pool_paths;
+        }
+        Q.shadow_key = ctx->d_sort_keys[0].as<uint32_t>();
+    }
     PtCounters* cnt = ctx->d_counters.as<PtCounters>();
     uint32_t* err = ctx->d_err.as<uint32_t>();
     size_t ev_i = 0;
@@ -1320,6 +1338,24 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                     if (n_live == 0) break;
                 }
             } else if (sc.n_lights > 0) {          // no lights: li() returns zero immediately (path.rs:71-74)
+                uint32_t* shadow_sorted = nullptr;          // the ordered shadow list for the next traversal launch, if one was made
+                auto trace = [&]() -> hipError_t {
+                    PtQueues Qt = Q;
+                    if (shadow_sorted) Qt.shadow = shadow_sorted;
+                    shadow_sorted = nullptr;
+                    return ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Qt, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err);
+                };
+                // after a bounce's shading: order its shadow rays by where they start (pt_raysort.hip); costs one counter read-back
+                auto sort_shadow = [&]() -> pt_status {
+                    if (!Q.shadow_key) return PT_OK;
+                    uint32_t n_sh = 0;
+                    PT_HIP(hipMemcpyAsync(&n_sh, Q.counts + PT_Q_SHADOW, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    PT_HIP(hipStreamSynchronize(ctx->stream));
+                    if (n_sh < (uint32_t)ctx->sort_shadow_min) return PT_OK;
+                    PT_HIP(ptk_sort_shadow_rays(ctx->stream, Q.shadow, ctx->d_sort_ids.as<uint32_t>(), ctx->d_sort_keys[0].as<uint32_t>(),
+                                                ctx->d_sort_keys[1].as<uint32_t>(), ctx->d_sort_temp.p, ctx->d_sort_temp.bytes, n_sh, &shadow_sorted));
+                    return PT_OK;
+                };
                 auto bounce = [&]() -> pt_status {
                     const bool timed = !no_events;
                     hipEvent_t a = nullptr, b = nullptr, c = nullptr;
@@ -1336,13 +1372,17 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                         ev_i += 3;
                         PT_HIP(hipEventRecord(a, ctx->stream));
                     }
-                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                    PT_HIP(trace());
                     if (timed) PT_HIP(hipEventRecord(b, ctx->stream));
                     PT_HIP(ptk_nee_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q));
                     ctx->trace_launches++;
                     PT_HIP(ptk_prep(ctx->stream, Q, 0));
                     PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, cnt));
                     PT_HIP(ptk_prep(ctx->stream, Q, 1));
+                    {
+                        const pt_status ss = sort_shadow();
+                        if (ss != PT_OK) return ss;
+                    }
                     if (timed) PT_HIP(hipEventRecord(c, ctx->stream));
                     std::swap(Q.cur, Q.next);
                     return PT_OK;
@@ -1357,7 +1397,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                     PT_HIP(hipStreamSynchronize(ctx->stream));
                     if (counts[PT_Q_CUR] == 0 && counts[PT_Q_NEE] == 0) break;
                     if (counts[PT_Q_CUR] == 0) {     // only NEE resolves left
-                        PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                        PT_HIP(trace());
                         PT_HIP(ptk_nee_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q));
                         ctx->trace_launches++;
                         PT_HIP(ptk_prep(ctx->stream, Q, 0));
@@ -1602,7 +1642,7 @@ pt_status pt_trace_wavefront(pt_context* ctx, uint32_t n, const float* o, const 
     PtQueues Q;
     Q.cur = ctx->d_qa.as<uint32_t>(); Q.next = ctx->d_qb.as<uint32_t>();
     Q.nee = ctx->d_qnee.as<uint32_t>(); Q.counts = ctx->d_counts.as<uint32_t>(); Q.sorted = ctx->d_qsorted.as<uint32_t>();
-    Q.shadow = ctx->d_qshadow.as<uint32_t>(); Q.probe = ctx->d_qprobe.as<uint32_t>();
+    Q.shadow = ctx->d_qshadow.as<uint32_t>(); Q.probe = ctx->d_qprobe.as<uint32_t>(); Q.shadow_key = nullptr;
     uint32_t* const dst_q[3] = {Q.cur, Q.shadow, Q.probe};
     for (int k = 0; k < 3; k++)
         if (!ids[k].empty()) PT_HIP(hipMemcpyAsync(dst_q[k], ids[k].data(), ids[k].size() * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -255,6 +255,7 @@ struct PtScene {
     uint32_t n_lights;
     uint32_t root_ref;           // node 0, or a leaf reference when the whole scene is one leaf
     uint32_t n_top;              // nodes 0 .. n_top-1 are the top of the world tree in breadth-first order (at most PT_TOP_BFS_NODES)
+    float cell_scale[3];         // 128 / the world bound's extent per axis (0 for a flat axis): ray origin -> 7-bit cell coordinate
     float wb_min[3], wb_max[3];  // BVH root bounds (Scene::world_bound)
     int32_t max_depth;
     float rr_threshold;
@@ -325,6 +326,7 @@ struct PtQueues {
     uint32_t* counts;    // counters, PT_Q_* below.  The ones every wave bumps with an atomic sit 128 bytes apart:
                          // atomics on one line serialise in a single L2 channel (k_shade was bound by exactly that)
     uint32_t* sorted;    // cur re-ordered by material bin, misses dropped (scenes with non-Matte materials)
+    uint32_t* shadow_key;// per entry of shadow: the sort key of its ray (origin cell | direction octant, pt_raysort.hip); nullptr: not wanted
 };
 #define PT_Q_CUR 0u          // items in cur
 #define PT_Q_MATTE_END 1u    // material sort: end of the Matte segment of sorted

@@ -36,6 +36,10 @@ hipError_t ptk_expand_tiles(hipStream_t st, const int4* tiles, const uint32_t* t
                             uint32_t* pixels, uint32_t* bitmap, uint32_t* err);
 hipError_t ptk_wavefront_results(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, uint32_t n, const uint8_t* kind, pt_hit* out, uint8_t* occ);
 int ptk_shade_prof_read(unsigned long long* out16);
+// pt_raysort.hip: the shadow rays of a launch ordered by origin cell and direction octant
+size_t ptk_sort_rays_temp_bytes(uint32_t cap);
+hipError_t ptk_sort_shadow_rays(hipStream_t st, uint32_t* ids, uint32_t* ids_alt, uint32_t* keys, uint32_t* keys_alt, void* temp, size_t temp_bytes, uint32_t n,
+                                uint32_t** sorted);
 int ptk_trace_dist_blocks_per_cu();      // blocks per CU the pooled-leaf traversal kernels were built for (LDS budget)
 hipError_t ptk_rec_init(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t n);
 hipError_t ptk_rec_enter(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtQueues& Qn, const PtRec& R, PtCounters* cnt,

@@ -2115,6 +2115,15 @@ __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material,
     if (mp.prog[12]) mp.m.eta = tex_eval(sc.textures, sc.tex_prog + mp.prog[12], th, sc.images).x;
     build_lobes(mp.m, a_r, a_u, a_v, *out);
 }
+// Sort key of a ray for pt_raysort.hip: Morton code of the 128^3 cell of its origin inside the world bound, direction octant on top
+PT_DEV uint32_t ray_sort_key(const PtScene& sc, V3 o, V3 d) {
+    const float fx = (o.x - sc.wb_min[0]) * sc.cell_scale[0], fy = (o.y - sc.wb_min[1]) * sc.cell_scale[1], fz = (o.z - sc.wb_min[2]) * sc.cell_scale[2];
+    uint32_t cx = (uint32_t)fminf(fmaxf(fx, 0.0f), 127.0f), cy = (uint32_t)fminf(fmaxf(fy, 0.0f), 127.0f), cz = (uint32_t)fminf(fmaxf(fz, 0.0f), 127.0f);
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 7u; b++) m |= (((cx >> b) & 1u) | (((cy >> b) & 1u) << 1) | (((cz >> b) & 1u) << 2)) << (3u * b);
+    return m | ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)) << 21;
+}
 // Diagnostic build -DPT_PROFILE_SHADE: wave clocks of shade_body by section (tools/tune_shade.sh "prof:-DPT_PROFILE_SHADE")
 #ifdef PT_PROFILE_SHADE
 __device__ unsigned long long g_shade_prof[16];
@@ -2133,6 +2142,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     // makes each later wait sit out the store's round trip as well.
     __shared__ float4 s_stage[7][PT_BLOCK];
     __shared__ uint32_t s_pend[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: path id (28 bits) | queue bits of the iterations not yet queued
+    __shared__ uint32_t s_pkey[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: the sort key of those iterations' shadow rays
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
     uint32_t n_vert = 0;
@@ -2177,7 +2187,10 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                          mp = __ballot((e & (8u << 28)) != 0);
                 if (e & (1u << 28)) Q.next[bc + (uint32_t)__popcll(mc & below)] = ep;
                 if (e & (2u << 28)) Q.nee[bn + (uint32_t)__popcll(mn & below)] = ep;
-                if (e & (4u << 28)) Q.shadow[bs + (uint32_t)__popcll(ms & below)] = ep;
+                if (e & (4u << 28)) {
+                    Q.shadow[bs + (uint32_t)__popcll(ms & below)] = ep;
+                    if (Q.shadow_key) Q.shadow_key[bs + (uint32_t)__popcll(ms & below)] = s_pkey[j][threadIdx.x];
+                }
                 if (e & (8u << 28)) Q.probe[bp + (uint32_t)__popcll(mp & below)] = ep;
                 bc += (uint32_t)__popcll(mc); bn += (uint32_t)__popcll(mn); bs += (uint32_t)__popcll(ms); bp += (uint32_t)__popcll(mp);
             }
@@ -2370,6 +2383,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                         V3 sd = target - origin;
                                         s_stage[0][threadIdx.x] = make_float4(origin.x, origin.y, origin.z, 1.0f - PT_SHADOW_EPS);
                                         s_stage[1][threadIdx.x] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+                                        if (Q.shadow_key) s_pkey[n_batch][threadIdx.x] = ray_sort_key(sc, origin, sd);
                                         wr |= 4u; PT_COMMIT_NOW();
                                         float weight = power_heuristic(lpdf, spdf);
                                         A = f * li * (weight / lpdf);

@@ -1,0 +1,35 @@
+// pt_raysort.hip -- the shadow rays of a traversal launch, ordered by where they start.
+//
+// Continuation rays reach k_trace in path (pixel) order and keep whatever coherence the image has; the next-event rays of a bounce start
+// at that bounce's hit points, which in a scene of small triangles are scattered through space, and all head for the lights.  Ordered by
+// the Morton cell of their origin (7 bits per axis inside the world bound) and the octant of their direction, neighbouring lanes walk
+// the same nodes and leaves: lanes that touch the same line share the L1's tag lookup, which is what bounds k_trace (DESIGN.md section
+// 4).  Only the work list is permuted -- path state stays where it is, results are written per path, so nothing downstream can tell.
+// The sort is rocprim's radix sort on 24-bit keys with the path id as the value.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <stdint.h>
+#include "pt_device.h"
+#include "pt_kernels.h"
+
+size_t ptk_sort_rays_temp_bytes(uint32_t cap) {
+    size_t bytes = 0;
+    rocprim::double_buffer<uint32_t> k(nullptr, nullptr), v(nullptr, nullptr);
+    if (rocprim::radix_sort_pairs(nullptr, bytes, k, v, cap, 0, 24, nullptr) != hipSuccess) return 0;
+    return bytes;
+}
+
+// ids[0 .. n): path ids of the launch's shadow rays, keys[0 .. n) their sort keys (k_shade writes both, entry by entry).  On return *sorted
+// points at the ordered list (either ids or ids_alt).
+hipError_t ptk_sort_shadow_rays(hipStream_t st, uint32_t* ids, uint32_t* ids_alt, uint32_t* keys, uint32_t* keys_alt, void* temp, size_t temp_bytes, uint32_t n,
+                                uint32_t** sorted) {
+    *sorted = ids;
+    if (n < 2) return hipSuccess;
+    rocprim::double_buffer<uint32_t> k(keys, keys_alt), v(ids, ids_alt);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, n, 0, 24, st);
+    if (e != hipSuccess) return e;
+    *sorted = v.current();
+    return hipGetLastError();
+}
