@@ -480,3 +480,21 @@ def test_crown_class_3p5m_triangles(gpu_ctx, oracle, split):
     n_hit, n_occ = _check(gpu_ctx, osc, o, d, t, kind)
     assert n_hit > 10000 and n_occ > 10000
     osc.close()
+
+
+@pytest.mark.parametrize("name,make", [("cornell", lambda: scenes.cornell_box(res=64, spp=16)), ("materials", lambda: fs.scene_materials_lights("spatial")),
+                                       ("spheres", lambda: fs.scene_spheres())])
+def test_shadow_ray_sorting_changes_nothing(oracle, monkeypatch, name, make):
+    """pt_raysort.hip orders each bounce's shadow rays by origin cell and direction octant before they are traced -- from a million rays
+    up, which no test scene reaches.  With the threshold at two (a context reads it when it is created) every bounce of these small scenes
+    is sorted: per-sample radiance, film and every counter must still be the oracle's, bit for bit."""
+    monkeypatch.setenv("PBRTGPU_SORT_SHADOW_MIN", "2")
+    ctx = pkg.Context(0)
+    try:
+        sd = make()
+        osc = oracle.scene(sd)
+        ctx.upload(sd)
+        _compare(ctx, osc, exact_film=True)
+        osc.close()
+    finally:
+        ctx.close()
