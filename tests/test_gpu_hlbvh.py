@@ -118,6 +118,10 @@ def test_device_sah_matches_host_sah(n, leaf, oracle):
             assert info.bvh_on_device == 1
             osc = oracle.scene(sd)
             assert (osc.info.n_nodes, osc.info.n_leaves) == (info.n_nodes, info.n_leaves)
+            # the leaf order: the device-built record array is byte-identical to the host builder's (digests above), and the host
+            # builder's order is the oracle's restatement of the reference's ordered_prims (build/node.rs:138-151)
+            order, n_nodes, n_leaves, _ = pkg.capi.bvh_leaf_order(sd)
+            assert np.array_equal(order, osc.ordered_prims()) and (n_nodes, n_leaves) == (info.n_nodes, info.n_leaves)
             o, d, tmax = random_rays(info, 20000, 9)
             g = ctx.trace_closest(o, d, tmax)
             r, _ = osc.trace_closest(o, d, tmax)
