@@ -1159,11 +1159,12 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
 
     // Paths in flight per pass.  Every k_trace launch ends with a drain tail (ray lengths are heavy-tailed and a
     // lane sees only a handful of rays per launch), so big launches pay: 4 M paths -> 662 Mrays/s, 64 M -> 850 on
-    // RT1M, 192 M (the 256-spp frame in two passes instead of five) 1 042 against 1 024: 192 M slots are 43 GB of path state, 4.6 GB of
-    // queues and 2.3 GB of sort buffers -- HBM3E is 288 GB, and a pool never takes more than half of what is free.
-    size_t pool_target = (size_t)192 << 20;
+    // RT1M, 192 M (the 256-spp frame in two passes instead of five) 1 037, 288 M (one pass: nine launches of up to 140 M rays) 1 048:
+    // 277 M slots are 64 GB of path state, 6.6 GB of queues and 3.3 GB of sort buffers -- HBM3E is 288 GB, and a pool never takes more
+    // than half of what is free.
+    size_t pool_target = (size_t)288 << 20;
     if (const char* e = std::getenv("PBRTGPU_POOL_PATHS")) pool_target = std::max<size_t>(65536, std::strtoull(e, nullptr, 10));
-    pool_target = std::min<size_t>(pool_target, (size_t)1 << 28);      // k_shade keeps (path id | queue bits) in one word
+    pool_target = std::min<size_t>(pool_target, (size_t)1 << 30);      // 32-bit path ids and queue counters with room to spare
     {   // never more than half of what the device has free
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ctx->pool_paths < pool_target) {

@@ -2141,7 +2141,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     // stores share one in-order counter (vmcnt), so a store issued in the middle of the dependent chain grid -> light table -> light
     // makes each later wait sit out the store's round trip as well.
     __shared__ float4 s_stage[7][PT_BLOCK];
-    __shared__ uint32_t s_pend[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: path id (28 bits) | queue bits of the iterations not yet queued
+    __shared__ uint32_t s_pend[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: path ids of the iterations not yet queued (their queue bits: `pend_want`)
     __shared__ uint32_t s_pkey[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: the sort key of those iterations' shadow rays
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
@@ -2155,7 +2155,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     // Queue entries are handed out in batches of PT_SHADE_FLUSH iterations.  A returning atomic on one address is served every 11.3 ns
     // (tools/ubench/atomic_rate.hip: 88 M/s however many waves ask), so one reservation per queue and 64 paths -- 540 k of them
     // for a 34 M-path bounce -- made the queue counter, not the shading, set this kernel's duration.
-    uint32_t n_batch = 0;
+    uint32_t n_batch = 0, pend_want = 0;      // pend_want: four queue bits (next, nee, shadow, probe) per pending iteration
     uint32_t pf_p = 0;                  // prefetched for the next iteration: path id, its hit record
     int32_t pf_rec = -1;
     bool pf_valid = false;
@@ -2166,9 +2166,9 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #pragma unroll
         for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++) {
             if (j < n_batch) {
-                const uint32_t e = s_pend[j][threadIdx.x];
-                tc += (uint32_t)__popcll(__ballot((e & (1u << 28)) != 0)); tn += (uint32_t)__popcll(__ballot((e & (2u << 28)) != 0));
-                ts += (uint32_t)__popcll(__ballot((e & (4u << 28)) != 0)); tp += (uint32_t)__popcll(__ballot((e & (8u << 28)) != 0));
+                const uint32_t e = pend_want >> (4u * j);
+                tc += (uint32_t)__popcll(__ballot((e & 1u) != 0)); tn += (uint32_t)__popcll(__ballot((e & 2u) != 0));
+                ts += (uint32_t)__popcll(__ballot((e & 4u) != 0)); tp += (uint32_t)__popcll(__ballot((e & 8u) != 0));
             }
         }
         uint32_t bc = 0, bn = 0, bs = 0, bp = 0;
@@ -2182,20 +2182,19 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #pragma unroll
         for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++) {
             if (j < n_batch) {
-                const uint32_t e = s_pend[j][threadIdx.x], ep = e & 0x0fffffffu;
-                const unsigned long long mc = __ballot((e & (1u << 28)) != 0), mn = __ballot((e & (2u << 28)) != 0), ms = __ballot((e & (4u << 28)) != 0),
-                                         mp = __ballot((e & (8u << 28)) != 0);
-                if (e & (1u << 28)) Q.next[bc + (uint32_t)__popcll(mc & below)] = ep;
-                if (e & (2u << 28)) Q.nee[bn + (uint32_t)__popcll(mn & below)] = ep;
-                if (e & (4u << 28)) {
+                const uint32_t e = pend_want >> (4u * j), ep = s_pend[j][threadIdx.x];
+                const unsigned long long mc = __ballot((e & 1u) != 0), mn = __ballot((e & 2u) != 0), ms = __ballot((e & 4u) != 0), mp = __ballot((e & 8u) != 0);
+                if (e & 1u) Q.next[bc + (uint32_t)__popcll(mc & below)] = ep;
+                if (e & 2u) Q.nee[bn + (uint32_t)__popcll(mn & below)] = ep;
+                if (e & 4u) {
                     Q.shadow[bs + (uint32_t)__popcll(ms & below)] = ep;
                     if (Q.shadow_key) Q.shadow_key[bs + (uint32_t)__popcll(ms & below)] = s_pkey[j][threadIdx.x];
                 }
-                if (e & (8u << 28)) Q.probe[bp + (uint32_t)__popcll(mp & below)] = ep;
+                if (e & 8u) Q.probe[bp + (uint32_t)__popcll(mp & below)] = ep;
                 bc += (uint32_t)__popcll(mc); bn += (uint32_t)__popcll(mn); bs += (uint32_t)__popcll(ms); bp += (uint32_t)__popcll(mp);
             }
         }
-        n_batch = 0;
+        n_batch = 0; pend_want = 0;
     };
     for (;;) {
         PT_SHP(11);
@@ -2484,7 +2483,8 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         // ---- everything this vertex writes in one burst, after the last load of the iteration
         commit();
         // ---- where it goes next: remembered (path | queue bits), queued with the batch
-        s_pend[n_batch][threadIdx.x] = p | ((cont ? 1u : 0u) | (want_nee ? 2u : 0u) | (want_sh ? 4u : 0u) | (want_pr ? 8u : 0u)) << 28;
+        s_pend[n_batch][threadIdx.x] = p;
+        pend_want |= ((cont ? 1u : 0u) | (want_nee ? 2u : 0u) | (want_sh ? 4u : 0u) | (want_pr ? 8u : 0u)) << (4u * n_batch);
         if (++n_batch == PT_SHADE_FLUSH) flush_batch();
         PT_SHP(9);
     }
