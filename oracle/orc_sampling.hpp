@@ -297,7 +297,10 @@ struct SobolSampler {
     }
     bool get_2d_array1(V2* out) {
         if (array_next >= n_arrays1) return false;
-        const uint32_t d = array_start_dim + 2u * array_next;
+        // every 2-D array is filled from the SAME pair of dimensions: start_pixel computes `dim` once, before the loop over the arrays,
+        // and never advances it (sobol.rs:60-75, halton.rs:193-208; pbrt-v3 has `dim += 2` there).  With "strategy all" every light's
+        // u_light and u_scattering arrays therefore hold the same points -- restated as is (quirk Q22).
+        const uint32_t d = array_start_dim;
         array_next++;
         *out = V2(sample_dimension(interval_sample_index, d), sample_dimension(interval_sample_index, d + 1));
         return true;

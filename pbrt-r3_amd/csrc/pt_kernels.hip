@@ -2952,8 +2952,10 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_enter(PtScene sc
                         for (uint32_t j = 0; j < sc.n_lights; j++) {
                             V2 u_light, u_scat;
                             if (arr + 2u <= R.n_arrays1) {
-                                u_light = mk2(sample_dimension(sc, sm.index, 5u + 2u * arr, sm.px, sm.py), sample_dimension(sc, sm.index, 6u + 2u * arr, sm.px, sm.py));
-                                u_scat = mk2(sample_dimension(sc, sm.index, 7u + 2u * arr, sm.px, sm.py), sample_dimension(sc, sm.index, 8u + 2u * arr, sm.px, sm.py));
+                                // all 2-D sample arrays of a pixel are filled from dimensions (5, 6): the reference computes the array dimension once,
+                                // before its loop over the arrays (sobol.rs:60-75, halton.rs:193-208; quirk Q22) -- u_light and u_scattering coincide
+                                u_light = mk2(sample_dimension(sc, sm.index, 5u, sm.px, sm.py), sample_dimension(sc, sm.index, 6u, sm.px, sm.py));
+                                u_scat = u_light;
                                 arr += 2u;
                             } else {
                                 arr = R.n_arrays1;
