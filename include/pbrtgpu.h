@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 7
+#define PT_ABI_VERSION 8
 
 typedef enum {
     PT_OK = 0,
@@ -164,6 +164,8 @@ typedef struct {
 typedef struct {
     float L[3];             /* "L" * "scale" */
     int32_t two_sided;      /* "twosided", default 0 */
+    int32_t n_samples;      /* ABI 8: "nsamples" (diffuse.rs:177-189), default 1; 0 is read as 1.  Only DirectLighting's "all" strategy looks at
+                             * it: every light of the shape is estimated from sample arrays of this size (directlighting.rs:51-64) */
 } pt_area_light;
 
 /* TriangleMesh flags (src/shapes/triangle.rs:10-22). */

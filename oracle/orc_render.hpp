@@ -117,6 +117,7 @@ struct AreaLight {          // lights/diffuse.rs:5-11
     RGB lemit;
     bool two_sided;
     Float area;
+    uint32_t n_samples = 1;     // "nsamples" (diffuse.rs:177-189): Light::get_sample_count
 };
 
 struct Scene {
@@ -733,17 +734,18 @@ inline RGB rec_li(const Scene& sc, Ray ray, RayDiff rd, SobolSampler& sampler, R
         l = surf_le(sc, isect, wo);
         if (n_lights > 0) {
             RGB ld_all;
-            if (sc.direct_strategy == PT_DIRECT_ALL) {              // uniform_sample_all_lights (sample_lights.rs:24-82), one sample per light
+            if (sc.direct_strategy == PT_DIRECT_ALL) {              // uniform_sample_all_lights (sample_lights.rs:24-78)
                 for (size_t j = 0; j < n_lights; j++) {
-                    V2 u_light, u_scattering;
-                    const bool a = sampler.get_2d_array1(&u_light), b = sampler.get_2d_array1(&u_scattering);
+                    const uint32_t n_samples = sc.lights[j].n_samples;       // n_light_samples[j] = round_count(get_sample_count()) = nsamples
+                    std::vector<V2> u_light_array, u_scattering_array;
+                    const bool a = sampler.get_2d_array(n_samples, &u_light_array), b = sampler.get_2d_array(n_samples, &u_scattering_array);
                     if (a && b) {
                         RGB ld;
-                        ld += estimate_direct(sc, isect, bsdf, j, u_light, u_scattering, rc);
-                        ld_all += ld / 1.0f;
+                        for (uint32_t k = 0; k < n_samples; k++) ld += estimate_direct(sc, isect, bsdf, j, u_light_array[k], u_scattering_array[k], rc);
+                        ld_all += ld / (Float)n_samples;
                     } else {
-                        u_light = sampler.get_2d();
-                        u_scattering = sampler.get_2d();
+                        const V2 u_light = sampler.get_2d();
+                        const V2 u_scattering = sampler.get_2d();
                         ld_all += estimate_direct(sc, isect, bsdf, j, u_light, u_scattering, rc);
                     }
                 }
@@ -1105,6 +1107,7 @@ inline bool Scene::build(const pt_scene_desc& d, const std::string& data_dir, st
             al.shape = ref;
             al.lemit = RGB(d.area_lights[lp].L[0], d.area_lights[lp].L[1], d.area_lights[lp].L[2]);
             al.two_sided = d.area_lights[lp].two_sided != 0;
+            al.n_samples = (uint32_t)std::max(1, d.area_lights[lp].n_samples);
             al.area = (ref & PRIM_SPHERE) ? geom.spheres[ref & ~PRIM_SPHERE].area() : TriRef(&geom, ref).area();
             prim_light[p] = (int32_t)lights.size();
             lights.push_back(al);

@@ -223,10 +223,10 @@ struct SobolSampler {
     static const uint32_t array_start_dim = 5;
     uint32_t array_end_dim = 5;
     uint32_t array2d_n = 0;          // size of the one requested 2-D sample array (AOIntegrator::new, ao.rs:24-31); 0 = none
-    // DirectLightingIntegrator::preprocess ("all" strategy, directlighting.rs:50-65): 2 * lights * maxdepth arrays of ONE sample each
-    // (area lights report one sample, round_count is the identity).  Array i of the current pixel sample is that sample's own
-    // value at dimensions (5 + 2 i, 6 + 2 i) (sobol.rs:60-75, base_sampler.rs:59-70); get_2d_array hands them out in request order
-    // and returns None once they are used up (then the caller falls back to get_2d).
+    // DirectLightingIntegrator::preprocess ("all" strategy, directlighting.rs:50-65): 2 * lights * maxdepth arrays, the two of light j
+    // of size n_j = round_count(light.get_sample_count()) -- round_count is the trait's identity for both global samplers
+    // (core/sampler/sampler.rs:41-43; pbrt-v3's Sobol' rounds up to a power of two), get_sample_count the area light's "nsamples".
+    // get_2d_array hands the arrays out in request order and returns None once they are used up (then the caller falls back to get_2d).
     uint32_t n_arrays1 = 0, array_next = 0;
 
     void init_halton(uint32_t samples_per_pixel, const int32_t sb[4], bool at_center) {   // halton.rs:57-112
@@ -295,14 +295,19 @@ struct SobolSampler {
         array_end_dim = array_start_dim + (array2d_n ? 2u : 0u) + 2u * n_arrays1;      // sobol.rs:43-45, halton.rs:176-178
         array_next = 0;
     }
-    bool get_2d_array1(V2* out) {
+    // get_2d_array(n) for one of the n_arrays1 requested arrays: false = None (all handed out).  Element k for the current pixel sample is
+    // sample_array2d[i][n * current + k] (base_sampler.rs:59-70), which start_pixel filled from sample number n * current + k -- and
+    // every 2-D array is filled from the SAME pair of dimensions: start_pixel computes `dim` once, before the loop over the arrays, and
+    // never advances it (sobol.rs:60-75, halton.rs:193-208; pbrt-v3 has `dim += 2` there).  With "strategy all" every light's u_light and
+    // u_scattering arrays therefore hold the same points -- restated as is (quirk Q22).
+    bool get_2d_array(uint32_t n, std::vector<V2>* out) {
         if (array_next >= n_arrays1) return false;
-        // every 2-D array is filled from the SAME pair of dimensions: start_pixel computes `dim` once, before the loop over the arrays,
-        // and never advances it (sobol.rs:60-75, halton.rs:193-208; pbrt-v3 has `dim += 2` there).  With "strategy all" every light's
-        // u_light and u_scattering arrays therefore hold the same points -- restated as is (quirk Q22).
-        const uint32_t d = array_start_dim;
         array_next++;
-        *out = V2(sample_dimension(interval_sample_index, d), sample_dimension(interval_sample_index, d + 1));
+        out->resize(n);
+        for (uint32_t k = 0; k < n; k++) {
+            const int64_t index = get_index_for_sample((int64_t)current_sample * (int64_t)n + (int64_t)k);
+            (*out)[k] = V2(sample_dimension(index, array_start_dim), sample_dimension(index, array_start_dim + 1));
+        }
         return true;
     }
     // Element k of get_2d_array(n) for the current pixel sample: start_pixel fills sample_array2d[0][j] from sample number j at

@@ -63,7 +63,7 @@ PT_MAPPING_UV, PT_MAPPING_SPHERICAL, PT_MAPPING_CYLINDRICAL, PT_MAPPING_PLANAR =
 
 
 class pt_area_light(C.Structure):
-    _fields_ = [("L", C.c_float * 3), ("two_sided", C.c_int32)]
+    _fields_ = [("L", C.c_float * 3), ("two_sided", C.c_int32), ("n_samples", C.c_int32)]
 
 
 class pt_mesh(C.Structure):

@@ -621,10 +621,11 @@ public:
         pt_area_light al;
         al.L[0] = L[0] * sc[0]; al.L[1] = L[1] * sc[1]; al.L[2] = L[2] * sc[2];
         al.two_sided = gs.area_light_params.find_one_bool("twosided", false) ? 1 : 0;
-        {   // "nsamples" (diffuse.rs:177-183) sizes the sample arrays of DirectLighting's "all" strategy; the ABI carries one sample per light
+        {   // "nsamples" (diffuse.rs:177-189) sizes the sample arrays of DirectLighting's "all" strategy
             int ns = gs.area_light_params.find_one_int("nsamples", 1);
             if (quick_render) ns = std::max(ns / 4, 1);
-            if (ns != 1) area_light_nsamples_not_one = true;
+            if (ns < 1 || ns > 4096) { fail("AreaLightSource \"nsamples\" outside [1, 4096] (the reference divides by it)"); return -1; }
+            al.n_samples = ns;
         }
         area_lights.push_back(al);
         return (int)area_lights.size() - 1;
@@ -878,10 +879,6 @@ public:
             // create_direct_lighting_integrator (directlighting.rs:137-158), create_whitted_integrator (whitted.rs:112-135)
             desc.direct_strategy = integrator_params.find_one_string("strategy", "all") == "one" ? PT_DIRECT_ONE : PT_DIRECT_ALL;
             if (integrator_params.ints.count("pixelbounds")) { fail("Integrator \"" + integrator_name + "\": \"pixelbounds\" is outside the accelerated path"); return; }
-            if (desc.integrator == PT_INTEGRATOR_DIRECTLIGHTING && desc.direct_strategy == PT_DIRECT_ALL && area_light_nsamples_not_one) {
-                fail("Integrator \"directlighting\" \"all\": area lights with \"nsamples\" other than 1 are outside the accelerated path");
-                return;
-            }
         }
         desc.ao_cos_sample = integrator_params.find_one_bool("cossample", true) ? 1 : 0;      // create_ao_integrator (ao.rs:118-138)
         desc.ao_samples = integrator_params.find_one_int("nsamples", 64);
@@ -928,7 +925,6 @@ private:
     std::vector<unsigned> bits;
     std::vector<GraphicsState> gstates;
     std::map<std::string, TransformSet> named_cs;
-    bool area_light_nsamples_not_one = false;
     std::string filter_name = "box", film_name = "image", sampler_name = "halton", accel_name = "bvh", integrator_name = "path", camera_name = "perspective";
     ParamSet filter_params, film_params, sampler_params, accel_params, integrator_params, camera_params;
     bool have_camera = false;

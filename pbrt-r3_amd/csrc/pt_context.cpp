@@ -92,6 +92,7 @@ struct pt_context {
     DevBuf d_rec, d_counts2; // recursive integrators (directlighting, whitted): frames, differentials, next-event entries and lists; the second counter block
     size_t rec_paths = 0;
     uint32_t rec_epp = 0, rec_depth = 0;
+    uint32_t light_samples_total = 0;     // sum of the lights' sample counts (DirectLighting "all")
     DevBuf d_ao;             // AO integrator: occlusion-ray batch (o, d, tmax, weight, occluded) for ao_rays_cap rays
     size_t ao_rays_cap = 0;
     size_t pixels_cap = 0;
@@ -423,6 +424,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if ((d->integrator == PT_INTEGRATOR_DIRECTLIGHTING || d->integrator == PT_INTEGRATOR_WHITTED) && d->max_depth > 16)
         return ctx->fail(PT_ERR_UNSUPPORTED, "directlighting / whitted: maxdepth above 16 (one frame per level is kept per camera sample)");
     if (d->n_materials > 0 && !d->materials) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "materials array missing");
+    if (d->n_area_lights > 0 && !d->area_lights) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "area lights array missing");
+    for (uint32_t i = 0; i < d->n_area_lights; i++)
+        if (d->area_lights[i].n_samples < 0 || d->area_lights[i].n_samples > 4096) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "area light nsamples outside [0, 4096]");
     if (d->sampler != PT_SAMPLER_SOBOL && d->sampler != PT_SAMPLER_HALTON)
         return ctx->fail(PT_ERR_UNSUPPORTED, "sampler not on the accelerated path: only the index-addressed samplers (sobol, halton) are reproducible on a wavefront");
     if (d->n_triangles >= 0x7fffffffu) return ctx->fail(PT_ERR_UNSUPPORTED, "too many triangles");
@@ -435,6 +439,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (d->meshes[m].material >= (int32_t)d->n_materials) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "material index out of range");
         if (d->meshes[m].material >= 65535) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 65534 materials");
         if (d->meshes[m].area_light >= (int32_t)d->n_area_lights) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "area light index out of range");
+
         int32_t mi = d->meshes[m].material;
         if (mi >= 0 && (d->materials[mi].type < PT_MATERIAL_NONE || d->materials[mi].type > PT_MATERIAL_SUBSTRATE))
             return ctx->fail(PT_ERR_UNSUPPORTED, "material type not on the accelerated path");
@@ -699,6 +704,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             L.area = sph[en.idx].area;
             L.mesh_flags = PT_LIGHT_SPHERE;
             L.two_sided = al.two_sided;
+            L.n_samples = (uint32_t)std::max(1, al.n_samples);
             std::memcpy(L.L, al.L, 12);
             L.tri_rec = rec;
             L.prim = prim;
@@ -719,6 +725,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             L.area = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);
             L.mesh_flags = ti.mesh_flags;
             L.two_sided = al.two_sided;
+            L.n_samples = (uint32_t)std::max(1, al.n_samples);
             std::memcpy(L.L, al.L, 12);
             L.tri_rec = rec;
             L.prim = prim;
@@ -856,6 +863,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     ctx->n_nodes_up = bvh.nodes.size(); ctx->n_tris_up = bvh.tris.size();
     if ((st = upload(ctx, ctx->d_tri_info, tinfo.data(), tinfo.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_materials, mats.data(), mats.size())) != PT_OK) return st;
+    ctx->light_samples_total = 0;
+    for (const PtLight& L : lights) ctx->light_samples_total += L.n_samples;
     if ((st = upload(ctx, ctx->d_lights, lights.data(), lights.size())) != PT_OK) return st;
     if (d->n_spheres) { if ((st = upload(ctx, ctx->d_spheres, sph.data(), sph.size())) != PT_OK) return st; } else ctx->d_spheres.release();
     if (d->n_instances) { if ((st = upload(ctx, ctx->d_instances, dinst.data(), dinst.size())) != PT_OK) return st; } else ctx->d_instances.release();
@@ -1174,7 +1183,9 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     }
     const bool ao = sc.integrator == PT_INTEGRATOR_AO;
     const bool rec = sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING || sc.integrator == PT_INTEGRATOR_WHITTED;
-    const uint32_t rec_epp = rec ? ((sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING && sc.direct_strategy == PT_DIRECT_ONE) ? 1u : std::max(1u, sc.n_lights)) : 0u;
+    // next-event entries per path: Whitted one per light, DirectLighting "one" a single one, "all" one per light sample
+    const uint32_t rec_epp = !rec ? 0u : (sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING && sc.direct_strategy == PT_DIRECT_ONE) ? 1u
+                             : sc.integrator == PT_INTEGRATOR_WHITTED ? std::max(1u, sc.n_lights) : std::max(1u, ctx->light_samples_total);
     const uint32_t rec_depth = (uint32_t)std::max(1, sc.max_depth);
     const size_t rec_per_path = 64 + (size_t)rec_depth * PT_REC_FRAME_F4 * 16 + (size_t)rec_epp * (6 * 16 + 1 + 4 + 4 + 8);
     if (rec) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, ((size_t)6 << 30) / rec_per_path));
@@ -1311,8 +1322,9 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 uint32_t* nl_probe = (uint32_t*)take(ne * 4);
                 R.occ = (uint8_t*)take(ne);
                 R.n_paths = (uint32_t)np; R.max_depth = rec_depth; R.epp = rec_epp;
-                R.n_arrays1 = (sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING && sc.direct_strategy == PT_DIRECT_ALL) ? 2u * sc.n_lights * (uint32_t)std::max(sc.max_depth, 0) : 0u;
-                if (5u + 2u * R.n_arrays1 > 60000u) return ctx->fail(PT_ERR_UNSUPPORTED, "directlighting \"all\": too many lights x maxdepth for the sampler's array dimensions");
+                R.n_arrays = (sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING && sc.direct_strategy == PT_DIRECT_ALL) ? 2u * sc.n_lights * (uint32_t)std::max(sc.max_depth, 0) : 0u;
+                R.s0 = s0; R.n_pix = n_pix;
+                if (5u + 2u * R.n_arrays > 60000u) return ctx->fail(PT_ERR_UNSUPPORTED, "directlighting \"all\": too many lights x maxdepth for the sampler's array dimensions");
                 PtPaths NP = ctx->paths;             // the node's next-event rays as shadow / probe work items
                 NP.sh_o = R.sh_o; NP.sh_d = R.sh_d; NP.pr_o = R.pr_o; NP.pr_d = R.pr_d; NP.occluded = R.occ; NP.probe_rec = R.prec;
                 PtQueues Qn = Q;

@@ -146,7 +146,7 @@ struct PtLight {
     float p2[3]; int32_t two_sided;
     float L[3];  uint32_t tri_rec;   // index of the triangle's PtTri record
     float n0[3]; uint32_t prim;
-    float n1[3]; uint32_t pad0;
+    float n1[3]; uint32_t n_samples;   // the light's sample count (DirectLighting "all": size of its sample arrays), >= 1
     float n2[3]; uint32_t pad1;
 };
 
@@ -300,12 +300,15 @@ struct PtRec {
     float4* diff;            // [4][n_paths]: the current ray's offset rays rx_o, ry_o, rx_d, ry_d (valid when PT_ST_DIFF is set)
     float4* frames;          // [max_depth][PT_REC_FRAME_F4][n_paths]: ray o | hit record, ray d | instance, rx_o | phase, ry_o, rx_d | pending scale,
                              //                                        ry_d, l, pending f
-    // next-event entries, entry e = path * epp + j (j: the light, or 0 for "one"): shadow ray, MIS probe ray, the two pending terms
-    float4 *sh_o, *sh_d, *pr_o, *pr_d, *A, *B;       // A.w = selection pdf of the light ("one"), B.w unused
+    // next-event entries, entry e = path * epp + j (j: light by light, one entry per light sample; 0 for "one"): shadow ray, MIS probe ray, the two
+    // pending terms
+    float4 *sh_o, *sh_d, *pr_o, *pr_d, *A, *B;       // A.w = what the light's summed estimate is divided by ("one": the selection pdf; "all": the sample count), B.w unused
     uint8_t* occ;            // shadow ray result
     int32_t* prec;           // probe ray result (closest record)
     uint32_t* flags;         // per entry: PT_NEE_SHADOW | PT_NEE_PROBE | light << 8
-    uint32_t n_paths, max_depth, epp, n_arrays1;     // n_arrays1: one-sample 2-D arrays requested per camera sample ("all" strategy)
+    uint32_t n_paths, max_depth, epp, n_arrays;      // epp: entries per path ("all": the lights' sample counts added up); n_arrays: 2-D sample arrays
+                                                     // requested per pixel ("all": two per light and depth)
+    uint32_t s0, n_pix;                              // of the pass: path p is sample number s0 + p / n_pix of its pixel (the arrays are indexed by it)
 };
 #define PT_REC_OUT_FRAME 0u      // k_rec_enter outcomes (bits 2..3 of the state's flag byte): a frame was pushed, next-event rays may be pending
 #define PT_REC_OUT_RETURN0 1u    // the ray left the scene (or Whitted met a surface without BSDF): the node returns zero

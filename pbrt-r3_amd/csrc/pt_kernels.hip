@@ -2798,7 +2798,7 @@ PT_DEV void rec_build(const PtScene& sc, V3 ro, V3 rd, int32_t rec, uint32_t ins
 PT_DEV float4* rec_frame(const PtRec& R, uint32_t depth, uint32_t k, uint32_t p) { return R.frames + ((size_t)depth * PT_REC_FRAME_F4 + k) * R.n_paths + p; }
 // estimate_direct (sample_lights.rs:178-328) for light `light_num`: the two MIS terms and their rays go to entry e, the rays' results
 // are combined by k_rec_next.  Returns the PT_NEE_* flags of the entry.
-PT_DEV uint32_t rec_estimate_direct(const PtScene& sc, const PtRec& R, const RecNode& nd, uint32_t light_num, V2 u_light, V2 u_scat, uint32_t e) {
+PT_DEV uint32_t rec_estimate_direct(const PtScene& sc, const PtRec& R, const RecNode& nd, uint32_t light_num, V2 u_light, V2 u_scat, uint32_t e, float divisor = 1.0f) {
     const Surf& s = nd.s;
     const PtLight& lt = sc.lights[light_num];
     const uint32_t kNoSpec = PT_BSDF_ALL & ~PT_BSDF_SPECULAR;
@@ -2845,7 +2845,7 @@ PT_DEV uint32_t rec_estimate_direct(const PtScene& sc, const PtRec& R, const Rec
             }
         }
     }
-    R.A[e] = make_float4(A.x, A.y, A.z, 1.0f);
+    R.A[e] = make_float4(A.x, A.y, A.z, divisor);
     R.B[e] = make_float4(B.x, B.y, B.z, 0.0f);
     R.flags[e] = nee;
     return nee;
@@ -2869,7 +2869,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_init(PtScene sc, Pt
         R.diff[2 * (size_t)R.n_paths + p] = make_float4(rdf.rx_d.x, rdf.rx_d.y, rdf.rx_d.z, 0.0f);
         R.diff[3 * (size_t)R.n_paths + p] = make_float4(rdf.ry_d.x, rdf.ry_d.y, rdf.ry_d.z, 0.0f);
         // get_2d right after the camera sample jumps over the array dimensions (sobol.rs:118-141): dimension 5 + 2 * arrays
-        P.state[p] = (5u + 2u * R.n_arrays1) | (0u << 16) | (PT_ST_DIFF << 24);
+        P.state[p] = (5u + 2u * R.n_arrays) | (0u << 16) | (PT_ST_DIFF << 24);
         P.nee[p] = 0;                        // arrays handed out so far
     }
 }
@@ -2947,22 +2947,30 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_enter(PtScene sc
             } else {
                 if (nd.s.light >= 0) l = light_L(sc.lights[nd.s.light], nd.s.n, nd.s.wo);          // isect.le(wo)
                 if (sc.n_lights > 0) {
-                    if (sc.direct_strategy == PT_DIRECT_ALL) {        // uniform_sample_all_lights: one sample per light, from the arrays while they last
-                        uint32_t arr = P.nee[p];
+                    if (sc.direct_strategy == PT_DIRECT_ALL) {        // uniform_sample_all_lights (sample_lights.rs:24-78): n_j estimates per light from its two
+                        // sample arrays while arrays are left, else one estimate from two plain 2-D draws.  Element k of an array of n, for pixel
+                        // sample s, is drawn at sample number s n + k (base_sampler.rs:59-70), and EVERY array comes from dimensions (5, 6): the
+                        // reference computes the array dimension once, before its loop over the arrays (sobol.rs:60-75, halton.rs:193-208;
+                        // quirk Q22) -- u_light and u_scattering coincide.
+                        uint32_t arr = P.nee[p], off = 0;
+                        const uint64_t sample_num = (uint64_t)R.s0 + p / R.n_pix;
                         for (uint32_t j = 0; j < sc.n_lights; j++) {
-                            V2 u_light, u_scat;
-                            if (arr + 2u <= R.n_arrays1) {
-                                // all 2-D sample arrays of a pixel are filled from dimensions (5, 6): the reference computes the array dimension once,
-                                // before its loop over the arrays (sobol.rs:60-75, halton.rs:193-208; quirk Q22) -- u_light and u_scattering coincide
-                                u_light = mk2(sample_dimension(sc, sm.index, 5u, sm.px, sm.py), sample_dimension(sc, sm.index, 6u, sm.px, sm.py));
-                                u_scat = u_light;
+                            const uint32_t n = sc.lights[j].n_samples;
+                            if (arr + 2u <= R.n_arrays) {
                                 arr += 2u;
+                                for (uint32_t k = 0; k < n; k++) {
+                                    const uint64_t idx = n == 1u ? sm.index : sampler_index(sc, sample_num * n + k, sm.px, sm.py);
+                                    const V2 u = mk2(sample_dimension(sc, idx, 5u, sm.px, sm.py), sample_dimension(sc, idx, 6u, sm.px, sm.py));
+                                    rec_estimate_direct(sc, R, nd, j, u, u, e0 + off + k, (float)n);
+                                }
                             } else {
-                                arr = R.n_arrays1;
-                                u_light = sm.get_2d(sc);
-                                u_scat = sm.get_2d(sc);
+                                arr = R.n_arrays;
+                                const V2 u_light = sm.get_2d(sc);
+                                const V2 u_scat = sm.get_2d(sc);
+                                rec_estimate_direct(sc, R, nd, j, u_light, u_scat, e0 + off, 1.0f);
+                                for (uint32_t k = 1; k < n; k++) R.flags[e0 + off + k] = 0u;
                             }
-                            rec_estimate_direct(sc, R, nd, j, u_light, u_scat, e0 + j);
+                            off += n;
                         }
                         P.nee[p] = arr;
                     } else {                                          // uniform_sample_one_light without a distribution (sample_lights.rs:105-127)
@@ -3174,19 +3182,30 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_next(PtScene sc,
                             l = l + term;
                         }
                     } else if (sc.n_lights > 0) {
+                        // per light: ld = sum of its estimates in order (each estimate = light half + BSDF half, estimate_direct's own sum),
+                        // then l += ld / n ("all": sample_lights.rs:43-57; the single-draw fallback has divisor 1) or ld / pdf ("one")
                         V3 ld_all = mk3(0.0f, 0.0f, 0.0f);
-                        const uint32_t cnt_e = sc.direct_strategy == PT_DIRECT_ALL ? sc.n_lights : 1u;
-                        for (uint32_t j = 0; j < cnt_e; j++) {
-                            const uint32_t fl = R.flags[e0 + j];
-                            const float4 A = R.A[e0 + j];
+                        const bool all = sc.direct_strategy == PT_DIRECT_ALL;
+                        const uint32_t n_groups = all ? sc.n_lights : 1u;
+                        uint32_t off = 0;
+                        for (uint32_t j = 0; j < n_groups; j++) {
+                            const uint32_t n = all ? sc.lights[j].n_samples : 1u;
+                            const float divisor = R.A[e0 + off].w;
                             V3 ld = mk3(0.0f, 0.0f, 0.0f);
-                            if ((fl & PT_NEE_SHADOW) && R.occ[e0 + j] == 0) ld = ld + f4_3(A);
-                            if (fl & PT_NEE_PROBE) {
-                                const int32_t best = R.prec[e0 + j];
-                                if (best >= 0 && (uint32_t)best == sc.lights[fl >> 8].tri_rec) ld = ld + f4_3(R.B[e0 + j]);
+                            for (uint32_t k = 0; k < n; k++) {
+                                const uint32_t e = e0 + off + k;
+                                const uint32_t fl = R.flags[e];
+                                V3 est = mk3(0.0f, 0.0f, 0.0f);
+                                if ((fl & PT_NEE_SHADOW) && R.occ[e] == 0) est = est + f4_3(R.A[e]);
+                                if (fl & PT_NEE_PROBE) {
+                                    const int32_t best = R.prec[e];
+                                    if (best >= 0 && (uint32_t)best == sc.lights[fl >> 8].tri_rec) est = est + f4_3(R.B[e]);
+                                }
+                                ld = ld + est;
                             }
-                            if (sc.direct_strategy == PT_DIRECT_ALL) ld_all = ld_all + ld / 1.0f;
-                            else ld_all = ld / A.w;
+                            if (all) ld_all = ld_all + ld / divisor;
+                            else ld_all = ld / divisor;
+                            off += n;
                         }
                         l = l + ld_all;
                     }

@@ -526,10 +526,11 @@ class SceneBuilder:
     def material_none(self):
         self.cur_material = -1
 
-    def area_light_source_diffuse(self, L=(1.0, 1.0, 1.0), scale=(1.0, 1.0, 1.0), twosided=False):
+    def area_light_source_diffuse(self, L=(1.0, 1.0, 1.0), scale=(1.0, 1.0, 1.0), twosided=False, nsamples=1):
         al = capi.pt_area_light()
         al.L[:] = [float(f32(l) * f32(s)) for l, s in zip(L, scale)]
         al.two_sided = 1 if twosided else 0
+        al.n_samples = int(nsamples)
         self.area_lights.append(al)
         self.cur_area_light = len(self.area_lights) - 1
 

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "missing export: " + name
     assert declared == set(pkg.capi.SYMBOLS), declared ^ set(pkg.capi.SYMBOLS)
-    assert lib.pt_abi_version() == 7
+    assert lib.pt_abi_version() == 8
 
 
 def test_struct_layouts_match_header():

@@ -17,11 +17,24 @@ def _with(sd, integrator, strategy="all", maxdepth=5):
     return sd
 
 
+def _nsamples(sd, n):
+    """AreaLightSource "nsamples" n on every emissive shape: the size of the sample arrays DirectLighting's "all" strategy gives each of its
+    lights (one light per emissive triangle / sphere)."""
+    for i in range(sd.desc.n_area_lights):
+        sd.desc.area_lights[i].n_samples = n
+    return sd
+
+
 SCENES = {
     # diffuse only: no tree, one node per camera sample
     "cornell_dl_all": lambda: _with(scenes.cornell_box(res=40, spp=8), "directlighting"),
     "cornell_dl_one_halton": lambda: _with(scenes.cornell_box(res=40, spp=6, sampler="halton"), "directlighting", "one"),
     "cornell_whitted": lambda: _with(scenes.cornell_box(res=40, spp=8), "whitted"),
+    # "nsamples" > 1: arrays of n estimates per light, drawn at sample numbers s n + k (not a power of two with Halton)
+    "cornell_dl_all_ns4": lambda: _nsamples(_with(scenes.cornell_box(res=40, spp=4), "directlighting"), 4),
+    "specular_dl_all_ns3_halton": lambda: _nsamples(_with(fs.scene_materials_render(["glass", "mirror", "plastic"], spp=3, sampler="halton"), "directlighting", maxdepth=4), 3),
+    "spheres_dl_all_ns2": lambda: _nsamples(_with(fs.scene_spheres(spp=4), "directlighting", maxdepth=3), 2),
+    "attributes_dl_all_ns5": lambda: _nsamples(_with(fs.scene_attributes(), "directlighting", maxdepth=3), 5),     # surfaces without a material use the arrays up
     # glass + mirror + plastic: reflect and transmit subtrees, the sampler consumed depth first
     "specular_dl_all": lambda: _with(fs.scene_materials_render(["glass", "mirror", "plastic"], spp=8), "directlighting", maxdepth=5),
     "specular_dl_one": lambda: _with(fs.scene_materials_render(["glass", "mirror", "uber_translucent"], spp=8), "directlighting", "one", maxdepth=4),
@@ -55,6 +68,21 @@ def test_oracle_direct_strategies_agree_in_the_mean(oracle):
     assert imgs["whitted"][:3].max() < imgs["all"][:3].max()          # the lamp itself is black for Whitted
 
 
+def test_oracle_light_sample_count_keeps_the_mean(oracle):
+    """uniform_sample_all_lights with arrays of four estimates per light (sample_lights.rs:43-57: their mean) against one estimate per
+    light: the same image up to noise -- and less noise."""
+    imgs = []
+    for n in (1, 4):
+        osc = oracle.scene(_nsamples(_with(scenes.cornell_box(res=24, spp=16), "directlighting", maxdepth=1), n))
+        x, c, _ = osc.render(threads=8)
+        imgs.append(osc.resolve_rgb(x))
+        assert c["shadow_rays"] > 0
+        osc.close()
+    a, b = imgs
+    assert abs(a.mean() - b.mean()) <= 0.02 * a.mean()
+    assert not np.array_equal(a, b)
+
+
 def test_oracle_depth_one_is_local_lighting(oracle):
     """maxdepth 1: depth + 1 < maxdepth never holds, no specular recursion and no sampler use beyond the node's own light samples."""
     sd = _with(fs.scene_materials_render(["glass", "mirror", "plastic"], spp=4), "directlighting", maxdepth=1)
@@ -83,8 +111,12 @@ def test_front_end_directlighting_and_whitted(tmp_path):
     assert (d.integrator, d.direct_strategy, d.max_depth) == (capi.PT_INTEGRATOR_DIRECTLIGHTING, capi.PT_DIRECT_ALL, 5)
     d = capi.ParsedScene(text=text.replace('"directlighting" "integer maxdepth" 7 "string strategy" "one"', '"whitted"'), work_dir=str(tmp_path)).desc
     assert (d.integrator, d.max_depth) == (capi.PT_INTEGRATOR_WHITTED, 5)
-    with pytest.raises(capi.PtError) as e:        # the "all" strategy sizes its sample arrays by the lights' nsamples; the ABI carries one each
-        capi.ParsedScene(text=text.replace('"string strategy" "one"', "").replace('"rgb L" [1 1 1]', '"rgb L" [1 1 1] "integer nsamples" 4'), work_dir=str(tmp_path))
+    # the "all" strategy sizes its sample arrays by the lights' "nsamples" (ABI 8 carries it per area light source)
+    d = capi.ParsedScene(text=text.replace('"string strategy" "one"', "").replace('"rgb L" [1 1 1]', '"rgb L" [1 1 1] "integer nsamples" 4'), work_dir=str(tmp_path)).desc
+    assert d.n_area_lights == 1 and d.area_lights[0].n_samples == 4
+    assert capi.ParsedScene(text=text, work_dir=str(tmp_path)).desc.area_lights[0].n_samples == 1
+    with pytest.raises(capi.PtError) as e:        # the reference divides the summed estimates by it
+        capi.ParsedScene(text=text.replace('"rgb L" [1 1 1]', '"rgb L" [1 1 1] "integer nsamples" 0'), work_dir=str(tmp_path))
     assert "nsamples" in str(e.value)
 
 
