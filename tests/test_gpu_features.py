@@ -483,7 +483,8 @@ def test_crown_class_3p5m_triangles(gpu_ctx, oracle, split):
 
 
 @pytest.mark.parametrize("name,make", [("cornell", lambda: scenes.cornell_box(res=64, spp=16)), ("materials", lambda: fs.scene_materials_lights("spatial")),
-                                       ("spheres", lambda: fs.scene_spheres())])
+                                       ("spheres", lambda: fs.scene_spheres()), ("instances", lambda: fs.scene_instances()),
+                                       ("textures", lambda: fs.scene_textures())])
 def test_shadow_ray_sorting_changes_nothing(oracle, monkeypatch, name, make):
     """pt_raysort.hip orders each bounce's shadow rays by origin cell and direction octant before they are traced -- from a million rays
     up, which no test scene reaches.  With the threshold at two (a context reads it when it is created) every bounce of these small scenes
