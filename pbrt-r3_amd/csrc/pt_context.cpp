@@ -937,7 +937,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (d->n_instances) { sc.general_materials = 1; sc.dist_leaves = 0; }      // k_trace_inst walks leaves per lane; one shade kernel handles everything
     sc.root_ref = bvh.root_ref;
     sc.n_top = n_top;
-    for (int a = 0; a < 3; a++) { const float ext = bvh.root_hi[a] - bvh.root_lo[a]; sc.cell_scale[a] = ext > 0.0f ? 128.0f / ext : 0.0f; }
+    for (int a = 0; a < 3; a++) { const float ext = bvh.root_hi[a] - bvh.root_lo[a]; sc.cell_scale[a] = ext > 0.0f ? (float)(1u << PT_SORT_CELL_BITS) / ext : 0.0f; }
     std::memcpy(sc.wb_min, bvh.root_lo, 12);
     std::memcpy(sc.wb_max, bvh.root_hi, 12);
     sc.max_depth = d->max_depth;

@@ -23,6 +23,10 @@
 #ifndef PT_TOP_NODES
 #define PT_TOP_NODES 85
 #endif
+#ifndef PT_SORT_CELL_BITS
+#define PT_SORT_CELL_BITS 4      // shadow-ray sort key (pt_raysort.hip): bits per axis of the origin's cell; the key is 3 x this + 3 octant bits wide.
+                                 // RT1M, k_trace ms per launch: no sort 164.9, 0 bits (octant only) 162.2, 1: 161.5, 2: 158.9, 3: 157.3, 4: 156.8, 5: 156.6, 6 .. 9: 156.8
+#endif
 #define PT_TOP_BFS_NODES 1365u   // what the upload renumbers breadth-first (levels 0..5), whatever PT_TOP_NODES the kernels were built with
 // LDS stack slots per lane of the pooled-leaf traversal kernels (slot 0 holds a sentinel; deeper entries spill to HBM)
 #if PT_NODE_STAGED
@@ -255,7 +259,7 @@ struct PtScene {
     uint32_t n_lights;
     uint32_t root_ref;           // node 0, or a leaf reference when the whole scene is one leaf
     uint32_t n_top;              // nodes 0 .. n_top-1 are the top of the world tree in breadth-first order (at most PT_TOP_BFS_NODES)
-    float cell_scale[3];         // 128 / the world bound's extent per axis (0 for a flat axis): ray origin -> 7-bit cell coordinate
+    float cell_scale[3];         // 2^PT_SORT_CELL_BITS / the world bound's extent per axis (0 for a flat axis): ray origin -> cell coordinate
     float wb_min[3], wb_max[3];  // BVH root bounds (Scene::world_bound)
     int32_t max_depth;
     float rr_threshold;

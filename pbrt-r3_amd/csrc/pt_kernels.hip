@@ -2115,14 +2115,15 @@ __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material,
     if (mp.prog[12]) mp.m.eta = tex_eval(sc.textures, sc.tex_prog + mp.prog[12], th, sc.images).x;
     build_lobes(mp.m, a_r, a_u, a_v, *out);
 }
-// Sort key of a ray for pt_raysort.hip: Morton code of the 128^3 cell of its origin inside the world bound, direction octant on top
+// Sort key of a ray for pt_raysort.hip: Morton code of the cell of its origin inside the world bound (2^PT_SORT_CELL_BITS cells per axis), direction octant on top
 PT_DEV uint32_t ray_sort_key(const PtScene& sc, V3 o, V3 d) {
     const float fx = (o.x - sc.wb_min[0]) * sc.cell_scale[0], fy = (o.y - sc.wb_min[1]) * sc.cell_scale[1], fz = (o.z - sc.wb_min[2]) * sc.cell_scale[2];
-    uint32_t cx = (uint32_t)fminf(fmaxf(fx, 0.0f), 127.0f), cy = (uint32_t)fminf(fmaxf(fy, 0.0f), 127.0f), cz = (uint32_t)fminf(fmaxf(fz, 0.0f), 127.0f);
+    const float top = (float)((1u << PT_SORT_CELL_BITS) - 1u);
+    uint32_t cx = (uint32_t)fminf(fmaxf(fx, 0.0f), top), cy = (uint32_t)fminf(fmaxf(fy, 0.0f), top), cz = (uint32_t)fminf(fmaxf(fz, 0.0f), top);
     uint32_t m = 0;
 #pragma unroll
-    for (uint32_t b = 0; b < 7u; b++) m |= (((cx >> b) & 1u) | (((cy >> b) & 1u) << 1) | (((cz >> b) & 1u) << 2)) << (3u * b);
-    return m | ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)) << 21;
+    for (uint32_t b = 0; b < (uint32_t)PT_SORT_CELL_BITS; b++) m |= (((cx >> b) & 1u) | (((cy >> b) & 1u) << 1) | (((cz >> b) & 1u) << 2)) << (3u * b);
+    return m | ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)) << (3u * PT_SORT_CELL_BITS);
 }
 // Diagnostic build -DPT_PROFILE_SHADE: wave clocks of shade_body by section (tools/tune_shade.sh "prof:-DPT_PROFILE_SHADE")
 #ifdef PT_PROFILE_SHADE

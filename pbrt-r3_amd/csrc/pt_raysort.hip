@@ -2,10 +2,10 @@
 //
 // Continuation rays reach k_trace in path (pixel) order and keep whatever coherence the image has; the next-event rays of a bounce start
 // at that bounce's hit points, which in a scene of small triangles are scattered through space, and all head for the lights.  Ordered by
-// the Morton cell of their origin (7 bits per axis inside the world bound) and the octant of their direction, neighbouring lanes walk
+// the Morton cell of their origin (PT_SORT_CELL_BITS per axis inside the world bound) and the octant of their direction, neighbouring lanes walk
 // the same nodes and leaves: lanes that touch the same line share the L1's tag lookup, which is what bounds k_trace (DESIGN.md section
 // 4).  Only the work list is permuted -- path state stays where it is, results are written per path, so nothing downstream can tell.
-// The sort is rocprim's radix sort on 24-bit keys with the path id as the value.
+// The sort is rocprim's radix sort on the 3 x PT_SORT_CELL_BITS + 3 key bits with the path id as the value.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string.h>
@@ -17,7 +17,7 @@
 size_t ptk_sort_rays_temp_bytes(uint32_t cap) {
     size_t bytes = 0;
     rocprim::double_buffer<uint32_t> k(nullptr, nullptr), v(nullptr, nullptr);
-    if (rocprim::radix_sort_pairs(nullptr, bytes, k, v, cap, 0, 24, nullptr) != hipSuccess) return 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, k, v, cap, 0, 3 * PT_SORT_CELL_BITS + 3, nullptr) != hipSuccess) return 0;
     return bytes;
 }
 
@@ -28,7 +28,7 @@ hipError_t ptk_sort_shadow_rays(hipStream_t st, uint32_t* ids, uint32_t* ids_alt
     *sorted = ids;
     if (n < 2) return hipSuccess;
     rocprim::double_buffer<uint32_t> k(keys, keys_alt), v(ids, ids_alt);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, n, 0, 24, st);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, n, 0, 3 * PT_SORT_CELL_BITS + 3, st);
     if (e != hipSuccess) return e;
     *sorted = v.current();
     return hipGetLastError();
