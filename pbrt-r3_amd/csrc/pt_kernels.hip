@@ -77,6 +77,22 @@ PT_DEV float halton_radical_inverse(uint32_t base, uint64_t magic, const uint16_
     const float inv_base = 1.0f / (float)base;
     uint64_t rev = 0;
     float inv_base_n = 1.0f;
+    if ((a >> 32) == 0) {
+        // every index a frame of up to 2^32 / stride samples produces: the same digits with 32-bit arithmetic.  mulhi64(a, magic) for a
+        // 32-bit a is the top word of a * magic_hi + (a * magic_lo >> 32) -- three 32-bit multiplies and a carry instead of the four
+        // multiply pairs of the general 64 x 64 product; the digit and the next quotient stay in one register each.
+        uint32_t a32 = (uint32_t)a;
+        const uint32_t mh = (uint32_t)(magic >> 32), ml = (uint32_t)magic;
+        while (a32 != 0) {
+            const uint32_t lo = a32 * mh, carry_in = __umulhi(a32, ml);
+            const uint32_t next = __umulhi(a32, mh) + ((lo + carry_in) < lo ? 1u : 0u);
+            const uint32_t digit = a32 - next * base;
+            rev = rev * base + (perm ? (uint32_t)perm[digit] : digit);
+            inv_base_n *= inv_base;
+            a32 = next;
+        }
+        a = 0;
+    }
     while (a != 0) {
         uint64_t next = div_small(a, base, magic);
         uint32_t digit = (uint32_t)(a - next * base);
