@@ -2084,6 +2084,9 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 #ifndef PT_SHADE_FLUSH
 #define PT_SHADE_FLUSH 4         // k_shade: iterations (of 64 paths) per queue reservation
 #endif
+#ifndef PT_SHADE_TEX_WAVES
+#define PT_SHADE_TEX_WAVES 1     // waves per SIMD the textured shading kernel is compiled for (2: 288 registers and 903 spilled -- slower)
+#endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
 #endif
@@ -2536,7 +2539,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_inst(P
     shade_body<true, true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
 }
 // scenes with textured materials (and possibly spheres): lobes are built per hit for the textured ones
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_TEX_WAVES) k_shade_general_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
 }
 
