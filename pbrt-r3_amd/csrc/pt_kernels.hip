@@ -2096,6 +2096,9 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 // compute_scattering_functions) into a copy of the parameter block, then build the BxDF list the host builds for constant
 // materials (pt_lobes.h).
 // bump: material_bump (core/material.rs:31-72) first -- it bends the shading frame (sh_n, sh_dpdu) in place.
+// build_lobes (pt_lobes.h, shared with the host) as a call: inlined into textured_lobes it made that function the register peak of
+// the textured shading kernel
+__device__ __noinline__ void build_lobes_call(const pt_material& in, float a_r, float a_u, float a_v, PtMaterial& m) { build_lobes(in, a_r, a_u, a_v, m); }
 __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material, const TexHit& th, PtMaterial* out, V3 n, V2 uv, V3* sh_n, V3* sh_dpdu,
                                             V3 sh_dpdv, V3 sh_dndu, V3 sh_dndv) {
     PtMatParams mp = sc.mat_params[material];
@@ -2132,7 +2135,7 @@ __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material,
     if (mp.prog[10]) { mp.m.uroughness = tex_eval(sc.textures, sc.tex_prog + mp.prog[10], th, sc.images).x; a_u = mp.m.remap_roughness ? pt_roughness_to_alpha(mp.m.uroughness) : mp.m.uroughness; }
     if (mp.prog[11]) { mp.m.vroughness = tex_eval(sc.textures, sc.tex_prog + mp.prog[11], th, sc.images).x; a_v = mp.m.remap_roughness ? pt_roughness_to_alpha(mp.m.vroughness) : mp.m.vroughness; }
     if (mp.prog[12]) mp.m.eta = tex_eval(sc.textures, sc.tex_prog + mp.prog[12], th, sc.images).x;
-    build_lobes(mp.m, a_r, a_u, a_v, *out);
+    build_lobes_call(mp.m, a_r, a_u, a_v, *out);
 }
 // Sort key of a ray for pt_raysort.hip: Morton code of the cell of its origin inside the world bound (2^PT_SORT_CELL_BITS cells per axis), direction octant on top
 PT_DEV uint32_t ray_sort_key(const PtScene& sc, V3 o, V3 d) {

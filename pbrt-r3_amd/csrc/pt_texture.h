@@ -75,7 +75,7 @@ PT_DEV V2 cylinder_st(const float* w2t, V3 p) {             // CylindricalMappin
     return mk2((PT_PI + pt_atan2f(vec.y, vec.x)) * (PT_INV_PI * 0.5f), vec.z);
 }
 PT_DEV float fix_wrap(float d) { return d > 0.5f ? 1.0f - d : (d < -0.5f ? -(d + 1.0f) : d); }
-PT_DEV void map2d(const pt_texture& t, const TexHit& si, V2* st, V2* dstdx, V2* dstdy) {
+__device__ __noinline__ void map2d(const pt_texture& t, const TexHit& si, V2* st, V2* dstdx, V2* dstdy) {
     if (t.mapping == PT_MAPPING_SPHERICAL || t.mapping == PT_MAPPING_CYLINDRICAL) {
         const bool sph = t.mapping == PT_MAPPING_SPHERICAL;
         const float delta = 0.1f;
@@ -240,7 +240,7 @@ __device__ __noinline__ V3 mip_ewa(const MipRef& m, uint32_t l, V2 st0, V2 d0, V
     float inv_sum = 1.0f / sum_wts;
     return mk3(sum.x * inv_sum, sum.y * inv_sum, sum.z * inv_sum);
 }
-PT_DEV V3 mip_lookup_delta(const MipRef& m, V2 st, V2 dst0, V2 dst1, bool trilinear, float max_aniso) {     // :819-852, :913-946
+__device__ __noinline__ V3 mip_lookup_delta(const MipRef& m, V2 st, V2 dst0, V2 dst1, bool trilinear, float max_aniso) {     // :819-852, :913-946
     if (trilinear) {
         float width = fmaxf(fmaxf(fabsf(dst0.x), fabsf(dst0.y)), fmaxf(fabsf(dst1.x), fabsf(dst1.y)));
         return mip_lookup(m, st, width);
@@ -262,7 +262,7 @@ PT_DEV V3 mip_lookup_delta(const MipRef& m, V2 st, V2 dst0, V2 dst1, bool trilin
 }
 
 // One node, its children already evaluated (c0, c1, c2 = tex1, tex2, amount).
-PT_DEV V3 tex_node(const pt_texture& t, const TexHit& si, V3 c0, V3 c1, V3 c2, const PtImage* images) {
+__device__ __noinline__ V3 tex_node(const pt_texture& t, const TexHit& si, V3 c0, V3 c1, V3 c2, const PtImage* images) {
     switch (t.type) {
         case PT_TEX_IMAGEMAP: {                                   // imagemap.rs:57-70
             V2 st, dx, dy;
