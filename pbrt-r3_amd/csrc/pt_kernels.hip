@@ -2085,7 +2085,8 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 #define PT_SHADE_FLUSH 4         // k_shade: iterations (of 64 paths) per queue reservation
 #endif
 #ifndef PT_SHADE_TEX_WAVES
-#define PT_SHADE_TEX_WAVES 1     // waves per SIMD the textured shading kernel is compiled for (2: 288 registers and 903 spilled -- slower)
+#define PT_SHADE_TEX_WAVES 2     // waves per SIMD the textured shading kernel is compiled for: 256 registers and 112 spilled, against 300 and none
+                                 // at one wave per SIMD -- 700 -> 729 Mrays/s on the textured bench (needs the texture code out of line, pt_texture.h)
 #endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
