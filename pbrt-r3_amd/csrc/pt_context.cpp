@@ -86,6 +86,7 @@ struct pt_context {
     ptbvh::Result host_bvh;                       // upload scratch: the world tree's arrays
     std::unique_ptr<ptbvh::Prim[]> host_prims;    // upload scratch (see pt_scene_upload); released when it exceeds 4 M primitives
     size_t host_prims_cap = 0;
+    DevBuf d_qbin;                                     // PtQueues::bin
     DevBuf d_sort_ids, d_sort_keys[2], d_sort_temp;   // pt_raysort.hip: the second id list, the key lists and rocprim's scratch
     size_t sort_cap = 0;
     int sort_shadow_min = 1 << 20;                     // shadow rays of a launch are ordered by origin cell from this many up (0: never)
@@ -1229,6 +1230,11 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     Q.sorted = ctx->d_qsorted.as<uint32_t>();
     Q.shadow = ctx->d_qshadow.as<uint32_t>();
     Q.probe = ctx->d_qprobe.as<uint32_t>();
+    Q.bin = nullptr;
+    if (sc.general_materials) {          // the material sort keeps each entry's bin between its two kernels
+        if (ctx->d_qbin.bytes < ctx->pool_paths * 2) PT_HIP(ctx->d_qbin.alloc(ctx->pool_paths * 2));
+        Q.bin = ctx->d_qbin.as<uint16_t>();
+    }
     Q.shadow_key = nullptr;
     if (ctx->sort_shadow_min > 0 && sc.integrator == PT_INTEGRATOR_PATH) {       // pt_raysort.hip: k_shade writes a key per shadow ray, each bounce's list is sorted by it
         if (ctx->sort_cap < ctx->pool_paths) {
@@ -1656,7 +1662,7 @@ pt_status pt_trace_wavefront(pt_context* ctx, uint32_t n, const float* o, const 
     PtQueues Q;
     Q.cur = ctx->d_qa.as<uint32_t>(); Q.next = ctx->d_qb.as<uint32_t>();
     Q.nee = ctx->d_qnee.as<uint32_t>(); Q.counts = ctx->d_counts.as<uint32_t>(); Q.sorted = ctx->d_qsorted.as<uint32_t>();
-    Q.shadow = ctx->d_qshadow.as<uint32_t>(); Q.probe = ctx->d_qprobe.as<uint32_t>(); Q.shadow_key = nullptr;
+    Q.shadow = ctx->d_qshadow.as<uint32_t>(); Q.probe = ctx->d_qprobe.as<uint32_t>(); Q.shadow_key = nullptr; Q.bin = nullptr;
     uint32_t* const dst_q[3] = {Q.cur, Q.shadow, Q.probe};
     for (int k = 0; k < 3; k++)
         if (!ids[k].empty()) PT_HIP(hipMemcpyAsync(dst_q[k], ids[k].data(), ids[k].size() * 4, hipMemcpyHostToDevice, ctx->stream));

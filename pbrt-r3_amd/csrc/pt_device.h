@@ -333,6 +333,7 @@ struct PtQueues {
     uint32_t* counts;    // counters, PT_Q_* below.  The ones every wave bumps with an atomic sit 128 bytes apart:
                          // atomics on one line serialise in a single L2 channel (k_shade was bound by exactly that)
     uint32_t* sorted;    // cur re-ordered by material bin, misses dropped (scenes with non-Matte materials)
+    uint16_t* bin;       // per entry of cur: its material bin (0xffff: a miss), written by k_sort_count for k_sort_scatter; nullptr: recomputed there
     uint32_t* shadow_key;// per entry of shadow: the sort key of its ray (origin cell | direction octant, pt_raysort.hip); nullptr: not wanted
 };
 #define PT_Q_CUR 0u          // items in cur

@@ -2021,6 +2021,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_count(PtScene sc, 
     for (uint32_t i = lo + threadIdx.x; i < ((hi + 63u) & ~63u); i += blockDim.x) {
         bool valid = i < hi;
         uint32_t bin = valid ? path_sort_bin(sc, P, Q.cur[i]) : 0xffffffffu;
+        if (valid && Q.bin) Q.bin[i] = (uint16_t)bin;          // the hit record -> triangle flags -> material chain is walked once per entry, here
         valid = valid && bin != 0xffffffffu;
         (void)wave_bin_reserve(s_cnt, valid ? bin : 0u, valid);
     }
@@ -2054,9 +2055,13 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
     uint32_t lo, hi;
     sort_chunk(Q.counts[PT_Q_CUR], &lo, &hi);
     const uint32_t hi_round = (hi + 63u) & ~63u;
+    auto bin_of = [&](uint32_t i, uint32_t p) -> uint32_t {
+        if (Q.bin) { const uint32_t b = Q.bin[i]; return b == 0xffffu ? 0xffffffffu : b; }
+        return path_sort_bin(sc, P, p);
+    };
     for (uint32_t i = lo + threadIdx.x; i < hi_round; i += blockDim.x) {
         bool valid = i < hi;
-        uint32_t bin = valid ? path_sort_bin(sc, P, Q.cur[i]) : 0xffffffffu;
+        uint32_t bin = valid ? bin_of(i, Q.bin ? 0u : Q.cur[i]) : 0xffffffffu;
         valid = valid && bin != 0xffffffffu;
         (void)wave_bin_reserve(s_cnt, valid ? bin : 0u, valid);
     }
@@ -2069,7 +2074,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
     for (uint32_t i = lo + threadIdx.x; i < hi_round; i += blockDim.x) {
         bool valid = i < hi;
         uint32_t p = valid ? Q.cur[i] : 0u;
-        uint32_t bin = valid ? path_sort_bin(sc, P, p) : 0xffffffffu;
+        uint32_t bin = valid ? bin_of(i, p) : 0xffffffffu;
         valid = valid && bin != 0xffffffffu;
         uint32_t pos = wave_bin_reserve(s_cnt, valid ? bin : 0u, valid);
         if (valid) Q.sorted[pos] = p;
