@@ -2089,6 +2089,9 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 #ifndef PT_SHADE_FLUSH
 #define PT_SHADE_FLUSH 4         // k_shade: iterations (of 64 paths) per queue reservation
 #endif
+#ifndef PT_SHADE_GEN_WAVES
+#define PT_SHADE_GEN_WAVES 1     // k_shade_general: 256 registers = two waves per SIMD; compiled for 3 (168 registers, 149 spilled): mixed bench 856 -> 835
+#endif
 #ifndef PT_SHADE_TEX_WAVES
 #define PT_SHADE_TEX_WAVES 2     // waves per SIMD the textured shading kernel is compiled for: 256 registers and 112 spilled, against 300 and none
                                  // at one wave per SIMD -- 700 -> 729 Mrays/s on the textured bench (needs the texture code out of line, pt_texture.h)
@@ -2532,7 +2535,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade(P
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) k_shade_matte_sorted(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<false, false>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], &Q.counts[PT_Q_TICKET]);
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_GEN_WAVES) k_shade_general(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, false>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_TEX_BEGIN], &Q.counts[PT_Q_TICKET2]);
 }
 // scenes with spheres: hits and lights may be spheres
