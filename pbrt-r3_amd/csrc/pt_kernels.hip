@@ -2089,6 +2089,9 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 #ifndef PT_SHADE_FLUSH
 #define PT_SHADE_FLUSH 4         // k_shade: iterations (of 64 paths) per queue reservation
 #endif
+#ifndef PT_WIDE_KERNEL_WAVES
+#define PT_WIDE_KERNEL_WAVES 2   // the sphere / instance shading kernels and the recursive integrators' two kernels: compiled for this many waves per SIMD
+#endif
 #ifndef PT_SHADE_GEN_WAVES
 #define PT_SHADE_GEN_WAVES 1     // k_shade_general: 256 registers = two waves per SIMD; compiled for 3 (168 registers, 149 spilled): mixed bench 856 -> 835
 #endif
@@ -2539,15 +2542,15 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_GEN_WAVES) k_sha
     shade_body<true, false>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_TEX_BEGIN], &Q.counts[PT_Q_TICKET2]);
 }
 // scenes with spheres: hits and lights may be spheres
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_matte_sorted_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_shade_matte_sorted_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<false, true>(sc, P, Q, cnt, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], &Q.counts[PT_Q_TICKET]);
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_shade_general_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_TEX_BEGIN], &Q.counts[PT_Q_TICKET2]);
 }
 // scenes with object instances: hits inside an instance are rebuilt in instance space and transformed back; every material
 // rides in the general half of the sorted queue, so this one kernel shades them all
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_shade_general_inst(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_shade_general_inst(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
 }
 // scenes with textured materials (and possibly spheres): lobes are built per hit for the textured ones
@@ -2911,7 +2914,7 @@ PT_DEV RayDiffs rec_load_diff(const PtRec& R, uint32_t p) {
     d.rx_d = f4_3(R.diff[2 * (size_t)R.n_paths + p]); d.ry_d = f4_3(R.diff[3 * (size_t)R.n_paths + p]);
     return d;
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_enter(PtScene sc, PtPaths P, PtQueues Q, PtRec R, PtCounters* cnt) {
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_enter(PtScene sc, PtPaths P, PtQueues Q, PtRec R, PtCounters* cnt) {
     const uint32_t n = Q.counts[PT_Q_CUR];
     const uint32_t lane = threadIdx.x & 63;
     const bool whitted = sc.integrator == PT_INTEGRATOR_WHITTED;
@@ -3154,7 +3157,7 @@ PT_DEV bool rec_sample_child(const PtScene& sc, const PtPaths& P, const PtRec& R
     *pend_scale = wi_ns / pdf;
     return true;
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, 1) k_rec_next(PtScene sc, PtPaths P, PtQueues Q, PtRec R) {
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_next(PtScene sc, PtPaths P, PtQueues Q, PtRec R) {
     const uint32_t n = Q.counts[PT_Q_CUR];
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
