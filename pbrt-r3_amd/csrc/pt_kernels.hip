@@ -1023,7 +1023,7 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #define PT_PROF_SET(name) do { } while (0)
 #endif
 #ifndef PT_REFILL_MIN
-#define PT_REFILL_MIN 12
+#define PT_REFILL_MIN 8
 #endif
 #ifndef PT_LEAF_MIN
 #define PT_LEAF_MIN 24          // k_trace_seq: leaf phase once this many lanes are parked on a leaf
