@@ -1,5 +1,7 @@
 // pth_texture_image.cpp -- see pth_texture_image.h.
 #include "pth_texture_image.h"
+#include "pth_exr_codecs.h"
+#include "pth_jpeg.h"
 #include <zlib.h>
 #include <algorithm>
 #include <cmath>
@@ -172,8 +174,8 @@ bool read_tga(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
 }
 
 // ---- OpenEXR (image::open -> codecs::openexr: the R, G, B channels of a single-part scan-line file as f32; alpha is read and
-// dropped by convert_from_rgba32f, read_image.rs:112-142).  Pixel types half and float; compression none, RLE, ZIPS, ZIP -- the
-// lossless byte-stream schemes; PIZ / PXR24 / B44 / DWA files are reported, not approximated.
+// dropped by convert_from_rgba32f, read_image.rs:112-142).  Pixel types half and float; compression none, RLE, ZIPS, ZIP (the
+// byte-stream schemes, below), PIZ and PXR24 (pth_exr_codecs.cpp); B44 / DWA files are reported, not approximated.
 float half_to_float(uint16_t h) {
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
     uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
@@ -263,9 +265,9 @@ bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
         pos = end;
     }
     if (channels.empty() || compression < 0 || dw[2] < dw[0] || dw[3] < dw[1]) { *err = "EXR: header lacks channels / compression / dataWindow"; return false; }
-    if (compression > 3) {
+    if (compression > 5) {
         static const char* names[] = {"none", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
-        *err = std::string("EXR compression ") + (compression < 10 ? names[compression] : "?") + " is not supported (none, RLE, ZIPS, ZIP are)";
+        *err = std::string("EXR compression ") + (compression < 10 ? names[compression] : "?") + " is not supported (none, RLE, ZIPS, ZIP, PIZ, PXR24 are)";
         return false;
     }
     const int64_t w = (int64_t)dw[2] - dw[0] + 1, h = (int64_t)dw[3] - dw[1] + 1;
@@ -282,7 +284,9 @@ bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
         if (channels[c].name == "B") rgb_at[2] = (int)c;
     }
     if (rgb_at[0] < 0 || rgb_at[1] < 0 || rgb_at[2] < 0) { *err = "EXR: no R, G, B channels (the reference's decoder needs an RGB layer)"; return false; }
-    const int lines_per_block = compression == 3 ? 16 : 1;
+    const int lines_per_block = compression == 4 ? 32 : (compression == 3 || compression == 5 ? 16 : 1);
+    std::vector<ExrPlane> planes;
+    for (const ExrChannel& ch : channels) planes.push_back(ExrPlane{ch.type == 1 ? 1 : 2});
     const size_t n_blocks = (size_t)((h + lines_per_block - 1) / lines_per_block);
     if (!need(n_blocks * 8)) { *err = "EXR: truncated offset table"; return false; }
     const size_t table = pos;
@@ -301,6 +305,11 @@ bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
         if (compression == 0) {
             if ((size_t)n_src != raw.size()) { *err = "EXR: bad uncompressed block size"; return false; }
             std::memcpy(raw.data(), &b[(size_t)off + 8], raw.size());
+        } else if (compression >= 4 && (size_t)n_src == raw.size()) std::memcpy(raw.data(), &b[(size_t)off + 8], raw.size());      // stored
+        else if (compression == 4) {
+            if (!exr_unpack_piz(&b[(size_t)off + 8], (size_t)n_src, planes, (size_t)w, (size_t)lines, &raw, err)) return false;
+        } else if (compression == 5) {
+            if (!exr_unpack_pxr24(&b[(size_t)off + 8], (size_t)n_src, planes, (size_t)w, (size_t)lines, &raw, err)) return false;
         } else if (!exr_unpack_block(&b[(size_t)off + 8], (size_t)n_src, compression, &raw, err)) return false;
         for (int64_t ly = 0; ly < lines; ly++) {
             for (int c = 0; c < 3; c++) {
@@ -407,7 +416,17 @@ bool read_image_file(const std::string& path, RgbImage* out, std::string* err) {
     if (ends_with(lower, ".png")) return read_png(bytes, out, err);
     if (ends_with(lower, ".tga")) return read_tga(bytes, out, err);
     if (ends_with(lower, ".exr")) return read_exr(bytes, out, err);
-    *err = "image format of \"" + path + "\" is not on the accelerated path (pfm, png, tga, exr are)";
+    if (ends_with(lower, ".jpg") || ends_with(lower, ".jpeg")) {      // image::open -> Luma8 / Rgb8 -> convert_from_luma8 / _rgb8 (read_image.rs:11-71)
+        int w = 0, h = 0, nch = 0;
+        std::vector<uint8_t> px;
+        if (!decode_jpeg(bytes, &w, &h, &nch, &px, err)) return false;
+        out->width = w; out->height = h;
+        out->rgb.resize((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; i++)
+            for (int c = 0; c < 3; c++) out->rgb[3 * i + c] = (float)px[i * (size_t)nch + (nch == 1 ? 0 : c)] / 255.0f;
+        return true;
+    }
+    *err = "image format of \"" + path + "\" is not on the accelerated path (pfm, png, tga, exr, jpg are)";
     return false;
 }
 

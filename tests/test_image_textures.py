@@ -250,8 +250,10 @@ def test_front_end_pyramid_matches_numpy_restatement(tmp_path, case):
 
 def write_exr(path, chans, compression, origin=(0, 0), version=2):
     """A single-part scan-line OpenEXR file written from the format's published layout (independent of the reader under test).
-    chans: {name: (H x W array, "half" | "float")}; compression 0 none, 1 RLE, 2 ZIPS, 3 ZIP (4 = PIZ: header only)."""
+    chans: {name: (H x W array, "half" | "float")}; compression 0 none, 1 RLE, 2 ZIPS, 3 ZIP, 4 PIZ, 5 PXR24 (6 = B44: header only).
+    Returns per block what the block coder reported (None for the byte-stream schemes), "stored" where compression did not pay."""
     import struct
+    import exr_block_codecs as codecs
     names = sorted(chans)
     h, w = chans[names[0]][0].shape
 
@@ -263,8 +265,8 @@ def write_exr(path, chans, compression, origin=(0, 0), version=2):
     hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
     hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0))
     hdr += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
-    lines = 16 if compression == 3 else 1
-    blocks = []
+    lines = 32 if compression == 4 else (16 if compression in (3, 5) else 1)
+    blocks, report = [], []
     for y0 in range(0, h, lines):
         raw = b"".join(chans[n][0][y].astype("<f2" if chans[n][1] == "half" else "<f4").tobytes()
                        for y in range(y0, min(h, y0 + lines)) for n in names)
@@ -293,6 +295,19 @@ def write_exr(path, chans, compression, origin=(0, 0), version=2):
             else:
                 enc = zlib.compress(d)
             data = enc if len(enc) < len(raw) else raw
+        info = None
+        if compression in (4, 5):
+            y1 = min(h, y0 + lines)
+            words = [1 if chans[n][1] == "half" else 2 for n in names]
+            planes = [np.ascontiguousarray(chans[n][0][y0:y1].astype("<f2" if chans[n][1] == "half" else "<f4")).view("<u2") for n in names]
+            if compression == 4:
+                enc, info = codecs.piz_compress_planes(planes, words)
+            else:
+                enc, info = codecs.pxr24_compress(planes, words), {}
+            data = enc if len(enc) < len(raw) else raw
+            if data is raw:
+                info = "stored"
+        report.append(info)
         blocks.append((origin[1] + y0, data))
     table_at = len(hdr)
     off = table_at + 8 * len(blocks)
@@ -301,6 +316,7 @@ def write_exr(path, chans, compression, origin=(0, 0), version=2):
         table += struct.pack("<Q", off + len(body))
         body += struct.pack("<ii", y, len(data)) + data
     open(path, "wb").write(hdr + table + body)
+    return report
 
 
 @pytest.mark.parametrize("case", ["zip_half_rgba_window", "none_float", "rle_mixed", "zips_float_stored", "own_writer"])
@@ -338,22 +354,123 @@ def test_exr_inputs(tmp_path, case):
         assert g.shape == w.shape and np.array_equal(bits(g), bits(w))
 
 
+@pytest.mark.parametrize("case", ["piz_half_rgba_odd", "piz_mixed_types", "piz_many_values", "piz_flat", "piz_stored", "pxr24_mixed"])
+def test_exr_block_coders(tmp_path, case):
+    """PIZ and PXR24 files (the `exr` crate behind image::open reads both): decoding is a function of the file alone, so the samples
+    must come back bit for bit.  The files are made by tests/exr_block_codecs.py, the forward half written from the format."""
+    rng = np.random.default_rng(21)
+
+    def smooth(h, w, c):                    # low-frequency content plus a little noise: many small wavelet coefficients, some runs
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([0.5 + 0.4 * np.sin(xx / (7.0 + k) + yy / (11.0 - k)) for k in range(c)], -1)
+        return (base + 0.002 * rng.standard_normal((h, w, c))).astype(np.float32)
+    if case == "piz_half_rgba_odd":         # 3 blocks (32 + 32 + 13 lines), odd width: the left-over column / line paths at several levels
+        a = smooth(77, 37, 4).astype(np.float16)
+        a[40:60, 5:30] = np.float16(0.75)   # a flat patch: zero coefficients, coded as runs
+        rep = write_exr(tmp_path / "a.exr", {"R": (a[..., 0], "half"), "G": (a[..., 1], "half"), "B": (a[..., 2], "half"), "A": (a[..., 3], "half")}, 4, origin=(-5, 9))
+        rgb = a[..., :3].astype(np.float32)
+        assert all(isinstance(r, dict) and r["max_value"] < (1 << 14) for r in rep)
+    elif case == "piz_mixed_types":         # a float channel is two interleaved 16-bit planes
+        rgb = smooth(45, 201, 3)                 # wide enough to pay for the value map (up to 8 KB a block)
+        rgb[..., 1] = rgb[..., 1].astype(np.float16)                # stored as float all the same: its low 16-bit plane holds 8 values
+        rgb[..., 0] = rgb[..., 0].astype(np.float16)
+        rgb[..., 2] = rgb[..., 2].astype(np.float16)
+        rep = write_exr(tmp_path / "a.exr", {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "half")}, 4)
+        assert all(isinstance(r, dict) for r in rep)
+    elif case == "piz_many_values":         # > 2^14 distinct 16-bit values in a block: the modulo-2^16 pair coding, long codes
+        rgb = smooth(40, 400, 3)
+        rep = write_exr(tmp_path / "a.exr", {"R": (rgb[..., 0], "float"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "float")}, 4)
+        assert isinstance(rep[0], dict) and rep[0]["max_value"] >= (1 << 14) and rep[0]["longest_code"] > 12
+    elif case == "piz_flat":                # one value everywhere: a single code and runs of 255
+        rgb = np.full((35, 64, 3), 0.25, np.float32)
+        rep = write_exr(tmp_path / "a.exr", {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "half"), "B": (rgb[..., 2], "half")}, 4)
+        assert all(isinstance(r, dict) for r in rep)
+    elif case == "piz_stored":              # noise in every bit does not compress: the block is stored as it is
+        rgb = rng.integers(0, 0x7f000000, (4, 16, 3)).astype("<u4").view("<f4")
+        rep = write_exr(tmp_path / "a.exr", {"R": (rgb[..., 0], "float"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "float")}, 4)
+        assert rep == ["stored"]
+    else:                                   # PXR24: half channels exact, float channels as written (low mantissa byte zero)
+        rgb = smooth(37, 23, 3)
+        rgb[..., 1] = rgb[..., 1].astype(np.float16)
+        for c in (0, 2):
+            rgb[..., c] = (np.ascontiguousarray(rgb[..., c]).view("<u4") & 0xffffff00).view("<f4")
+        rep = write_exr(tmp_path / "a.exr", {"R": (rgb[..., 0], "float"), "G": (rgb[..., 1], "half"), "B": (rgb[..., 2], "float"), "A": (rgb[..., 1], "half")}, 5, origin=(2, 2))
+        assert all(r == {} for r in rep)
+    ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.exr"')
+    want = pyramid_ref(np.ascontiguousarray(rgb, np.float32), 3, 1.0, False, "repeat", "repeat")
+    got = front_end_levels(ps)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and np.array_equal(bits(g), bits(w))
+
+
+def test_exr_corrupt_piz_blocks_are_reported(tmp_path):
+    a = np.linspace(0, 1, 32 * 16, dtype=np.float32).reshape(32, 16).astype(np.float16)
+    write_exr(tmp_path / "a.exr", {"R": (a, "half"), "G": (a, "half"), "B": (a, "half")}, 4)
+    good = open(tmp_path / "a.exr", "rb").read()
+    for cut in (len(good) - 9, len(good) - 40):          # truncated Huffman data / a damaged length field
+        bad = bytearray(good[:cut] + b"\0" * (len(good) - cut))
+        open(tmp_path / "bad.exr", "wb").write(bad)
+        with pytest.raises(capi.PtError) as e:
+            parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "bad.exr"')
+        assert "PIZ" in str(e.value), str(e.value)
+
+
 def test_exr_variants_outside_the_subset_are_reported(tmp_path):
     y = np.ones((4, 4), np.float32)
-    write_exr(tmp_path / "piz.exr", {"R": (y, "half"), "G": (y, "half"), "B": (y, "half")}, 4)
+    write_exr(tmp_path / "piz.exr", {"R": (y, "half"), "G": (y, "half"), "B": (y, "half")}, 6)
     write_exr(tmp_path / "lum.exr", {"Y": (y, "half")}, 0)
     write_exr(tmp_path / "tiled.exr", {"R": (y, "half"), "G": (y, "half"), "B": (y, "half")}, 0, version=2 | 0x200)
-    for name, msg in (("piz.exr", "PIZ is not supported"), ("lum.exr", "no R, G, B channels"), ("tiled.exr", "tiled")):
+    for name, msg in (("piz.exr", "B44 is not supported"), ("lum.exr", "no R, G, B channels"), ("tiled.exr", "tiled")):
         with pytest.raises(capi.PtError) as e:
             parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "%s"' % name)
         assert msg in str(e.value), str(e.value)
+
+
+def _jpeg_test_image(h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0), 128 + 90 * np.cos(xx / 5.0 + yy / 13.0), 40 + 3.0 * xx + 1.5 * yy], -1)
+    rgb[h // 4:h // 2, w // 4:w // 2] = (250, 20, 30)          # a hard edge: strong high-frequency coefficients, saturated chroma
+    return np.clip(rgb, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("case", ["gray", "444", "422", "420", "420_odd_restart", "rgb_q100"])
+def test_jpeg_inputs(tmp_path, case):
+    """read_image.rs:145-183 hands .jpg to the image crate (jpeg-decoder): Luma8 / Rgb8 -> /255.  Entropy decoding is exact; the
+    inverse DCT, chroma upsampling and colour conversion follow that crate's integer pipeline as published, with no fixture from the
+    reference to pin them (pth_jpeg.h says so) -- so this test compares with libjpeg (PIL) within +-3 levels, mean error < 0.6."""
+    Image = pytest.importorskip("PIL.Image")
+    h, w = (32, 64) if case != "420_odd_restart" else (37, 51)
+    rgb = _jpeg_test_image(h, w)
+    name = tmp_path / "wall_bump.jpg"                             # "_bump": gamma off, so level 0 is the decoded image / 255
+    if case == "gray":
+        Image.fromarray(rgb[..., 0], "L").save(name, quality=90)
+    elif case == "rgb_q100":
+        Image.fromarray(rgb, "RGB").save(name, quality=100, subsampling=0)
+    elif case == "420_odd_restart":
+        Image.fromarray(rgb, "RGB").save(name, quality=85, subsampling=2, restart_marker_blocks=3)
+    else:
+        Image.fromarray(rgb, "RGB").save(name, quality=90, subsampling={"444": 0, "422": 1, "420": 2}[case])
+    ref = np.asarray(Image.open(name).convert("RGB"), np.float32)
+    ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "wall_bump.jpg"')
+    got = front_end_levels(ps)[0] * np.float32(255.0)
+    if case == "420_odd_restart":           # 51 x 37 (partial MCUs at both edges, restart markers): both decodes resampled to 64 x 64
+        want = pyramid_ref(ref / np.float32(255.0), 3, 1.0, False, "repeat", "repeat")[0] * np.float32(255.0)
+    else:
+        want = ref[::-1]
+    err = np.abs(got - want)
+    assert got.shape == want.shape and err.max() <= 3.0 and err.mean() < 0.6, (err.max(), err.mean())
 
 
 def test_unsupported_image_inputs_fail_loudly(tmp_path):
     open(tmp_path / "a.jpg", "wb").write(b"\xff\xd8\xff")
     with pytest.raises(capi.PtError) as e:
         parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.jpg"')
-    assert e.value.status == 4 and "not on the accelerated path (pfm, png, tga, exr are)" in str(e.value)
+    assert e.value.status == 4 and "JPEG: not a JPEG file" in str(e.value)
+    open(tmp_path / "a.bmp", "wb").write(b"BM")
+    with pytest.raises(capi.PtError) as e:
+        parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "a.bmp"')
+    assert e.value.status == 4 and "not on the accelerated path (pfm, png, tga, exr, jpg are)" in str(e.value)
     with pytest.raises(capi.PtError) as e:
         parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "missing.png"')
     assert "File not found" in str(e.value)
