@@ -141,12 +141,82 @@ void idct_block(const int d[64], uint8_t* out, size_t stride) {
     }
 }
 
+// One block of one progressive scan (T.81 annex G): DC first / refinement, AC first / refinement with end-of-band runs.
+// Returns nullptr or what is wrong.
+const char* progressive_block(Bits& bits, int* blk, int Ss, int Se, int Ah, int Al, const HuffTable& dct, const HuffTable& act, int* pred, int* eobrun) {
+    if (Ss == 0) {
+        if (Ah == 0) {
+            const int t = decode_symbol(bits, dct);
+            if (t < 0 || t > 11) return "corrupt entropy-coded data (DC)";
+            *pred += t ? extend(bits.get(t), t) : 0;
+            blk[0] = *pred * (1 << Al);
+        } else if (bits.get(1)) blk[0] |= 1 << Al;
+        return nullptr;
+    }
+    if (Ah == 0) {
+        if (*eobrun > 0) { (*eobrun)--; return nullptr; }
+        for (int k = Ss; k <= Se;) {
+            const int rs = decode_symbol(bits, act);
+            if (rs < 0) return "corrupt entropy-coded data (AC)";
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+                if (r < 15) {
+                    *eobrun = (1 << r) - 1;
+                    if (r) *eobrun += bits.get(r);
+                    break;
+                }
+                k += 16;
+                continue;
+            }
+            k += r;
+            if (k > Se) return "corrupt entropy-coded data (run)";
+            blk[kZigzag[k]] = extend(bits.get(sz), sz) * (1 << Al);
+            k++;
+        }
+        return nullptr;
+    }
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    auto correct = [&](int* c) {
+        if (bits.get(1) && (*c & p1) == 0) *c += *c >= 0 ? p1 : m1;
+    };
+    int k = Ss;
+    if (*eobrun == 0) {
+        for (; k <= Se; k++) {
+            const int rs = decode_symbol(bits, act);
+            if (rs < 0) return "corrupt entropy-coded data (AC)";
+            int r = rs >> 4, v = rs & 15;
+            if (v) v = bits.get(1) ? p1 : m1;
+            else if (r != 15) {
+                *eobrun = 1 << r;
+                if (r) *eobrun += bits.get(r);
+                break;
+            }
+            do {                                   // pass the coefficients that have a history, and r that do not
+                int* c = &blk[kZigzag[k]];
+                if (*c != 0) correct(c);
+                else if (--r < 0) break;
+                k++;
+            } while (k <= Se);
+            if (v && k <= Se) blk[kZigzag[k]] = v;
+        }
+    }
+    if (*eobrun > 0) {
+        for (; k <= Se; k++) {
+            int* c = &blk[kZigzag[k]];
+            if (*c != 0) correct(c);
+        }
+        (*eobrun)--;
+    }
+    return nullptr;
+}
+
 struct Component {
     int id = 0, h = 1, v = 1, tq = 0;
     int dc_table = 0, ac_table = 0, pred = 0;
     int width = 0, height = 0;                 // true size of the plane (ceil of the scaled image size)
     int blocks_w = 0, blocks_h = 0;            // allocated size in blocks (whole MCUs)
     std::vector<uint8_t> plane;                // blocks_w * 8 bytes per row
+    std::vector<int> coefs;                    // progressive files: 64 per block, natural order, built up scan by scan
 };
 
 // One output row of a component stretched to the image width.  2:1 ratios use a triangle filter (3/4 nearer + 1/4 farther sample),
@@ -220,7 +290,7 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
     HuffTable dc[4], ac[4];
     std::vector<Component> comps;
     int W = 0, H = 0, hmax = 1, vmax = 1, restart_interval = 0, adobe_transform = -1;
-    bool have_frame = false, jfif = false;
+    bool have_frame = false, jfif = false, progressive = false;
     size_t blocks_done = 0;
     for (;;) {
         while (pos < b.size() && b[pos] != 0xff) pos++;          // tolerate stray bytes between segments
@@ -235,7 +305,8 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
         const uint8_t* s = &b[pos + 2];
         const size_t n = len - 2;
         pos += len;
-        if (m == 0xc0 || m == 0xc1) {                             // SOF0 / SOF1
+        if (m == 0xc0 || m == 0xc1 || m == 0xc2) {                // SOF0 / SOF1 / SOF2
+            progressive = m == 0xc2;
             if (have_frame) return fail("more than one frame");
             if (n < 6) return fail("bad frame header");
             if (s[0] != 8) return fail("only 8-bit samples are supported");
@@ -259,10 +330,10 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
                 c.height = (H * c.v + vmax - 1) / vmax;
                 c.blocks_w = mcux * c.h; c.blocks_h = mcuy * c.v;
                 c.plane.assign((size_t)c.blocks_w * 8 * (size_t)c.blocks_h * 8, 0);
+                if (progressive) c.coefs.assign((size_t)c.blocks_w * (size_t)c.blocks_h * 64, 0);
             }
             have_frame = true;
-        } else if (m == 0xc2) return fail("progressive files are not supported (baseline and extended sequential are)");
-        else if (m == 0xc3 || (m >= 0xc5 && m <= 0xc7) || (m >= 0xc9 && m <= 0xcb) || (m >= 0xcd && m <= 0xcf))
+        } else if (m == 0xc3 || (m >= 0xc5 && m <= 0xc7) || (m >= 0xc9 && m <= 0xcb) || (m >= 0xcd && m <= 0xcf))
             return fail("lossless, hierarchical and arithmetic-coded files are not supported");
         else if (m == 0xc4) {                                     // DHT
             size_t at = 0;
@@ -297,23 +368,27 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
             if (n < 1) return fail("bad scan header");
             const int ns = s[0];
             if (ns < 1 || ns > (int)comps.size() || n < 1 + 2 * (size_t)ns + 3) return fail("bad scan header");
+            const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+            if (!progressive) { if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return fail("spectral selection in a sequential file"); }
+            else if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah != 0 && Ah != Al + 1)) return fail("bad progressive scan parameters");
+            const bool need_dc = !progressive || Ss == 0, need_ac = !progressive || Ss > 0;
             std::vector<Component*> sc;
             for (int i = 0; i < ns; i++) {
                 Component* c = nullptr;
                 for (Component& k : comps) if (k.id == s[1 + 2 * i]) c = &k;
                 if (!c) return fail("scan names an unknown component");
                 c->dc_table = s[2 + 2 * i] >> 4; c->ac_table = s[2 + 2 * i] & 15;
-                if (c->dc_table > 3 || c->ac_table > 3 || !dc[c->dc_table].present || !ac[c->ac_table].present) return fail("scan uses a missing Huffman table");
+                if (c->dc_table > 3 || c->ac_table > 3 || (need_dc && Ah == 0 && !dc[c->dc_table].present) || (need_ac && !ac[c->ac_table].present))
+                    return fail("scan uses a missing Huffman table");
                 if (!have_quant[c->tq]) return fail("scan uses a missing quantisation table");
                 c->pred = 0;
                 sc.push_back(c);
             }
-            if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return fail("spectral selection in a sequential file");
             Bits bits{&b[pos], b.data() + b.size()};
             int mcus_x, mcus_y;
             if (ns == 1) { mcus_x = (sc[0]->width + 7) / 8; mcus_y = (sc[0]->height + 7) / 8; }
             else { mcus_x = (W + 8 * hmax - 1) / (8 * hmax); mcus_y = (H + 8 * vmax - 1) / (8 * vmax); }
-            int until_restart = restart_interval, next_rst = 0;
+            int until_restart = restart_interval, next_rst = 0, eobrun = 0;
             for (int my = 0; my < mcus_y; my++)
                 for (int mx = 0; mx < mcus_x; mx++) {
                     if (restart_interval && until_restart == 0) {
@@ -327,11 +402,21 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
                         next_rst = (next_rst + 1) & 7;
                         until_restart = restart_interval;
                         for (Component* c : sc) c->pred = 0;
+                        eobrun = 0;
                     }
                     for (Component* c : sc) {
                         const int bh = ns == 1 ? 1 : c->h, bv = ns == 1 ? 1 : c->v;
                         for (int by = 0; by < bv; by++)
                             for (int bx = 0; bx < bh; bx++) {
+                                if (progressive) {
+                                    const int block_x = mx * bh + bx, block_y = my * bv + by;
+                                    if (block_x >= c->blocks_w || block_y >= c->blocks_h) return fail("block outside the frame");
+                                    int* blk = &c->coefs[((size_t)block_y * (size_t)c->blocks_w + (size_t)block_x) * 64];
+                                    const char* what = progressive_block(bits, blk, Ss, Se, Ah, Al, dc[c->dc_table], ac[c->ac_table], &c->pred, &eobrun);
+                                    if (what) return fail(what);
+                                    blocks_done++;
+                                    continue;
+                                }
                                 int coef[64];
                                 std::memset(coef, 0, sizeof coef);
                                 const int t = decode_symbol(bits, dc[c->dc_table]);
@@ -371,6 +456,17 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
         // every other segment (APPn, COM, ...) is skipped
     }
     if (!have_frame || blocks_done == 0) return fail("no image data");
+    if (progressive)
+        for (Component& c : comps) {
+            if (!have_quant[c.tq]) return fail("missing quantisation table");
+            int coef[64];
+            for (int by = 0; by < c.blocks_h; by++)
+                for (int bx = 0; bx < c.blocks_w; bx++) {
+                    const int* blk = &c.coefs[((size_t)by * (size_t)c.blocks_w + (size_t)bx) * 64];
+                    for (int k = 0; k < 64; k++) coef[k] = blk[k] * quant[c.tq][k];
+                    idct_block(coef, &c.plane[((size_t)by * 8 * (size_t)c.blocks_w + (size_t)bx) * 8], (size_t)c.blocks_w * 8);
+                }
+        }
     *width = W; *height = H;
     *channels = (int)comps.size();
     pixels->assign((size_t)W * H * comps.size(), 0);

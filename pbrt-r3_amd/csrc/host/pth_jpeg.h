@@ -1,10 +1,10 @@
-// pth_jpeg.h -- baseline / extended-sequential Huffman JPEG (ITU T.81, 8-bit) for `imagemap` textures.
+// pth_jpeg.h -- baseline, extended-sequential and progressive Huffman JPEG (ITU T.81, 8-bit) for `imagemap` textures.
 // The reference reads .jpg through image 0.24 -> jpeg-decoder 0.3 (a Cargo dependency that is not vendored under the reference tree
 // and whose exact version no lock file pins).  Entropy decoding is exact by the standard; the lossy back end -- inverse DCT,
 // chroma upsampling, YCbCr -> RGB -- is restated here from that crate's published integer pipeline (stb_image's IDCT constants,
 // triangle-filter upsampling, 20-bit fixed-point colour conversion).  PARITY UNPINNED: there is no fixture from the reference for
 // this path, the tests compare with another decoder within a tolerance of +-3 levels, not bit for bit.
-// Progressive, lossless, arithmetic-coded, 12-bit and four-component (CMYK) files are reported.
+// Lossless, hierarchical, arithmetic-coded, 12-bit and four-component (CMYK) files are reported.
 #pragma once
 #include <cstdint>
 #include <string>

@@ -434,13 +434,13 @@ def _jpeg_test_image(h, w):
     return np.clip(rgb, 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("case", ["gray", "444", "422", "420", "420_odd_restart", "rgb_q100"])
+@pytest.mark.parametrize("case", ["gray", "444", "422", "420", "420_odd_restart", "rgb_q100", "progressive_420", "progressive_gray_odd", "progressive_444_restart"])
 def test_jpeg_inputs(tmp_path, case):
     """read_image.rs:145-183 hands .jpg to the image crate (jpeg-decoder): Luma8 / Rgb8 -> /255.  Entropy decoding is exact; the
     inverse DCT, chroma upsampling and colour conversion follow that crate's integer pipeline as published, with no fixture from the
     reference to pin them (pth_jpeg.h says so) -- so this test compares with libjpeg (PIL) within +-3 levels, mean error < 0.6."""
     Image = pytest.importorskip("PIL.Image")
-    h, w = (32, 64) if case != "420_odd_restart" else (37, 51)
+    h, w = (37, 51) if "odd" in case else (32, 64)
     rgb = _jpeg_test_image(h, w)
     name = tmp_path / "wall_bump.jpg"                             # "_bump": gamma off, so level 0 is the decoded image / 255
     if case == "gray":
@@ -449,12 +449,18 @@ def test_jpeg_inputs(tmp_path, case):
         Image.fromarray(rgb, "RGB").save(name, quality=100, subsampling=0)
     elif case == "420_odd_restart":
         Image.fromarray(rgb, "RGB").save(name, quality=85, subsampling=2, restart_marker_blocks=3)
+    elif case == "progressive_420":         # libjpeg's default script: DC first, AC bands per component, then the refinement passes
+        Image.fromarray(rgb, "RGB").save(name, quality=88, subsampling=2, progressive=True)
+    elif case == "progressive_gray_odd":
+        Image.fromarray(rgb[..., 1], "L").save(name, quality=93, progressive=True)
+    elif case == "progressive_444_restart":
+        Image.fromarray(rgb, "RGB").save(name, quality=75, subsampling=0, progressive=True, restart_marker_blocks=5)
     else:
         Image.fromarray(rgb, "RGB").save(name, quality=90, subsampling={"444": 0, "422": 1, "420": 2}[case])
     ref = np.asarray(Image.open(name).convert("RGB"), np.float32)
     ps = parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "wall_bump.jpg"')
     got = front_end_levels(ps)[0] * np.float32(255.0)
-    if case == "420_odd_restart":           # 51 x 37 (partial MCUs at both edges, restart markers): both decodes resampled to 64 x 64
+    if "odd" in case:                       # 51 x 37 (partial MCUs at both edges, restart markers): both decodes resampled to 64 x 64
         want = pyramid_ref(ref / np.float32(255.0), 3, 1.0, False, "repeat", "repeat")[0] * np.float32(255.0)
     else:
         want = ref[::-1]
