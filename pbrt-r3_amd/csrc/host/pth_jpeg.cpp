@@ -81,24 +81,29 @@ inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 :
 
 // Dequantised coefficients -> 8x8 samples: two passes of a 1-D integer IDCT with 12-bit constants, two extra bits kept between the
 // passes, + 128 and clamp at the end.
-inline int f2f(float x) { return (int)(x * 4096.0f + 0.5f); }
-struct Idct1D { int x0, x1, x2, x3, t0, t1, t2, t3; };
+// Arithmetic wraps modulo 2^32 (a damaged file can carry coefficients far outside the range a real image produces).
+struct W32 { int32_t v; };
+inline W32 operator+(W32 a, W32 b) { return W32{(int32_t)((uint32_t)a.v + (uint32_t)b.v)}; }
+inline W32 operator-(W32 a, W32 b) { return W32{(int32_t)((uint32_t)a.v - (uint32_t)b.v)}; }
+inline W32 operator*(W32 a, W32 b) { return W32{(int32_t)((uint32_t)a.v * (uint32_t)b.v)}; }
+inline W32 f2f(float x) { return W32{(int32_t)(x * 4096.0f + 0.5f)}; }
+struct Idct1D { W32 x0, x1, x2, x3, t0, t1, t2, t3; };
 inline Idct1D idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
-    int p2 = s2, p3 = s6;
-    int p1 = (p2 + p3) * f2f(0.5411961f);
-    int t2 = p1 + p3 * f2f(-1.847759065f);
-    int t3 = p1 + p2 * f2f(0.765366865f);
-    p2 = s0; p3 = s4;
-    int t0 = (p2 + p3) * 4096;
-    int t1 = (p2 - p3) * 4096;
+    W32 p2{s2}, p3{s6};
+    W32 p1 = (p2 + p3) * f2f(0.5411961f);
+    W32 t2 = p1 + p3 * f2f(-1.847759065f);
+    W32 t3 = p1 + p2 * f2f(0.765366865f);
+    p2 = W32{s0}; p3 = W32{s4};
+    W32 t0 = (p2 + p3) * W32{4096};
+    W32 t1 = (p2 - p3) * W32{4096};
     Idct1D r;
     r.x0 = t0 + t3; r.x3 = t0 - t3; r.x1 = t1 + t2; r.x2 = t1 - t2;
-    t0 = s7; t1 = s5; t2 = s3; t3 = s1;
+    t0 = W32{s7}; t1 = W32{s5}; t2 = W32{s3}; t3 = W32{s1};
     p3 = t0 + t2;
-    int p4 = t1 + t3;
+    W32 p4 = t1 + t3;
     p1 = t0 + t3;
     p2 = t1 + t2;
-    const int p5 = (p3 + p4) * f2f(1.175875602f);
+    const W32 p5 = (p3 + p4) * f2f(1.175875602f);
     t0 = t0 * f2f(0.298631336f);
     t1 = t1 * f2f(2.053119869f);
     t2 = t2 * f2f(3.072711026f);
@@ -117,27 +122,28 @@ void idct_block(const int d[64], uint8_t* out, size_t stride) {
         const int* c = d + i;
         int* v = val + i;
         if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
-            const int dc = c[0] * 4;
+            const int dc = (W32{c[0]} * W32{4}).v;
             for (int k = 0; k < 8; k++) v[8 * k] = dc;
         } else {
             Idct1D r = idct_1d(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56]);
-            r.x0 += 512; r.x1 += 512; r.x2 += 512; r.x3 += 512;
-            v[0] = (r.x0 + r.t3) >> 10; v[56] = (r.x0 - r.t3) >> 10;
-            v[8] = (r.x1 + r.t2) >> 10; v[48] = (r.x1 - r.t2) >> 10;
-            v[16] = (r.x2 + r.t1) >> 10; v[40] = (r.x2 - r.t1) >> 10;
-            v[24] = (r.x3 + r.t0) >> 10; v[32] = (r.x3 - r.t0) >> 10;
+            const W32 half{512};
+            r.x0 = r.x0 + half; r.x1 = r.x1 + half; r.x2 = r.x2 + half; r.x3 = r.x3 + half;
+            v[0] = (r.x0 + r.t3).v >> 10; v[56] = (r.x0 - r.t3).v >> 10;
+            v[8] = (r.x1 + r.t2).v >> 10; v[48] = (r.x1 - r.t2).v >> 10;
+            v[16] = (r.x2 + r.t1).v >> 10; v[40] = (r.x2 - r.t1).v >> 10;
+            v[24] = (r.x3 + r.t0).v >> 10; v[32] = (r.x3 - r.t0).v >> 10;
         }
     }
     for (int i = 0; i < 8; i++) {
         const int* v = val + 8 * i;
         uint8_t* o = out + (size_t)i * stride;
         Idct1D r = idct_1d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-        const int bias = 65536 + (128 << 17);
-        r.x0 += bias; r.x1 += bias; r.x2 += bias; r.x3 += bias;
-        o[0] = clamp8((r.x0 + r.t3) >> 17); o[7] = clamp8((r.x0 - r.t3) >> 17);
-        o[1] = clamp8((r.x1 + r.t2) >> 17); o[6] = clamp8((r.x1 - r.t2) >> 17);
-        o[2] = clamp8((r.x2 + r.t1) >> 17); o[5] = clamp8((r.x2 - r.t1) >> 17);
-        o[3] = clamp8((r.x3 + r.t0) >> 17); o[4] = clamp8((r.x3 - r.t0) >> 17);
+        const W32 bias{65536 + (128 << 17)};
+        r.x0 = r.x0 + bias; r.x1 = r.x1 + bias; r.x2 = r.x2 + bias; r.x3 = r.x3 + bias;
+        o[0] = clamp8((r.x0 + r.t3).v >> 17); o[7] = clamp8((r.x0 - r.t3).v >> 17);
+        o[1] = clamp8((r.x1 + r.t2).v >> 17); o[6] = clamp8((r.x1 - r.t2).v >> 17);
+        o[2] = clamp8((r.x2 + r.t1).v >> 17); o[5] = clamp8((r.x2 - r.t1).v >> 17);
+        o[3] = clamp8((r.x3 + r.t0).v >> 17); o[4] = clamp8((r.x3 - r.t0).v >> 17);
     }
 }
 
@@ -148,8 +154,8 @@ const char* progressive_block(Bits& bits, int* blk, int Ss, int Se, int Ah, int 
         if (Ah == 0) {
             const int t = decode_symbol(bits, dct);
             if (t < 0 || t > 11) return "corrupt entropy-coded data (DC)";
-            *pred += t ? extend(bits.get(t), t) : 0;
-            blk[0] = *pred * (1 << Al);
+            *pred = (int)((uint32_t)*pred + (uint32_t)(t ? extend(bits.get(t), t) : 0));
+            blk[0] = (int)((uint32_t)*pred << Al);
         } else if (bits.get(1)) blk[0] |= 1 << Al;
         return nullptr;
     }
@@ -422,9 +428,9 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
                                 const int t = decode_symbol(bits, dc[c->dc_table]);
                                 if (t < 0 || t > 11) return fail("corrupt entropy-coded data (DC)");
                                 const int diff = t ? extend(bits.get(t), t) : 0;
-                                c->pred += diff;
+                                c->pred = (int)((uint32_t)c->pred + (uint32_t)diff);
                                 const uint16_t* q = quant[c->tq];
-                                coef[0] = c->pred * q[0];
+                                coef[0] = (int)((uint32_t)c->pred * (uint32_t)q[0]);
                                 for (int k = 1; k < 64;) {
                                     const int rs = decode_symbol(bits, ac[c->ac_table]);
                                     if (rs < 0) return fail("corrupt entropy-coded data (AC)");
@@ -437,7 +443,7 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
                                     k += r;
                                     if (k > 63) return fail("corrupt entropy-coded data (run)");
                                     const int z = kZigzag[k];
-                                    coef[z] = extend(bits.get(sz), sz) * q[z];
+                                    coef[z] = (int)((uint32_t)extend(bits.get(sz), sz) * (uint32_t)q[z]);
                                     k++;
                                 }
                                 const int block_x = mx * bh + bx, block_y = my * bv + by;
@@ -463,7 +469,7 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
             for (int by = 0; by < c.blocks_h; by++)
                 for (int bx = 0; bx < c.blocks_w; bx++) {
                     const int* blk = &c.coefs[((size_t)by * (size_t)c.blocks_w + (size_t)bx) * 64];
-                    for (int k = 0; k < 64; k++) coef[k] = blk[k] * quant[c.tq][k];
+                    for (int k = 0; k < 64; k++) coef[k] = (int)((uint32_t)blk[k] * (uint32_t)quant[c.tq][k]);
                     idct_block(coef, &c.plane[((size_t)by * 8 * (size_t)c.blocks_w + (size_t)bx) * 8], (size_t)c.blocks_w * 8);
                 }
         }

@@ -1,0 +1,30 @@
+import sys; import os; R=os.path.join(os.path.dirname(os.path.abspath(__file__)),"..",".."); sys.path.insert(0,os.path.join(R,"tests")); sys.path.insert(0,R)
+import numpy as np, pathlib
+from PIL import Image
+import test_image_textures as t
+rng=np.random.default_rng(int(sys.argv[1]))
+d=pathlib.Path(sys.argv[2]); d.mkdir(parents=True,exist_ok=True)
+rgb=t._jpeg_test_image(37,51)
+seeds={}
+Image.fromarray(rgb,"RGB").save(d/"b.jpg",quality=85,subsampling=2,restart_marker_blocks=3); seeds["base.jpg"]=open(d/"b.jpg","rb").read()
+Image.fromarray(rgb,"RGB").save(d/"b2.jpg",quality=60,subsampling=1); seeds["b422.jpg"]=open(d/"b2.jpg","rb").read()
+Image.fromarray(rgb,"RGB").save(d/"p.jpg",quality=85,subsampling=2,progressive=True); seeds["prog.jpg"]=open(d/"p.jpg","rb").read()
+Image.fromarray(rgb[...,0],"L").save(d/"g.jpg",quality=85,progressive=True); seeds["gprog.jpg"]=open(d/"g.jpg","rb").read()
+a=(rgb[...,:3]/255.0).astype(np.float16)
+t.write_exr(d/"z.exr",{"R":(a[...,0],"half"),"G":(a[...,1].astype(np.float32),"float"),"B":(a[...,2],"half")},4); seeds["piz.exr"]=open(d/"z.exr","rb").read()
+t.write_exr(d/"x.exr",{"R":(a[...,0],"half"),"G":(a[...,1],"half"),"B":(a[...,2],"half")},5); seeds["pxr.exr"]=open(d/"x.exr","rb").read()
+t.write_exr(d/"y.exr",{"R":(a[...,0],"half"),"G":(a[...,1],"half"),"B":(a[...,2],"half")},3); seeds["zip.exr"]=open(d/"y.exr","rb").read()
+n=int(sys.argv[3])
+for it in range(n):
+    name=list(seeds)[it%len(seeds)]
+    data=bytearray(seeds[name])
+    mode=rng.integers(0,4)
+    if mode==0:
+        for _ in range(rng.integers(1,6)): data[rng.integers(0,len(data))]=rng.integers(0,256)
+    elif mode==1:
+        data=data[:rng.integers(4,len(data))]
+    elif mode==2:
+        i=rng.integers(0,len(data)); data[i:i+rng.integers(1,40)]=bytes(rng.integers(0,256,rng.integers(0,40),dtype=np.uint8))
+    else:   # header-area mutation
+        for _ in range(rng.integers(1,4)): data[rng.integers(0,min(700,len(data)))]=rng.integers(0,256)
+    open(d/("f%05d_%s"%(it,name)),"wb").write(data)
