@@ -173,7 +173,7 @@ bool read_tga(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
     return true;
 }
 
-// ---- OpenEXR (image::open -> codecs::openexr: the R, G, B channels of a single-part scan-line file as f32; alpha is read and
+// ---- OpenEXR (image::open -> codecs::openexr: the R, G, B channels of a single-part scan-line or tiled file as f32; alpha is read and
 // dropped by convert_from_rgba32f, read_image.rs:112-142).  Pixel types half and float; compression none, RLE, ZIPS, ZIP (the
 // byte-stream schemes, below), PIZ and PXR24 (pth_exr_codecs.cpp); B44 / DWA files are reported, not approximated.
 float half_to_float(uint16_t h) {
@@ -238,7 +238,9 @@ bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
     };
     if (b.size() < 8 || rd_i32(0) != 20000630) { *err = "not an OpenEXR file"; return false; }
     const uint32_t version = (uint32_t)rd_i32(4);
-    if ((version & 0xffu) != 2 || (version & 0x1a00u)) { *err = "EXR: tiled, deep and multi-part files are not supported (single-part scan-line files are)"; return false; }
+    if ((version & 0xffu) != 2 || (version & 0x1800u)) { *err = "EXR: deep and multi-part files are not supported (single-part scan-line and tiled files are)"; return false; }
+    const bool tiled = (version & 0x200u) != 0;
+    int64_t tile_w = 0, tile_h = 0;
     pos = 8;
     std::vector<ExrChannel> channels;
     int compression = -1, dw[4] = {0, 0, -1, -1};
@@ -262,6 +264,7 @@ bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
             }
         } else if (name == "compression" && size == 1) compression = b[pos];
         else if (name == "dataWindow" && size == 16) for (int i = 0; i < 4; i++) dw[i] = rd_i32(pos + 4 * (size_t)i);
+        else if (name == "tiles" && size == 9) { tile_w = (uint32_t)rd_i32(pos); tile_h = (uint32_t)rd_i32(pos + 4); }      // the level mode does not matter: level (0, 0) is read
         pos = end;
     }
     if (channels.empty() || compression < 0 || dw[2] < dw[0] || dw[3] < dw[1]) { *err = "EXR: header lacks channels / compression / dataWindow"; return false; }
@@ -288,11 +291,52 @@ bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
     std::vector<ExrPlane> planes;
     for (const ExrChannel& ch : channels) planes.push_back(ExrPlane{ch.type == 1 ? 1 : 2});
     const size_t n_blocks = (size_t)((h + lines_per_block - 1) / lines_per_block);
-    if (!need(n_blocks * 8)) { *err = "EXR: truncated offset table"; return false; }
+    if (!tiled && !need(n_blocks * 8)) { *err = "EXR: truncated offset table"; return false; }
     const size_t table = pos;
     out->width = (int)w; out->height = (int)h;
     out->rgb.assign((size_t)w * (size_t)h * 3, 0.0f);
     std::vector<uint8_t> raw;
+    if (tiled) {
+        // Tiled files (the `exr` crate reads the largest level): the offset table starts with the tiles of level (0, 0), row by row;
+        // a chunk is tile x, tile y, level x, level y, byte count, then the tile's lines coded as one block.
+        if (tile_w <= 0 || tile_h <= 0 || tile_w > 65536 || tile_h > 65536) { *err = "EXR: tiled file without a valid tile description"; return false; }
+        const int64_t ntx = (w + tile_w - 1) / tile_w, nty = (h + tile_h - 1) / tile_h;
+        if (!need((size_t)(ntx * nty) * 8)) { *err = "EXR: truncated offset table"; return false; }
+        std::vector<uint8_t> tile_raw;
+        for (int64_t t = 0; t < ntx * nty; t++) {
+            uint64_t off;
+            std::memcpy(&off, &b[table + 8 * (size_t)t], 8);
+            if (off + 20 > b.size()) { *err = "EXR: block offset outside the file"; return false; }
+            const int64_t tx = rd_i32((size_t)off), ty = rd_i32((size_t)off + 4);
+            const int32_t lx = rd_i32((size_t)off + 8), ly = rd_i32((size_t)off + 12), n_src = rd_i32((size_t)off + 16);
+            if (tx < 0 || tx >= ntx || ty < 0 || ty >= nty || lx != 0 || ly != 0 || n_src < 0 || off + 20 + (uint64_t)n_src > b.size()) { *err = "EXR: bad tile header"; return false; }
+            const int64_t tw = std::min<int64_t>(tile_w, w - tx * tile_w), th = std::min<int64_t>(tile_h, h - ty * tile_h);
+            size_t tile_line_bytes = 0;
+            std::vector<size_t> t_off(channels.size());
+            for (size_t c = 0; c < channels.size(); c++) { t_off[c] = tile_line_bytes; tile_line_bytes += (size_t)tw * (channels[c].type == 1 ? 2 : 4); }
+            tile_raw.assign((size_t)th * tile_line_bytes, 0);
+            const uint8_t* src = &b[(size_t)off + 20];
+            if (compression == 0 || (size_t)n_src == tile_raw.size()) {
+                if ((size_t)n_src != tile_raw.size()) { *err = "EXR: bad uncompressed tile size"; return false; }
+                std::memcpy(tile_raw.data(), src, tile_raw.size());
+            } else if (compression == 4) {
+                if (!exr_unpack_piz(src, (size_t)n_src, planes, (size_t)tw, (size_t)th, &tile_raw, err)) return false;
+            } else if (compression == 5) {
+                if (!exr_unpack_pxr24(src, (size_t)n_src, planes, (size_t)tw, (size_t)th, &tile_raw, err)) return false;
+            } else if (!exr_unpack_block(src, (size_t)n_src, compression, &tile_raw, err)) return false;
+            for (int64_t yy = 0; yy < th; yy++)
+                for (int c = 0; c < 3; c++) {
+                    const ExrChannel& ch = channels[(size_t)rgb_at[c]];
+                    const uint8_t* line = tile_raw.data() + (size_t)yy * tile_line_bytes + t_off[(size_t)rgb_at[c]];
+                    float* dst = &out->rgb[((size_t)(ty * tile_h + yy) * (size_t)w + (size_t)(tx * tile_w)) * 3 + (size_t)c];
+                    for (int64_t x = 0; x < tw; x++) {
+                        if (ch.type == 1) { uint16_t hv; std::memcpy(&hv, line + 2 * x, 2); dst[3 * x] = half_to_float(hv); }
+                        else std::memcpy(&dst[3 * x], line + 4 * x, 4);
+                    }
+                }
+        }
+        return true;
+    }
     for (size_t k = 0; k < n_blocks; k++) {
         uint64_t off;
         std::memcpy(&off, &b[table + 8 * k], 8);

@@ -248,7 +248,7 @@ def test_front_end_pyramid_matches_numpy_restatement(tmp_path, case):
         assert np.array_equal(bits(g), bits(w))
 
 
-def write_exr(path, chans, compression, origin=(0, 0), version=2):
+def write_exr(path, chans, compression, origin=(0, 0), version=2, tiles=None):
     """A single-part scan-line OpenEXR file written from the format's published layout (independent of the reader under test).
     chans: {name: (H x W array, "half" | "float")}; compression 0 none, 1 RLE, 2 ZIPS, 3 ZIP, 4 PIZ, 5 PXR24 (6 = B44: header only).
     Returns per block what the block coder reported (None for the byte-stream schemes), "stored" where compression did not pay."""
@@ -264,12 +264,19 @@ def write_exr(path, chans, compression, origin=(0, 0), version=2):
     hdr = struct.pack("<ii", 20000630, version) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
     hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
     hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0))
-    hdr += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    hdr += attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    if tiles:                               # (tile width, tile height, level mode): chunks are tiles of level (0, 0), one block each
+        hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tiles[0], tiles[1], tiles[2]))
+    hdr += b"\0"
     lines = 32 if compression == 4 else (16 if compression in (3, 5) else 1)
     blocks, report = [], []
-    for y0 in range(0, h, lines):
-        raw = b"".join(chans[n][0][y].astype("<f2" if chans[n][1] == "half" else "<f4").tobytes()
-                       for y in range(y0, min(h, y0 + lines)) for n in names)
+    if tiles:
+        regions = [(x0, min(w, x0 + tiles[0]), y0, min(h, y0 + tiles[1])) for y0 in range(0, h, tiles[1]) for x0 in range(0, w, tiles[0])]
+    else:
+        regions = [(0, w, y0, min(h, y0 + lines)) for y0 in range(0, h, lines)]
+    for x0, x1, y0, y1 in regions:
+        raw = b"".join(chans[n][0][y, x0:x1].astype("<f2" if chans[n][1] == "half" else "<f4").tobytes()
+                       for y in range(y0, y1) for n in names)
         data = raw
         if compression in (1, 2, 3):
             t = np.frombuffer(raw[0::2] + raw[1::2], np.uint8).astype(np.int32)
@@ -297,9 +304,8 @@ def write_exr(path, chans, compression, origin=(0, 0), version=2):
             data = enc if len(enc) < len(raw) else raw
         info = None
         if compression in (4, 5):
-            y1 = min(h, y0 + lines)
             words = [1 if chans[n][1] == "half" else 2 for n in names]
-            planes = [np.ascontiguousarray(chans[n][0][y0:y1].astype("<f2" if chans[n][1] == "half" else "<f4")).view("<u2") for n in names]
+            planes = [np.ascontiguousarray(chans[n][0][y0:y1, x0:x1].astype("<f2" if chans[n][1] == "half" else "<f4")).view("<u2") for n in names]
             if compression == 4:
                 enc, info = codecs.piz_compress_planes(planes, words)
             else:
@@ -308,13 +314,18 @@ def write_exr(path, chans, compression, origin=(0, 0), version=2):
             if data is raw:
                 info = "stored"
         report.append(info)
-        blocks.append((origin[1] + y0, data))
+        blocks.append(((x0 // tiles[0], y0 // tiles[1]) if tiles else origin[1] + y0, data))
     table_at = len(hdr)
     off = table_at + 8 * len(blocks)
     table, body = b"", b""
+    if tiles and tiles[2] == 1:             # a MIPMAP file: the table goes on with the smaller levels, which a reader of level 0 skips
+        table_pad = 8 * 3
+        off += table_pad
     for y, data in blocks:
         table += struct.pack("<Q", off + len(body))
-        body += struct.pack("<ii", y, len(data)) + data
+        body += (struct.pack("<iiiii", y[0], y[1], 0, 0, len(data)) if tiles else struct.pack("<ii", y, len(data))) + data
+    if tiles and tiles[2] == 1:
+        table += struct.pack("<3Q", 0, 0, 0)
     open(path, "wb").write(hdr + table + body)
     return report
 
@@ -354,7 +365,8 @@ def test_exr_inputs(tmp_path, case):
         assert g.shape == w.shape and np.array_equal(bits(g), bits(w))
 
 
-@pytest.mark.parametrize("case", ["piz_half_rgba_odd", "piz_mixed_types", "piz_many_values", "piz_flat", "piz_stored", "pxr24_mixed"])
+@pytest.mark.parametrize("case", ["piz_half_rgba_odd", "piz_mixed_types", "piz_many_values", "piz_flat", "piz_stored", "pxr24_mixed",
+                                  "tiled_zip", "tiled_piz_mipmap", "tiled_none"])
 def test_exr_block_coders(tmp_path, case):
     """PIZ and PXR24 files (the `exr` crate behind image::open reads both): decoding is a function of the file alone, so the samples
     must come back bit for bit.  The files are made by tests/exr_block_codecs.py, the forward half written from the format."""
@@ -389,6 +401,16 @@ def test_exr_block_coders(tmp_path, case):
         rgb = rng.integers(0, 0x7f000000, (4, 16, 3)).astype("<u4").view("<f4")
         rep = write_exr(tmp_path / "a.exr", {"R": (rgb[..., 0], "float"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "float")}, 4)
         assert rep == ["stored"]
+    elif case.startswith("tiled"):          # tiles of level (0, 0), partial tiles at the right and bottom edges, window off the origin
+        rgb = smooth(70, 90, 3).astype(np.float16).astype(np.float32)
+        ch = {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "half"), "A": (rgb[..., 0], "half")}
+        if case == "tiled_zip":
+            write_exr(tmp_path / "a.exr", ch, 3, origin=(4, -3), version=2 | 0x200, tiles=(32, 32, 0))
+        elif case == "tiled_none":
+            write_exr(tmp_path / "a.exr", ch, 0, version=2 | 0x200, tiles=(64, 16, 0))
+        else:                               # 64 x 48 tiles (taller than a scan-line PIZ block), MIPMAP level mode
+            rep = write_exr(tmp_path / "a.exr", ch, 4, version=2 | 0x200, tiles=(64, 48, 1))
+            assert isinstance(rep[0], dict)
     else:                                   # PXR24: half channels exact, float channels as written (low mantissa byte zero)
         rgb = smooth(37, 23, 3)
         rgb[..., 1] = rgb[..., 1].astype(np.float16)
@@ -420,8 +442,8 @@ def test_exr_variants_outside_the_subset_are_reported(tmp_path):
     y = np.ones((4, 4), np.float32)
     write_exr(tmp_path / "piz.exr", {"R": (y, "half"), "G": (y, "half"), "B": (y, "half")}, 6)
     write_exr(tmp_path / "lum.exr", {"Y": (y, "half")}, 0)
-    write_exr(tmp_path / "tiled.exr", {"R": (y, "half"), "G": (y, "half"), "B": (y, "half")}, 0, version=2 | 0x200)
-    for name, msg in (("piz.exr", "B44 is not supported"), ("lum.exr", "no R, G, B channels"), ("tiled.exr", "tiled")):
+    write_exr(tmp_path / "deep.exr", {"R": (y, "half"), "G": (y, "half"), "B": (y, "half")}, 0, version=2 | 0x800)
+    for name, msg in (("piz.exr", "B44 is not supported"), ("lum.exr", "no R, G, B channels"), ("deep.exr", "deep and multi-part")):
         with pytest.raises(capi.PtError) as e:
             parse_with_texture(tmp_path, 'Texture "t" "spectrum" "imagemap" "string filename" "%s"' % name)
         assert msg in str(e.value), str(e.value)

@@ -14,6 +14,8 @@ a=(rgb[...,:3]/255.0).astype(np.float16)
 t.write_exr(d/"z.exr",{"R":(a[...,0],"half"),"G":(a[...,1].astype(np.float32),"float"),"B":(a[...,2],"half")},4); seeds["piz.exr"]=open(d/"z.exr","rb").read()
 t.write_exr(d/"x.exr",{"R":(a[...,0],"half"),"G":(a[...,1],"half"),"B":(a[...,2],"half")},5); seeds["pxr.exr"]=open(d/"x.exr","rb").read()
 t.write_exr(d/"y.exr",{"R":(a[...,0],"half"),"G":(a[...,1],"half"),"B":(a[...,2],"half")},3); seeds["zip.exr"]=open(d/"y.exr","rb").read()
+t.write_exr(d/"t.exr",{"R":(a[...,0],"half"),"G":(a[...,1].astype(np.float32),"float"),"B":(a[...,2],"half")},4,version=2|0x200,tiles=(32,16,1)); seeds["tiledpiz.exr"]=open(d/"t.exr","rb").read()
+t.write_exr(d/"u.exr",{"R":(a[...,0],"half"),"G":(a[...,1],"half"),"B":(a[...,2],"half")},3,version=2|0x200,tiles=(16,16,0)); seeds["tiledzip.exr"]=open(d/"u.exr","rb").read()
 n=int(sys.argv[3])
 for it in range(n):
     name=list(seeds)[it%len(seeds)]
