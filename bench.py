@@ -12,10 +12,16 @@ metric  Mrays/s  = rays counted exactly as the reference's "Regular ray intersec
                    + "Shadow ray intersection tests" (src/core/scene/scene.rs:11-12), summed
                    over ranks, / wall time of the K timed steps (scene upload + BVH build
                    excluded; inputs are resident in HBM when timing starts).
-roofline         = the traversal kernel (k_trace): algorithmic bytes per launch
-                   (48 B/closest ray, 36 B/any-hit ray, 128 B/node,
-                   48 B/triangle test) / mean launch duration from HIP events recorded inside
-                   the library on the stream the kernel runs on, vs 8 TB/s.
+roofline         = the traversal kernel (k_trace).  Primary bound: the request rate of the CU's
+                   vector L1 (lane requests per launch, from the library's exact counters, / mean
+                   launch duration from HIP events recorded inside the library on the stream the
+                   kernel runs on, vs one request per clock per CU) -- the bound that holds while
+                   the scene is cache-resident.  Beside it, `hbm`: bytes that left L2 per launch
+                   (FETCH_SIZE x 2 + WRITE_SIZE from rocprofv3 --pmc passes on exactly this
+                   workload, profiles/traffic_*.json) / the same duration vs 8 TB/s, and
+                   SURVEY.md section 8d's algorithmic bytes (48 B/closest ray, 36 B/any-hit ray,
+                   128 B/node, 48 B/triangle test) as `algorithmic_gbps` (cache-served: may
+                   exceed the HBM peak).  `bound` names whichever of the two fractions is larger.
 cpu_baseline     = the CPU oracle (C++ restatement of the reference; the Rust binary cannot
                    be built in this image) rendering a bounded sample of the same workload on
                    the host cores of rank 0.
@@ -63,6 +69,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--triangles", type=int, default=1000000)
+    ap.add_argument("--tri-size", type=float, default=0.005, help="half-extent of a filler triangle's vertex box (0.005 = the headline).  Opacity goes with "
+                    "triangles x size^2: --triangles 16000000 --tri-size 0.00125 keeps RT1M's ray depth over a 1.1 GB tree (the beyond-the-Infinity-Cache run)")
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--max-depth", type=int, default=8)
@@ -132,7 +140,7 @@ def main():
     t_prog = time.time()
     pkg = importlib.import_module("pbrt-r3_amd")
     t0 = time.time()
-    sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, materials=args.materials, sampler=args.sampler, light=args.light)
+    sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, s=args.tri_size, materials=args.materials, sampler=args.sampler, light=args.light)
     if args.integrator == "ao":
         sd.desc.integrator, sd.desc.ao_samples, sd.desc.ao_cos_sample = pkg.capi.PT_INTEGRATOR_AO, 64, 1
     elif args.integrator in ("directlighting", "whitted"):
@@ -151,9 +159,14 @@ def main():
 
     film_ptr, film_n = None, 0
 
+    t_render, t_reduce = [0.0], [0.0]      # this rank's host wall time inside render / inside the film reduce, over the timed steps
+
     def step():
         ctx.film_clear()
-        ctx.render(my_tiles)
+        ta = time.time()
+        ctx.render(my_tiles)               # returns with the rank's film complete on the device
+        tb = time.time()
+        t_render[0] += tb - ta
         if use_dist:
             # the one collective of the path: sum the per-rank XYZW films (disjoint tiles)
             if rehearse:
@@ -166,6 +179,7 @@ def main():
                 ctx.film_commit_xyzw()
             else:
                 pkg.dist.reduce_film(ctx, local_rank, staged=os.environ.get("BENCH_REDUCE_IN_PLACE") != "1")
+            t_reduce[0] += time.time() - tb      # includes the wait for the slowest rank's render
 
     def fence():
         torch.cuda.synchronize()
@@ -187,6 +201,7 @@ def main():
         log("warmup step %d done" % i)
     fence()
     ctx.reset_counters()
+    t_render[0] = t_reduce[0] = 0.0
     t_start = time.time()
     for i in range(args.steps):
         step()
@@ -200,7 +215,17 @@ def main():
     stats = torch.tensor([elapsed, cnt["regular_rays"], cnt["shadow_rays"], cnt["nodes_visited"], cnt["tris_tested"],
                           cnt["path_vertices"], cnt["trace_ms"], cnt["trace_launches"], cnt["camera_rays"], cnt["shade_ms"]],
                          dtype=torch.float64, device="cpu" if rehearse else "cuda")
+    per_rank = None
     if use_dist:
+        # per-rank breakdown, so that a scaling run can be read from its JSON line: who rendered how long, who waited in the reduce
+        mine = torch.tensor([t_render[0] * 1e3 / max(1, args.steps), t_reduce[0] * 1e3 / max(1, args.steps), float(len(my_tiles)),
+                             cnt["regular_rays"] + cnt["shadow_rays"], cnt["trace_ms"] / max(1, args.steps), cnt["shade_ms"] / max(1, args.steps)],
+                            dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "render_ms": round(float(v[0]), 3), "reduce_ms": round(float(v[1]), 3), "tiles": int(v[2]),
+                     "rays_per_step": int(float(v[3]) / max(1, args.steps)), "trace_ms": round(float(v[4]), 3), "shade_ms": round(float(v[5]), 3)}
+                    for r, v in enumerate(every)]
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -232,18 +257,30 @@ def main():
         scene_bytes = 128.0 * info.n_nodes + 48.0 * sd.desc.n_triangles
         compulsory = (48.0 * cnt["regular_rays"] + 36.0 * cnt["shadow_rays"]) / launches + scene_bytes
         traffic, traffic_note = None, "no PMC measurement for this workload"
-        tp = os.path.join(ROOT, "profiles", "traffic_r02.json")
         key = {"triangles": args.triangles, "res": args.res, "spp": args.spp, "max_depth": args.max_depth, "materials": args.materials,
                "sampler": args.sampler, "light": args.light, "integrator": args.integrator}
-        if os.path.exists(tp):
+        if args.tri_size != 0.005:
+            key["tri_size"] = args.tri_size
+        import glob
+        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):     # newest round first
             try:
                 tj = json.load(open(tp))
-                if tj.get("workload") == key:      # measured on exactly this workload (passes of the same size), else null
-                    traffic, traffic_note = tj.get("fabric_bytes_per_launch"), tj.get("note", "")
             except Exception:
-                pass
-        roofline = {"bound": "l1_req", "kernel": "k_trace_sph_dist" if args.light == "sphere" else "k_trace", "achieved": round(achieved, 2), "peak": round(peak, 1),
-                    "unit": "Greq/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                continue
+            for ent in (tj if isinstance(tj, list) else [tj]):
+                # measured on exactly this workload (passes of the same size), else null
+                if traffic is None and isinstance(ent, dict) and ent.get("workload") == key and ent.get("fabric_bytes_per_launch"):
+                    traffic, traffic_note = ent["fabric_bytes_per_launch"], ent.get("note", "") + " (%s)" % os.path.basename(tp)
+        hbm_frac = (traffic / avg_launch_s / 8e12) if (traffic and avg_launch_s > 0) else None
+        l1_frac = achieved / peak
+        l1_blk = {"bound": "l1_req", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "Greq/s", "frac": round(l1_frac, 4)}
+        hbm_blk = ({"bound": "hbm", "achieved": round(traffic / avg_launch_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(hbm_frac, 4)}
+                   if hbm_frac is not None else None)
+        top = hbm_blk if (hbm_blk and hbm_frac > l1_frac) else l1_blk       # the bound that actually holds for this workload
+        roofline = dict(top)
+        roofline.update({
+                    "kernel": "k_trace_sph_dist" if args.light == "sphere" else "k_trace", "traffic": traffic,
+                    "l1_req": l1_blk, "hbm": hbm_blk,
                     "requests_per_launch": round(reqs / launches, 1), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
                     "nodes_per_ray": round(cnt["nodes_visited"] / max(1.0, n_rays), 2), "tris_per_ray": round(cnt["tris_tested"] / max(1.0, n_rays), 2),
                     "node_visits_from_lds": round(cnt.get("nodes_from_lds", 0) / max(1.0, cnt["nodes_visited"]), 4),
@@ -252,12 +289,13 @@ def main():
                     # informational: SURVEY.md section 8d's algorithmic bytes (cache-served, can exceed the HBM peak), what HBM must move at least,
                     # and the measured L2-miss (fabric) traffic where profiles/ holds it for this workload
                     "algorithmic_gbps": round((alg_bytes / launches) / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else 0.0,
+                    "scene_bytes": scene_bytes, "infinity_cache_bytes": 256 * 2 ** 20,
                     "hbm_compulsory_bytes_per_launch": round(compulsory, 1),
                     "hbm_compulsory_frac_of_8TBps": round(compulsory / avg_launch_s / 8e12, 5) if avg_launch_s > 0 else 0.0,
-                    "fabric_frac_of_8TBps": round(traffic / avg_launch_s / 8e12, 4) if (traffic and avg_launch_s > 0) else None,
-                    "note": "bound = lane requests to the CU's vector L1 (one 16-byte request per clock per CU): "
-                            "%g per node visit that is not served from the LDS copy of the top of the tree, 3 per triangle test, 5 per ray; traffic = FETCH_SIZE/WRITE_SIZE-derived bytes leaving L2 "
-                            "(Infinity Cache hits included) per launch: %s" % (per_visit, traffic_note)}
+                    "fabric_frac_of_8TBps": round(hbm_frac, 4) if hbm_frac is not None else None,
+                    "note": "l1_req = lane requests to the CU's vector L1 (one 16-byte request per clock per CU): "
+                            "%g per node visit that is not served from the LDS copy of the top of the tree, 3 per triangle test, 5 per ray; hbm / traffic = FETCH_SIZE x 2 + WRITE_SIZE bytes leaving L2 "
+                            "(Infinity Cache hits included) per launch: %s" % (per_visit, traffic_note)})
         cpu, parity, spp1024 = None, None, None
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only (rank 0 would keep the other ranks waiting)
             import oracle_lib
@@ -303,7 +341,7 @@ def main():
         if world == 1 and not args.no_spp1024 and args.spp != 1024:
             # north_star's target sentence quotes 1024 spp for the same scene (BASELINE config 2 says 256; Mrays/s is spp-independent,
             # wall-clock scales): one extra frame at 1024 spp, wall-clock reported beside the headline
-            sd4 = pkg.scenes.rt1m(args.triangles, res=args.res, spp=1024, max_depth=args.max_depth, materials=args.materials, sampler=args.sampler, light=args.light)
+            sd4 = pkg.scenes.rt1m(args.triangles, res=args.res, spp=1024, max_depth=args.max_depth, s=args.tri_size, materials=args.materials, sampler=args.sampler, light=args.light)
             sd4.desc.integrator, sd4.desc.ao_samples, sd4.desc.ao_cos_sample = sd.desc.integrator, sd.desc.ao_samples, sd.desc.ao_cos_sample
             sd4.desc.direct_strategy = sd.desc.direct_strategy
             if args.integrator in ("directlighting", "whitted"):
@@ -323,16 +361,19 @@ def main():
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "RT1M: %d random %s triangles%s, %dx%d, %s %d spp, path maxdepth %d, BVH sah/4, spatial lights"
+            "config": {"workload": "RT1M: %d random %s triangles%s%s, %dx%d, %s %d spp, path maxdepth %d, BVH sah/4, spatial lights"
                                    % (sd.desc.n_triangles, "matte" if args.materials == "matte" else ("mixed-material (matte/plastic/metal/glass/mirror/substrate)" + (", texture-driven colours and bump maps" if args.materials == "textured" else "")),
-                                      " + a sphere area light" if args.light == "sphere" else "", args.res, args.res, "Sobol" if args.sampler == "sobol" else "Halton", info.spp, args.max_depth),
+                                      " + a sphere area light" if args.light == "sphere" else "", "" if args.tri_size == 0.005 else " of half-extent %g" % args.tri_size, args.res, args.res, "Sobol" if args.sampler == "sobol" else "Halton", info.spp, args.max_depth),
                        "partition": "16x16 film tiles round-robin over %d rank(s), RCCL all-reduce of the XYZW film" % world,
                        "rays_per_step": int(rays / max(1, args.steps)), "camera_samples_per_step": int(tot[8] / max(1, args.steps)),
                        "bvh_build_ms": round(rebuild_ms, 1), "upload_ms": round(reupload_ms, 1),
                        "bvh_build_first_upload_ms": round(first_build_ms, 1), "first_upload_ms": round(first_upload_ms, 1),
-                       "scene_gen_s": round(t_scene, 2)},
+                       "scene_gen_s": round(t_scene, 2), "workload_key": key},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "spp1024": spp1024,
         }
+        if per_rank is not None:
+            # reduce_ms of a rank = its wait for the slowest rank + the collective itself; min over ranks ~ the collective alone
+            out["per_rank"] = per_rank
         if args.integrator in ("directlighting", "whitted"):
             out["config"]["workload"] = out["config"]["workload"].replace("path maxdepth %d" % args.max_depth, args.integrator + " maxdepth 5")
         if args.integrator == "ao":

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 8
+#define PT_ABI_VERSION 9
 
 typedef enum {
     PT_OK = 0,
@@ -380,6 +380,11 @@ pt_status pt_film_commit_xyzw(pt_context* ctx);
  * its share of the tiles into a zero-initialised film).  root < 0: ncclAllReduce; root >= 0: ncclReduce to that rank.
  * Runs on the library's stream; librccl.so.1 is resolved at run time (the copy already loaded in the process if any). */
 pt_status pt_film_allreduce(pt_context* ctx, void* nccl_comm, int root);
+/* ABI 9.  The same exchange step without a collective: add another rank's {X,Y,Z,weight} film (4*W*H floats in host memory, as
+ * pt_film_download_xyzw returns it) to this context's film and mark the sum authoritative -- Film::merge_film_tile
+ * (src/core/film/film.rs:219-241) across ranks that share no RCCL communicator (MPI / shared-memory hosts; several contexts on one
+ * device, which ncclCommInitAll refuses).  Ranks added in rank order give the sums an all-reduce gives when tiles are disjoint. */
+pt_status pt_film_add_xyzw(pt_context* ctx, const float* xyzw);
 /* Film::write_image arithmetic: rgb = xyz_to_rgb(xyz)/weight, clamp >=0, *scale. */
 pt_status pt_film_resolve_rgb(pt_context* ctx, float* rgb_out /* 3*W*H */);
 

@@ -146,7 +146,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("prim", "<i4"), ("b0", "<f4"), ("b1", "<f4"
 SYMBOLS = [
     "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_abi_version", "pt_set_data_dir",
     "pt_scene_upload", "pt_scene_info_get", "pt_film_clear", "pt_render", "pt_film_download_xyzw",
-    "pt_film_device_xyzw", "pt_film_commit_xyzw", "pt_film_allreduce", "pt_film_resolve_rgb", "pt_trace_closest", "pt_trace_any", "pt_trace_wavefront",
+    "pt_film_device_xyzw", "pt_film_commit_xyzw", "pt_film_allreduce", "pt_film_add_xyzw", "pt_film_resolve_rgb", "pt_trace_closest", "pt_trace_any", "pt_trace_wavefront",
     "pt_generate_camera_rays", "pt_sobol_samples", "pt_radiance_samples", "pt_get_counters", "pt_reset_counters",
     "pt_bvh_leaf_order", "pt_bsdf_eval", "pt_bsdf_sample", "pt_set_bvh_build", "pt_scene_bvh_digest",
 ]
@@ -179,6 +179,7 @@ def load_library(path=None):
     lib.pt_film_device_xyzw.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.pt_film_commit_xyzw.argtypes = [vp]
     lib.pt_film_allreduce.argtypes = [vp, vp, C.c_int]
+    lib.pt_film_add_xyzw.argtypes = [vp, fp]
     lib.pt_film_resolve_rgb.argtypes = [vp, vp]
     lib.pt_trace_closest.argtypes = [vp, u32, vp, vp, vp, vp]
     lib.pt_trace_any.argtypes = [vp, u32, vp, vp, vp, vp]
@@ -363,6 +364,13 @@ class Context:
 
     def film_commit_xyzw(self):
         self._check(self.lib.pt_film_commit_xyzw(self.h))
+
+    def film_add_xyzw(self, xyzw):
+        """Add another rank's {X,Y,Z,weight} film (as film_xyzw() returns it) and make the sum authoritative: the exchange step staged
+        through the host."""
+        a = np.ascontiguousarray(xyzw, np.float32)
+        assert a.size == 4 * self.film_shape[0] * self.film_shape[1]
+        self._check(self.lib.pt_film_add_xyzw(self.h, a.ctypes.data_as(C.POINTER(C.c_float))))
 
     def film_allreduce(self, nccl_comm, root=-1):
         """Sum the XYZW film over an RCCL communicator (ncclComm_t as an integer / c_void_p) inside the library."""

@@ -5,7 +5,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -13,6 +15,14 @@
 #include <dlfcn.h>
 
 #include "../../../include/pbrtgpu_host.h"
+
+static bool write_floats(const std::string& path, const std::vector<float>& v) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    const bool ok = f && std::fwrite(v.data(), 4, v.size(), f) == v.size();
+    if (f) std::fclose(f);
+    if (!ok) std::fprintf(stderr, "pbrt_gpu: cannot write %s\n", path.c_str());
+    return ok;
+}
 
 static void usage() {
     std::fprintf(stderr,
@@ -31,31 +41,61 @@ static void usage() {
                  "      --device <d>          HIP device index\n"
                  "      --display-server <host:port>   stream the image to a tev viewer while it renders (bands of tile rows)\n"
                  "      --gpus <n>            film tiles dealt round-robin to n GPUs (devices 0..n-1, one host thread and one\n"
-                 "                            library context each), films summed with one RCCL reduce to device 0\n");
+                 "                            library context each), films summed with one RCCL reduce to device 0\n"
+                 "      --devices <a,b,..>    the devices --gpus uses, one rank each (default 0..n-1).  A device named twice runs two\n"
+                 "                            contexts on it and sums the films through the host: the rehearsal of the n-GPU flow on one GPU\n"
+                 "      --xyzw <file>         also write the raw {X,Y,Z,weight} film (4 floats per pixel, native byte order)\n");
 }
 
 // --gpus N: the reference's tile loop (sampler.rs:266-301) sharded over GPUs inside one process.  Every device holds the whole
-// scene and renders tiles r, r+N, r+2N, ...; the only exchange is pt_film_allreduce.  No Python, no torch: RCCL's communicators
-// come from ncclCommInitAll (librccl.so.1, resolved at run time like the library does).
-static int render_multi_gpu(const pt_scene_desc* dsc, int n_gpus, std::vector<float>& rgb, pt_scene_info* info_out, pt_counters* total, double* secs_out) {
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    auto init_all = h ? reinterpret_cast<int (*)(void**, int, const int*)>(dlsym(h, "ncclCommInitAll")) : nullptr;
-    auto destroy = h ? reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy")) : nullptr;
-    if (!init_all || !destroy) { std::fprintf(stderr, "pbrt_gpu: --gpus needs librccl.so.1 (ncclCommInitAll)\n"); return 1; }
+// scene and renders tiles r, r+N, r+2N, ...; the only exchange is the film sum.  No Python, no torch: RCCL's communicators come
+// from ncclCommInitAll (librccl.so.1, resolved at run time like the library does) and the sum is pt_film_allreduce.  When the
+// device list names one device twice (--devices 0,0: the rehearsal a one-GPU box allows -- RCCL refuses two ranks on one
+// device) the films are summed through the host instead, rank by rank (pt_film_download_xyzw -> pt_film_add_xyzw on rank 0).
+struct RankReport { int device = 0; size_t tiles = 0; double render_ms = 0, reduce_ms = 0; pt_counters cnt; };
+
+// All ranks meet here before the exchange; if any of them has failed, nobody enters it (a collective entered by some ranks only
+// never returns).
+struct Rendezvous {
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0, generation = 0, n = 0;
+    bool any_failed = false;
+    bool arrive(bool failed) {
+        std::unique_lock<std::mutex> lk(m);
+        any_failed = any_failed || failed;
+        const int gen = generation;
+        if (++waiting == n) { waiting = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+        return !any_failed;
+    }
+};
+
+static int render_multi_gpu(const pt_scene_desc* dsc, const std::vector<int>& devs, std::vector<float>& rgb, pt_scene_info* info_out, pt_counters* total,
+                            double* secs_out, std::vector<RankReport>* reports, std::vector<float>* xyzw_out) {
+    const int n_gpus = (int)devs.size();
+    bool shared_device = false;
+    for (int i = 0; i < n_gpus; i++)
+        for (int j = 0; j < i; j++) shared_device = shared_device || devs[(size_t)i] == devs[(size_t)j];
     std::vector<void*> comms((size_t)n_gpus, nullptr);
-    std::vector<int> devs((size_t)n_gpus);
-    for (int i = 0; i < n_gpus; i++) devs[(size_t)i] = i;
-    if (init_all(comms.data(), n_gpus, devs.data()) != 0) { std::fprintf(stderr, "pbrt_gpu: ncclCommInitAll failed for %d devices\n", n_gpus); return 1; }
+    int (*destroy)(void*) = nullptr;
+    if (!shared_device) {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        auto init_all = h ? reinterpret_cast<int (*)(void**, int, const int*)>(dlsym(h, "ncclCommInitAll")) : nullptr;
+        destroy = h ? reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy")) : nullptr;
+        if (!init_all || !destroy) { std::fprintf(stderr, "pbrt_gpu: --gpus needs librccl.so.1 (ncclCommInitAll)\n"); return 1; }
+        if (init_all(comms.data(), n_gpus, devs.data()) != 0) { std::fprintf(stderr, "pbrt_gpu: ncclCommInitAll failed for %d devices\n", n_gpus); return 1; }
+    }
     std::vector<pt_context*> ctxs((size_t)n_gpus, nullptr);
     std::vector<int> rc((size_t)n_gpus, 0);
-    std::vector<pt_counters> cnts((size_t)n_gpus);
     std::vector<std::string> errs((size_t)n_gpus);
+    reports->assign((size_t)n_gpus, RankReport());
     auto each = [&](auto body) {
         std::vector<std::thread> th;
-        for (int r = 0; r < n_gpus; r++) th.emplace_back([&, r] { if (rc[(size_t)r] == 0) body(r); });
+        for (int r = 0; r < n_gpus; r++) th.emplace_back([&, r] { body(r); });
         for (auto& t : th) t.join();
-        for (int r = 0; r < n_gpus; r++) if (rc[(size_t)r]) { std::fprintf(stderr, "pbrt_gpu: device %d: %s\n", r, errs[(size_t)r].c_str()); return false; }
+        for (int r = 0; r < n_gpus; r++) if (rc[(size_t)r]) { std::fprintf(stderr, "pbrt_gpu: rank %d (device %d): %s\n", r, devs[(size_t)r], errs[(size_t)r].c_str()); return false; }
         return true;
     };
     auto check = [&](int r, pt_status st, const char* what) {
@@ -63,7 +103,7 @@ static int render_multi_gpu(const pt_scene_desc* dsc, int n_gpus, std::vector<fl
         return st == PT_OK;
     };
     bool ok = each([&](int r) {
-        if (!check(r, pt_context_create(r, &ctxs[(size_t)r]), "no usable HIP device")) return;
+        if (!check(r, pt_context_create(devs[(size_t)r], &ctxs[(size_t)r]), "no usable HIP device")) return;
         check(r, pt_scene_upload(ctxs[(size_t)r], dsc), "scene upload");
     });
     double secs = 0;
@@ -74,13 +114,33 @@ static int render_multi_gpu(const pt_scene_desc* dsc, int n_gpus, std::vector<fl
         int k = 0;
         for (int32_t y = sb[1]; y < sb[3]; y += 16)
             for (int32_t x = sb[0]; x < sb[2]; x += 16, k++) mine[(size_t)(k % n_gpus)].push_back({x, y, std::min(x + 16, sb[2]), std::min(y + 16, sb[3])});
+        const size_t film_floats = (size_t)(info_out->cropped_bounds[2] - info_out->cropped_bounds[0]) * (size_t)(info_out->cropped_bounds[3] - info_out->cropped_bounds[1]) * 4;
+        std::vector<std::vector<float>> staged((size_t)n_gpus);
+        Rendezvous meet;
+        meet.n = n_gpus;
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         auto t0 = std::chrono::steady_clock::now();
         ok = each([&](int r) {
             pt_context* c = ctxs[(size_t)r];
-            if (!check(r, pt_film_clear(c), "film clear")) return;
-            if (!mine[(size_t)r].empty() && !check(r, pt_render(c, mine[(size_t)r].data(), (uint32_t)mine[(size_t)r].size()), "render")) { /* still join the collective */ }
-            check(r, pt_film_allreduce(c, comms[(size_t)r], 0), "film reduce");
-            pt_get_counters(c, &cnts[(size_t)r]);
+            RankReport& rep = (*reports)[(size_t)r];
+            rep.device = devs[(size_t)r]; rep.tiles = mine[(size_t)r].size();
+            auto ta = std::chrono::steady_clock::now();
+            if (check(r, pt_film_clear(c), "film clear") && !mine[(size_t)r].empty())
+                check(r, pt_render(c, mine[(size_t)r].data(), (uint32_t)mine[(size_t)r].size()), "render");
+            auto tb = std::chrono::steady_clock::now();
+            rep.render_ms = ms(ta, tb);
+            if (shared_device && r > 0 && rc[(size_t)r] == 0) {        // host-staged exchange: hand the film over before the meeting point
+                staged[(size_t)r].resize(film_floats);
+                check(r, pt_film_download_xyzw(c, staged[(size_t)r].data()), "film download");
+            }
+            if (meet.arrive(rc[(size_t)r] != 0)) {                      // everybody rendered: the exchange
+                if (!shared_device) check(r, pt_film_allreduce(c, comms[(size_t)r], 0), "film reduce");
+                else if (r == 0)
+                    for (int q = 1; q < n_gpus; q++)
+                        if (!check(0, pt_film_add_xyzw(c, staged[(size_t)q].data()), "film add")) break;
+            }
+            rep.reduce_ms = ms(tb, std::chrono::steady_clock::now());   // the wait for the slowest rank + the exchange itself
+            pt_get_counters(c, &rep.cnt);
         });
         if (ok) {
             int w = info_out->cropped_bounds[2] - info_out->cropped_bounds[0], hgt = info_out->cropped_bounds[3] - info_out->cropped_bounds[1];
@@ -88,13 +148,15 @@ static int render_multi_gpu(const pt_scene_desc* dsc, int n_gpus, std::vector<fl
             ok = pt_film_resolve_rgb(ctxs[0], rgb.data()) == PT_OK;
         }
         secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (ok && xyzw_out) { xyzw_out->resize(film_floats); ok = pt_film_download_xyzw(ctxs[0], xyzw_out->data()) == PT_OK; }
     }
     std::memset(total, 0, sizeof(*total));
     for (int r = 0; r < n_gpus; r++) {
-        total->regular_rays += cnts[(size_t)r].regular_rays; total->shadow_rays += cnts[(size_t)r].shadow_rays;
-        total->camera_rays += cnts[(size_t)r].camera_rays; total->path_vertices += cnts[(size_t)r].path_vertices;
+        const pt_counters& c = (*reports)[(size_t)r].cnt;
+        total->regular_rays += c.regular_rays; total->shadow_rays += c.shadow_rays;
+        total->camera_rays += c.camera_rays; total->path_vertices += c.path_vertices;
         if (ctxs[(size_t)r]) pt_context_destroy(ctxs[(size_t)r]);
-        if (comms[(size_t)r]) destroy(comms[(size_t)r]);
+        if (comms[(size_t)r] && destroy) destroy(comms[(size_t)r]);
     }
     *secs_out = secs;
     return ok ? 0 : 1;
@@ -103,6 +165,8 @@ static int render_multi_gpu(const pt_scene_desc* dsc, int n_gpus, std::vector<fl
 int main(int argc, char** argv) {
     std::string input, outfile, display_server;
     int spp = 0, device = 0, gpus = 0;
+    std::vector<int> devices;
+    std::string xyzw_file;
     bool quiet = false, cat = false, stats = false;
     pth_options opts;
     std::memset(&opts, 0, sizeof(opts));
@@ -119,6 +183,8 @@ int main(int argc, char** argv) {
         else if (a == "--nthreads" || a == "-j") (void)need("--nthreads");
         else if (a == "--device") device = std::atoi(need("--device"));
         else if (a == "--gpus") gpus = std::max(1, std::atoi(need("--gpus")));
+        else if (a == "--devices") { for (const char* q = need("--devices"); *q;) { devices.push_back(std::atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } }
+        else if (a == "--xyzw") xyzw_file = need("--xyzw");
         else if (a == "--display-server") display_server = need("--display-server");
         else if (a == "--quiet") quiet = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -152,21 +218,31 @@ int main(int argc, char** argv) {
         std::string ext = dot == std::string::npos ? std::string() : outfile.substr(dot);
         if (ext != ".exr" && ext != ".png" && ext != ".pfm") outfile = (dot == std::string::npos ? outfile : outfile.substr(0, dot)) + ".pfm";
     }
-    if (gpus > 0) {
+    if (gpus > 0 || !devices.empty()) {
+        if (devices.empty()) for (int i = 0; i < gpus; i++) devices.push_back(i);
+        if (gpus > 0 && (int)devices.size() != gpus) { std::fprintf(stderr, "pbrt_gpu: --gpus %d but --devices lists %zu\n", gpus, devices.size()); pth_scene_free(scene); return 2; }
+        gpus = (int)devices.size();
         std::vector<float> rgb;
         pt_scene_info info;
         pt_counters c;
         double secs = 0;
-        if (render_multi_gpu(pth_scene_get_desc(scene), gpus, rgb, &info, &c, &secs) != 0) { pth_scene_free(scene); return 1; }
+        std::vector<RankReport> reports;
+        std::vector<float> xyzw;
+        if (render_multi_gpu(pth_scene_get_desc(scene), devices, rgb, &info, &c, &secs, &reports, xyzw_file.empty() ? nullptr : &xyzw) != 0) { pth_scene_free(scene); return 1; }
+        if (!xyzw_file.empty() && !write_floats(xyzw_file, xyzw)) return 1;
         int w = info.cropped_bounds[2] - info.cropped_bounds[0], h = info.cropped_bounds[3] - info.cropped_bounds[1];
         const pt_scene_desc* dsc = pth_scene_get_desc(scene);
         if (pth_write_image(outfile.c_str(), rgb.data(), w, h, info.cropped_bounds[0], info.cropped_bounds[1], dsc->xres, dsc->yres) != PT_OK) { std::fprintf(stderr, "pbrt_gpu: cannot write %s\n", outfile.c_str()); return 1; }
         if (!quiet)
-            std::fprintf(stderr, "pbrt_gpu: %s  %dx%d, %d spp on %d GPU(s)  rendered + reduced in %.3f s  %.1f Mrays/s  -> %s\n", input.c_str(), w, h, info.spp, gpus, secs,
+            std::fprintf(stderr, "pbrt_gpu: %s  %dx%d, %d spp on %d rank(s)  rendered + reduced in %.3f s  %.1f Mrays/s  -> %s\n", input.c_str(), w, h, info.spp, gpus, secs,
                          (double)(c.regular_rays + c.shadow_rays) / secs / 1e6, outfile.c_str());
-        if (stats)
+        if (stats) {
             std::fprintf(stderr, "  Regular ray intersection tests %llu\n  Shadow ray intersection tests  %llu\n  Camera rays %llu, path vertices %llu\n",
                          (unsigned long long)c.regular_rays, (unsigned long long)c.shadow_rays, (unsigned long long)c.camera_rays, (unsigned long long)c.path_vertices);
+            for (size_t r = 0; r < reports.size(); r++)      // who rendered how long, who waited in the exchange
+                std::fprintf(stderr, "  rank %zu device %d: tiles %zu  render_ms %.3f  reduce_ms %.3f  rays %llu\n", r, reports[r].device, reports[r].tiles, reports[r].render_ms,
+                             reports[r].reduce_ms, (unsigned long long)(reports[r].cnt.regular_rays + reports[r].cnt.shadow_rays));
+        }
         pth_scene_free(scene);
         return 0;
     }
@@ -204,6 +280,11 @@ int main(int argc, char** argv) {
         pth_display_close(disp);
     } else if (pt_film_clear(ctx) != PT_OK || pt_render(ctx, nullptr, 0) != PT_OK) return fail("render");
     if (pt_film_resolve_rgb(ctx, rgb.data()) != PT_OK) return fail("film resolve");
+    if (!xyzw_file.empty()) {
+        std::vector<float> xyzw((size_t)w * h * 4);
+        if (pt_film_download_xyzw(ctx, xyzw.data()) != PT_OK) return fail("film download");
+        if (!write_floats(xyzw_file, xyzw)) return 1;
+    }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     pt_counters c;
     pt_get_counters(ctx, &c);

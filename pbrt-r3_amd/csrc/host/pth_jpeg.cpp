@@ -319,6 +319,9 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
             H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4];
             const int nc = s[5];
             if (W <= 0 || H <= 0) return fail("zero-sized image (DNL-defined height is not supported)");
+            // every 8x8 block of every scan costs at least one bit of entropy-coded data: a header that claims more blocks than
+            // the file has bits is damaged, and is turned away before its planes are allocated
+            if ((int64_t)W * H > kMaxImagePixels || (int64_t)((W + 7) / 8) * ((H + 7) / 8) > (int64_t)b.size() * 8) return fail("frame size implausible for the file size");
             if (nc == 4) return fail("four-component (CMYK / YCCK) files are not supported");
             if ((nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc) return fail("bad component count");
             comps.resize((size_t)nc);
@@ -390,7 +393,7 @@ bool decode_jpeg(const std::vector<uint8_t>& b, int* width, int* height, int* ch
                 c->pred = 0;
                 sc.push_back(c);
             }
-            Bits bits{&b[pos], b.data() + b.size()};
+            Bits bits{b.data() + pos, b.data() + b.size()};      // pos may be b.size(): a scan header that ends the file
             int mcus_x, mcus_y;
             if (ns == 1) { mcus_x = (sc[0]->width + 7) / 8; mcus_y = (sc[0]->height + 7) / 8; }
             else { mcus_x = (W + 8 * hmax - 1) / (8 * hmax); mcus_y = (H + 8 * vmax - 1) / (8 * vmax); }

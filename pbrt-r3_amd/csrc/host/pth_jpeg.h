@@ -12,6 +12,9 @@
 
 namespace pth {
 
+// Largest image any reader allocates for (16 K x 16 K); a header that claims more is turned away.
+constexpr int64_t kMaxImagePixels = int64_t(1) << 28;
+
 // pixels: channels (1 = gray, 3 = RGB) bytes per pixel, top row first.
 bool decode_jpeg(const std::vector<uint8_t>& file, int* width, int* height, int* channels, std::vector<uint8_t>* pixels, std::string* err);
 

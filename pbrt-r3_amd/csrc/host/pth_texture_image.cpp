@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 
 namespace pth {
 namespace {
@@ -274,7 +276,7 @@ bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
         return false;
     }
     const int64_t w = (int64_t)dw[2] - dw[0] + 1, h = (int64_t)dw[3] - dw[1] + 1;
-    if (w > 65536 || h > 65536) { *err = "EXR: image too large"; return false; }
+    if (w > 65536 || h > 65536 || w * h > kMaxImagePixels) { *err = "EXR: image too large"; return false; }
     int rgb_at[3] = {-1, -1, -1};
     size_t line_bytes = 0;
     std::vector<size_t> ch_off(channels.size());
@@ -306,10 +308,10 @@ bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
         for (int64_t t = 0; t < ntx * nty; t++) {
             uint64_t off;
             std::memcpy(&off, &b[table + 8 * (size_t)t], 8);
-            if (off + 20 > b.size()) { *err = "EXR: block offset outside the file"; return false; }
+            if (off > b.size() || b.size() - off < 20) { *err = "EXR: block offset outside the file"; return false; }      // no sum on the file's own 64-bit value: it wraps
             const int64_t tx = rd_i32((size_t)off), ty = rd_i32((size_t)off + 4);
             const int32_t lx = rd_i32((size_t)off + 8), ly = rd_i32((size_t)off + 12), n_src = rd_i32((size_t)off + 16);
-            if (tx < 0 || tx >= ntx || ty < 0 || ty >= nty || lx != 0 || ly != 0 || n_src < 0 || off + 20 + (uint64_t)n_src > b.size()) { *err = "EXR: bad tile header"; return false; }
+            if (tx < 0 || tx >= ntx || ty < 0 || ty >= nty || lx != 0 || ly != 0 || n_src < 0 || (uint64_t)n_src > b.size() - off - 20) { *err = "EXR: bad tile header"; return false; }
             const int64_t tw = std::min<int64_t>(tile_w, w - tx * tile_w), th = std::min<int64_t>(tile_h, h - ty * tile_h);
             size_t tile_line_bytes = 0;
             std::vector<size_t> t_off(channels.size());
@@ -340,10 +342,10 @@ bool read_exr(const std::vector<uint8_t>& b, RgbImage* out, std::string* err) {
     for (size_t k = 0; k < n_blocks; k++) {
         uint64_t off;
         std::memcpy(&off, &b[table + 8 * k], 8);
-        if (off + 8 > b.size()) { *err = "EXR: block offset outside the file"; return false; }
+        if (off > b.size() || b.size() - off < 8) { *err = "EXR: block offset outside the file"; return false; }
         const int64_t y0 = (int64_t)rd_i32((size_t)off) - dw[1];
         const int32_t n_src = rd_i32((size_t)off + 4);
-        if (y0 < 0 || y0 >= h || n_src < 0 || off + 8 + (uint64_t)n_src > b.size()) { *err = "EXR: bad block header"; return false; }
+        if (y0 < 0 || y0 >= h || n_src < 0 || (uint64_t)n_src > b.size() - off - 8) { *err = "EXR: bad block header"; return false; }
         const int64_t lines = std::min<int64_t>(lines_per_block, h - y0);
         raw.assign((size_t)lines * line_bytes, 0);
         if (compression == 0) {
@@ -451,7 +453,22 @@ void resample(const std::vector<float>& img, int c, int w, int h, int swrap, int
 
 }  // namespace
 
+static bool read_image_file_checked(const std::string& path, RgbImage* out, std::string* err);
+
+// Files come from outside: a header may claim any size, so the readers bound what they allocate (kMaxImagePixels) and whatever
+// still cannot be allocated comes back as an error string -- nothing is thrown across the extern "C" entry points.
 bool read_image_file(const std::string& path, RgbImage* out, std::string* err) {
+    try {
+        return read_image_file_checked(path, out, err);
+    } catch (const std::bad_alloc&) {
+        *err = "\"" + path + "\": not enough memory for the image its header describes";
+    } catch (const std::length_error&) {
+        *err = "\"" + path + "\": the image its header describes is too large";
+    }
+    return false;
+}
+
+static bool read_image_file_checked(const std::string& path, RgbImage* out, std::string* err) {
     std::vector<uint8_t> bytes;
     if (!read_all(path, &bytes)) { *err = "File not found: " + path; return false; }
     std::string lower = path;

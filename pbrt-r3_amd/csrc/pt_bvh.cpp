@@ -9,6 +9,8 @@
 // vector, large subtrees are built on worker threads, and the output is the 128-byte
 // PtNode / 48-byte PtTri layout of pt_device.h with leaves folded into child refs.
 #include "pt_bvh.h"
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -463,16 +465,21 @@ struct Collapser {
 // Page-locked staging for the bounds a device build uploads (24 bytes per primitive): from pageable memory that copy is staged by
 // the runtime at 2-3 GB/s -- 10 ms per million triangles, more than the build itself.  One buffer per calling thread, kept and regrown.
 static float* pinned_floats(size_t n) {
-    static thread_local float* buf = nullptr;
-    static thread_local size_t cap = 0;
-    if (n > cap) {
-        if (buf) (void)hipHostFree(buf);
-        buf = nullptr; cap = 0;
+    struct Holder {       // freed when the thread ends: `pbrt_gpu --gpus N` uploads from N short-lived threads
+        float* buf = nullptr;
+        size_t cap = 0;
+        // (not for the process's first thread: it ends while the runtime is being torn down, and the process's memory goes with it)
+        ~Holder() { if (buf && getpid() != (pid_t)syscall(SYS_gettid)) (void)hipHostFree(buf); }
+    };
+    static thread_local Holder h;
+    if (n > h.cap) {
+        if (h.buf) (void)hipHostFree(h.buf);
+        h.buf = nullptr; h.cap = 0;
         void* q = nullptr;
         if (hipHostMalloc(&q, n * sizeof(float), hipHostMallocDefault) != hipSuccess) return nullptr;
-        buf = (float*)q; cap = n;
+        h.buf = (float*)q; h.cap = n;
     }
-    return buf;
+    return h.buf;
 }
 
 // Generic entry: any mix of primitives, each with its world bound and its ready-made 48-byte leaf record.

@@ -1309,13 +1309,15 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
             } else if (rec) {
                 // DirectLighting / Whitted: depth-first walk over the specular trees, two traversal launches per tree level
                 const uint32_t n_paths = n_pix * ns;
-                if (ctx->rec_paths < ctx->pool_paths || ctx->rec_epp != rec_epp || ctx->rec_depth != rec_depth || !ctx->d_rec.p) {
-                    PT_HIP(ctx->d_rec.alloc(ctx->pool_paths * rec_per_path + 65536));
-                    ctx->rec_paths = ctx->pool_paths; ctx->rec_epp = rec_epp; ctx->rec_depth = rec_depth;
+                // sized by THIS render's largest pass (chunk_pix * S, which the 6 GB bound on pool_target above limits), not by the path
+                // pool: the pool never shrinks, and a context that has rendered a 288 M-path frame before would ask for 230 GB here
+                const size_t np = chunk_pix * (size_t)S, ne = np * rec_epp;
+                if (ctx->rec_paths < np || ctx->rec_epp != rec_epp || ctx->rec_depth != rec_depth || !ctx->d_rec.p) {
+                    PT_HIP(ctx->d_rec.alloc(np * rec_per_path + 65536));
+                    ctx->rec_paths = np; ctx->rec_epp = rec_epp; ctx->rec_depth = rec_depth;
                     if (!ctx->d_counts2.p) PT_HIP(ctx->d_counts2.alloc(PT_COUNTS_WORDS * 4));
                 }
                 PT_HIP(hipMemsetAsync(ctx->d_counts2.p, 0, PT_COUNTS_WORDS * 4, ctx->stream));
-                const size_t np = ctx->rec_paths, ne = np * rec_epp;
                 PtRec R;
                 char* rb = ctx->d_rec.as<char>();
                 auto take = [&](size_t bytes) { char* q = rb; rb += (bytes + 255) & ~(size_t)255; return q; };
@@ -1537,6 +1539,24 @@ pt_status pt_film_commit_xyzw(pt_context* ctx) {
     return PT_OK;
 }
 
+// The exchange step without a collective: add another rank's film, handed over in host memory (a host whose ranks talk through MPI or
+// shared memory rather than RCCL; two contexts on one device, which RCCL refuses to put in one communicator).
+pt_status pt_film_add_xyzw(pt_context* ctx, const float* xyzw) {
+    if (!ctx || !xyzw) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
+    (void)hipSetDevice(ctx->device);
+    pt_status st = film_to_xyzw(ctx);
+    if (st != PT_OK) return st;
+    const uint32_t n = ctx->film_w * ctx->film_h;
+    DevBuf other;
+    PT_HIP(other.alloc((size_t)n * 16));
+    PT_HIP(hipMemcpyAsync(other.p, xyzw, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ptk_film_add(ctx->stream, ctx->d_xyzw.as<float4>(), other.as<float4>(), n));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->xyzw_committed = true;
+    return PT_OK;
+}
+
 // The path's one exchange step, inside the library: sum the per-rank XYZW films over an RCCL communicator the caller owns
 // (Film::merge_film_tile across GPUs, film.rs:219-241).  librccl is looked up at run time -- first the copy already mapped into
 // the process (the communicator must come from that very copy: a torch process carries its own), else the system's.
@@ -1546,19 +1566,22 @@ struct RcclApi {
     int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
     const char* (*error_string)(int) = nullptr;
-    bool tried = false;
 };
-RcclApi& rccl_api() {
-    static RcclApi api;
-    if (api.tried) return api;
-    api.tried = true;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return api;
-    api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(dlsym(h, "ncclAllReduce"));
-    api.reduce = reinterpret_cast<decltype(api.reduce)>(dlsym(h, "ncclReduce"));
-    api.error_string = reinterpret_cast<decltype(api.error_string)>(dlsym(h, "ncclGetErrorString"));
+// Resolved once, by whichever thread asks first: `pbrt_gpu --gpus N` calls pt_film_allreduce from N host threads at the same time, and a
+// thread that saw a half-filled table would skip the collective its peers are already blocked in.  (A function-local static's
+// initialiser runs under the language's own once-guard.)
+const RcclApi& rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.all_reduce = reinterpret_cast<decltype(a.all_reduce)>(dlsym(h, "ncclAllReduce"));
+        a.reduce = reinterpret_cast<decltype(a.reduce)>(dlsym(h, "ncclReduce"));
+        a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(h, "ncclGetErrorString"));
+        return a;
+    }();
     return api;
 }
 }  // namespace
@@ -1568,7 +1591,7 @@ pt_status pt_film_allreduce(pt_context* ctx, void* nccl_comm, int root) {
     if (!ctx || !nccl_comm) return PT_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return ctx->fail(PT_ERR_NO_SCENE, "no scene uploaded");
     (void)hipSetDevice(ctx->device);
-    RcclApi& api = rccl_api();
+    const RcclApi& api = rccl_api();
     if (!api.all_reduce || !api.reduce) return ctx->fail(PT_ERR_UNSUPPORTED, "librccl.so.1 (ncclAllReduce / ncclReduce) not found");
     pt_status st = film_to_xyzw(ctx);
     if (st != PT_OK) return st;

@@ -11,6 +11,8 @@
 // (node numbering differs -- it is link-walked by the collapse, never compared).  The one thing emit_lbvh does that is not done here
 // is the centroid-median fallback below the last code bit (split_node, hlbvh.rs:102-157, it re-sorts items): a range that needs it
 // raises `fallback` and the caller rebuilds on the host.  So do non-finite bounds, whose min / max are order dependent.
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <chrono>
@@ -261,10 +263,12 @@ struct ScratchArena {
     char* base = nullptr;
     size_t cap = 0, used = 0, wanted = 0;
     int dev = -1;
+    // an upload thread that ends (`pbrt_gpu --gpus N`) gives its block back; the process's first thread ends during runtime teardown and keeps it
+    ~ScratchArena() { if (base && getpid() != (pid_t)syscall(SYS_gettid)) (void)hipFree(base); }
     void begin() {
         int d = 0;
         (void)hipGetDevice(&d);
-        if (d != dev) { base = nullptr; cap = 0; dev = d; }      // another device: its own arena (the old block stays with its device)
+        if (d != dev) { if (base) (void)hipFree(base); base = nullptr; cap = 0; dev = d; }      // another device: its own arena
         used = 0; wanted = 0;
     }
     void end() {                                                   // every block handed out has been returned (Scratch destructors ran)

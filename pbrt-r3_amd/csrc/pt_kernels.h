@@ -16,6 +16,7 @@ hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths&
 hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,
                     float4* own, float4* spill, float* radiance_out, uint32_t s0, uint32_t spp_total);
 hipError_t ptk_film_xyzw(hipStream_t st, const float4* own, const float4* spill, float4* xyzw, uint32_t n);
+hipError_t ptk_film_add(hipStream_t st, float4* xyzw, const float4* other, uint32_t n);
 hipError_t ptk_film_rgb(hipStream_t st, const float4* xyzw, float* rgb, uint32_t n, float scale);
 hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32_t n_vox);
 hipError_t ptk_camera_rays(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* o, float* d,

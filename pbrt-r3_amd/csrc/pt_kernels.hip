@@ -2643,6 +2643,13 @@ extern "C" __global__ void k_film_xyzw(const float4* own, const float4* spill, f
         xyzw[i] = make_float4(xa.x + xb.x, xa.y + xb.y, xa.z + xb.z, a.w + b.w);
     }
 }
+// Film::merge_film_tile across hosts without a collective (film.rs:219-241): another rank's {X,Y,Z,weight} film, staged through the host, is added
+extern "C" __global__ void k_film_add(float4* xyzw, const float4* other, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 a = xyzw[i], b = other[i];
+        xyzw[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
 // Film::write_image (film.rs:440-484)
 extern "C" __global__ void k_film_rgb(const float4* xyzw, float* rgb, uint32_t n, float scale) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -3522,6 +3529,10 @@ hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& 
 }
 hipError_t ptk_film_xyzw(hipStream_t st, const float4* own, const float4* spill, float4* xyzw, uint32_t n) {
     hipLaunchKernelGGL(k_film_xyzw, dim3(1024), dim3(PT_BLOCK), 0, st, own, spill, xyzw, n);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_film_add(hipStream_t st, float4* xyzw, const float4* other, uint32_t n) {
+    hipLaunchKernelGGL(k_film_add, dim3(1024), dim3(PT_BLOCK), 0, st, xyzw, other, n);
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_film_rgb(hipStream_t st, const float4* xyzw, float* rgb, uint32_t n, float scale) {

@@ -18,6 +18,8 @@
 // needs a stable sort of the range by centroid) and non-finite bounds -- both raise `fallback` and the caller builds on the host.
 // -0.0 and +0.0 bounds compare equal on the host (first come, first kept) and ordered here (-0 < +0): pt_context.cpp writes zeros of
 // node boxes as +0 for both builders.
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <chrono>
@@ -322,10 +324,12 @@ struct ScratchArena {
     char* base = nullptr;
     size_t cap = 0, used = 0, wanted = 0;
     int dev = -1;
+    // an upload thread that ends (`pbrt_gpu --gpus N`) gives its block back; the process's first thread ends during runtime teardown and keeps it
+    ~ScratchArena() { if (base && getpid() != (pid_t)syscall(SYS_gettid)) (void)hipFree(base); }
     void begin() {
         int d = 0;
         (void)hipGetDevice(&d);
-        if (d != dev) { base = nullptr; cap = 0; dev = d; }      // another device: its own arena (the old block stays with its device)
+        if (d != dev) { if (base) (void)hipFree(base); base = nullptr; cap = 0; dev = d; }      // another device: its own arena
         used = 0; wanted = 0;
     }
     void end() {                                                   // every block handed out has been returned (Scratch destructors ran)

@@ -96,3 +96,37 @@ def test_cpp_driver_gpus_1(tmp_path):
             return np.frombuffer(f.read(), "<f4").reshape(h, w, 3)
     ia, ib = pfm(a), pfm(b)        # two renders: pixels with edge-split samples (float atomics) may differ in the last bits
     assert ia.shape == ib.shape and np.allclose(ia, ib, rtol=2e-6, atol=1e-7) and (ia.view(np.uint32) == ib.view(np.uint32)).mean() > 0.95
+
+
+def test_cpp_driver_two_ranks_on_one_device(tmp_path):
+    """BASELINE config 3's flow rehearsed on the one GPU a box has: `pbrt_gpu --devices 0,0` runs TWO ranks (host threads, one library
+    context each, tiles dealt round-robin, both rendering concurrently on device 0), every rank reaches the meeting point, and the
+    films are summed through the host (pt_film_add_xyzw) because RCCL refuses two ranks on one device.  Disjoint tiles under the box
+    filter: every pixel's weight comes from one rank, so the reduced film's weights are bit-equal to the single-context film's and the
+    colours agree to the last bits (edge-split samples go through float atomics in either run).  Three ranks as well (4 225 tiles do
+    not divide evenly)."""
+    exe = os.path.join(ROOT, "pbrt-r3_amd", "csrc", "pbrt_gpu")
+    scene = os.path.join(ROOT, "tests", "scenes", "cornell.pbrt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = str(tmp_path / "one.xyzw")
+    subprocess.check_call([exe, scene, "-o", str(tmp_path / "one.pfm"), "--xyzw", one, "--pixelsamples", "8", "--quiet"], env=env)
+    want = np.fromfile(one, np.float32).reshape(-1, 4)
+    assert want[:, 3].sum() > 0
+    for devices in ("0,0", "0,0,0"):
+        out = str(tmp_path / ("n%d.xyzw" % len(devices)))
+        r = subprocess.run([exe, scene, "-o", str(tmp_path / "n.pfm"), "--xyzw", out, "--pixelsamples", "8", "--devices", devices, "--stats"],
+                           env=env, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        got = np.fromfile(out, np.float32).reshape(-1, 4)
+        assert np.array_equal(bits(got[:, 3]), bits(want[:, 3]))                  # every camera sample exactly once
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-7) and (bits(got) == bits(want)).mean() > 0.95
+        ranks = [ln for ln in r.stderr.splitlines() if ln.strip().startswith("rank ")]
+        assert len(ranks) == devices.count(",") + 1 and all("render_ms" in ln and "reduce_ms" in ln for ln in ranks)
+        tiles = [int(ln.split("tiles")[1].split()[0]) for ln in ranks]
+        assert sum(tiles) > 0 and max(tiles) - min(tiles) <= 1                     # round-robin deal
+
+
+def test_film_add_xyzw_is_the_host_staged_sum(gpu_ctx):
+    want = _rendered(gpu_ctx)
+    gpu_ctx.film_add_xyzw(want)                       # a second rank with the same film
+    assert np.array_equal(bits(gpu_ctx.film_xyzw()), bits(want + want))

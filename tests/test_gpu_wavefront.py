@@ -124,6 +124,20 @@ def test_wavefront_rt1m_2m_rays(gpu_ctx, oracle):
     osc.close()
 
 
+def test_wavefront_rt16m_beyond_the_infinity_cache(gpu_ctx, oracle):
+    """16 M triangles: nodes + leaf records are ~1.1 GB, four times the 256 MiB Infinity Cache, so node and record fetches really
+    come from HBM (the regime BASELINE config 5 is written for; the tree is ~4 levels deeper than RT1M's).  300 k mixed work items,
+    every hit / t / barycentric / occlusion flag and the node / triangle counters equal to the oracle's."""
+    sd = scenes.rt1m(16000000, res=1024, spp=4)
+    osc = oracle.scene(sd)
+    info = gpu_ctx.upload(sd)
+    assert 128 * info.n_nodes + 48 * 16000000 > 4 * 256 * 2 ** 20
+    o, d, t, kind = _rays(gpu_ctx, osc, 300007, 61)
+    n_hit, n_occ = _check(gpu_ctx, osc, o, d, t, kind)
+    assert n_hit > 10000 and n_occ > 10000
+    osc.close()
+
+
 def test_top_of_tree_is_served_from_lds(gpu_ctx, oracle):
     """The upload numbers the top of the world tree breadth-first and k_trace keeps its first nodes in LDS: the visits counted as
     served from there are a real share of all node visits (every ray starts at the root), never more than all of them, and the

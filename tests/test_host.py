@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -9,6 +10,11 @@ import pytest
 from helpers import pkg, scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PT_ABI = 9      # include/pbrtgpu.h PT_ABI_VERSION; bump together with the header, capi.py and INTEGRATION.md (generated)
+
+
+def pkg_symbols():
+    return pkg.capi.SYMBOLS
 
 
 def test_library_exports_every_declared_symbol():
@@ -20,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "missing export: " + name
     assert declared == set(pkg.capi.SYMBOLS), declared ^ set(pkg.capi.SYMBOLS)
-    assert lib.pt_abi_version() == 8
+    assert lib.pt_abi_version() == PT_ABI
 
 
 def test_struct_layouts_match_header():
@@ -137,3 +143,30 @@ def test_all_tiles_cover_sample_bounds():
     assert len(t) == 65 * 65                   # 4225 tiles
     area = sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in t)
     assert area == 1026 * 1026
+
+
+def test_rust_ffi_block_matches_header(tmp_path):
+    """INTEGRATION.md's Rust `#[repr(C)]` / `extern "C"` block is generated from include/pbrtgpu.h (tools/gen_rust_ffi.py): the document must
+    be the generator's current output, and the sizes, alignments and field offsets the generator computed (and printed into the block)
+    must be the C compiler's for every ABI struct -- an ABI change that forgets the document fails here."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi as g
+    h = g.Header()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a, b = doc.index(g.BEGIN), doc.index(g.END) + len(g.END)
+    assert doc[a:b] == g.generated_block(h), "INTEGRATION.md is stale: run tools/gen_rust_ffi.py --update"
+    src = tmp_path / "layout.c"
+    src.write_text(h.layout_c_program())
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    from_c = subprocess.check_output([exe], text=True).split("\n")
+    assert [ln for ln in from_c if ln] == h.layout_lines()
+    # every struct, every exported function and the ABI number are in the block
+    names = {n for n, _ in h.structs}
+    assert {"pt_scene_desc", "pt_material", "pt_counters", "pt_hit", "pt_scene_info", "pt_texture", "pt_sphere", "pt_instance", "pt_image"} <= names
+    block = doc[a:b]
+    for n in names:
+        assert "pub struct %s " % n in block
+    assert {f[0] for f in h.functions} == set(pkg_symbols())
+    assert "(ABI %d)" % PT_ABI in block and "pub struct pt_material {      // 164 bytes" in block
