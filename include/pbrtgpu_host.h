@@ -67,6 +67,11 @@ void pth_scene_free(pth_scene* s);
  * directive per line (cf. the reference's PrintContext, --cat).  On a syntax error out holds the message. */
 pt_status pth_parse_to_log(const char* text, const char* work_dir, char* out, size_t cap);
 
+/* Planck's law as the front end evaluates it for "blackbody" spectra: out[i] = blackbody(lambda_nm[i], t_kelvin) in W / (m^2 sr m)
+ * (src/core/spectrum/blackbody.rs:3-22; zero for t <= 0).  Exported so that the reference's own known-answer test
+ * (tests/spectrum.rs:10-40) runs against this restatement. */
+void pth_blackbody(const double* lambda_nm, int n, double t_kelvin, double* out);
+
 /* Linear-RGB float image as PFM (the smallest float format the reference can also write,
  * src/core/imageio/write_image.rs:59-76). */
 pt_status pth_write_pfm(const char* path, const float* rgb, int width, int height);

@@ -212,7 +212,7 @@ def tiles_array(tiles):
 
 HOST_SYMBOLS = ["pth_parse_file", "pth_parse_file_opts", "pth_parse_string", "pth_scene_get_desc", "pth_scene_output_filename",
                 "pth_scene_set_pixelsamples", "pth_scene_warnings", "pth_scene_free", "pth_write_pfm", "pth_write_image", "pth_parse_to_log",
-                "pth_display_connect", "pth_display_start", "pth_display_update", "pth_display_close", "pth_tev_create_packet", "pth_tev_update_packet"]
+                "pth_display_connect", "pth_display_start", "pth_display_update", "pth_display_close", "pth_tev_create_packet", "pth_tev_update_packet", "pth_blackbody"]
 
 
 class ParsedScene:

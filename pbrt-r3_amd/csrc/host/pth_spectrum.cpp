@@ -171,6 +171,7 @@ double planck(double lambda_nm, double t) {                  // blackbody.rs:5-2
     return (2.0 * H * C * C) / (lambda5 * (std::exp((H * C) / (l * KB * t)) - 1.0));
 }
 }  // namespace
+double planck_law(double lambda_nm, double t) { return planck(lambda_nm, t); }
 
 void rgb_from_blackbody(const SpectrumTables& T, const std::vector<float>& values, float rgb[3]) {
     float s[kSpectralSamples];
@@ -216,3 +217,7 @@ bool rgb_from_spd_file(const SpectrumTables& T, const std::string& path, float r
 }
 
 }  // namespace pth
+
+extern "C" void pth_blackbody(const double* lambda_nm, int n, double t_kelvin, double* out) {      // blackbody.rs:3-22
+    for (int i = 0; i < n; i++) out[i] = t_kelvin <= 0.0 ? 0.0 : pth::planck_law(lambda_nm[i], t_kelvin);
+}

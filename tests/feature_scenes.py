@@ -579,3 +579,37 @@ def scene_ao(sampler="sobol", cossample=True, nsamples=16, spp=4, res=40, kind="
         t = T.transform_mul(T.transform_translate(0.3, -0.5, 0.1), T.transform_rotate_x(30.0))
         b.shape_sphere(radius=0.4, zmin=-0.3, zmax=0.35, phimax=300.0, object_to_world=t[0], world_to_object=t[1])
     return b.build()
+
+
+# ---- committed golden fixtures of the other SamplerIntegrators (tools/make_golden.py writes them from the oracle; tests/test_oracle_kat.py
+# holds the oracle to them, tests/test_gpu_features.py the device): name -> (scene, tile of per-sample radiance)
+def _golden_integrator(kind):
+    import importlib
+    capi = importlib.import_module("pbrt-r3_amd").capi
+    if kind == "directlighting":         # strategy "all", three samples per light: the 2-D sample arrays (and quirk Q22) are in play
+        sd = scene_materials_render(["glass", "mirror", "plastic"], spp=4)
+        sd.desc.integrator, sd.desc.direct_strategy, sd.desc.max_depth = capi.PT_INTEGRATOR_DIRECTLIGHTING, capi.PT_DIRECT_ALL, 4
+        for i in range(sd.desc.n_area_lights):
+            sd.desc.area_lights[i].n_samples = 3
+    elif kind == "whitted":              # glass + mirror trees to depth 4
+        sd = scene_materials_render(["glass", "mirror", "metal"], spp=4)
+        sd.desc.integrator, sd.desc.max_depth = capi.PT_INTEGRATOR_WHITTED, 4
+    else:                                # ao: 16 cosine-distributed occlusion rays per camera sample
+        from helpers import scenes
+        sd = scenes.cornell_box(res=32, spp=4)
+        sd.desc.integrator, sd.desc.ao_samples, sd.desc.ao_cos_sample = capi.PT_INTEGRATOR_AO, 16, 1
+    return sd
+
+
+GOLDEN_INTEGRATORS = {
+    "directlighting_all_ns3_40x40_4spp": lambda: _golden_integrator("directlighting"),
+    "whitted_depth4_40x40_4spp": lambda: _golden_integrator("whitted"),
+    "ao_16cos_cornell_32x32_4spp": lambda: _golden_integrator("ao"),
+}
+
+
+def golden_tile(info):
+    """The 12x12 tile whose per-sample radiance a fixture holds: the middle of the film (objects, their shadows and reflections)."""
+    sb = list(info.sample_bounds)
+    cx, cy = (sb[0] + sb[2]) // 2, (sb[1] + sb[3]) // 2
+    return (cx - 6, cy - 6, cx + 6, cy + 6)

@@ -180,6 +180,21 @@ def test_golden_fixtures(gpu_ctx):
     assert np.array_equal(bits(rad), bits(np.load(os.path.join(G, "materials_sobol_40x40_8spp_samples.npy"))))
 
 
+@pytest.mark.parametrize("name", ["directlighting_all_ns3_40x40_4spp", "whitted_depth4_40x40_4spp", "ao_16cos_cornell_32x32_4spp"])
+def test_golden_fixtures_other_integrators(gpu_ctx, name):
+    """The committed fixtures of the directlighting / whitted / ao integrators (tools/make_golden.py, from the oracle): per-sample radiance
+    of the middle tile bit for bit, the ray counters, the film within tolerance."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    gpu_ctx.upload(fs.GOLDEN_INTEGRATORS[name]())
+    rad = gpu_ctx.radiance_samples(fs.golden_tile(gpu_ctx.info))
+    assert np.array_equal(bits(rad), bits(g["radiance"]))
+    gpu_ctx.film_clear(); gpu_ctx.reset_counters(); gpu_ctx.render()
+    c = gpu_ctx.counters()
+    assert [c[k] for k in ("camera_rays", "regular_rays", "shadow_rays", "path_vertices")] == list(g["counters"])
+    got = gpu_ctx.film_xyzw()
+    assert np.array_equal(bits(got[..., 3]), bits(g["xyzw"][..., 3])) and rel_l2(got[..., :3], g["xyzw"][..., :3]) <= 1e-3
+
+
 def test_baseline_size_properties(gpu_ctx, oracle):
     """BASELINE.json full size (RT1M: 1M triangles, 1024x1024): size-independent checks that need no
     full CPU render -- camera rays of a pixel sample exact, closest hits of 200k rays exact against the

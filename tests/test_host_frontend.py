@@ -570,6 +570,30 @@ def test_spectrum_files_and_blackbody(tmp_path):
     assert e.value.status == 4
 
 
+def test_reference_kat_spectrum_blackbody():
+    """/root/reference/tests/spectrum.rs:10-40 (`spectrum_blackbody`) restated 1:1 against the front end's Planck function
+    (host/pth_spectrum.cpp, the one "blackbody L" goes through): four radiance values from spectralcalc.com to 1e-3 relative, and
+    Wien's displacement law -- the returned radiance peaks at lambda_max = 2.8977721e-3 / T for five temperatures."""
+    import ctypes as C
+    lib = capi.load_library()
+    lib.pth_blackbody.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_double)]
+    lib.pth_blackbody.restype = None
+
+    def blackbody(lams, t):
+        a = (C.c_double * len(lams))(*[float(x) for x in lams])
+        o = (C.c_double * len(lams))()
+        lib.pth_blackbody(a, len(lams), float(t), o)
+        return list(o)
+    for lam, t, expected in ((483, 6000, 3.1849e13), (600, 6000, 2.86772e13), (500, 3700, 1.59845e12), (600, 4500, 7.46497e12)):
+        le = blackbody([lam], t)[0]
+        assert abs(le - expected) / expected < 0.001
+    for t in (2700, 3000, 4500, 5600, 6000):
+        lambda_max = 2.8977721e-3 / t * 1e9
+        le = blackbody([0.999 * lambda_max, lambda_max, 1.001 * lambda_max], t)
+        assert le[0] < le[1] and le[1] > le[2]
+    assert blackbody([500.0], 0.0) == [0.0] and blackbody([500.0], -10.0) == [0.0]      # blackbody.rs:6-8
+
+
 def _write_ply(path, fmt, P, N, UV, faces, gz=False):
     import gzip, struct
     hdr = ["ply", "format %s 1.0" % fmt, "comment made by the test", "element vertex %d" % len(P),

@@ -320,6 +320,22 @@ def test_oracle_matches_committed_golden(oracle):
     sc4.close()
 
 
+@pytest.mark.parametrize("name", ["directlighting_all_ns3_40x40_4spp", "whitted_depth4_40x40_4spp", "ao_16cos_cornell_32x32_4spp"])
+def test_oracle_other_integrators_match_committed_golden(oracle, name):
+    """The oracle's directlighting / whitted / ao restatements (orc_render.hpp) frozen against accidental edits: film, per-sample
+    radiance of the middle tile and the ray counters of tools/make_golden.py's fixtures, bit for bit."""
+    import feature_scenes as fs
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sc = oracle.scene(fs.GOLDEN_INTEGRATORS[name]())
+    xyzw, cnt, _ = sc.render(threads=4)
+    assert np.array_equal(bits(xyzw), bits(g["xyzw"]))
+    rad = sc.radiance_samples(fs.golden_tile(sc.info))
+    assert np.array_equal(bits(rad), bits(g["radiance"]))
+    assert [cnt[k] for k in ("camera_rays", "regular_rays", "shadow_rays", "path_vertices")] == list(g["counters"])
+    assert np.isfinite(rad).all() and rad.max() > 0 and len(np.unique(rad)) > 10          # a real image, not a constant (cosine-sampled ao takes multiples of pi / nsamples)
+    sc.close()
+
+
 def test_cornell_energy_sanity(oracle):
     """Analytic sanity (no reference image exists): the light is visible and its pixels carry
     exactly Le = (17,12,4); the image is finite, non-negative and not black."""

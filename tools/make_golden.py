@@ -7,6 +7,8 @@ against accidental change and give the GPU tests a committed target:
   tests/golden/rt2k_32x32_4spp_xyzw.npy
   tests/golden/materials_halton_40x40_6spp_xyzw.npy   plastic sphere + mirror + glass slabs, Halton, HLBVH
   tests/golden/materials_sobol_40x40_8spp_samples.npy per-sample radiance of a 12x12 tile: metal / uber / substrate
+  tests/golden/{directlighting_all_ns3,whitted_depth4,ao_16cos_cornell}_*.npz   the other integrators: film, per-sample radiance of the
+                                                      middle tile, ray counters (tests/feature_scenes.py::GOLDEN_INTEGRATORS)
 """
 import importlib, os, sys
 import numpy as np
@@ -42,4 +44,14 @@ sd4 = fs.scene_materials_render(["metal", "uber", "substrate"], spp=8)
 sc4 = orc.scene(sd4)
 sb4 = list(sc4.info.sample_bounds)
 np.save(os.path.join(G, "materials_sobol_40x40_8spp_samples.npy"), sc4.radiance_samples((sb4[0] + 14, sb4[1] + 14, sb4[0] + 26, sb4[1] + 26)))
+# the other SamplerIntegrators: film + per-sample radiance of the middle tile + ray counters, so an edit to the oracle's
+# directlighting / whitted / ao paths (orc_render.hpp) cannot pass unnoticed
+for name, make in fs.GOLDEN_INTEGRATORS.items():
+    sdi = make()
+    sci = orc.scene(sdi)
+    xyzw_i, cnt_i, _ = sci.render(threads=1)
+    rad_i = sci.radiance_samples(fs.golden_tile(sci.info))
+    np.savez_compressed(os.path.join(G, name + ".npz"), xyzw=xyzw_i, radiance=rad_i,
+                        counters=np.array([cnt_i[k] for k in ("camera_rays", "regular_rays", "shadow_rays", "path_vertices")], np.int64))
+    sci.close()
 print("golden written:", os.listdir(G))
