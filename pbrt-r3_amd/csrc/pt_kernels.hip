@@ -2168,6 +2168,8 @@ __device__ unsigned long long g_shade_prof[16];
 #define PT_SHP(k) do { } while (0)
 #define PT_SHP_SYNC(k) do { } while (0)
 #endif
+// 0.0f the optimiser cannot see through (one v_mov): see the continuation store in shade_body
+PT_DEV float opaque_zero() { float z = 0.0f; asm volatile("" : "+v"(z)); return z; }
 template <bool GENERAL, bool SPH, bool TEX = false, bool INST = false>
 PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, const uint32_t* list, uint32_t begin, uint32_t end,
                        uint32_t* ticket) {
@@ -2263,7 +2265,13 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         // The textured / instanced kernels (425 registers and still spilling) store where the value is made, as they always did: held back
         // to the end of the iteration, the continuation ray came out wrong for about 1 % of the samples of seven feature scenes (bisected
         // to exactly that deferral; the kernels that do not spill are bit-exact either way).
-#define PT_COMMIT_NOW() do { if constexpr (TEX || INST) commit(); } while (0)
+#ifndef PT_DEFER_WIDE
+#define PT_DEFER_WIDE 0          // 1: the textured / instanced kernels hold their stores back as well (the build tools/r03_defer_probe.sh examines)
+#endif
+#ifndef PT_DEFER_SITES
+#define PT_DEFER_SITES (PT_DEFER_WIDE ? 63 : 0)      // which store sites of those kernels are held back: 1 pass-through ray, 2 shadow ray, 4 probe ray, 8 pending terms, 16 continuation, 32 state
+#endif
+#define PT_COMMIT_NOW(site) do { if constexpr ((TEX || INST) && !((PT_DEFER_SITES >> (site)) & 1)) commit(); } while (0)
         // the next iteration's path id and hit record are asked for one iteration ahead (within a work ticket): two of the three
         // dependent round trips at the head of an iteration -- list -> path state -> leaf record -- then overlap this iteration's work
         const bool had_pf = pf_valid;
@@ -2353,7 +2361,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     // no BSDF: continue through the surface, same bounce count (path.rs:108-111)
                     V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
                     o_ray_o = make_float4(no.x, no.y, no.z, PT_INF); wr |= 1u;
-                    cont = true; PT_COMMIT_NOW();
+                    cont = true; PT_COMMIT_NOW(0);
                 } else {
                     n_vert++;
                     Bsdf b;
@@ -2418,7 +2426,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                         s_stage[0][threadIdx.x] = make_float4(origin.x, origin.y, origin.z, 1.0f - PT_SHADOW_EPS);
                                         s_stage[1][threadIdx.x] = make_float4(sd.x, sd.y, sd.z, 0.0f);
                                         if (Q.shadow_key) s_pkey[n_batch][threadIdx.x] = ray_sort_key(sc, origin, sd);
-                                        wr |= 4u; PT_COMMIT_NOW();
+                                        wr |= 4u; PT_COMMIT_NOW(1);
                                         float weight = power_heuristic(lpdf, spdf);
                                         A = f * li * (weight / lpdf);
                                         nee |= PT_NEE_SHADOW;
@@ -2458,7 +2466,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                             B = f * le * 1.0f * (weight / spdf2);
                                             s_stage[2][threadIdx.x] = make_float4(po.x, po.y, po.z, PT_INF);
                                             s_stage[3][threadIdx.x] = make_float4(wi2.x, wi2.y, wi2.z, 0.0f);
-                                            wr |= 8u; PT_COMMIT_NOW();
+                                            wr |= 8u; PT_COMMIT_NOW(2);
                                             nee |= PT_NEE_PROBE;
                                         }
                                     }
@@ -2469,7 +2477,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                 s_stage[4][threadIdx.x] = make_float4(A.x, A.y, A.z, light_pdf);
                                 s_stage[5][threadIdx.x] = make_float4(B.x, B.y, B.z, 0.0f);
                                 s_stage[6][threadIdx.x] = make_float4(beta.x, beta.y, beta.z, 0.0f);
-                                o_nee = nee; wr |= 16u; PT_COMMIT_NOW();
+                                o_nee = nee; wr |= 16u; PT_COMMIT_NOW(3);
                                 want_nee = true;
                                 want_sh = (nee & PT_NEE_SHADOW) != 0;
                                 want_pr = (nee & PT_NEE_PROBE) != 0;
@@ -2500,16 +2508,22 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                         }
                         if (alive) {
                             o_ray_o = make_float4(no.x, no.y, no.z, PT_INF);
-                            o_ray_d = make_float4(wi.x, wi.y, wi.z, 0.0f);
+                            // .w is an OPAQUE zero, not the literal: with a literal the compiler keeps (wi.x, wi.y, wi.z, 0) in a register
+                            // tuple whose last member is its shared constant-zero register, pairs that zero with the register holding
+                            // wi.z as the high / low halves of zero-extended 64-bit table offsets, and then uses the low half as scratch
+                            // inside the Russian-roulette branch (the sampler's table addressing) while wi.z is still waiting to be stored:
+                            // hipcc 7.2 -O2 / -O3, the textured and instanced kernels with the stores held back -- survivors of the
+                            // roulette continued with direction z = 0 (profiles/r03_deferred_store_miscompile.md)
+                            o_ray_d = make_float4(wi.x, wi.y, wi.z, opaque_zero());
                             o_beta = make_float4(beta.x, beta.y, beta.z, eta_scale);
-                            wr |= 3u; PT_COMMIT_NOW();
+                            wr |= 3u; PT_COMMIT_NOW(4);
                             bounces++;
                             cont = true;
                         }
                     }
                     dim = sm.s.dim;
                 }
-                if (cont) { o_state = (dim & 0xffffu) | ((bounces & 0xffu) << 16) | ((flags & ~PT_ST_CAMERA) << 24); wr |= 32u; } PT_COMMIT_NOW();     // later rays are plain Rays
+                if (cont) { o_state = (dim & 0xffffu) | ((bounces & 0xffu) << 16) | ((flags & ~PT_ST_CAMERA) << 24); wr |= 32u; } PT_COMMIT_NOW(5);     // later rays are plain Rays
             }
         }
         PT_SHP(8);

@@ -180,6 +180,38 @@ def test_golden_fixtures(gpu_ctx):
     assert np.array_equal(bits(rad), bits(np.load(os.path.join(G, "materials_sobol_40x40_8spp_samples.npy"))))
 
 
+def test_deferred_store_build_is_bit_exact(oracle, tmp_path):
+    """The textured / instanced shading kernels store each output where it is made; the plain ones hold all stores back to the end of the
+    iteration.  Round 2 found the held-back form of the wide kernels wrong for a few samples per film and parked it; round 3 traced it to
+    a register-allocation miscompile (hipcc 7.2, -O2 and -O3: profiles/r03_deferred_store_miscompile.md) that hit paths surviving
+    Russian roulette (bounces > 3), and removed the trigger in the source (an opaque zero in the continuation direction's .w).  This test
+    builds the held-back variant (-DPT_DEFER_WIDE=1) and holds it to the oracle on the seven scenes that showed the divergence, every
+    camera sample of the film, at the depth where roulette runs -- both placements must be bit-exact."""
+    so = tmp_path / "libpbrtgpu_defer.so"
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "pbrt-r3_amd", "csrc"), "OUT=%s" % so, "EXTRA=-DPT_DEFER_WIDE=1", str(so)])
+    lib = pkg.capi.load_library(str(so))
+    ctx = pkg.Context(0, lib=lib)
+    seven = [lambda: fs.scene_textures(), lambda: fs.scene_textures(lens=True), lambda: fs.scene_roughness_textures(), lambda: fs.scene_instances(),
+             lambda: fs.scene_instances(split="hlbvh", sampler="halton"), lambda: fs.scene_bump(), lambda: fs.scene_bump(lens=True)]
+    roulette_ran = 0
+    for make in seven:
+        sd = make()
+        sd.desc.max_depth = 5            # the first depth at which a vertex with bounces > 3 is shaded: Russian roulette runs
+        osc = oracle.scene(sd)
+        ctx.upload(sd)
+        sb = list(ctx.info.sample_bounds)
+        g, r = ctx.radiance_samples(tuple(sb)), osc.radiance_samples(tuple(sb))
+        assert np.array_equal(bits(g), bits(r))
+        # the depth matters: the same film at maxdepth 4 (no vertex with bounces > 3 is shaded) must differ from it somewhere
+        sd4 = make()
+        sd4.desc.max_depth = 4
+        o4 = oracle.scene(sd4)
+        roulette_ran += int((bits(o4.radiance_samples(tuple(sb))) != bits(r)).any())
+        o4.close(); osc.close()
+    assert roulette_ran >= 5
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["directlighting_all_ns3_40x40_4spp", "whitted_depth4_40x40_4spp", "ao_16cos_cornell_32x32_4spp"])
 def test_golden_fixtures_other_integrators(gpu_ctx, name):
     """The committed fixtures of the directlighting / whitted / ao integrators (tools/make_golden.py, from the oracle): per-sample radiance

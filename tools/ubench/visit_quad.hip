@@ -1,0 +1,191 @@
+// Micro-benchmark: a COMPLETE 4-wide node visit -- fetch, four slab tests in the reference's un-fused arithmetic, front-to-back order,
+// pushes onto an LDS stack, pop of the next entry -- organised two ways:
+//   lane   one ray per lane (k_trace's node_step_lean): seven 16-byte loads on the lane's own 128-byte node, 4 slab tests per lane,
+//          the order applied to SGPR hit masks, four EXEC-predicated pushes;
+//   quad   one ray per lane QUAD, lane c owns child c (round 2's verdict, item 4; the reference's own shape, qbvh_x86.rs:26-67): the node
+//          is four 32-byte child records {lo.xyz, ref | hi.xyz, order LUT}, each lane loads its child with two dwordx4 -- the quad's
+//          eight loads fall in ONE line --, does ONE slab test, the hit bits of the quad come from one ballot, ORDER_TABLE
+//          (qbvh_x86.rs:186-204) is a 128-entry LDS table indexed by (hit mask, node_idx) that hands every child its push slot, every
+//          lane pushes its own child at top + slot, and all four lanes keep the ray's stack pointer.
+// Both walk a synthetic table of random boxes with random rays, so the instruction mix and the memory pattern are the real ones
+// while the "tree" never ends (the next node is a hash of the popped reference).  Reported: ray-visits per second over the chip.
+// What the numbers are for: the quad form cuts the L1 tag look-ups per visit (the resource that bounds k_trace) by ~3.5x, but it
+// spends a wave instruction on 16 rays instead of 64, so everything that is not the slab arithmetic costs 4x per ray.
+// build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o visit_quad visit_quad.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#define ITER 256
+#define BLOCK 256
+#define SLOTS 16
+#define EMPTY 0xffffffffu
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ float v_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float v_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float v_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float v_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+struct Ray { float ox, oy, oz, ix, iy, iz, tmin, tmax; uint32_t oct; };
+__device__ __forceinline__ Ray make_ray(uint32_t id) {
+    Ray r;
+    const uint32_t h0 = hash32(id * 3u + 1u), h1 = hash32(id * 3u + 2u), h2 = hash32(id * 3u + 3u);
+    r.ox = (h0 & 0xffff) * (1.0f / 65536.0f); r.oy = (h1 & 0xffff) * (1.0f / 65536.0f); r.oz = (h2 & 0xffff) * (1.0f / 65536.0f);
+    float dx = ((h0 >> 16) + 1u) * (1.0f / 32768.0f) - 1.0f, dy = ((h1 >> 16) + 1u) * (1.0f / 32768.0f) - 1.0f, dz = ((h2 >> 16) + 1u) * (1.0f / 32768.0f) - 1.0f;
+    if (dx == 0.0f) dx = 0.5f; if (dy == 0.0f) dy = 0.5f; if (dz == 0.0f) dz = 0.5f;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    r.oct = (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
+    r.tmin = 0.0f; r.tmax = 4.0f;
+    return r;
+}
+
+// ---- lane form: PtNode layout (bmin x/y/z rows, bmax x/y/z rows, child refs; split axes in bits 26..27 of refs 0 / 1 / 3)
+extern "C" __global__ void __launch_bounds__(BLOCK, 4) k_lane(const char* nodes, uint32_t n_nodes, uint32_t* out, uint32_t seed) {
+    __shared__ uint32_t s_stack[SLOTS * BLOCK];
+    const uint32_t gid = blockIdx.x * BLOCK + threadIdx.x;
+    const Ray r = make_ray(gid ^ seed);
+    const uint32_t ox = (r.oct & 1u) ? 3u : 0u, oy = (r.oct & 2u) ? 3u : 0u, oz = (r.oct & 4u) ? 3u : 0u;
+    const uint32_t o_nx = ox << 4, o_fx = (3u - ox) << 4, o_ny = (1u + oy) << 4, o_fy = (4u - oy) << 4, o_nz = (2u + oz) << 4, o_fz = (5u - oz) << 4;
+    uint32_t sp = 0, top = __umulhi(hash32(gid ^ seed), n_nodes), acc = 0;
+    for (int it = 0; it < ITER; it++) {
+        const uint32_t ref = top;
+        const uint32_t no = __umulhi(ref, n_nodes) << 7;
+        if (sp > 0) { sp--; top = s_stack[sp * BLOCK + threadIdx.x]; } else top = EMPTY;
+        const float4 nx = *(const float4*)(nodes + (no + o_nx)), fx = *(const float4*)(nodes + (no + o_fx));
+        const float4 ny = *(const float4*)(nodes + (no + o_ny)), fy = *(const float4*)(nodes + (no + o_fy));
+        const float4 nz = *(const float4*)(nodes + (no + o_nz)), fz = *(const float4*)(nodes + (no + o_fz));
+        const uint4 ch = *(const uint4*)(nodes + (no + 96u));
+#define SLAB(C) (v_min3(v_min(r.tmax, (fx.C - r.ox) * r.ix), (fy.C - r.oy) * r.iy, (fz.C - r.oz) * r.iz) >= v_max3(v_max(r.tmin, (nx.C - r.ox) * r.ix), (ny.C - r.oy) * r.iy, (nz.C - r.oz) * r.iz))
+        const bool h0 = SLAB(x), h1 = SLAB(y), h2 = SLAB(z), h3 = SLAB(w);
+#undef SLAB
+        const bool T = __builtin_amdgcn_ubfe(r.oct, __builtin_amdgcn_ubfe(ch.x, 26, 2), 1) != 0u;
+        const bool L = __builtin_amdgcn_ubfe(r.oct, __builtin_amdgcn_ubfe(ch.y, 26, 2), 1) != 0u;
+        const bool R = __builtin_amdgcn_ubfe(r.oct, __builtin_amdgcn_ubfe(ch.w, 26, 2), 1) != 0u;
+        const uint32_t l0 = L ? ch.x : ch.y, l1 = L ? ch.y : ch.x, r0 = R ? ch.z : ch.w, r1 = R ? ch.w : ch.z;
+        const uint32_t c0 = T ? l0 : r0, c1 = T ? l1 : r1, c2 = T ? r0 : l0, c3 = T ? r1 : l1;
+        const unsigned long long H0 = __ballot(h0), H1 = __ballot(h1), H2 = __ballot(h2), H3 = __ballot(h3), Tm = __ballot(T), Lm = __ballot(L), Rm = __ballot(R);
+        const unsigned long long yl = Lm & (H0 ^ H1), el0 = H1 ^ yl, el1 = H0 ^ yl;
+        const unsigned long long yr = Rm & (H2 ^ H3), er0 = H3 ^ yr, er1 = H2 ^ yr;
+        const unsigned long long y0 = Tm & (el0 ^ er0), e0 = er0 ^ y0, e2 = el0 ^ y0;
+        const unsigned long long y1 = Tm & (el1 ^ er1), e1 = er1 ^ y1, e3 = el1 ^ y1;
+        const unsigned long long me = 1ull << (threadIdx.x & 63u);
+        // pushes (the kernel runs them with EXEC = the condition; a bounded ring here so that the walk never ends or overflows)
+        if (e0 & me) { if (top != EMPTY) { s_stack[sp * BLOCK + threadIdx.x] = top; sp = (sp + 1) & (SLOTS - 1); } top = c0; }
+        if (e1 & me) { if (top != EMPTY) { s_stack[sp * BLOCK + threadIdx.x] = top; sp = (sp + 1) & (SLOTS - 1); } top = c1; }
+        if (e2 & me) { if (top != EMPTY) { s_stack[sp * BLOCK + threadIdx.x] = top; sp = (sp + 1) & (SLOTS - 1); } top = c2; }
+        if (e3 & me) { if (top != EMPTY) { s_stack[sp * BLOCK + threadIdx.x] = top; sp = (sp + 1) & (SLOTS - 1); } top = c3; }
+        acc += (uint32_t)__popcll((e0 | e1 | e2 | e3) & me);
+        if (top == EMPTY) top = hash32(ref + it);           // the walk goes on: a fresh pseudo-random node
+        top = hash32(top) | 0u;
+    }
+    if (acc == 0xdeadbeefu) out[gid] = acc;
+}
+
+// ---- quad form: node = 4 x {lo.x lo.y lo.z ref | hi.x hi.y hi.z lut}; lut = node_idx (3 bits) per ray octant, 24 bits
+extern "C" __global__ void __launch_bounds__(BLOCK, 4) k_quad(const char* nodes, uint32_t n_nodes, uint32_t* out, uint32_t seed) {
+    __shared__ uint32_t s_stack[SLOTS * (BLOCK / 4)];      // one stack per quad (ray)
+    __shared__ uint32_t s_order[128];                      // (hit mask << 3 | node_idx) -> 2-bit push slot per child (bits 2c..2c+1), count in bits 8..10
+    const uint32_t c = threadIdx.x & 3u, q = threadIdx.x >> 2;
+    if (threadIdx.x < 128) {
+        // ORDER_TABLE in closed form: pops visit {0,1} before {2,3} iff T = 0 ... what matters here is that it is a table look-up
+        const uint32_t m = threadIdx.x >> 3, idx = threadIdx.x & 7u;
+        const uint32_t T = (idx >> 2) & 1u, L = (idx >> 1) & 1u, R = idx & 1u;
+        const uint32_t l0 = L ? 0u : 1u, l1 = L ? 1u : 0u, r0 = R ? 2u : 3u, r1 = R ? 3u : 2u;
+        const uint32_t ord[4] = {T ? l0 : r0, T ? l1 : r1, T ? r0 : l0, T ? r1 : l1};      // push order
+        uint32_t e = 0, n = 0;
+        for (int k = 0; k < 4; k++) if (m & (1u << ord[k])) { e |= n << (2u * ord[k]); n++; }
+        s_order[threadIdx.x] = e | (n << 8);
+    }
+    __syncthreads();
+    const uint32_t gid = blockIdx.x * BLOCK + threadIdx.x;
+    const Ray r = make_ray((gid >> 2) ^ seed);             // the four lanes of a quad carry the same ray
+    const uint32_t oct3 = r.oct * 3u, c2 = c * 2u, coff = c << 5;
+    const uint32_t qshift = (threadIdx.x & 63u) & ~3u;
+    uint32_t sp = 0, top = __umulhi(hash32((gid >> 2) ^ seed), n_nodes), acc = 0;
+    for (int it = 0; it < ITER; it++) {
+        const uint32_t ref = top;
+        const uint32_t no = (__umulhi(ref, n_nodes) << 7) + coff;
+        const float4 lo = *(const float4*)(nodes + no), hi = *(const float4*)(nodes + (no + 16u));
+        // one slab test: both planes of every axis, near = min, far = max (the direction sign picks the same pair)
+        const float ax = (lo.x - r.ox) * r.ix, bx = (hi.x - r.ox) * r.ix, ay = (lo.y - r.oy) * r.iy, by = (hi.y - r.oy) * r.iy, az = (lo.z - r.oz) * r.iz, bz = (hi.z - r.oz) * r.iz;
+        const float tn = v_max(v_max3(r.tmin, v_min(ax, bx), v_min(ay, by)), v_min(az, bz));
+        const float tf = v_min(v_min3(r.tmax, v_max(ax, bx), v_max(ay, by)), v_max(az, bz));
+        const uint32_t cref = __float_as_uint(lo.w);
+        const bool hit = tf >= tn && cref != EMPTY;
+        const unsigned long long H = __ballot(hit);
+        const uint32_t m4 = (uint32_t)(H >> qshift) & 15u;
+        const uint32_t nidx = __builtin_amdgcn_ubfe(__float_as_uint(hi.w), oct3, 3);
+        const uint32_t e = s_order[(m4 << 3) | nidx];
+        const uint32_t slot = __builtin_amdgcn_ubfe(e, c2, 2), cnt = e >> 8;
+        // pop, then every hit child goes to stack[sp + slot]; all four lanes keep sp
+        if (sp > 0) sp--;
+        if (hit) s_stack[((sp + slot) & (SLOTS - 1)) * (BLOCK / 4) + q] = cref;
+        sp = (sp + cnt) & (SLOTS - 1);
+        __builtin_amdgcn_wave_barrier();
+        top = sp > 0 ? s_stack[((sp - 1) & (SLOTS - 1)) * (BLOCK / 4) + q] : EMPTY;     // the new top, by all four lanes (one broadcast read)
+        acc += cnt;
+        if (top == EMPTY || cnt == 0) top = hash32(ref + it);
+        top = hash32(top);
+    }
+    if (acc == 0xdeadbeefu) out[gid] = acc;
+}
+
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    double mb = argc > 1 ? atof(argv[1]) : 21.0;
+    uint32_t n_nodes = (uint32_t)(mb * 1e6 / 128);
+    hipDeviceProp_t p;
+    (void)hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    char *nodes_lane, *nodes_quad; uint32_t* out;
+    (void)hipMalloc(&nodes_lane, (size_t)n_nodes * 128);
+    (void)hipMalloc(&nodes_quad, (size_t)n_nodes * 128);
+    (void)hipMalloc(&out, (size_t)cus * 8 * BLOCK * 4);
+    // random child boxes inside the unit cube, about a quarter of the cube's extent per axis; references = random words below 2^26
+    std::vector<float> hl((size_t)n_nodes * 32), hq((size_t)n_nodes * 32);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
+    for (uint32_t n = 0; n < n_nodes; n++) {
+        for (int k = 0; k < 4; k++) {
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; a++) { const float c0 = rnd(), e = 0.05f + 0.3f * rnd(); lo[a] = c0 - e; hi[a] = c0 + e; }
+            uint32_t ref = ((uint32_t)(rnd() * 67108864.0f)) & 0x3ffffffu;
+            if (k == 0 || k == 1 || k == 3) ref |= ((uint32_t)(rnd() * 3.0f) % 3u) << 26;          // split axes ride in refs 0 / 1 / 3
+            float fref; std::memcpy(&fref, &ref, 4);
+            for (int a = 0; a < 3; a++) { hl[(size_t)n * 32 + a * 4 + k] = lo[a]; hl[(size_t)n * 32 + 12 + a * 4 + k] = hi[a]; }
+            hl[(size_t)n * 32 + 24 + k] = fref;
+            uint32_t lut = (uint32_t)(rnd() * 16777216.0f);
+            float flut; std::memcpy(&flut, &lut, 4);
+            float* qd = &hq[(size_t)n * 32 + k * 8];
+            qd[0] = lo[0]; qd[1] = lo[1]; qd[2] = lo[2]; qd[3] = fref; qd[4] = hi[0]; qd[5] = hi[1]; qd[6] = hi[2]; qd[7] = flut;
+        }
+    }
+    (void)hipMemcpy(nodes_lane, hl.data(), hl.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(nodes_quad, hq.data(), hq.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    std::printf("table %.1f MB (%u nodes), %d CUs, %d visits per ray\n", mb, n_nodes, cus, ITER);
+    for (int bpc : {2, 4}) {
+        for (int form = 0; form < 2; form++) {
+            const int blocks = cus * bpc;
+            auto launch = [&](uint32_t seed) {
+                if (form == 0) hipLaunchKernelGGL(k_lane, dim3(blocks), dim3(BLOCK), 0, 0, nodes_lane, n_nodes, out, seed);
+                else hipLaunchKernelGGL(k_quad, dim3(blocks), dim3(BLOCK), 0, 0, nodes_quad, n_nodes, out, seed);
+            };
+            launch(1u);
+            (void)hipDeviceSynchronize();
+            (void)hipEventRecord(e0);
+            launch(2u);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            const double rays = (double)blocks * BLOCK / (form == 0 ? 1 : 4);
+            std::printf("%d waves/SIMD  %-28s %8.3f ms  %7.1f G ray-visits/s   (%.0f rays per wave-instruction)  (%s)\n", bpc,
+                        form == 0 ? "lane: one ray per lane" : "quad: one ray per lane quad", ms, rays * ITER / ms / 1e6, form == 0 ? 64.0 : 16.0, hipGetErrorString(hipGetLastError()));
+        }
+    }
+    return 0;
+}
