@@ -299,7 +299,7 @@ struct SobolSampler {
     // sample_array2d[i][n * current + k] (base_sampler.rs:59-70), which start_pixel filled from sample number n * current + k -- and
     // every 2-D array is filled from the SAME pair of dimensions: start_pixel computes `dim` once, before the loop over the arrays, and
     // never advances it (sobol.rs:60-75, halton.rs:193-208; pbrt-v3 has `dim += 2` there).  With "strategy all" every light's u_light and
-    // u_scattering arrays therefore hold the same points -- restated as is (quirk Q22).
+    // u_scattering arrays therefore hold the same points -- restated as is (quirk Q23).
     bool get_2d_array(uint32_t n, std::vector<V2>* out) {
         if (array_next >= n_arrays1) return false;
         array_next++;

@@ -89,6 +89,25 @@ int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t ma
 // pt_sah.hip: the SAH binary build on the GPU, level by level.  Same conventions: 0 = order / nodes filled (nodes[0] is the root), 1 = the
 // host has to build (a split needs the equal-counts fallback, non-finite bounds, maxnodeprims < 2), -1 = HIP error.
 int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes, hipError_t* err);
+// pt_sah.hip: a triangle-only world list built, collapsed and finished on the device (SAH).  In: the scene's arrays on the host (they are staged
+// and uploaded here) and three per-mesh tables -- the record flag word of the mesh's triangles (PT_TRI_* | material field), its material, its
+// PT_MESH_* flags with the attributes the scene does not carry masked out.  Out: device blocks the caller owns -- the finished PtNode array
+// (breadth-first top, order tables, axis bits, inverted empty slots: what pt_scene_upload uploads on the host path, byte for byte), the
+// PtTri records in leaf order + the pad record, the PtTriInfo records, the primitive -> record map (for the light list; free it after).
+struct SceneIn {
+    const float* P; uint32_t n_vertices;
+    const uint32_t* indices; const uint32_t* tri_mesh; uint32_t n_tris;
+    const uint32_t* mesh_triflags; const int32_t* mesh_material; const uint32_t* mesh_flags; uint32_t n_meshes;
+};
+struct SceneOut {
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_tinfo = nullptr, *d_rec_of_prim = nullptr;
+    uint32_t n_nodes4 = 0, n_leaves = 0, max_leaf = 0, max_depth4 = 0, n_top = 0, any_one_sided = 0;
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+    void free_all();
+};
+// 0 = done, 1 = this list needs the host path (a fallback split, non-finite bounds), -1 = HIP error
+int device_sah_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, SceneOut* out, hipError_t* err);
+int device_scene_lights(hipStream_t st, SceneOut* out, const uint32_t* prims, uint32_t n, uint32_t* recs_host, hipError_t* err);
 // Where the lower half of an HLBVH build runs: PT_BVH_BUILD_AUTO picks the device from kDeviceMinPrims primitives up.
 struct DeviceBuild { hipStream_t stream; int mode; bool used; hipError_t err; };
 const uint32_t kDeviceMinPrims = 1u << 16;

@@ -89,6 +89,10 @@ struct pt_context {
     DevBuf d_qbin;                                     // PtQueues::bin
     DevBuf d_sort_ids, d_sort_keys[2], d_sort_temp;   // pt_raysort.hip: the second id list, the key lists and rocprim's scratch
     size_t sort_cap = 0;
+    DevBuf d_csort_ids, d_csort_keys[2], d_csort_temp; // the continuation rays' key list, the ordered copy (ids + keys) and rocprim's scratch
+    size_t csort_cap = 0;
+    int sort_cont = -1;                                // continuation rays of a bounce ordered like the shadow rays: 0 never, 1 for the traversal kernel only
+                                                       // (shading keeps path order), 2 for both, -1 (default): mode 1 for scenes larger than the Infinity Cache
     int sort_shadow_min = 1 << 20;                     // shadow rays of a launch are ordered by origin cell from this many up (0: never)
     DevBuf d_rec, d_counts2; // recursive integrators (directlighting, whitted): frames, differentials, next-event entries and lists; the second counter block
     size_t rec_paths = 0;
@@ -235,6 +239,7 @@ pt_status pt_context_create(int device, pt_context** out) {
     ctx->grid_shade = ctx->n_cu * 2;
     if (const char* e = std::getenv("PBRTGPU_SHADE_BLOCKS_PER_CU")) ctx->grid_shade = ctx->n_cu * std::max(1, std::atoi(e));
     if (const char* e = std::getenv("PBRTGPU_SORT_SHADOW_MIN")) ctx->sort_shadow_min = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("PBRTGPU_SORT_CONT")) ctx->sort_cont = std::min(2, std::max(-1, std::atoi(e)));
     ctx->grid_wide = ctx->n_cu * 8;
     // Sobol' tables: $PBRTGPU_DATA_DIR, else <directory of this shared library>/../data
     const char* dd = std::getenv("PBRTGPU_DATA_DIR");
@@ -503,8 +508,115 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     const bool build_trace = std::getenv("PBRTGPU_BUILD_TRACE") != nullptr;
     double tm_last = t0;
     auto mark = [&](const char* what) { if (build_trace) { const double t = now_ms(); std::fprintf(stderr, "[upload] %s %.1f ms\n", what, t - tm_last); tm_last = t; } };
+    // What either path below leaves for the rest of the upload.
+    std::vector<PtSphere> sph;
+    std::vector<PtInstance> dinst;
+    std::vector<PtLight> lights;
+    std::vector<PtTriInfo> tinfo;                   // host path: per leaf record (sphere / instance entries unused)
+    std::vector<uint32_t> tri_flags;
+    ptbvh::Result& bvh = ctx->host_bvh;             // host path: the build's output arrays live in the context between uploads (cleared, capacity retained) while they stay below 1 GB
+    struct TrimBvh { pt_context* c; ~TrimBvh() { if (c->host_bvh.nodes.capacity() * sizeof(PtNode) > ((size_t)1 << 30)) c->host_bvh = ptbvh::Result(); } } trim_bvh{ctx};
+    size_t n_world_nodes = 0;
+    uint32_t n_top = 0, up_root_ref = PT_EMPTY_REF, up_max_leaf = 0, up_n_leaves = 0;
+    size_t up_n_nodes = 0, up_n_tris = 0;
+    float up_root_lo[3] = {0, 0, 0}, up_root_hi[3] = {0, 0, 0};
+    bool any_one_sided = false;
+    double t1 = t0;
+    ptbvh::DeviceBuild dev_build{ctx->stream, ctx->bvh_build_where, false, hipSuccess};
+    const int max_node_prims = d->max_node_prims > 0 ? d->max_node_prims : 4;
+
+    // ---- BVH, records and nodes on the device --------------------------------
+    // A world list of triangles only (no spheres, objects or instances) under the SAH split -- BASELINE's scenes -- never leaves the
+    // device: vertices and indices go up, pt_sah.hip builds the binary tree, writes the leaf and shading records in leaf order, collapses
+    // the tree into the 4-wide node array in the reference's depth-first numbering and finishes it (breadth-first top, order tables, axis
+    // bits, inverted empty slots).  Same arrays as the host path below, byte for byte (tests/test_gpu_hlbvh.py compares the digests).
+    // A list that needs a fallback split, PT_BVH_BUILD_HOST or PBRTGPU_HOST_FINISH=1 take the host path.
+    bool fast = false;
+    {
+        uint32_t any_object = 0;
+        for (uint32_t i = 0; i < d->n_meshes; i++) any_object |= d->meshes[i].object;
+        const int mnp = std::min(std::max(max_node_prims, 0), 255);
+        if (d->n_spheres == 0 && d->n_instances == 0 && any_object == 0 && d->split_method == PT_SPLIT_SAH && mnp >= 2 && d->n_triangles >= 2 &&
+            d->n_triangles < PT_LEAF_FIRST_MASK - 16u && ctx->bvh_build_where != PT_BVH_BUILD_HOST &&
+            (ctx->bvh_build_where == PT_BVH_BUILD_DEVICE || d->n_triangles >= ptbvh::kDeviceMinPrims) && !std::getenv("PBRTGPU_HOST_FINISH")) {
+            std::vector<uint32_t> m_triflags(d->n_meshes), m_flags(d->n_meshes);
+            std::vector<int32_t> m_material(d->n_meshes);
+            for (uint32_t i = 0; i < d->n_meshes; i++) {
+                uint32_t mf = d->meshes[i].flags, f = 0;
+                if (!(mf & PT_MESH_TWO_SIDED)) f |= PT_TRI_ONE_SIDED;
+                if (((mf & PT_MESH_REVERSE_ORIENTATION) != 0) ^ ((mf & PT_MESH_SWAPS_HANDEDNESS) != 0)) f |= PT_TRI_FLIP;
+                if (((mf & PT_MESH_HAS_N) && d->N) || ((mf & PT_MESH_HAS_S) && d->S) || ((mf & PT_MESH_HAS_UV) && d->UV)) f |= PT_TRI_HAS_ATTR;
+                const int32_t mat = d->meshes[i].material;
+                if (mat >= 0 && d->materials[mat].type != PT_MATERIAL_NONE) f |= (uint32_t)(mat + 1) << PT_TRI_MATERIAL_SHIFT;
+                m_triflags[i] = f;
+                if (!d->N) mf &= ~PT_MESH_HAS_N;
+                if (!d->S) mf &= ~PT_MESH_HAS_S;
+                if (!d->UV) mf &= ~PT_MESH_HAS_UV;
+                m_flags[i] = mf;
+                m_material[i] = mat;
+            }
+            ptbvh::SceneIn in{d->P, d->n_vertices, d->indices, d->tri_mesh, d->n_triangles, m_triflags.data(), m_material.data(), m_flags.data(), d->n_meshes};
+            ptbvh::SceneOut out;
+            hipError_t herr = hipSuccess;
+            const int rc = ptbvh::device_sah_scene(ctx->stream, in, (uint32_t)mnp, &out, &herr);
+            if (rc < 0) return ctx->hip_fail(herr, "scene build on the device");
+            mark("device scene (bounds, SAH, records, collapse)");
+            if (rc == 0) {
+                // light i = the i-th emissive triangle in primitive order (scene_context.rs:1218-1231)
+                std::vector<uint32_t> lit;
+                bool any_light_mesh = false;
+                for (uint32_t i = 0; i < d->n_meshes; i++) any_light_mesh |= d->meshes[i].area_light >= 0;
+                if (any_light_mesh) for (uint32_t t = 0; t < d->n_triangles; t++) if (d->meshes[d->tri_mesh[t]].area_light >= 0) lit.push_back(t);
+                if (lit.size() >= (1u << 24)) { out.free_all(); return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^24 emissive primitives"); }
+                std::vector<uint32_t> lit_rec(lit.size());
+                if (ptbvh::device_scene_lights(ctx->stream, &out, lit.data(), (uint32_t)lit.size(), lit_rec.data(), &herr) < 0) { out.free_all(); return ctx->hip_fail(herr, "light records on the device"); }
+                for (size_t i = 0; i < lit.size(); i++) {
+                    const uint32_t t = lit[i];
+                    const pt_mesh& m = d->meshes[d->tri_mesh[t]];
+                    const pt_area_light& al = d->area_lights[m.area_light];
+                    PtLight L;
+                    std::memset(&L, 0, sizeof(L));
+                    const uint32_t v0 = d->indices[3 * (size_t)t], v1 = d->indices[3 * (size_t)t + 1], v2 = d->indices[3 * (size_t)t + 2];
+                    const float* p0 = d->P + 3 * (size_t)v0; const float* p1 = d->P + 3 * (size_t)v1; const float* p2 = d->P + 3 * (size_t)v2;
+                    std::memcpy(L.p0, p0, 12); std::memcpy(L.p1, p1, 12); std::memcpy(L.p2, p2, 12);
+                    // Triangle::area (triangle.rs:579-588)
+                    float ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
+                    float bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
+                    float cx = (ay * bz) - (az * by), cy = (az * bx) - (ax * bz), cz = (ax * by) - (ay * bx);
+                    L.area = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);
+                    L.mesh_flags = m_flags[d->tri_mesh[t]];
+                    L.two_sided = al.two_sided;
+                    L.n_samples = (uint32_t)std::max(1, al.n_samples);
+                    std::memcpy(L.L, al.L, 12);
+                    L.tri_rec = lit_rec[i];
+                    L.prim = t;
+                    if (L.mesh_flags & PT_MESH_HAS_N) { std::memcpy(L.n0, d->N + 3 * (size_t)v0, 12); std::memcpy(L.n1, d->N + 3 * (size_t)v1, 12); std::memcpy(L.n2, d->N + 3 * (size_t)v2, 12); }
+                    lights.push_back(L);
+                }
+                (void)hipFree(out.d_rec_of_prim);
+                out.d_rec_of_prim = nullptr;
+                // the context's buffers take the blocks over
+                ctx->d_nodes.release(); ctx->d_tris.release(); ctx->d_tri_info.release();
+                ctx->d_nodes.p = out.d_nodes; ctx->d_nodes.bytes = (size_t)out.n_nodes4 * sizeof(PtNode);
+                ctx->d_tris.p = out.d_tris; ctx->d_tris.bytes = ((size_t)d->n_triangles + 1) * sizeof(PtTri);
+                ctx->d_tri_info.p = out.d_tinfo; ctx->d_tri_info.bytes = (size_t)d->n_triangles * sizeof(PtTriInfo);
+                up_n_nodes = out.n_nodes4; up_n_tris = (size_t)d->n_triangles + 1;
+                n_world_nodes = out.n_nodes4; n_top = out.n_top;
+                up_root_ref = 0; up_max_leaf = out.max_leaf; up_n_leaves = out.n_leaves;
+                std::memcpy(up_root_lo, out.root_lo, 12); std::memcpy(up_root_hi, out.root_hi, 12);
+                any_one_sided = out.any_one_sided != 0;
+                ctx->max_stack = 3u * out.max_depth4 + 2u;
+                dev_build.used = true;
+                fast = true;
+                t1 = now_ms();
+                mark("lights + hand-over");
+            }
+        }
+    }
+
+    if (!fast) {
     // ---- BVH (host) ---------------------------------------------------------
-    std::vector<uint32_t> tri_flags(d->n_triangles);
+    tri_flags.resize(d->n_triangles);
     ptbvh::parallel_for(d->n_triangles, [&](size_t t0_, size_t t1_) {
     for (size_t t = t0_; t < t1_; t++) {
         uint32_t mf = d->meshes[d->tri_mesh[t]].flags, f = 0;
@@ -517,7 +629,6 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     });
     mark("triangle flags");
-    std::vector<PtSphere> sph;
     std::vector<ptbvh::SpherePrim> sprims;
     build_spheres(d, sph, sprims);
     // Primitive lists (render_options.primitives and each object's list, scene_context.rs:1301-1316): triangles in array order with
@@ -545,10 +656,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         }
         return out;
     };
-    const int max_node_prims = d->max_node_prims > 0 ? d->max_node_prims : 4;
     const char* hlbvh_msg = "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)";
     // objects first: an instance's bound is its object's root bound under the instance transform
-    ptbvh::DeviceBuild dev_build{ctx->stream, ctx->bvh_build_where, false, hipSuccess};
     struct ObjectBvh { std::vector<Entry> list; ptbvh::Result res; float lo[3], hi[3]; bool direct = false; };
     std::vector<ObjectBvh> objs(n_objects);
     auto fill_prim = [&](const Entry& en, ptbvh::Prim* pr) {
@@ -578,15 +687,12 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     for (uint32_t i = 0; i < d->n_instances; i++)
         if (d->instances[i].object >= n_objects || objs[d->instances[i].object].list.empty()) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "instance of an unknown or empty object");
-    std::vector<PtInstance> dinst(d->n_instances);
+    dinst.resize(d->n_instances);
     mark("object trees");
     std::vector<Entry> world = make_list(0);
     mark("world primitive list");
     if (world.empty()) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "scene has no world primitives (objects are only rendered through ObjectInstance)");
     if ((uint64_t)world.size() >= PT_LEAF_FIRST_MASK - 16u) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "more than 2^26 primitives");
-    // the build's output arrays live in the context between uploads (cleared, capacity retained) while they stay below 1 GB
-    ptbvh::Result& bvh = ctx->host_bvh;
-    struct TrimBvh { pt_context* c; ~TrimBvh() { if (c->host_bvh.nodes.capacity() * sizeof(PtNode) > ((size_t)1 << 30)) c->host_bvh = ptbvh::Result(); } } trim_bvh{ctx};
     {
         // the world's primitive list: uninitialised storage, first touched by the threads that fill it, kept by the context for the next
         // upload (allocating and returning 72 MB per million triangles costs more than the device-side build)
@@ -625,7 +731,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     if (ctx->host_prims_cap > ((size_t)4 << 20)) { ctx->host_prims.reset(); ctx->host_prims_cap = 0; }
     mark("free primitive list");
-    const size_t n_world_nodes = bvh.nodes.size();          // the objects' trees are appended behind these
+    n_world_nodes = bvh.nodes.size();          // the objects' trees are appended behind these
     if (d->n_instances) for (size_t prim = 0; prim < world.size(); prim++) if (world[prim].kind == 2) dinst[world[prim].idx].world_prim = (uint32_t)prim;
     // one node array and one record array: the world first, then each object with its references shifted
     std::vector<Entry> rec_entry(bvh.tris.size() - 1);        // record -> what it stands for (shading records below)
@@ -668,11 +774,11 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         }
     }
     mark("record map + objects");
-    double t1 = now_ms();
+    t1 = now_ms();
     ctx->max_stack = bvh.max_stack + max_inner_stack;
 
     // ---- shading records ----------------------------------------------------
-    std::vector<PtTriInfo> tinfo(bvh.tris.size() - 1);      // per leaf record (sphere / instance entries unused)
+    tinfo.resize(bvh.tris.size() - 1);
     for (size_t r = 0; r < tinfo.size(); r++) {
         PtTriInfo& ti = tinfo[r];
         std::memset(&ti, 0, sizeof(ti));
@@ -693,7 +799,6 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     // one DiffuseAreaLight per emissive world primitive, in primitive order (scene_context.rs:1218-1231); lights inside objects are
     // dropped as in the reference (:1302-1304), instances carry none (TransformedPrimitive::get_area_light)
-    std::vector<PtLight> lights;
     for (uint32_t prim = 0; prim < world.size(); prim++) {
         const Entry& en = world[prim];
         const uint32_t rec = bvh.rec_of_prim[prim];
@@ -739,6 +844,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         }
     }
     if (lights.size() >= (1u << 24)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^24 emissive primitives");
+    for (uint32_t f : tri_flags) if (f & PT_TRI_ONE_SIDED) { any_one_sided = true; break; }
+    }          // host path
     std::vector<PtMaterial> mats(std::max<uint32_t>(d->n_materials, 1));
     std::memset(mats.data(), 0, mats.size() * sizeof(PtMaterial));
     bool general_materials = false;
@@ -809,11 +916,11 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     // What the lean node visit (pt_kernels.hip node_step_lean) reads beside the builder's output: the per-octant order tables, and
     // empty child slots as inverted boxes so that they fail the slab test by themselves (the builders leave them all-zero, as the
     // reference does; the general visit masks them out by the occupied-slot bits either way).
-    if (bvh.nodes.size() >= (1u << 25)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^25 BVH nodes (32-bit node offsets)");
+    if (!fast && bvh.nodes.size() >= (1u << 25)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^25 BVH nodes (32-bit node offsets)");
     // The builders emit nodes depth-first.  The top of the WORLD tree is renumbered breadth-first (the first PT_TOP_BFS_NODES nodes in
     // level order, everything else behind them in the old order), so that "node index < n" means "one of the top levels": k_trace keeps
     // those in LDS (PT_TOP_NODES).  Traversal order, boxes and references are untouched -- only where a node lives.
-    uint32_t n_top = 0;
+    if (!fast) {
     if (n_world_nodes > 0 && !(bvh.root_ref & PT_LEAF_BIT) && bvh.root_ref != PT_EMPTY_REF) {
         std::vector<uint32_t> bfs;
         bfs.reserve(PT_TOP_BFS_NODES);
@@ -861,8 +968,13 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     });
     if ((st = upload(ctx, ctx->d_nodes, bvh.nodes.data(), bvh.nodes.size())) != PT_OK) return st;
     if ((st = upload(ctx, ctx->d_tris, bvh.tris.data(), bvh.tris.size())) != PT_OK) return st;
-    ctx->n_nodes_up = bvh.nodes.size(); ctx->n_tris_up = bvh.tris.size();
     if ((st = upload(ctx, ctx->d_tri_info, tinfo.data(), tinfo.size())) != PT_OK) return st;
+    up_n_nodes = bvh.nodes.size(); up_n_tris = bvh.tris.size();
+    up_root_ref = bvh.root_ref; up_max_leaf = bvh.max_leaf; up_n_leaves = bvh.n_leaves;
+    std::memcpy(up_root_lo, bvh.root_lo, 12); std::memcpy(up_root_hi, bvh.root_hi, 12);
+    }          // host path
+    if (up_n_nodes >= (1u << 25)) return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^25 BVH nodes (32-bit node offsets)");
+    ctx->n_nodes_up = up_n_nodes; ctx->n_tris_up = up_n_tris;
     if ((st = upload(ctx, ctx->d_materials, mats.data(), mats.size())) != PT_OK) return st;
     ctx->light_samples_total = 0;
     for (const PtLight& L : lights) ctx->light_samples_total += L.n_samples;
@@ -919,9 +1031,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     sc.UV = d->UV ? ctx->d_UV.as<float>() : nullptr;
     sc.materials = ctx->d_materials.as<PtMaterial>();
     sc.general_materials = general_materials ? 1u : 0u;
-    sc.any_one_sided = 0;
-    for (uint32_t f : tri_flags) if (f & PT_TRI_ONE_SIDED) { sc.any_one_sided = 1; break; }
-    sc.dist_leaves = (bvh.max_leaf <= 8 && !std::getenv("PBRTGPU_SEQ_LEAVES")) ? 1u : 0u;
+    sc.any_one_sided = any_one_sided ? 1u : 0u;
+    sc.dist_leaves = (up_max_leaf <= 8 && !std::getenv("PBRTGPU_SEQ_LEAVES")) ? 1u : 0u;
     ctx->n_materials = d->n_materials;
     sc.lights = ctx->d_lights.as<PtLight>();
     sc.n_lights = (uint32_t)lights.size();
@@ -936,11 +1047,11 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     sc.n_spheres = d->n_spheres;
     if (d->n_spheres) sc.general_materials = 1;     // sphere scenes run the sphere-capable kernel instantiations (sorted shade queue)
     if (d->n_instances) { sc.general_materials = 1; sc.dist_leaves = 0; }      // k_trace_inst walks leaves per lane; one shade kernel handles everything
-    sc.root_ref = bvh.root_ref;
+    sc.root_ref = up_root_ref;
     sc.n_top = n_top;
-    for (int a = 0; a < 3; a++) { const float ext = bvh.root_hi[a] - bvh.root_lo[a]; sc.cell_scale[a] = ext > 0.0f ? (float)(1u << PT_SORT_CELL_BITS) / ext : 0.0f; }
-    std::memcpy(sc.wb_min, bvh.root_lo, 12);
-    std::memcpy(sc.wb_max, bvh.root_hi, 12);
+    for (int a = 0; a < 3; a++) { const float ext = up_root_hi[a] - up_root_lo[a]; sc.cell_scale[a] = ext > 0.0f ? (float)(1u << PT_SORT_CELL_BITS) / ext : 0.0f; }
+    std::memcpy(sc.wb_min, up_root_lo, 12);
+    std::memcpy(sc.wb_max, up_root_hi, 12);
     sc.max_depth = d->max_depth;
     sc.integrator = d->integrator;
     sc.direct_strategy = d->direct_strategy;
@@ -1106,8 +1217,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     for (int i = 0; i < 4; i++) { inf.sample_bounds[i] = fm.sample_bounds[i]; inf.cropped_bounds[i] = fm.crop[i]; }
     inf.spp = (int32_t)sb.spp;
     inf.n_lights = sc.n_lights;
-    inf.n_nodes = (uint32_t)bvh.nodes.size();
-    inf.n_leaves = bvh.n_leaves;
+    inf.n_nodes = (uint32_t)up_n_nodes;
+    inf.n_leaves = up_n_leaves;
     std::memcpy(inf.world_bound, sc.wb_min, 12);
     std::memcpy(inf.world_bound + 3, sc.wb_max, 12);
     inf.bvh_build_ms = t1 - t0;
@@ -1248,6 +1359,24 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
         }
         Q.shadow_key = ctx->d_sort_keys[0].as<uint32_t>();
     }
+    // Continuation rays in origin order as well, where it pays: once nodes + leaf records outgrow the 256 MiB Infinity Cache the traversal
+    // kernel waits on HBM, and rays that start in one cell miss the caches together instead of one by one.
+    Q.next_key = nullptr;
+    int sort_cont = ctx->sort_cont;
+    if (sort_cont < 0) sort_cont = (ctx->n_nodes_up * sizeof(PtNode) + ctx->n_tris_up * sizeof(PtTri) > ((size_t)256 << 20)) ? 1 : 0;
+    if (sc.integrator != PT_INTEGRATOR_PATH) sort_cont = 0;
+    if (sort_cont) {
+        if (ctx->csort_cap < ctx->pool_paths) {
+            const size_t tb = ptk_sort_rays_keep_temp_bytes((uint32_t)ctx->pool_paths);
+            if (tb == 0) return ctx->fail(PT_ERR_DEVICE, "radix sort scratch size query failed");
+            PT_HIP(ctx->d_csort_ids.alloc(ctx->pool_paths * 4));
+            PT_HIP(ctx->d_csort_keys[0].alloc(ctx->pool_paths * 4));
+            PT_HIP(ctx->d_csort_keys[1].alloc(ctx->pool_paths * 4));
+            PT_HIP(ctx->d_csort_temp.alloc(tb));
+            ctx->csort_cap = ctx->pool_paths;
+        }
+        Q.next_key = ctx->d_csort_keys[0].as<uint32_t>();
+    }
     PtCounters* cnt = ctx->d_counters.as<PtCounters>();
     uint32_t* err = ctx->d_err.as<uint32_t>();
     size_t ev_i = 0;
@@ -1361,19 +1490,31 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 }
             } else if (sc.n_lights > 0) {          // no lights: li() returns zero immediately (path.rs:71-74)
                 uint32_t* shadow_sorted = nullptr;          // the ordered shadow list for the next traversal launch, if one was made
+                uint32_t* cont_sorted = nullptr;            // the ordered copy of cur for the next traversal launch (sort_cont == 1)
+                uint32_t* cont_spare = ctx->d_csort_ids.as<uint32_t>();
                 auto trace = [&]() -> hipError_t {
                     PtQueues Qt = Q;
                     if (shadow_sorted) Qt.shadow = shadow_sorted;
                     shadow_sorted = nullptr;
+                    if (cont_sorted) Qt.cur = cont_sorted;
+                    cont_sorted = nullptr;
                     return ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Qt, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err);
                 };
                 // after a bounce's shading: order its shadow rays by where they start (pt_raysort.hip); costs one counter read-back
                 auto sort_shadow = [&]() -> pt_status {
-                    if (!Q.shadow_key) return PT_OK;
-                    uint32_t n_sh = 0;
-                    PT_HIP(hipMemcpyAsync(&n_sh, Q.counts + PT_Q_SHADOW, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    if (!Q.shadow_key && !Q.next_key) return PT_OK;
+                    uint32_t qc[PT_Q_SHADOW + 1];             // one read-back: the next bounce's continuation rays (prep has moved next to cur) and its shadow rays
+                    PT_HIP(hipMemcpyAsync(qc, Q.counts, sizeof(qc), hipMemcpyDeviceToHost, ctx->stream));
                     PT_HIP(hipStreamSynchronize(ctx->stream));
-                    if (n_sh < (uint32_t)ctx->sort_shadow_min) return PT_OK;
+                    const uint32_t n_sh = qc[PT_Q_SHADOW], n_next = qc[PT_Q_CUR];
+                    if (Q.next_key && n_next >= (uint32_t)std::max(ctx->sort_shadow_min, 1)) {
+                        // Q.next holds the list k_shade has just written; the ordered copy goes to the spare list
+                        PT_HIP(ptk_sort_rays_keep(ctx->stream, Q.next, cont_spare, ctx->d_csort_keys[0].as<uint32_t>(), ctx->d_csort_keys[1].as<uint32_t>(),
+                                                  ctx->d_csort_temp.p, ctx->d_csort_temp.bytes, n_next));
+                        if (sort_cont == 2) std::swap(Q.next, cont_spare);      // shading walks the ordered list too; the old list is the spare now
+                        else cont_sorted = cont_spare;
+                    }
+                    if (!Q.shadow_key || n_sh < (uint32_t)ctx->sort_shadow_min) return PT_OK;
                     PT_HIP(ptk_sort_shadow_rays(ctx->stream, Q.shadow, ctx->d_sort_ids.as<uint32_t>(), ctx->d_sort_keys[0].as<uint32_t>(),
                                                 ctx->d_sort_keys[1].as<uint32_t>(), ctx->d_sort_temp.p, ctx->d_sort_temp.bytes, n_sh, &shadow_sorted));
                     return PT_OK;
@@ -1685,7 +1826,7 @@ pt_status pt_trace_wavefront(pt_context* ctx, uint32_t n, const float* o, const 
     PtQueues Q;
     Q.cur = ctx->d_qa.as<uint32_t>(); Q.next = ctx->d_qb.as<uint32_t>();
     Q.nee = ctx->d_qnee.as<uint32_t>(); Q.counts = ctx->d_counts.as<uint32_t>(); Q.sorted = ctx->d_qsorted.as<uint32_t>();
-    Q.shadow = ctx->d_qshadow.as<uint32_t>(); Q.probe = ctx->d_qprobe.as<uint32_t>(); Q.shadow_key = nullptr; Q.bin = nullptr;
+    Q.shadow = ctx->d_qshadow.as<uint32_t>(); Q.probe = ctx->d_qprobe.as<uint32_t>(); Q.shadow_key = nullptr; Q.next_key = nullptr; Q.bin = nullptr;
     uint32_t* const dst_q[3] = {Q.cur, Q.shadow, Q.probe};
     for (int k = 0; k < 3; k++)
         if (!ids[k].empty()) PT_HIP(hipMemcpyAsync(dst_q[k], ids[k].data(), ids[k].size() * 4, hipMemcpyHostToDevice, ctx->stream));

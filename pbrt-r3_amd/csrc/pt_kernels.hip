@@ -2180,6 +2180,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     __shared__ float4 s_stage[7][PT_BLOCK];
     __shared__ uint32_t s_pend[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: path ids of the iterations not yet queued (their queue bits: `pend_want`)
     __shared__ uint32_t s_pkey[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: the sort key of those iterations' shadow rays
+    __shared__ uint32_t s_ckey[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: the sort key of their continuation rays (Q.next_key)
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
     uint32_t n_vert = 0;
@@ -2221,7 +2222,10 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             if (j < n_batch) {
                 const uint32_t e = pend_want >> (4u * j), ep = s_pend[j][threadIdx.x];
                 const unsigned long long mc = __ballot((e & 1u) != 0), mn = __ballot((e & 2u) != 0), ms = __ballot((e & 4u) != 0), mp = __ballot((e & 8u) != 0);
-                if (e & 1u) Q.next[bc + (uint32_t)__popcll(mc & below)] = ep;
+                if (e & 1u) {
+                    Q.next[bc + (uint32_t)__popcll(mc & below)] = ep;
+                    if (Q.next_key) Q.next_key[bc + (uint32_t)__popcll(mc & below)] = s_ckey[j][threadIdx.x];
+                }
                 if (e & 2u) Q.nee[bn + (uint32_t)__popcll(mn & below)] = ep;
                 if (e & 4u) {
                     Q.shadow[bs + (uint32_t)__popcll(ms & below)] = ep;
@@ -2361,6 +2365,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     // no BSDF: continue through the surface, same bounce count (path.rs:108-111)
                     V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
                     o_ray_o = make_float4(no.x, no.y, no.z, PT_INF); wr |= 1u;
+                    if (Q.next_key) s_ckey[n_batch][threadIdx.x] = ray_sort_key(sc, no, rd);
                     cont = true; PT_COMMIT_NOW(0);
                 } else {
                     n_vert++;
@@ -2516,6 +2521,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                             // roulette continued with direction z = 0 (profiles/r03_deferred_store_miscompile.md)
                             o_ray_d = make_float4(wi.x, wi.y, wi.z, opaque_zero());
                             o_beta = make_float4(beta.x, beta.y, beta.z, eta_scale);
+                            if (Q.next_key) s_ckey[n_batch][threadIdx.x] = ray_sort_key(sc, no, wi);
                             wr |= 3u; PT_COMMIT_NOW(4);
                             bounces++;
                             cont = true;
@@ -3007,7 +3013,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
                         // sample arrays while arrays are left, else one estimate from two plain 2-D draws.  Element k of an array of n, for pixel
                         // sample s, is drawn at sample number s n + k (base_sampler.rs:59-70), and EVERY array comes from dimensions (5, 6): the
                         // reference computes the array dimension once, before its loop over the arrays (sobol.rs:60-75, halton.rs:193-208;
-                        // quirk Q22) -- u_light and u_scattering coincide.
+                        // quirk Q23) -- u_light and u_scattering coincide.
                         uint32_t arr = P.nee[p], off = 0;
                         const uint64_t sample_num = (uint64_t)R.s0 + p / R.n_pix;
                         for (uint32_t j = 0; j < sc.n_lights; j++) {

@@ -25,6 +25,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "pt_bvh.h"
 
@@ -34,6 +35,9 @@ namespace {
 
 constexpr int kB = 12;                   // SAH buckets (sah.rs)
 constexpr uint32_t ST_NEW = 0, ST_SPLIT = 1, ST_LEAF = 2;
+constexpr uint32_t kEqualMode = 0xffffffffu;   // SNodes::minb of a node split by equal counts
+constexpr uint32_t kEqualMax = 4096;           // longest range the equal-counts fallback orders on the device
+constexpr uint32_t kEqualGrid = 256;           // workgroups of k_sah_equal_rank (each takes every 256th listed node)
 
 __device__ inline uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ inline float ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
@@ -192,7 +196,7 @@ __device__ inline float box_area(const Box& b) {
 }
 // per splitting node: the SAH costs in the host's order of operations, the split, the children
 __global__ __launch_bounds__(64) void k_sah_split(SNodes N, const uint32_t* act, uint32_t n_act, const uint32_t* bcnt, const uint32_t* bbox, uint32_t* next_act, uint32_t* counters,
-                                                 uint32_t* flags) {
+                                                 uint32_t* flags, uint32_t* eq_list) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_act) return;
     const uint32_t nd = act[k];
@@ -227,10 +231,20 @@ __global__ __launch_bounds__(64) void k_sah_split(SNodes N, const uint32_t* act,
     uint32_t nl = 0;
     for (int b = 0; b <= min_bucket; b++) nl += (uint32_t)count[b];
     const uint32_t lo = N.lo[nd], hi = N.hi[nd];
-    if (nl == 0 || nl == hi - lo) { atomicOr(flags, 2u); N.state[nd] = ST_LEAF; return; }      // equal-counts fallback: the host builds
+    bool equal_counts = false;
+    if (nl == 0 || nl == hi - lo) {
+        // The cheapest split leaves one side empty: split_equal_counts (build/equal_counts.rs; pt_bvh.cpp "!have_split") -- the range in
+        // stable centroid order, cut in the middle.  Ranges k_sah_equal_rank can hold in LDS are ordered here; longer ones (many primitives
+        // with one centroid bucket between them: not seen outside constructed inputs) go back to the host.
+        if (hi - lo > kEqualMax) { atomicOr(flags, 2u); N.state[nd] = ST_LEAF; return; }
+        equal_counts = true;
+        nl = (hi - lo) / 2u;
+        const uint32_t e = atomicAdd(&counters[4], 1u);
+        eq_list[e] = nd;
+    }
     const uint32_t c = atomicAdd(&counters[0], 2u);
     if (c + 2u > N.cap) { atomicOr(flags, 4u); N.state[nd] = ST_LEAF; return; }
-    N.minb[nd] = (uint32_t)min_bucket;
+    N.minb[nd] = equal_counts ? kEqualMode : (uint32_t)min_bucket;
     N.mid[nd] = lo + nl;
     N.left[nd] = c; N.right[nd] = c + 1u;
     for (uint32_t ch = 0; ch < 2; ch++) {
@@ -247,7 +261,28 @@ __global__ __launch_bounds__(256) void k_sah_flags(const uint32_t* __restrict__ 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t nd = node_of[i];
-    flag[i] = (N.state[nd] == ST_SPLIT && (uint32_t)bucket[i] <= N.minb[nd]) ? 1u : 0u;
+    flag[i] = (N.state[nd] == ST_SPLIT && N.minb[nd] != kEqualMode && (uint32_t)bucket[i] <= N.minb[nd]) ? 1u : 0u;
+}
+// split_equal_counts: one workgroup per such node ranks its items by (centroid along the split axis, position) -- the order std::stable_sort
+// leaves -- and k_sah_scatter sends item i to lo + rank
+__global__ __launch_bounds__(256) void k_sah_equal_rank(const SItem* __restrict__ items, SNodes N, const uint32_t* __restrict__ eq_list, const uint32_t* __restrict__ counters,
+                                                       uint32_t* eq_rank) {
+    __shared__ float s_key[kEqualMax];
+    const uint32_t n_eq = counters[4];               // this level's equal-counts nodes (almost always none: the launch costs a few microseconds)
+    for (uint32_t e = blockIdx.x; e < n_eq; e += gridDim.x) {
+        const uint32_t nd = eq_list[e];
+        const uint32_t lo = N.lo[nd], n = N.hi[nd] - lo;
+        const int dim = (int)N.axis[nd];
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_key[i] = items[lo + i].c[dim];
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const float k = s_key[i];
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < n; j++) r += (s_key[j] < k || (j < i && !(k < s_key[j]))) ? 1u : 0u;
+            eq_rank[lo + i] = r;
+        }
+    }
 }
 // exclusive prefix sum of flag[] in three steps: 1024-item blocks, the block totals by one workgroup, add back
 __global__ __launch_bounds__(256) void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t n, uint32_t* out, uint32_t* totals) {
@@ -289,12 +324,16 @@ __global__ __launch_bounds__(1024) void k_scan_totals(uint32_t* totals, uint32_t
     }
 }
 __global__ __launch_bounds__(256) void k_sah_scatter(const SItem* __restrict__ src, const uint32_t* __restrict__ node_of, const uint32_t* __restrict__ flag,
-                                                    const uint32_t* __restrict__ pre, const uint32_t* __restrict__ totals, uint32_t n, SNodes N, SItem* dst, uint32_t* node_of_dst) {
+                                                    const uint32_t* __restrict__ pre, const uint32_t* __restrict__ totals, uint32_t n, SNodes N, SItem* dst, uint32_t* node_of_dst,
+                                                    const uint32_t* __restrict__ eq_rank) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t nd = node_of[i];
     uint32_t to = i, child = nd;
-    if (N.state[nd] == ST_SPLIT) {
+    if (N.state[nd] == ST_SPLIT && N.minb[nd] == kEqualMode) {
+        to = N.lo[nd] + eq_rank[i];
+        child = to < N.mid[nd] ? N.left[nd] : N.right[nd];
+    } else if (N.state[nd] == ST_SPLIT) {
         const uint32_t lo = N.lo[nd];
         const uint32_t rank_l = (pre[i] + totals[i >> 10]) - (pre[lo] + totals[lo >> 10]);        // left items of the range before this one
         if (flag[i]) { to = lo + rank_l; child = N.left[nd]; }
@@ -315,6 +354,209 @@ __global__ __launch_bounds__(256) void k_sah_export(SNodes N, uint32_t n_nodes, 
 __global__ __launch_bounds__(256) void k_sah_order(const SItem* __restrict__ items, uint32_t n, uint32_t* order) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) order[i] = items[i].prim;
+}
+
+
+// ---- the rest of an upload on the device (triangle-only world lists): bounds from the vertices, leaf records and shading records in leaf
+// order, the collapse of the binary tree into 128-byte 4-wide nodes in the reference's depth-first numbering (qbvh_x86.rs:93-176, the host
+// version is Collapser in pt_bvh.cpp), the breadth-first renumbering of the top of the tree and the finishing pass of pt_context.cpp --
+// so that neither the tree nor the primitive order ever crosses PCIe.  Byte for byte the arrays the host path uploads.
+__global__ __launch_bounds__(256) void k_sc_bounds(const float* __restrict__ P, const uint32_t* __restrict__ idx, uint32_t n, float* raw) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float* p0 = P + 3 * (size_t)idx[3 * (size_t)t];
+    const float* p1 = P + 3 * (size_t)idx[3 * (size_t)t + 1];
+    const float* p2 = P + 3 * (size_t)idx[3 * (size_t)t + 2];
+    for (int a = 0; a < 3; a++) {                        // union3 (triangle.rs:189-200)
+        raw[(size_t)t * 6 + a] = fminf(fminf(p0[a], p1[a]), p2[a]);
+        raw[(size_t)t * 6 + 3 + a] = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
+    }
+}
+// record r = primitive order[r]: the 48-byte leaf record, the 32-byte shading record, the primitive -> record map
+__global__ __launch_bounds__(256) void k_sc_records(const uint32_t* __restrict__ order, const float* __restrict__ P, const uint32_t* __restrict__ idx,
+                                                   const uint32_t* __restrict__ tri_mesh, const uint32_t* __restrict__ mesh_triflags, const int32_t* __restrict__ mesh_material,
+                                                   const uint32_t* __restrict__ mesh_flags, uint32_t n, PtTri* tris, PtTriInfo* tinfo, uint32_t* rec_of_prim, uint32_t* small) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n) return;
+    if (r == n) {                                        // one zero pad record: the kernels fetch triangle records two at a time
+        PtTri pad;
+        pad.p0[0] = pad.p0[1] = pad.p0[2] = 0.0f; pad.p1[0] = pad.p1[1] = pad.p1[2] = 0.0f; pad.p2[0] = pad.p2[1] = pad.p2[2] = 0.0f;
+        pad.prim = 0; pad.flags = PT_TRI_LAST; pad.light1 = 0;
+        tris[n] = pad;
+        return;
+    }
+    const uint32_t t = order[r];
+    const uint32_t v0 = idx[3 * (size_t)t], v1 = idx[3 * (size_t)t + 1], v2 = idx[3 * (size_t)t + 2], m = tri_mesh[t];
+    PtTri tr;
+    for (int a = 0; a < 3; a++) { tr.p0[a] = P[3 * (size_t)v0 + a]; tr.p1[a] = P[3 * (size_t)v1 + a]; tr.p2[a] = P[3 * (size_t)v2 + a]; }
+    const uint32_t f = mesh_triflags[m];
+    tr.prim = t;
+    tr.flags = f & ~(PT_TRI_LAST | PT_TRI_SPHERE | PT_TRI_INSTANCE);
+    tr.light1 = 0;
+    tris[r] = tr;
+    PtTriInfo ti;
+    ti.v[0] = v0; ti.v[1] = v1; ti.v[2] = v2; ti.mesh = m; ti.light = -1; ti.material = mesh_material[m]; ti.mesh_flags = mesh_flags[m]; ti.pad = 0;
+    tinfo[r] = ti;
+    rec_of_prim[t] = r;
+    if (f & PT_TRI_ONE_SIDED) small[4] = 1u;             // PtScene::any_one_sided
+}
+// PT_TRI_LAST closes each leaf; leaves and the largest leaf are counted
+__global__ __launch_bounds__(256) void k_sc_leafmark(const LbvhNode* __restrict__ nodes, uint32_t n_nodes, PtTri* tris, uint32_t* small) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool leaf = k < n_nodes && nodes[k].count > 0;
+    uint32_t cnt = 0;
+    if (leaf) { cnt = nodes[k].count; tris[nodes[k].first + cnt - 1u].flags |= PT_TRI_LAST; }
+    const unsigned long long m = __ballot(leaf);
+    uint32_t mx = cnt;
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) { atomicAdd(&small[0], (uint32_t)__popcll(m)); atomicMax(&small[1], mx); }
+}
+// the (up to four) binary nodes that fill the slots of the 4-wide node made from binary node b (Collapser::slots_of)
+__device__ inline void sc_slots(const LbvhNode* __restrict__ nodes, uint32_t b, int32_t s[4]) {
+    const int32_t l = nodes[b].left, r = nodes[b].right;
+    s[0] = s[1] = s[2] = s[3] = -1;
+    if (nodes[l].count > 0) s[0] = l; else { s[0] = nodes[l].left; s[1] = nodes[l].right; }
+    if (nodes[r].count > 0) s[2] = r; else { s[2] = nodes[r].left; s[3] = nodes[r].right; }
+}
+// bottom-up, one launch per even binary level: 4-wide nodes in the subtree of each interior node of the level (itself included)
+__global__ __launch_bounds__(256) void k_sc_size4(const LbvhNode* __restrict__ nodes, uint32_t begin, uint32_t count, uint32_t* size4, uint32_t level, uint32_t* small) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t b = begin + i;
+    if (nodes[b].count > 0) return;
+    int32_t s[4];
+    sc_slots(nodes, b, s);
+    uint32_t c = 1;
+    for (int k = 0; k < 4; k++) if (s[k] >= 0 && nodes[s[k]].count == 0) c += size4[s[k]];
+    size4[b] = c;
+    atomicMax(&small[2], level / 2u + 1u);               // deepest 4-wide level
+}
+// top-down: the node takes the index it was given, its subtrees follow in slot order (depth-first numbering)
+__global__ __launch_bounds__(256) void k_sc_idx4(const LbvhNode* __restrict__ nodes, uint32_t begin, uint32_t count, const uint32_t* __restrict__ size4, uint32_t* idx4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t b = begin + i;
+    if (nodes[b].count > 0) return;
+    int32_t s[4];
+    sc_slots(nodes, b, s);
+    uint32_t next = idx4[b] + 1u;
+    for (int k = 0; k < 4; k++)
+        if (s[k] >= 0 && nodes[s[k]].count == 0) { idx4[s[k]] = next; next += size4[s[k]]; }
+}
+// The first PT_TOP_BFS_NODES 4-wide nodes in level order (children in slot order), as pt_context.cpp numbers them: top[k] = depth-first index
+// of the k-th, sorted[] the same indices in increasing order (a node that is not among them moves up by the number of those below it).
+__global__ __launch_bounds__(1024) void k_sc_top(const LbvhNode* __restrict__ nodes, const uint32_t* __restrict__ idx4, uint32_t* top_bin, uint32_t* top_sorted, uint32_t* small) {
+    __shared__ uint32_t s_list[PT_TOP_BFS_NODES];       // binary node ids, level order
+    __shared__ uint32_t s_old[PT_TOP_BFS_NODES];
+    __shared__ uint32_t s_scan[1024];
+    __shared__ uint32_t s_total, s_lvl_begin, s_lvl_end;
+    if (threadIdx.x == 0) { s_list[0] = 0; s_total = 1; s_lvl_begin = 0; s_lvl_end = 1; }
+    __syncthreads();
+    for (;;) {
+        const uint32_t lb = s_lvl_begin, le = s_lvl_end, total = s_total;
+        if (lb == le || total >= PT_TOP_BFS_NODES) break;
+        uint32_t carry = 0;                              // children appended so far for this level
+        for (uint32_t base = lb; base < le; base += 1024u) {
+            const uint32_t j = base + threadIdx.x;
+            int32_t s[4] = {-1, -1, -1, -1};
+            uint32_t c = 0;
+            if (j < le) {
+                sc_slots(nodes, s_list[j], s);
+                for (int k = 0; k < 4; k++) { if (s[k] >= 0 && nodes[s[k]].count == 0) c++; else s[k] = -1; }
+            }
+            s_scan[threadIdx.x] = c;
+            __syncthreads();
+            for (uint32_t off = 1; off < 1024u; off <<= 1) {
+                const uint32_t v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
+                __syncthreads();
+                s_scan[threadIdx.x] += v;
+                __syncthreads();
+            }
+            uint32_t at = total + carry + s_scan[threadIdx.x] - c;
+            for (int k = 0; k < 4; k++) if (s[k] >= 0) { if (at < PT_TOP_BFS_NODES) s_list[at] = (uint32_t)s[k]; at++; }
+            carry += s_scan[1023];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { s_lvl_begin = le; s_total = min(total + carry, (uint32_t)PT_TOP_BFS_NODES); s_lvl_end = s_total; }
+        __syncthreads();
+    }
+    const uint32_t n_top = s_total;
+    for (uint32_t k = threadIdx.x; k < n_top; k += 1024u) { s_old[k] = idx4[s_list[k]]; top_bin[k] = s_list[k]; }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_top; k += 1024u) {
+        const uint32_t v = s_old[k];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n_top; j++) rank += s_old[j] < v ? 1u : 0u;
+        top_sorted[rank] = v;
+    }
+    if (threadIdx.x == 0) small[3] = n_top;
+}
+// where depth-first index `old` lives after the renumbering
+__device__ inline uint32_t sc_new_index(uint32_t old, const uint32_t* s_sorted, const uint32_t* s_rank_of_sorted, uint32_t n_top) {
+    uint32_t lo = 0, hi = n_top;                          // lower bound
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_sorted[mid] < old) lo = mid + 1; else hi = mid; }
+    if (lo < n_top && s_sorted[lo] == old) return s_rank_of_sorted[lo];
+    return n_top + old - lo;
+}
+// one 4-wide node per interior node of an even level, finished as pt_context.cpp finishes it: order tables, +0 for zeros, the split axes
+// in bits 26..27 of the child references, inverted boxes in the empty slots
+__global__ __launch_bounds__(256) void k_sc_emit(const LbvhNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ idx4, const uint32_t* __restrict__ top_bin,
+                                                const uint32_t* __restrict__ top_sorted, const uint32_t* __restrict__ small, PtNode* out) {
+    __shared__ uint32_t s_sorted[PT_TOP_BFS_NODES], s_rank[PT_TOP_BFS_NODES];
+    const uint32_t n_top = small[3];
+    for (uint32_t k = threadIdx.x; k < n_top; k += blockDim.x) s_sorted[k] = top_sorted[k];
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_top; k += blockDim.x) {      // breadth-first rank of the node whose old index is the j-th smallest
+        const uint32_t old = idx4[top_bin[k]];
+        uint32_t lo = 0, hi = n_top;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_sorted[mid] < old) lo = mid + 1; else hi = mid; }
+        s_rank[lo] = k;
+    }
+    __syncthreads();
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_nodes || idx4[b] == 0xffffffffu) return;
+    const LbvhNode n = nodes[b];
+    const LbvhNode c0 = nodes[n.left], c1 = nodes[n.right];
+    int32_t s[4];
+    sc_slots(nodes, b, s);
+    PtNode nd;
+    uint32_t axes = (uint32_t)n.axis | ((uint32_t)c0.axis << 2) | ((uint32_t)c1.axis << 4);
+    const uint32_t ax_of[4] = {axes & 3u, (axes >> 2) & 3u, 0u, (axes >> 4) & 3u};
+    for (int k = 0; k < 4; k++) {
+        if (s[k] < 0) {
+            nd.child[k] = PT_EMPTY_REF;
+            for (int a = 0; a < 3; a++) { nd.bmin[a][k] = __builtin_inff(); nd.bmax[a][k] = -__builtin_inff(); }
+            continue;
+        }
+        const LbvhNode sl = nodes[s[k]];
+        for (int a = 0; a < 3; a++) {
+            nd.bmin[a][k] = sl.lo[a] == 0.0f ? 0.0f : sl.lo[a];
+            nd.bmax[a][k] = sl.hi[a] == 0.0f ? 0.0f : sl.hi[a];
+        }
+        uint32_t ref;
+        if (sl.count > 0) ref = PT_LEAF_BIT | ((min(sl.count, 8u) - 1u) << PT_LEAF_COUNT_SHIFT) | sl.first;
+        else ref = sc_new_index(idx4[s[k]], s_sorted, s_rank, n_top);
+        nd.child[k] = (ref & ~(3u << PT_REF_AXIS_SHIFT)) | (ax_of[k] << PT_REF_AXIS_SHIFT);
+        axes |= 1u << (8 + k);
+    }
+    nd.axes = axes;
+    uint32_t lut = 0;
+    for (uint32_t oct = 0; oct < 8; oct++)
+        for (uint32_t k = 0; k < 3; k++)
+            if ((oct >> ((axes >> (2 * k)) & 3u)) & 1u) lut |= 1u << (8 * k + oct);
+    nd.order_lut = lut;
+    nd.pad[0] = 0; nd.pad[1] = 0;
+    out[sc_new_index(idx4[b], s_sorted, s_rank, n_top)] = nd;
+}
+// emissive primitives: record of each (for the host's light list), then the light numbers back into the records
+__global__ __launch_bounds__(256) void k_sc_light_recs(const uint32_t* __restrict__ prims, uint32_t n, const uint32_t* __restrict__ rec_of_prim, uint32_t* recs, PtTri* tris,
+                                                      PtTriInfo* tinfo) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = rec_of_prim[prims[i]];
+    recs[i] = r;
+    tris[r].light1 = i + 1u;
+    tinfo[r].light = (int32_t)i;
 }
 
 // Device scratch for one build.  The blocks come out of an arena the calling thread keeps per device (one hipMalloc, reused by every
@@ -356,6 +598,22 @@ struct Scratch {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 struct ArenaScope { ArenaScope() { t_arena.begin(); } ~ArenaScope() { t_arena.end(); } };
+// page-locked staging for a scene's vertices / indices, kept by the calling thread and regrown
+static float* scene_staging(size_t bytes) {
+    struct Holder {
+        void* buf = nullptr;
+        size_t cap = 0;
+        ~Holder() { if (buf && getpid() != (pid_t)syscall(SYS_gettid)) (void)hipHostFree(buf); }
+    };
+    static thread_local Holder h;
+    if (bytes > h.cap) {
+        if (h.buf) (void)hipHostFree(h.buf);
+        h.buf = nullptr; h.cap = 0;
+        if (hipHostMalloc(&h.buf, bytes, hipHostMallocDefault) != hipSuccess) { h.buf = nullptr; return nullptr; }
+        h.cap = bytes;
+    }
+    return (float*)h.buf;
+}
 #define SAH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { if (err) *err = e_; return -1; } } while (0)
 
 }  // namespace
@@ -363,7 +621,10 @@ struct ArenaScope { ArenaScope() { t_arena.begin(); } ~ArenaScope() { t_arena.en
 // SAH binary build on the device.  raw_bounds = n x {lo[3], hi[3]} (host memory, not yet inflated).  On success (0): order[k] = primitive
 // stored k-th, nodes[0] the root.  1: the host has to build instead (equal-counts fallback needed, non-finite bounds, too few items);
 // -1: HIP error.
-int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes, hipError_t* err) {
+// With `scene` the bounds come from the scene's vertices (uploaded here) and nothing is read back: the leaf records, the shading records and
+// the finished 4-wide node array are produced on the device and handed over in `sout` (plain hipMalloc blocks the caller owns from then on).
+static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes, hipError_t* err,
+                     const SceneIn* scene, SceneOut* sout) {
     ArenaScope arena_scope;          // declared before every Scratch: destroyed after them
     const bool trace = std::getenv("PBRTGPU_BUILD_TRACE") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -384,6 +645,9 @@ int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max
     const uint32_t n_sblocks = (n + 1023u) / 1024u;
     SAH_TRY(d_tot.alloc((size_t)n_sblocks * 4));
     SAH_TRY(d_small.alloc(64));
+    Scratch d_eqlist, d_eqrank;
+    SAH_TRY(d_eqlist.alloc((size_t)max_split * 4));
+    SAH_TRY(d_eqrank.alloc((size_t)n * 4));
     SNodes N;
     {
         uint32_t* b = d_nodes.as<uint32_t>();
@@ -395,9 +659,32 @@ int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max
     uint32_t* counters = d_small.as<uint32_t>();       // [0] nodes, [1] splitting this level, [2] next active, [3] leaves
     uint32_t* flags = counters + 8;
     SAH_TRY(hipMemsetAsync(d_small.p, 0, 64, st));
-    SAH_TRY(hipMemcpyAsync(d_raw.p, raw_bounds, (size_t)n * 24, hipMemcpyHostToDevice, st));
-    if (trace) { const double ta = now(); (void)hipStreamSynchronize(st); std::fprintf(stderr, "[bvh] device SAH: bounds upload %.2f ms (%.1f MB)\n", now() - ta, n * 24e-6); }
     const uint32_t blocks = (n + 255u) / 256u;
+    Scratch d_P, d_idx, d_tmesh, d_mtab;
+    if (scene) {
+        // the scene's arrays go up through page-locked staging filled by the host's threads (from pageable memory the runtime stages the copy
+        // itself at a few GB/s); the per-mesh tables are tiny
+        const size_t nP = 3 * (size_t)scene->n_vertices, nI = 3 * (size_t)n, nm = scene->n_meshes;
+        SAH_TRY(d_P.alloc(nP * 4)); SAH_TRY(d_idx.alloc(nI * 4)); SAH_TRY(d_tmesh.alloc((size_t)n * 4)); SAH_TRY(d_mtab.alloc(nm * 12 + 16));
+        float* stage = scene_staging((nP + nI + n + 3 * nm) * 4);
+        if (!stage) return 1;
+        uint32_t* su = reinterpret_cast<uint32_t*>(stage);
+        parallel_for(nP, [&](size_t a, size_t b) { std::memcpy(stage + a, scene->P + a, (b - a) * 4); });
+        parallel_for(nI, [&](size_t a, size_t b) { std::memcpy(su + nP + a, scene->indices + a, (b - a) * 4); });
+        parallel_for((size_t)n, [&](size_t a, size_t b) { std::memcpy(su + nP + nI + a, scene->tri_mesh + a, (b - a) * 4); });
+        std::memcpy(su + nP + nI + n, scene->mesh_triflags, nm * 4);
+        std::memcpy(su + nP + nI + n + nm, scene->mesh_material, nm * 4);
+        std::memcpy(su + nP + nI + n + 2 * nm, scene->mesh_flags, nm * 4);
+        SAH_TRY(hipMemcpyAsync(d_P.p, stage, nP * 4, hipMemcpyHostToDevice, st));
+        SAH_TRY(hipMemcpyAsync(d_idx.p, su + nP, nI * 4, hipMemcpyHostToDevice, st));
+        SAH_TRY(hipMemcpyAsync(d_tmesh.p, su + nP + nI, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        SAH_TRY(hipMemcpyAsync(d_mtab.p, su + nP + nI + n, nm * 12, hipMemcpyHostToDevice, st));
+        k_sc_bounds<<<blocks, 256, 0, st>>>(d_P.as<float>(), d_idx.as<uint32_t>(), n, d_raw.as<float>());
+        if (trace) { const double ta = now(); (void)hipStreamSynchronize(st); std::fprintf(stderr, "[bvh] device scene: vertices + indices staged and uploaded (%.1f MB), bounds on the device: %.2f ms since entry, %.2f ms waiting\n", (nP + nI + n) * 4e-6, now() - t0, now() - ta); }
+    } else {
+        SAH_TRY(hipMemcpyAsync(d_raw.p, raw_bounds, (size_t)n * 24, hipMemcpyHostToDevice, st));
+        if (trace) { const double ta = now(); (void)hipStreamSynchronize(st); std::fprintf(stderr, "[bvh] device SAH: bounds upload %.2f ms (%.1f MB)\n", now() - ta, n * 24e-6); }
+    }
     k_sah_items<<<blocks < 4096u ? blocks : 4096u, 256, 0, st>>>(d_raw.as<float>(), n, d_items[0].as<SItem>(), d_nodeof[0].as<uint32_t>(), flags);
     k_sah_root<<<1, 64, 0, st>>>(N, n, counters);
     const uint32_t root_act = 0;
@@ -406,6 +693,8 @@ int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max
     int cur = 0, acur = 0;
     uint32_t n_act = 1, levels = 0;
     uint32_t host_small[12];
+    std::vector<uint32_t> level_begin(1, 0u);          // binary nodes of level l: [level_begin[l], level_begin[l + 1]) -- node numbers come from one counter, level by level
+    level_begin.push_back(1u);
     while (n_act > 0) {
         if (++levels > 512u) return 1;
         SItem* items = d_items[cur].as<SItem>();
@@ -413,15 +702,17 @@ int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max
         const uint32_t* act = d_act[acur].as<uint32_t>();
         uint32_t* next_act = d_act[acur ^ 1].as<uint32_t>();
         SAH_TRY(hipMemsetAsync(counters + 1, 0, 8, st));         // splitting / next-active counts of this level
+        SAH_TRY(hipMemsetAsync(counters + 4, 0, 4, st));         // ... and its equal-counts nodes
         k_sah_bounds<<<blocks, 256, 0, st>>>(items, node_of, n, N);
         k_sah_decide<<<(n_act + 255u) / 256u, 256, 0, st>>>(N, act, n_act, max_prims, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), counters);
         k_sah_buckets<<<blocks, 256, 0, st>>>(items, node_of, n, N, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), d_bucket.as<uint8_t>());
-        k_sah_split<<<(n_act + 63u) / 64u, 64, 0, st>>>(N, act, n_act, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), next_act, counters, flags);
+        k_sah_split<<<(n_act + 63u) / 64u, 64, 0, st>>>(N, act, n_act, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), next_act, counters, flags, d_eqlist.as<uint32_t>());
+        k_sah_equal_rank<<<kEqualGrid, 256, 0, st>>>(items, N, d_eqlist.as<uint32_t>(), counters, d_eqrank.as<uint32_t>());
         k_sah_flags<<<blocks, 256, 0, st>>>(node_of, d_bucket.as<uint8_t>(), n, N, d_flag.as<uint32_t>());
         k_scan_blocks<<<n_sblocks, 256, 0, st>>>(d_flag.as<uint32_t>(), n, d_pre.as<uint32_t>(), d_tot.as<uint32_t>());
         k_scan_totals<<<1, 1024, 0, st>>>(d_tot.as<uint32_t>(), n_sblocks);
         k_sah_scatter<<<blocks, 256, 0, st>>>(items, node_of, d_flag.as<uint32_t>(), d_pre.as<uint32_t>(), d_tot.as<uint32_t>(), n, N, d_items[cur ^ 1].as<SItem>(),
-                                              d_nodeof[cur ^ 1].as<uint32_t>());
+                                              d_nodeof[cur ^ 1].as<uint32_t>(), d_eqrank.as<uint32_t>());
         SAH_TRY(hipGetLastError());
         SAH_TRY(hipMemcpyAsync(host_small, counters, 48, hipMemcpyDeviceToHost, st));
         SAH_TRY(hipStreamSynchronize(st));
@@ -431,6 +722,7 @@ int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max
         }
         n_act = host_small[2];
         cur ^= 1; acur ^= 1;
+        if (host_small[0] > level_begin.back()) level_begin.push_back(host_small[0]);
     }
     const double t2 = now();
     const uint32_t n_nodes = host_small[0];
@@ -439,12 +731,88 @@ int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max
     k_sah_export<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(N, n_nodes, d_export.as<LbvhNode>());
     k_sah_order<<<blocks, 256, 0, st>>>(d_items[cur].as<SItem>(), n, d_order.as<uint32_t>());
     SAH_TRY(hipGetLastError());
+    if (scene) {
+        // ---- everything else of the upload, on the device
+        const LbvhNode* bn = d_export.as<LbvhNode>();
+        const uint32_t* mtab = d_mtab.as<uint32_t>();
+        const uint32_t nm = scene->n_meshes;
+        struct Owned { void* p = nullptr; ~Owned() { if (p) (void)hipFree(p); } void* release() { void* q = p; p = nullptr; return q; } };
+        Owned o_tris, o_tinfo, o_rop, o_nodes;
+        SAH_TRY(hipMalloc(&o_tris.p, ((size_t)n + 1) * sizeof(PtTri)));
+        SAH_TRY(hipMalloc(&o_tinfo.p, (size_t)n * sizeof(PtTriInfo)));
+        SAH_TRY(hipMalloc(&o_rop.p, (size_t)n * 4));
+        Scratch d_size4, d_idx4, d_topbin, d_topsorted, d_s2;
+        SAH_TRY(d_size4.alloc((size_t)n_nodes * 4)); SAH_TRY(d_idx4.alloc((size_t)n_nodes * 4));
+        SAH_TRY(d_topbin.alloc(PT_TOP_BFS_NODES * 4)); SAH_TRY(d_topsorted.alloc(PT_TOP_BFS_NODES * 4)); SAH_TRY(d_s2.alloc(64));
+        uint32_t* small = d_s2.as<uint32_t>();          // [0] leaves, [1] largest leaf, [2] deepest 4-wide level, [3] n_top, [4] any one-sided
+        SAH_TRY(hipMemsetAsync(small, 0, 64, st));
+        SAH_TRY(hipMemsetAsync(d_size4.p, 0, (size_t)n_nodes * 4, st));
+        SAH_TRY(hipMemsetAsync(d_idx4.p, 0xff, (size_t)n_nodes * 4, st));
+        k_sc_records<<<(n + 1u + 255u) / 256u, 256, 0, st>>>(d_order.as<uint32_t>(), d_P.as<float>(), d_idx.as<uint32_t>(), d_tmesh.as<uint32_t>(), mtab,
+                                                           reinterpret_cast<const int32_t*>(mtab + nm), mtab + 2 * nm, n, (PtTri*)o_tris.p, (PtTriInfo*)o_tinfo.p, (uint32_t*)o_rop.p, small);
+        k_sc_leafmark<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(bn, n_nodes, (PtTri*)o_tris.p, small);
+        const size_t n_lv = level_begin.size() - 1;
+        for (size_t l = n_lv; l-- > 0;)
+            if ((l & 1) == 0) { const uint32_t b = level_begin[l], c = level_begin[l + 1] - b; k_sc_size4<<<(c + 255u) / 256u, 256, 0, st>>>(bn, b, c, d_size4.as<uint32_t>(), (uint32_t)l, small); }
+        SAH_TRY(hipMemsetAsync(d_idx4.p, 0, 4, st));                // the root is 4-wide node 0
+        for (size_t l = 0; l < n_lv; l += 2) { const uint32_t b = level_begin[l], c = level_begin[l + 1] - b; k_sc_idx4<<<(c + 255u) / 256u, 256, 0, st>>>(bn, b, c, d_size4.as<uint32_t>(), d_idx4.as<uint32_t>()); }
+        k_sc_top<<<1, 1024, 0, st>>>(bn, d_idx4.as<uint32_t>(), d_topbin.as<uint32_t>(), d_topsorted.as<uint32_t>(), small);
+        SAH_TRY(hipGetLastError());
+        uint32_t h_small[8], n4 = 0;
+        LbvhNode h_root;
+        SAH_TRY(hipMemcpyAsync(h_small, small, 32, hipMemcpyDeviceToHost, st));
+        SAH_TRY(hipMemcpyAsync(&n4, d_size4.p, 4, hipMemcpyDeviceToHost, st));
+        SAH_TRY(hipMemcpyAsync(&h_root, bn, sizeof(LbvhNode), hipMemcpyDeviceToHost, st));
+        SAH_TRY(hipStreamSynchronize(st));
+        if (n4 == 0 || n4 >= (1u << 25)) return 1;
+        SAH_TRY(hipMalloc(&o_nodes.p, (size_t)n4 * sizeof(PtNode)));
+        k_sc_emit<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(bn, n_nodes, d_idx4.as<uint32_t>(), d_topbin.as<uint32_t>(), d_topsorted.as<uint32_t>(), small, (PtNode*)o_nodes.p);
+        SAH_TRY(hipGetLastError());
+        SAH_TRY(hipStreamSynchronize(st));
+        sout->n_nodes4 = n4; sout->n_leaves = h_small[0]; sout->max_leaf = h_small[1]; sout->max_depth4 = h_small[2]; sout->n_top = h_small[3]; sout->any_one_sided = h_small[4];
+        for (int a = 0; a < 3; a++) { sout->root_lo[a] = h_root.lo[a]; sout->root_hi[a] = h_root.hi[a]; }
+        sout->d_nodes = o_nodes.release(); sout->d_tris = o_tris.release(); sout->d_tinfo = o_tinfo.release(); sout->d_rec_of_prim = o_rop.release();
+        if (trace) std::fprintf(stderr, "[bvh] device scene: %u items, %u binary nodes in %zu levels -> %u 4-wide nodes (top %u renumbered), %u leaves: setup %.2f levels %.2f records + collapse %.2f ms\n", n,
+                                n_nodes, n_lv, n4, sout->n_top, sout->n_leaves, t1 - t0, t2 - t1, now() - t2);
+        return 0;
+    }
     nodes->resize(n_nodes);
     order->resize(n);
     SAH_TRY(hipMemcpyAsync(nodes->data(), d_export.p, (size_t)n_nodes * sizeof(LbvhNode), hipMemcpyDeviceToHost, st));
     SAH_TRY(hipMemcpyAsync(order->data(), d_order.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     SAH_TRY(hipStreamSynchronize(st));
     if (trace) std::fprintf(stderr, "[bvh] device SAH: %u items, %u nodes, %u levels: setup %.2f levels %.2f read-back %.2f ms\n", n, n_nodes, levels, t1 - t0, t2 - t1, now() - t2);
+    return 0;
+}
+
+int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes, hipError_t* err) {
+    return sah_build(st, raw_bounds, n, max_prims, order, nodes, err, nullptr, nullptr);
+}
+int device_sah_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, SceneOut* out, hipError_t* err) {
+    return sah_build(st, nullptr, in.n_tris, max_prims, nullptr, nullptr, err, &in, out);
+}
+void SceneOut::free_all() {
+    if (d_nodes) (void)hipFree(d_nodes);
+    if (d_tris) (void)hipFree(d_tris);
+    if (d_tinfo) (void)hipFree(d_tinfo);
+    if (d_rec_of_prim) (void)hipFree(d_rec_of_prim);
+    d_nodes = d_tris = d_tinfo = d_rec_of_prim = nullptr;
+}
+// light i = emissive primitive prims[i] (primitive order): its record comes back for the host's light list, its number goes into the records
+int device_scene_lights(hipStream_t st, SceneOut* out, const uint32_t* prims, uint32_t n, uint32_t* recs_host, hipError_t* err) {
+    if (n == 0) return 0;
+    void* d = nullptr;
+    SAH_TRY(hipMalloc(&d, (size_t)n * 8));
+    uint32_t* d_prims = (uint32_t*)d;
+    hipError_t e = hipMemcpyAsync(d_prims, prims, (size_t)n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_sc_light_recs<<<(n + 255u) / 256u, 256, 0, st>>>(d_prims, n, (const uint32_t*)out->d_rec_of_prim, d_prims + n, (PtTri*)out->d_tris, (PtTriInfo*)out->d_tinfo);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(recs_host, d_prims + n, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) { if (err) *err = e; return -1; }
     return 0;
 }
 

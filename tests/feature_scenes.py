@@ -586,7 +586,7 @@ def scene_ao(sampler="sobol", cossample=True, nsamples=16, spp=4, res=40, kind="
 def _golden_integrator(kind):
     import importlib
     capi = importlib.import_module("pbrt-r3_amd").capi
-    if kind == "directlighting":         # strategy "all", three samples per light: the 2-D sample arrays (and quirk Q22) are in play
+    if kind == "directlighting":         # strategy "all", three samples per light: the 2-D sample arrays (and quirk Q23) are in play
         sd = scene_materials_render(["glass", "mirror", "plastic"], spp=4)
         sd.desc.integrator, sd.desc.direct_strategy, sd.desc.max_depth = capi.PT_INTEGRATOR_DIRECTLIGHTING, capi.PT_DIRECT_ALL, 4
         for i in range(sd.desc.n_area_lights):

@@ -529,6 +529,27 @@ def test_crown_class_3p5m_triangles(gpu_ctx, oracle, split):
     osc.close()
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("name,make", [("cornell", lambda: scenes.cornell_box(res=64, spp=16)), ("materials", lambda: fs.scene_materials_lights("spatial")),
+                                       ("spheres", lambda: fs.scene_spheres()), ("instances", lambda: fs.scene_instances()),
+                                       ("textures", lambda: fs.scene_textures())])
+def test_continuation_ray_sorting_changes_nothing(oracle, monkeypatch, name, make, mode):
+    """Scenes larger than the Infinity Cache get their CONTINUATION rays ordered by origin cell and direction octant as well (mode 1: the
+    ordered copy feeds the traversal kernel, shading keeps path order; mode 2: both walk the ordered list).  Forced on for these small
+    scenes, every bounce: per-sample radiance, film and every counter must still be the oracle's, bit for bit -- only work lists move."""
+    monkeypatch.setenv("PBRTGPU_SORT_SHADOW_MIN", "2")
+    monkeypatch.setenv("PBRTGPU_SORT_CONT", mode)
+    ctx = pkg.Context(0)
+    try:
+        sd = make()
+        osc = oracle.scene(sd)
+        ctx.upload(sd)
+        _compare(ctx, osc, exact_film=True)
+        osc.close()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("name,make", [("cornell", lambda: scenes.cornell_box(res=64, spp=16)), ("materials", lambda: fs.scene_materials_lights("spatial")),
                                        ("spheres", lambda: fs.scene_spheres()), ("instances", lambda: fs.scene_instances()),
                                        ("textures", lambda: fs.scene_textures())])

@@ -160,3 +160,60 @@ def test_device_sah_clustered_and_feature_scenes(oracle):
             osc.close()
         finally:
             ctx.close()
+
+
+# ---- the whole upload on the device (pt_sah.hip device_sah_scene): bounds, SAH, records, shading records, collapse, finish
+def _eligible(sd):
+    d = sd.desc
+    return d.n_spheres == 0 and d.n_instances == 0 and d.split_method == 0 and all(d.meshes[i].object == 0 for i in range(d.n_meshes))
+
+
+def test_device_scene_path_shading_records_and_lights(oracle):
+    """A triangle-only world list under SAH is built, collapsed and finished on the device, which also writes the shading records
+    (vertex indices, mesh flags, material, light) and numbers the lights' records.  The digests of the tests above pin the node and
+    leaf-record arrays; here the same path is held to the oracle where those other arrays matter: textured and bump-mapped materials
+    (uv / normals through PtTriInfo), several emissive meshes with `nsamples`, one-sided lights, materials of every kind -- per-sample
+    radiance, film and every counter, on scenes small enough that only the forced device path runs them there."""
+    from test_gpu_features import _compare
+    makes = [lambda: scenes.cornell_box(res=40, spp=8), lambda: fs.scene_materials_lights("spatial"), lambda: fs.scene_materials_lights("power"),
+             lambda: fs.scene_bump(), lambda: fs.scene_imagemaps(), lambda: fs.scene_textures(), lambda: fs.scene_noise_textures(), lambda: fs.scene_attributes(),
+             lambda: fs.scene_materials_render(["glass", "mirror", "plastic"], spp=4), lambda: fs.scene_accel("sah", 2)]
+    ran = 0
+    for make in makes:
+        sd = make()
+        if not _eligible(sd):
+            continue
+        ctx = pkg.Context(0)
+        try:
+            ctx.set_bvh_build(DEVICE)
+            info = ctx.upload(sd)
+            assert info.bvh_on_device == 1
+            osc = oracle.scene(sd)
+            assert (osc.info.n_nodes, osc.info.n_leaves, osc.info.n_lights) == (info.n_nodes, info.n_leaves, info.n_lights)
+            _compare(ctx, osc, exact_film=True)
+            osc.close()
+            ran += 1
+        finally:
+            ctx.close()
+    assert ran >= 5
+
+
+def test_device_scene_path_equals_host_finish(monkeypatch):
+    """The same device-built binary tree finished on the host (PBRTGPU_HOST_FINISH=1: tree and order read back, records, collapse and
+    finishing pass on the host's threads) and on the device: byte-identical node and record arrays, same counts and bounds."""
+    sd = scenes.rt1m(200000, res=16, spp=1, max_depth=1)
+    got = []
+    for host_finish in ("1", None):
+        if host_finish:
+            monkeypatch.setenv("PBRTGPU_HOST_FINISH", host_finish)
+        else:
+            monkeypatch.delenv("PBRTGPU_HOST_FINISH", raising=False)
+        ctx = pkg.Context(0)
+        try:
+            ctx.set_bvh_build(DEVICE)
+            info = ctx.upload(sd)
+            assert info.bvh_on_device == 1
+            got.append((ctx.bvh_digest(), info.n_nodes, info.n_leaves, tuple(info.world_bound)))
+        finally:
+            ctx.close()
+    assert got[0] == got[1]
