@@ -566,7 +566,15 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                 std::vector<uint32_t> lit;
                 bool any_light_mesh = false;
                 for (uint32_t i = 0; i < d->n_meshes; i++) any_light_mesh |= d->meshes[i].area_light >= 0;
-                if (any_light_mesh) for (uint32_t t = 0; t < d->n_triangles; t++) if (d->meshes[d->tri_mesh[t]].area_light >= 0) lit.push_back(t);
+                if (any_light_mesh) {                     // the host's threads scan their share of the triangles; the shares are joined in order
+                    const size_t n_chunks = 64, step = ((size_t)d->n_triangles + n_chunks - 1) / n_chunks;
+                    std::vector<std::vector<uint32_t>> part(n_chunks);
+                    ptbvh::parallel_tasks(n_chunks, [&](size_t c) {
+                        const size_t a = c * step, b = std::min((size_t)d->n_triangles, a + step);
+                        for (size_t t = a; t < b; t++) if (d->meshes[d->tri_mesh[t]].area_light >= 0) part[c].push_back((uint32_t)t);
+                    });
+                    for (const auto& v : part) lit.insert(lit.end(), v.begin(), v.end());
+                }
                 if (lit.size() >= (1u << 24)) { out.free_all(); return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^24 emissive primitives"); }
                 std::vector<uint32_t> lit_rec(lit.size());
                 if (ptbvh::device_scene_lights(ctx->stream, &out, lit.data(), (uint32_t)lit.size(), lit_rec.data(), &herr) < 0) { out.free_all(); return ctx->hip_fail(herr, "light records on the device"); }

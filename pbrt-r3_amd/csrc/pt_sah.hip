@@ -574,6 +574,14 @@ struct ScratchArena {
         if (d != dev) { if (base) (void)hipFree(base); base = nullptr; cap = 0; dev = d; }      // another device: its own arena
         used = 0; wanted = 0;
     }
+    // a first build knows roughly what it will ask for: one block now instead of two dozen separate allocations (0.3-0.5 ms each)
+    void reserve(size_t bytes) {
+        if (used != 0 || cap >= bytes || bytes > ((size_t)4 << 30)) return;
+        if (base) (void)hipFree(base);
+        base = nullptr; cap = 0;
+        void* q = nullptr;
+        if (hipMalloc(&q, bytes) == hipSuccess) { base = (char*)q; cap = bytes; }
+    }
     void end() {                                                   // every block handed out has been returned (Scratch destructors ran)
         if (wanted > cap && wanted <= ((size_t)4 << 30)) {
             if (base) (void)hipFree(base);
@@ -633,6 +641,7 @@ static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32
     if (n < 2 || n > (1u << 26) || max_prims < 2) return 1;
     const uint32_t cap = 2u * n + 2u;
     const uint32_t max_split = n / (max_prims + 1u) + 2u;          // nodes splitting in one level hold more than max_prims items each
+    t_arena.reserve((size_t)n * (scene ? 480 : 400) + (size_t)max_split * 340 + (scene ? (size_t)scene->n_vertices * 12 : 0) + ((size_t)2 << 20));
     Scratch d_raw, d_items[2], d_nodeof[2], d_nodes, d_bcnt, d_bbox, d_bucket, d_flag, d_pre, d_tot, d_act[2], d_small, d_export, d_order;
     SAH_TRY(d_raw.alloc((size_t)n * 24));
     for (int i = 0; i < 2; i++) { SAH_TRY(d_items[i].alloc((size_t)n * sizeof(SItem))); SAH_TRY(d_nodeof[i].alloc((size_t)n * 4)); SAH_TRY(d_act[i].alloc((size_t)cap * 4)); }
