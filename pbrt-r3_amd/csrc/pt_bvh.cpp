@@ -462,6 +462,14 @@ struct Collapser {
 
 }  // namespace
 
+int32_t hlbvh_upper_tree(NoInitVec<LbvhNode>& tree, uint32_t n_roots) {
+    Hlbvh h{nullptr, nullptr, 0, tree};
+    std::vector<int32_t> roots(n_roots);
+    for (uint32_t k = 0; k < n_roots; k++) roots[k] = (int32_t)k;
+    const int32_t root = h.upper(roots);
+    return (h.failed || root < 0) ? -1 : root;
+}
+
 // Page-locked staging for the bounds a device build uploads (24 bytes per primitive): from pageable memory that copy is staged by
 // the runtime at 2-3 GB/s -- 10 ms per million triangles, more than the build itself.  One buffer per calling thread, kept and regrown.
 static float* pinned_floats(size_t n) {

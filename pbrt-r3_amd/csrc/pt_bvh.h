@@ -86,6 +86,14 @@ struct LbvhNode {                       // plain data (no initialisers): arrays 
 // when the host has to build instead (a range needs the centroid-median fallback, non-finite bounds, no memory), -1 on a HIP error.
 int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes,
                 uint32_t* n_treelets, hipError_t* err);
+// The same with bounds that are on the device already and results that stay there (pt_sah.hip device_hlbvh_scene): order_dev[n] the
+// primitive order, nodes_dev[0 .. *n_nodes) the binary nodes (room for node_cap >= 2 n), the first *n_treelets of them the treelet roots,
+// copied to roots_host for the upper SAH.
+int device_lbvh_keep(hipStream_t st, const float* raw_dev, uint32_t n, uint32_t max_prims, uint32_t* order_dev, LbvhNode* nodes_dev, uint32_t node_cap, uint32_t* n_nodes,
+                     uint32_t* n_treelets, std::vector<LbvhNode>* roots_host, hipError_t* err);
+// build_upper_sah (hlbvh.rs:254-352) over the treelet roots tree[0 .. n_roots): appends the joining nodes to `tree` and returns the index of
+// the root, -1 where the reference panics (all centroids of a subset coincide along the split axis).
+int32_t hlbvh_upper_tree(NoInitVec<LbvhNode>& tree, uint32_t n_roots);
 // pt_sah.hip: the SAH binary build on the GPU, level by level.  Same conventions: 0 = order / nodes filled (nodes[0] is the root), 1 = the
 // host has to build (a split needs the equal-counts fallback, non-finite bounds, maxnodeprims < 2), -1 = HIP error.
 int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes, hipError_t* err);
@@ -107,6 +115,7 @@ struct SceneOut {
 };
 // 0 = done, 1 = this list needs the host path (a fallback split, non-finite bounds), -1 = HIP error
 int device_sah_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, SceneOut* out, hipError_t* err);
+int device_hlbvh_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, SceneOut* out, hipError_t* err);      // the same under "splitmethod" "hlbvh": -2 = the reference panics on this input
 int device_scene_lights(hipStream_t st, SceneOut* out, const uint32_t* prims, uint32_t n, uint32_t* recs_host, hipError_t* err);
 // Where the lower half of an HLBVH build runs: PT_BVH_BUILD_AUTO picks the device from kDeviceMinPrims primitives up.
 struct DeviceBuild { hipStream_t stream; int mode; bool used; hipError_t err; };

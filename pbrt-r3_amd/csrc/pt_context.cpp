@@ -526,8 +526,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     const int max_node_prims = d->max_node_prims > 0 ? d->max_node_prims : 4;
 
     // ---- BVH, records and nodes on the device --------------------------------
-    // A world list of triangles only (no spheres, objects or instances) under the SAH split -- BASELINE's scenes -- never leaves the
-    // device: vertices and indices go up, pt_sah.hip builds the binary tree, writes the leaf and shading records in leaf order, collapses
+    // A world list of triangles only (no spheres, objects or instances) under the SAH or HLBVH split -- BASELINE's scenes -- never leaves the
+    // device: vertices and indices go up, pt_sah.hip / pt_hlbvh.hip build the binary tree, pt_sah.hip writes the leaf and shading records in leaf order, collapses
     // the tree into the 4-wide node array in the reference's depth-first numbering and finishes it (breadth-first top, order tables, axis
     // bits, inverted empty slots).  Same arrays as the host path below, byte for byte (tests/test_gpu_hlbvh.py compares the digests).
     // A list that needs a fallback split, PT_BVH_BUILD_HOST or PBRTGPU_HOST_FINISH=1 take the host path.
@@ -536,7 +536,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         uint32_t any_object = 0;
         for (uint32_t i = 0; i < d->n_meshes; i++) any_object |= d->meshes[i].object;
         const int mnp = std::min(std::max(max_node_prims, 0), 255);
-        if (d->n_spheres == 0 && d->n_instances == 0 && any_object == 0 && d->split_method == PT_SPLIT_SAH && mnp >= 2 && d->n_triangles >= 2 &&
+        const bool sah = d->split_method == PT_SPLIT_SAH && mnp >= 2, hl = d->split_method == PT_SPLIT_HLBVH && mnp >= 1;
+        if (d->n_spheres == 0 && d->n_instances == 0 && any_object == 0 && (sah || hl) && d->n_triangles >= 2 &&
             d->n_triangles < PT_LEAF_FIRST_MASK - 16u && ctx->bvh_build_where != PT_BVH_BUILD_HOST &&
             (ctx->bvh_build_where == PT_BVH_BUILD_DEVICE || d->n_triangles >= ptbvh::kDeviceMinPrims) && !std::getenv("PBRTGPU_HOST_FINISH")) {
             std::vector<uint32_t> m_triflags(d->n_meshes), m_flags(d->n_meshes);
@@ -558,7 +559,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             ptbvh::SceneIn in{d->P, d->n_vertices, d->indices, d->tri_mesh, d->n_triangles, m_triflags.data(), m_material.data(), m_flags.data(), d->n_meshes};
             ptbvh::SceneOut out;
             hipError_t herr = hipSuccess;
-            const int rc = ptbvh::device_sah_scene(ctx->stream, in, (uint32_t)mnp, &out, &herr);
+            const int rc = sah ? ptbvh::device_sah_scene(ctx->stream, in, (uint32_t)mnp, &out, &herr) : ptbvh::device_hlbvh_scene(ctx->stream, in, (uint32_t)mnp, &out, &herr);
+            if (rc == -2) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "hlbvh: all treelet centroids coincide along the split axis (the reference panics on this input)");
             if (rc < 0) return ctx->hip_fail(herr, "scene build on the device");
             mark("device scene (bounds, SAH, records, collapse)");
             if (rc == 0) {

@@ -194,39 +194,57 @@ __global__ __launch_bounds__(64) void k_hl_roots(const uint32_t* __restrict__ tl
 }
 
 // emit_lbvh for the work items [begin, begin + count): a leaf, or an interior node whose two halves are queued for the next launch.
+// A range that runs out of code bits with more than max_prims items goes on by centroid medians (split_node, hlbvh.rs:102-157; the
+// host version is Hlbvh::median_split): Work::bit = -2 - dim marks such an item, its range is put in stable centroid order along `dim`
+// by k_hl_median_sort right after this launch (the halves are cut in the middle whatever the order), the halves cycle the axis.
+constexpr uint32_t kMedianMax = 4096;        // longest range the median fallback orders on the device
 __global__ __launch_bounds__(256) void k_hl_level(Work* __restrict__ work, uint32_t begin, uint32_t count, const uint32_t* __restrict__ code, const uint32_t* __restrict__ idx,
                                                   const float* __restrict__ ib, uint32_t max_prims, LbvhNode* __restrict__ nodes, uint32_t node_cap, uint32_t work_cap,
-                                                  uint32_t* __restrict__ counters, uint32_t* __restrict__ flags) {
+                                                  uint32_t* __restrict__ counters, uint32_t* __restrict__ flags, uint32_t* __restrict__ med_list) {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= count) return;
     const Work e = work[begin + w];
     int bit = e.bit;
-    bool leaf = false, give_up = false;
-    for (;;) {
-        if (e.hi - e.lo <= max_prims) { leaf = true; break; }
-        if (bit < 0) { give_up = true; atomicOr(flags, 2u); break; }     // split_node territory: the host rebuilds
-        const uint32_t mask = 1u << bit;
-        if ((code[e.lo] & mask) != (code[e.hi - 1] & mask)) break;
-        bit--;
-    }
+    bool leaf = false, give_up = false, median = e.bit <= -2;
+    int dim = median ? -2 - e.bit : 2;                   // emit_lbvh enters split_node with dim 2 (hlbvh.rs:190)
+    if (median) leaf = e.hi - e.lo <= max_prims;
+    else
+        for (;;) {
+            if (e.hi - e.lo <= max_prims) { leaf = true; break; }
+            if (bit < 0) { median = true; break; }
+            const uint32_t mask = 1u << bit;
+            if ((code[e.lo] & mask) != (code[e.hi - 1] & mask)) break;
+            bit--;
+        }
     LbvhNode nd;
     nd.left = -1; nd.right = -1; nd.first = 0; nd.count = 0; nd.axis = 0;
-    if (!leaf && !give_up) {
-        const uint32_t mask = 1u << bit;
-        uint32_t a = e.lo, b = e.hi - 1;
-        const uint32_t first_bit = code[a] & mask;
-        while (a + 1 != b) {
-            const uint32_t m = (uint32_t)(((uint64_t)a + b) / 2);
-            if ((code[m] & mask) == first_bit) a = m; else b = m;
+    if (!leaf) {
+        uint32_t b;
+        if (median) {
+            b = e.lo + (e.hi - e.lo) / 2u;
+            if (e.hi - e.lo > kMedianMax) { atomicOr(flags, 2u); give_up = true; }      // longer than the sort kernel's LDS: the host rebuilds
+        } else {
+            const uint32_t mask = 1u << bit;
+            uint32_t a = e.lo;
+            b = e.hi - 1;
+            const uint32_t first_bit = code[a] & mask;
+            while (a + 1 != b) {
+                const uint32_t m = (uint32_t)(((uint64_t)a + b) / 2);
+                if ((code[m] & mask) == first_bit) a = m; else b = m;
+            }
         }
-        const uint32_t l = atomicAdd(&counters[0], 2u);
-        const uint32_t q = atomicAdd(&counters[1], 2u);
-        if (l + 2 > node_cap || q + 2 > work_cap) { atomicOr(flags, 4u); give_up = true; }
-        else {
-            nd.left = (int32_t)l; nd.right = (int32_t)l + 1; nd.axis = (uint8_t)(bit % 3);
-            for (int i = 0; i < 3; i++) { nd.lo[i] = 0; nd.hi[i] = 0; }
-            work[q] = Work{e.lo, b, bit - 1, (int32_t)l};
-            work[q + 1] = Work{b, e.hi, bit - 1, (int32_t)l + 1};
+        if (!give_up) {
+            const uint32_t l = atomicAdd(&counters[0], 2u);
+            const uint32_t q = atomicAdd(&counters[1], 2u);
+            if (l + 2 > node_cap || q + 2 > work_cap) { atomicOr(flags, 4u); give_up = true; }
+            else {
+                const int child_bit = median ? -2 - (dim + 2) % 3 : bit - 1;
+                nd.left = (int32_t)l; nd.right = (int32_t)l + 1; nd.axis = (uint8_t)(median ? dim : bit % 3);
+                for (int i = 0; i < 3; i++) { nd.lo[i] = 0; nd.hi[i] = 0; }
+                work[q] = Work{e.lo, b, child_bit, (int32_t)l};
+                work[q + 1] = Work{b, e.hi, child_bit, (int32_t)l + 1};
+                if (median) med_list[atomicAdd(&flags[1], 1u)] = begin + w;
+            }
         }
     }
     if (leaf) {
@@ -243,6 +261,28 @@ __global__ __launch_bounds__(256) void k_hl_level(Work* __restrict__ work, uint3
         nd.left = -1; nd.right = -1; nd.first = e.lo; nd.count = 1; nd.axis = 0;
     }
     nodes[e.node] = nd;
+}
+// The ranges k_hl_level has just split by medians, in stable centroid order along the node's axis: one workgroup per range ranks its
+// items by (centroid, position) -- what std::stable_sort leaves -- and rewrites that part of the primitive order.
+__global__ __launch_bounds__(256) void k_hl_median_sort(const Work* __restrict__ work, const uint32_t* __restrict__ med_list, const LbvhNode* __restrict__ nodes,
+                                                        const float* __restrict__ ib, uint32_t* idx) {
+    __shared__ float s_key[kMedianMax];
+    __shared__ uint32_t s_idx[kMedianMax];
+    const Work e = work[med_list[blockIdx.x]];
+    const uint32_t n = e.hi - e.lo;
+    const int dim = (int)nodes[e.node].axis;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t p = idx[e.lo + i];
+        s_idx[i] = p;
+        s_key[i] = (ib[(size_t)p * 6 + dim] + ib[(size_t)p * 6 + 3 + dim]) * 0.5f;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float k = s_key[i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n; j++) r += (s_key[j] < k || (j < i && !(k < s_key[j]))) ? 1u : 0u;
+        idx[e.lo + r] = s_idx[i];
+    }
 }
 
 // Interior boxes of one level from its children (finished by the launches for the deeper levels).
@@ -300,8 +340,11 @@ struct ArenaScope { ArenaScope() { t_arena.begin(); } ~ArenaScope() { t_arena.en
 
 #define HL_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { if (err) *err = e_; return e_ == hipErrorOutOfMemory ? 1 : -1; } } while (0)
 
-int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes,
-                uint32_t* n_treelets, hipError_t* err) {
+// raw_dev != nullptr: the bounds are on the device already and the results stay there -- the primitive order in order_dev[n], the binary
+// nodes in nodes_dev (room for node_cap_dev of them; the first *n_treelets are the treelet roots in Morton order), *n_nodes_out of them
+// written; only the roots come back to the host (roots_host), for the upper SAH.
+static int lbvh_core(hipStream_t st, const float* raw_bounds, const float* raw_dev, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes,
+                     uint32_t* n_treelets, hipError_t* err, uint32_t* order_dev, LbvhNode* nodes_dev, uint32_t node_cap_dev, uint32_t* n_nodes_out, std::vector<LbvhNode>* roots_host) {
     ArenaScope arena_scope;          // declared before every Scratch: destroyed after them
     const bool trace = std::getenv("PBRTGPU_BUILD_TRACE") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -311,24 +354,28 @@ int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t ma
     const uint32_t n_tiles = (n + kSortTile - 1) / kSortTile;
     const uint32_t node_cap = 2u * n, work_cap = 2u * n;
     Scratch d_raw, d_ib, d_gb, d_key[2], d_val[2], d_hist, d_tl, d_work, d_nodes, d_small;
-    HL_TRY(d_raw.alloc((size_t)n * 24));
+    if (raw_dev && node_cap_dev < node_cap) return 1;
+    if (!raw_dev) HL_TRY(d_raw.alloc((size_t)n * 24));
     HL_TRY(d_ib.alloc((size_t)n * 24));
     HL_TRY(d_small.alloc(64));                       // gb[6], flags, counters[2]
     for (int i = 0; i < 2; i++) { HL_TRY(d_key[i].alloc((size_t)n * 4)); HL_TRY(d_val[i].alloc((size_t)n * 4)); }
     HL_TRY(d_hist.alloc((size_t)kRadix * n_tiles * 4));
     HL_TRY(d_tl.alloc(2 * 4096 * 4));
     HL_TRY(d_work.alloc((size_t)work_cap * sizeof(Work)));
-    HL_TRY(d_nodes.alloc((size_t)node_cap * sizeof(LbvhNode)));
+    if (!raw_dev) HL_TRY(d_nodes.alloc((size_t)node_cap * sizeof(LbvhNode)));
+    LbvhNode* const bnodes = raw_dev ? nodes_dev : d_nodes.as<LbvhNode>();
+    Scratch d_med;
+    HL_TRY(d_med.alloc(((size_t)n / 2 + 2) * 4));          // work items split by medians in one level (each holds more than max_prims >= 1 items)
     uint32_t* gb = d_small.as<uint32_t>();
     uint32_t* flags = gb + 6;
     uint32_t* counters = gb + 8;
     const double t1 = now();
     const uint32_t init[10] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     HL_TRY(hipMemcpyAsync(gb, init, sizeof(init), hipMemcpyHostToDevice, st));
-    HL_TRY(hipMemcpyAsync(d_raw.p, raw_bounds, (size_t)n * 24, hipMemcpyHostToDevice, st));
+    if (!raw_dev) HL_TRY(hipMemcpyAsync(d_raw.p, raw_bounds, (size_t)n * 24, hipMemcpyHostToDevice, st));
     HL_TRY(hipMemsetAsync(d_tl.p, 0, 2 * 4096 * 4, st));
     const uint32_t blocks = (n + 255) / 256;
-    k_hl_prepare<<<blocks < 1024u ? blocks : 1024u, 256, 0, st>>>(d_raw.as<float>(), n, d_ib.as<float>(), gb, flags);
+    k_hl_prepare<<<blocks < 1024u ? blocks : 1024u, 256, 0, st>>>(raw_dev ? raw_dev : d_raw.as<float>(), n, d_ib.as<float>(), gb, flags);
     k_hl_codes<<<blocks, 256, 0, st>>>(d_ib.as<float>(), n, gb, d_key[0].as<uint32_t>(), d_val[0].as<uint32_t>());
     int cur = 0;
     for (int pass = 0; pass < 30 / kRadixBits; pass++) {
@@ -340,7 +387,7 @@ int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t ma
         cur ^= 1;
     }
     const uint32_t* code = d_key[cur].as<uint32_t>();
-    const uint32_t* idx = d_val[cur].as<uint32_t>();
+    uint32_t* idx = d_val[cur].as<uint32_t>();
     uint32_t* tl_start = d_tl.as<uint32_t>();
     uint32_t* tl_end = tl_start + 4096;
     k_hl_treelets<<<blocks, 256, 0, st>>>(code, n, tl_start, tl_end);
@@ -353,34 +400,58 @@ int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t ma
     const uint32_t n_roots = host_small[3];
     std::vector<uint32_t> level_begin, level_count;
     uint32_t begin = 0, count = n_roots;
-    while (count > 0) {               // bits 17..0 and the leaves below: at most 19 levels
-        if (level_begin.size() > 40) return -1;
+    while (count > 0) {               // bits 17..0 and the leaves below: at most 19 levels, plus what the median fallback adds
+        if (level_begin.size() > 96) return -1;
         level_begin.push_back(begin); level_count.push_back(count);
-        k_hl_level<<<(count + 255) / 256, 256, 0, st>>>(d_work.as<Work>(), begin, count, code, idx, d_ib.as<float>(), max_prims, d_nodes.as<LbvhNode>(), node_cap, work_cap,
-                                                        counters, flags);
+        HL_TRY(hipMemsetAsync(flags + 1, 0, 4, st));            // this level's median splits
+        k_hl_level<<<(count + 255) / 256, 256, 0, st>>>(d_work.as<Work>(), begin, count, code, idx, d_ib.as<float>(), max_prims, bnodes, node_cap, work_cap,
+                                                        counters, flags, d_med.as<uint32_t>());
         HL_TRY(hipGetLastError());
         HL_TRY(hipMemcpyAsync(host_small, flags, 16, hipMemcpyDeviceToHost, st));
         HL_TRY(hipStreamSynchronize(st));
         if (host_small[0] != 0) return 1;
+        if (host_small[1] != 0) {         // their ranges into centroid order before the next level reads them
+            k_hl_median_sort<<<host_small[1], 256, 0, st>>>(d_work.as<Work>(), d_med.as<uint32_t>(), bnodes, d_ib.as<float>(), idx);
+            HL_TRY(hipGetLastError());
+        }
         const uint32_t total = host_small[3];
         begin += count;
         count = total - begin;
     }
     for (size_t l = level_begin.size(); l-- > 0;)
-        k_hl_up<<<(level_count[l] + 255) / 256, 256, 0, st>>>(d_work.as<Work>(), level_begin[l], level_count[l], d_nodes.as<LbvhNode>());
+        k_hl_up<<<(level_count[l] + 255) / 256, 256, 0, st>>>(d_work.as<Work>(), level_begin[l], level_count[l], bnodes);
     HL_TRY(hipGetLastError());
     if (trace) (void)hipStreamSynchronize(st);
     const double t2 = now();
     const uint32_t n_nodes = host_small[2];
+    if (raw_dev) {
+        roots_host->resize(n_roots);
+        HL_TRY(hipMemcpyAsync(order_dev, idx, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        HL_TRY(hipMemcpyAsync(roots_host->data(), bnodes, (size_t)n_roots * sizeof(LbvhNode), hipMemcpyDeviceToHost, st));
+        HL_TRY(hipStreamSynchronize(st));
+        *n_treelets = n_roots;
+        *n_nodes_out = n_nodes;
+        if (trace) std::fprintf(stderr, "[lbvh] n=%u nodes=%u treelets=%u levels=%zu (kept on the device): alloc %.2f kernels %.2f ms\n", n, n_nodes, n_roots, level_begin.size(), t1 - t0, now() - t1);
+        return 0;
+    }
     order->resize(n);
     nodes->resize(n_nodes);
     HL_TRY(hipMemcpyAsync(order->data(), idx, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HL_TRY(hipMemcpyAsync(nodes->data(), d_nodes.p, (size_t)n_nodes * sizeof(LbvhNode), hipMemcpyDeviceToHost, st));
+    HL_TRY(hipMemcpyAsync(nodes->data(), bnodes, (size_t)n_nodes * sizeof(LbvhNode), hipMemcpyDeviceToHost, st));
     HL_TRY(hipStreamSynchronize(st));
     *n_treelets = n_roots;
     if (trace) std::fprintf(stderr, "[lbvh] n=%u nodes=%u treelets=%u levels=%zu: alloc %.2f upload+kernels %.2f readback %.2f ms\n", n, n_nodes, n_roots, level_begin.size(),
                             t1 - t0, t2 - t1, now() - t2);
     return 0;
+}
+
+int device_lbvh(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes,
+                uint32_t* n_treelets, hipError_t* err) {
+    return lbvh_core(st, raw_bounds, nullptr, n, max_prims, order, nodes, n_treelets, err, nullptr, nullptr, 0, nullptr, nullptr);
+}
+int device_lbvh_keep(hipStream_t st, const float* raw_dev, uint32_t n, uint32_t max_prims, uint32_t* order_dev, LbvhNode* nodes_dev, uint32_t node_cap, uint32_t* n_nodes,
+                     uint32_t* n_treelets, std::vector<LbvhNode>* roots_host, hipError_t* err) {
+    return lbvh_core(st, nullptr, raw_dev, n, max_prims, nullptr, nullptr, n_treelets, err, order_dev, nodes_dev, node_cap, n_nodes, roots_host);
 }
 
 }  // namespace ptbvh

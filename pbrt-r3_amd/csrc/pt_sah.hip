@@ -418,11 +418,21 @@ __device__ inline void sc_slots(const LbvhNode* __restrict__ nodes, uint32_t b, 
     if (nodes[l].count > 0) s[0] = l; else { s[0] = nodes[l].left; s[1] = nodes[l].right; }
     if (nodes[r].count > 0) s[2] = r; else { s[2] = nodes[r].left; s[3] = nodes[r].right; }
 }
-// bottom-up, one launch per even binary level: 4-wide nodes in the subtree of each interior node of the level (itself included)
-__global__ __launch_bounds__(256) void k_sc_size4(const LbvhNode* __restrict__ nodes, uint32_t begin, uint32_t count, uint32_t* size4, uint32_t level, uint32_t* small) {
+// the next level of a binary tree as a list of node numbers (HLBVH trees are not numbered level by level)
+__global__ __launch_bounds__(256) void k_sc_next_level(const LbvhNode* __restrict__ nodes, uint32_t* list, uint32_t begin, uint32_t count, uint32_t* counter) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const uint32_t b = begin + i;
+    const LbvhNode n = nodes[list[begin + i]];
+    if (n.count > 0) return;
+    const uint32_t at = atomicAdd(counter, 2u);
+    list[at] = (uint32_t)n.left; list[at + 1] = (uint32_t)n.right;
+}
+// bottom-up, one launch per even binary level: 4-wide nodes in the subtree of each interior node of the level (itself included)
+__global__ __launch_bounds__(256) void k_sc_size4(const LbvhNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t begin, uint32_t count, uint32_t* size4,
+                                                 uint32_t level, uint32_t* small) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t b = list ? list[begin + i] : begin + i;          // the level's nodes: a list (HLBVH), or consecutive numbers (SAH build: level order)
     if (nodes[b].count > 0) return;
     int32_t s[4];
     sc_slots(nodes, b, s);
@@ -432,10 +442,11 @@ __global__ __launch_bounds__(256) void k_sc_size4(const LbvhNode* __restrict__ n
     atomicMax(&small[2], level / 2u + 1u);               // deepest 4-wide level
 }
 // top-down: the node takes the index it was given, its subtrees follow in slot order (depth-first numbering)
-__global__ __launch_bounds__(256) void k_sc_idx4(const LbvhNode* __restrict__ nodes, uint32_t begin, uint32_t count, const uint32_t* __restrict__ size4, uint32_t* idx4) {
+__global__ __launch_bounds__(256) void k_sc_idx4(const LbvhNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t begin, uint32_t count,
+                                                const uint32_t* __restrict__ size4, uint32_t* idx4) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const uint32_t b = begin + i;
+    const uint32_t b = list ? list[begin + i] : begin + i;
     if (nodes[b].count > 0) return;
     int32_t s[4];
     sc_slots(nodes, b, s);
@@ -445,12 +456,13 @@ __global__ __launch_bounds__(256) void k_sc_idx4(const LbvhNode* __restrict__ no
 }
 // The first PT_TOP_BFS_NODES 4-wide nodes in level order (children in slot order), as pt_context.cpp numbers them: top[k] = depth-first index
 // of the k-th, sorted[] the same indices in increasing order (a node that is not among them moves up by the number of those below it).
-__global__ __launch_bounds__(1024) void k_sc_top(const LbvhNode* __restrict__ nodes, const uint32_t* __restrict__ idx4, uint32_t* top_bin, uint32_t* top_sorted, uint32_t* small) {
+__global__ __launch_bounds__(1024) void k_sc_top(const LbvhNode* __restrict__ nodes, uint32_t root, const uint32_t* __restrict__ idx4, uint32_t* top_bin, uint32_t* top_sorted,
+                                                 uint32_t* small) {
     __shared__ uint32_t s_list[PT_TOP_BFS_NODES];       // binary node ids, level order
     __shared__ uint32_t s_old[PT_TOP_BFS_NODES];
     __shared__ uint32_t s_scan[1024];
     __shared__ uint32_t s_total, s_lvl_begin, s_lvl_end;
-    if (threadIdx.x == 0) { s_list[0] = 0; s_total = 1; s_lvl_begin = 0; s_lvl_end = 1; }
+    if (threadIdx.x == 0) { s_list[0] = root; s_total = 1; s_lvl_begin = 0; s_lvl_end = 1; }
     __syncthreads();
     for (;;) {
         const uint32_t lb = s_lvl_begin, le = s_lvl_end, total = s_total;
@@ -629,6 +641,75 @@ static float* scene_staging(size_t bytes) {
 // SAH binary build on the device.  raw_bounds = n x {lo[3], hi[3]} (host memory, not yet inflated).  On success (0): order[k] = primitive
 // stored k-th, nodes[0] the root.  1: the host has to build instead (equal-counts fallback needed, non-finite bounds, too few items);
 // -1: HIP error.
+// The scene's arrays go up through page-locked staging filled by the host's threads (from pageable memory the runtime stages the copy itself at
+// a few GB/s); the per-mesh tables are tiny.  Then the triangles' bounds, on the device.
+static int upload_scene_arrays(hipStream_t st, const SceneIn& sc, Scratch& d_P, Scratch& d_idx, Scratch& d_tmesh, Scratch& d_mtab, float* d_raw, hipError_t* err) {
+    const uint32_t n = sc.n_tris;
+    const size_t nP = 3 * (size_t)sc.n_vertices, nI = 3 * (size_t)n, nm = sc.n_meshes;
+    SAH_TRY(d_P.alloc(nP * 4)); SAH_TRY(d_idx.alloc(nI * 4)); SAH_TRY(d_tmesh.alloc((size_t)n * 4)); SAH_TRY(d_mtab.alloc(nm * 12 + 16));
+    float* stage = scene_staging((nP + nI + n + 3 * nm) * 4);
+    if (!stage) return 1;
+    uint32_t* su = reinterpret_cast<uint32_t*>(stage);
+    parallel_for(nP, [&](size_t a, size_t b) { std::memcpy(stage + a, sc.P + a, (b - a) * 4); });
+    parallel_for(nI, [&](size_t a, size_t b) { std::memcpy(su + nP + a, sc.indices + a, (b - a) * 4); });
+    parallel_for((size_t)n, [&](size_t a, size_t b) { std::memcpy(su + nP + nI + a, sc.tri_mesh + a, (b - a) * 4); });
+    std::memcpy(su + nP + nI + n, sc.mesh_triflags, nm * 4);
+    std::memcpy(su + nP + nI + n + nm, sc.mesh_material, nm * 4);
+    std::memcpy(su + nP + nI + n + 2 * nm, sc.mesh_flags, nm * 4);
+    SAH_TRY(hipMemcpyAsync(d_P.p, stage, nP * 4, hipMemcpyHostToDevice, st));
+    SAH_TRY(hipMemcpyAsync(d_idx.p, su + nP, nI * 4, hipMemcpyHostToDevice, st));
+    SAH_TRY(hipMemcpyAsync(d_tmesh.p, su + nP + nI, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    SAH_TRY(hipMemcpyAsync(d_mtab.p, su + nP + nI + n, nm * 12, hipMemcpyHostToDevice, st));
+    k_sc_bounds<<<(n + 255u) / 256u, 256, 0, st>>>(d_P.as<float>(), d_idx.as<uint32_t>(), n, d_raw);
+    SAH_TRY(hipGetLastError());
+    return 0;
+}
+
+// Records, shading records, collapse and finishing pass for a binary tree that sits on the device (`levels`: its nodes level by level, as
+// ranges of `list`, or of the node numbers themselves when `list` is null).  The blocks of `sout` belong to the caller afterwards.
+static int finish_scene(hipStream_t st, const LbvhNode* bn, uint32_t n_nodes, uint32_t root, const std::vector<std::pair<uint32_t, uint32_t>>& levels, const uint32_t* list,
+                        const uint32_t* d_order, const float* d_P, const uint32_t* d_idx, const uint32_t* d_tmesh, const uint32_t* mtab, uint32_t nm, uint32_t n, SceneOut* sout,
+                        hipError_t* err) {
+        struct Owned { void* p = nullptr; ~Owned() { if (p) (void)hipFree(p); } void* release() { void* q = p; p = nullptr; return q; } };
+        Owned o_tris, o_tinfo, o_rop, o_nodes;
+        SAH_TRY(hipMalloc(&o_tris.p, ((size_t)n + 1) * sizeof(PtTri)));
+        SAH_TRY(hipMalloc(&o_tinfo.p, (size_t)n * sizeof(PtTriInfo)));
+        SAH_TRY(hipMalloc(&o_rop.p, (size_t)n * 4));
+        Scratch d_size4, d_idx4, d_topbin, d_topsorted, d_s2;
+        SAH_TRY(d_size4.alloc((size_t)n_nodes * 4)); SAH_TRY(d_idx4.alloc((size_t)n_nodes * 4));
+        SAH_TRY(d_topbin.alloc(PT_TOP_BFS_NODES * 4)); SAH_TRY(d_topsorted.alloc(PT_TOP_BFS_NODES * 4)); SAH_TRY(d_s2.alloc(64));
+        uint32_t* small = d_s2.as<uint32_t>();          // [0] leaves, [1] largest leaf, [2] deepest 4-wide level, [3] n_top, [4] any one-sided
+        SAH_TRY(hipMemsetAsync(small, 0, 64, st));
+        SAH_TRY(hipMemsetAsync(d_size4.p, 0, (size_t)n_nodes * 4, st));
+        SAH_TRY(hipMemsetAsync(d_idx4.p, 0xff, (size_t)n_nodes * 4, st));
+        k_sc_records<<<(n + 1u + 255u) / 256u, 256, 0, st>>>(d_order, d_P, d_idx, d_tmesh, mtab,
+                                                           reinterpret_cast<const int32_t*>(mtab + nm), mtab + 2 * nm, n, (PtTri*)o_tris.p, (PtTriInfo*)o_tinfo.p, (uint32_t*)o_rop.p, small);
+        k_sc_leafmark<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(bn, n_nodes, (PtTri*)o_tris.p, small);
+        const size_t n_lv = levels.size();
+        for (size_t l = n_lv; l-- > 0;)
+            if ((l & 1) == 0 && levels[l].second) k_sc_size4<<<(levels[l].second + 255u) / 256u, 256, 0, st>>>(bn, list, levels[l].first, levels[l].second, d_size4.as<uint32_t>(), (uint32_t)l, small);
+        SAH_TRY(hipMemsetAsync(d_idx4.as<uint32_t>() + root, 0, 4, st));                // the root is 4-wide node 0
+        for (size_t l = 0; l < n_lv; l += 2)
+            if (levels[l].second) k_sc_idx4<<<(levels[l].second + 255u) / 256u, 256, 0, st>>>(bn, list, levels[l].first, levels[l].second, d_size4.as<uint32_t>(), d_idx4.as<uint32_t>());
+        k_sc_top<<<1, 1024, 0, st>>>(bn, root, d_idx4.as<uint32_t>(), d_topbin.as<uint32_t>(), d_topsorted.as<uint32_t>(), small);
+        SAH_TRY(hipGetLastError());
+        uint32_t h_small[8], n4 = 0;
+        LbvhNode h_root;
+        SAH_TRY(hipMemcpyAsync(h_small, small, 32, hipMemcpyDeviceToHost, st));
+        SAH_TRY(hipMemcpyAsync(&n4, d_size4.as<uint32_t>() + root, 4, hipMemcpyDeviceToHost, st));
+        SAH_TRY(hipMemcpyAsync(&h_root, bn + root, sizeof(LbvhNode), hipMemcpyDeviceToHost, st));
+        SAH_TRY(hipStreamSynchronize(st));
+        if (n4 == 0 || n4 >= (1u << 25)) return 1;
+        SAH_TRY(hipMalloc(&o_nodes.p, (size_t)n4 * sizeof(PtNode)));
+        k_sc_emit<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(bn, n_nodes, d_idx4.as<uint32_t>(), d_topbin.as<uint32_t>(), d_topsorted.as<uint32_t>(), small, (PtNode*)o_nodes.p);
+        SAH_TRY(hipGetLastError());
+        SAH_TRY(hipStreamSynchronize(st));
+        sout->n_nodes4 = n4; sout->n_leaves = h_small[0]; sout->max_leaf = h_small[1]; sout->max_depth4 = h_small[2]; sout->n_top = h_small[3]; sout->any_one_sided = h_small[4];
+        for (int a = 0; a < 3; a++) { sout->root_lo[a] = h_root.lo[a]; sout->root_hi[a] = h_root.hi[a]; }
+        sout->d_nodes = o_nodes.release(); sout->d_tris = o_tris.release(); sout->d_tinfo = o_tinfo.release(); sout->d_rec_of_prim = o_rop.release();
+        return 0;
+}
+
 // With `scene` the bounds come from the scene's vertices (uploaded here) and nothing is read back: the leaf records, the shading records and
 // the finished 4-wide node array are produced on the device and handed over in `sout` (plain hipMalloc blocks the caller owns from then on).
 static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max_prims, NoInitVec<uint32_t>* order, NoInitVec<LbvhNode>* nodes, hipError_t* err,
@@ -671,25 +752,9 @@ static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32
     const uint32_t blocks = (n + 255u) / 256u;
     Scratch d_P, d_idx, d_tmesh, d_mtab;
     if (scene) {
-        // the scene's arrays go up through page-locked staging filled by the host's threads (from pageable memory the runtime stages the copy
-        // itself at a few GB/s); the per-mesh tables are tiny
-        const size_t nP = 3 * (size_t)scene->n_vertices, nI = 3 * (size_t)n, nm = scene->n_meshes;
-        SAH_TRY(d_P.alloc(nP * 4)); SAH_TRY(d_idx.alloc(nI * 4)); SAH_TRY(d_tmesh.alloc((size_t)n * 4)); SAH_TRY(d_mtab.alloc(nm * 12 + 16));
-        float* stage = scene_staging((nP + nI + n + 3 * nm) * 4);
-        if (!stage) return 1;
-        uint32_t* su = reinterpret_cast<uint32_t*>(stage);
-        parallel_for(nP, [&](size_t a, size_t b) { std::memcpy(stage + a, scene->P + a, (b - a) * 4); });
-        parallel_for(nI, [&](size_t a, size_t b) { std::memcpy(su + nP + a, scene->indices + a, (b - a) * 4); });
-        parallel_for((size_t)n, [&](size_t a, size_t b) { std::memcpy(su + nP + nI + a, scene->tri_mesh + a, (b - a) * 4); });
-        std::memcpy(su + nP + nI + n, scene->mesh_triflags, nm * 4);
-        std::memcpy(su + nP + nI + n + nm, scene->mesh_material, nm * 4);
-        std::memcpy(su + nP + nI + n + 2 * nm, scene->mesh_flags, nm * 4);
-        SAH_TRY(hipMemcpyAsync(d_P.p, stage, nP * 4, hipMemcpyHostToDevice, st));
-        SAH_TRY(hipMemcpyAsync(d_idx.p, su + nP, nI * 4, hipMemcpyHostToDevice, st));
-        SAH_TRY(hipMemcpyAsync(d_tmesh.p, su + nP + nI, (size_t)n * 4, hipMemcpyHostToDevice, st));
-        SAH_TRY(hipMemcpyAsync(d_mtab.p, su + nP + nI + n, nm * 12, hipMemcpyHostToDevice, st));
-        k_sc_bounds<<<blocks, 256, 0, st>>>(d_P.as<float>(), d_idx.as<uint32_t>(), n, d_raw.as<float>());
-        if (trace) { const double ta = now(); (void)hipStreamSynchronize(st); std::fprintf(stderr, "[bvh] device scene: vertices + indices staged and uploaded (%.1f MB), bounds on the device: %.2f ms since entry, %.2f ms waiting\n", (nP + nI + n) * 4e-6, now() - t0, now() - ta); }
+        const int urc = upload_scene_arrays(st, *scene, d_P, d_idx, d_tmesh, d_mtab, d_raw.as<float>(), err);
+        if (urc != 0) return urc;
+        if (trace) { const double ta = now(); (void)hipStreamSynchronize(st); std::fprintf(stderr, "[bvh] device scene: vertices + indices staged and uploaded, bounds on the device: %.2f ms since entry, %.2f ms waiting\n", now() - t0, now() - ta); }
     } else {
         SAH_TRY(hipMemcpyAsync(d_raw.p, raw_bounds, (size_t)n * 24, hipMemcpyHostToDevice, st));
         if (trace) { const double ta = now(); (void)hipStreamSynchronize(st); std::fprintf(stderr, "[bvh] device SAH: bounds upload %.2f ms (%.1f MB)\n", now() - ta, n * 24e-6); }
@@ -741,49 +806,13 @@ static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32
     k_sah_order<<<blocks, 256, 0, st>>>(d_items[cur].as<SItem>(), n, d_order.as<uint32_t>());
     SAH_TRY(hipGetLastError());
     if (scene) {
-        // ---- everything else of the upload, on the device
-        const LbvhNode* bn = d_export.as<LbvhNode>();
-        const uint32_t* mtab = d_mtab.as<uint32_t>();
-        const uint32_t nm = scene->n_meshes;
-        struct Owned { void* p = nullptr; ~Owned() { if (p) (void)hipFree(p); } void* release() { void* q = p; p = nullptr; return q; } };
-        Owned o_tris, o_tinfo, o_rop, o_nodes;
-        SAH_TRY(hipMalloc(&o_tris.p, ((size_t)n + 1) * sizeof(PtTri)));
-        SAH_TRY(hipMalloc(&o_tinfo.p, (size_t)n * sizeof(PtTriInfo)));
-        SAH_TRY(hipMalloc(&o_rop.p, (size_t)n * 4));
-        Scratch d_size4, d_idx4, d_topbin, d_topsorted, d_s2;
-        SAH_TRY(d_size4.alloc((size_t)n_nodes * 4)); SAH_TRY(d_idx4.alloc((size_t)n_nodes * 4));
-        SAH_TRY(d_topbin.alloc(PT_TOP_BFS_NODES * 4)); SAH_TRY(d_topsorted.alloc(PT_TOP_BFS_NODES * 4)); SAH_TRY(d_s2.alloc(64));
-        uint32_t* small = d_s2.as<uint32_t>();          // [0] leaves, [1] largest leaf, [2] deepest 4-wide level, [3] n_top, [4] any one-sided
-        SAH_TRY(hipMemsetAsync(small, 0, 64, st));
-        SAH_TRY(hipMemsetAsync(d_size4.p, 0, (size_t)n_nodes * 4, st));
-        SAH_TRY(hipMemsetAsync(d_idx4.p, 0xff, (size_t)n_nodes * 4, st));
-        k_sc_records<<<(n + 1u + 255u) / 256u, 256, 0, st>>>(d_order.as<uint32_t>(), d_P.as<float>(), d_idx.as<uint32_t>(), d_tmesh.as<uint32_t>(), mtab,
-                                                           reinterpret_cast<const int32_t*>(mtab + nm), mtab + 2 * nm, n, (PtTri*)o_tris.p, (PtTriInfo*)o_tinfo.p, (uint32_t*)o_rop.p, small);
-        k_sc_leafmark<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(bn, n_nodes, (PtTri*)o_tris.p, small);
-        const size_t n_lv = level_begin.size() - 1;
-        for (size_t l = n_lv; l-- > 0;)
-            if ((l & 1) == 0) { const uint32_t b = level_begin[l], c = level_begin[l + 1] - b; k_sc_size4<<<(c + 255u) / 256u, 256, 0, st>>>(bn, b, c, d_size4.as<uint32_t>(), (uint32_t)l, small); }
-        SAH_TRY(hipMemsetAsync(d_idx4.p, 0, 4, st));                // the root is 4-wide node 0
-        for (size_t l = 0; l < n_lv; l += 2) { const uint32_t b = level_begin[l], c = level_begin[l + 1] - b; k_sc_idx4<<<(c + 255u) / 256u, 256, 0, st>>>(bn, b, c, d_size4.as<uint32_t>(), d_idx4.as<uint32_t>()); }
-        k_sc_top<<<1, 1024, 0, st>>>(bn, d_idx4.as<uint32_t>(), d_topbin.as<uint32_t>(), d_topsorted.as<uint32_t>(), small);
-        SAH_TRY(hipGetLastError());
-        uint32_t h_small[8], n4 = 0;
-        LbvhNode h_root;
-        SAH_TRY(hipMemcpyAsync(h_small, small, 32, hipMemcpyDeviceToHost, st));
-        SAH_TRY(hipMemcpyAsync(&n4, d_size4.p, 4, hipMemcpyDeviceToHost, st));
-        SAH_TRY(hipMemcpyAsync(&h_root, bn, sizeof(LbvhNode), hipMemcpyDeviceToHost, st));
-        SAH_TRY(hipStreamSynchronize(st));
-        if (n4 == 0 || n4 >= (1u << 25)) return 1;
-        SAH_TRY(hipMalloc(&o_nodes.p, (size_t)n4 * sizeof(PtNode)));
-        k_sc_emit<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(bn, n_nodes, d_idx4.as<uint32_t>(), d_topbin.as<uint32_t>(), d_topsorted.as<uint32_t>(), small, (PtNode*)o_nodes.p);
-        SAH_TRY(hipGetLastError());
-        SAH_TRY(hipStreamSynchronize(st));
-        sout->n_nodes4 = n4; sout->n_leaves = h_small[0]; sout->max_leaf = h_small[1]; sout->max_depth4 = h_small[2]; sout->n_top = h_small[3]; sout->any_one_sided = h_small[4];
-        for (int a = 0; a < 3; a++) { sout->root_lo[a] = h_root.lo[a]; sout->root_hi[a] = h_root.hi[a]; }
-        sout->d_nodes = o_nodes.release(); sout->d_tris = o_tris.release(); sout->d_tinfo = o_tinfo.release(); sout->d_rec_of_prim = o_rop.release();
-        if (trace) std::fprintf(stderr, "[bvh] device scene: %u items, %u binary nodes in %zu levels -> %u 4-wide nodes (top %u renumbered), %u leaves: setup %.2f levels %.2f records + collapse %.2f ms\n", n,
-                                n_nodes, n_lv, n4, sout->n_top, sout->n_leaves, t1 - t0, t2 - t1, now() - t2);
-        return 0;
+        std::vector<std::pair<uint32_t, uint32_t>> lv;
+        for (size_t l = 0; l + 1 < level_begin.size(); l++) lv.push_back({level_begin[l], level_begin[l + 1] - level_begin[l]});
+        const int frc = finish_scene(st, d_export.as<LbvhNode>(), n_nodes, 0u, lv, nullptr, d_order.as<uint32_t>(), d_P.as<float>(), d_idx.as<uint32_t>(), d_tmesh.as<uint32_t>(),
+                                     d_mtab.as<uint32_t>(), scene->n_meshes, n, sout, err);
+        if (trace && frc == 0) std::fprintf(stderr, "[bvh] device scene (sah): %u items, %u binary nodes in %zu levels -> %u 4-wide nodes (top %u renumbered), %u leaves: setup %.2f levels %.2f records + collapse %.2f ms\n", n,
+                                            n_nodes, lv.size(), sout->n_nodes4, sout->n_top, sout->n_leaves, t1 - t0, t2 - t1, now() - t2);
+        return frc;
     }
     nodes->resize(n_nodes);
     order->resize(n);
@@ -799,6 +828,65 @@ int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max
 }
 int device_sah_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, SceneOut* out, hipError_t* err) {
     return sah_build(st, nullptr, in.n_tris, max_prims, nullptr, nullptr, err, &in, out);
+}
+// "splitmethod" "hlbvh" the same way: bounds from the vertices on the device, Morton sort / treelets / emit_lbvh (pt_hlbvh.hip) with the tree
+// and the order kept there, the upper SAH over the <= 4096 treelet roots on the host (their boxes come back, the joining nodes go up behind
+// the treelets' nodes), then the same records / collapse / finishing kernels -- over level lists, since these nodes are not numbered by level.
+int device_hlbvh_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, SceneOut* out, hipError_t* err) {
+    ArenaScope arena_scope;
+    const bool trace = std::getenv("PBRTGPU_BUILD_TRACE") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    if (err) *err = hipSuccess;
+    const uint32_t n = in.n_tris;
+    if (n < 2 || n > (1u << 26)) return 1;
+    const uint32_t node_cap = 2u * n + 2u * 4096u + 8u;
+    t_arena.reserve((size_t)n * 200 + (size_t)in.n_vertices * 12 + ((size_t)2 << 20));
+    Scratch d_raw, d_P, d_idx, d_tmesh, d_mtab, d_bn, d_order, d_list, d_cnt;
+    SAH_TRY(d_raw.alloc((size_t)n * 24));
+    SAH_TRY(d_bn.alloc((size_t)node_cap * sizeof(LbvhNode)));
+    SAH_TRY(d_order.alloc((size_t)n * 4));
+    const int urc = upload_scene_arrays(st, in, d_P, d_idx, d_tmesh, d_mtab, d_raw.as<float>(), err);
+    if (urc != 0) return urc;
+    uint32_t n_nodes = 0, n_roots = 0;
+    std::vector<LbvhNode> roots;
+    const int rc = device_lbvh_keep(st, d_raw.as<float>(), n, max_prims, d_order.as<uint32_t>(), d_bn.as<LbvhNode>(), node_cap, &n_nodes, &n_roots, &roots, err);
+    if (rc != 0) return rc;
+    const double t1 = now();
+    // upper SAH on the host; its nodes refer to roots (< n_roots) and to each other (>= n_roots there, >= n_nodes on the device)
+    NoInitVec<LbvhNode> tree(roots.begin(), roots.end());
+    const int32_t root_h = hlbvh_upper_tree(tree, n_roots);
+    if (root_h < 0) return -2;
+    const uint32_t n_upper = (uint32_t)tree.size() - n_roots;
+    if (n_nodes + n_upper > node_cap) return 1;
+    auto remap = [&](int32_t k) { return k < 0 || (uint32_t)k < n_roots ? k : (int32_t)((uint32_t)k - n_roots + n_nodes); };
+    for (uint32_t k = n_roots; k < tree.size(); k++) { tree[k].left = remap(tree[k].left); tree[k].right = remap(tree[k].right); }
+    if (n_upper) SAH_TRY(hipMemcpyAsync(d_bn.as<LbvhNode>() + n_nodes, tree.data() + n_roots, (size_t)n_upper * sizeof(LbvhNode), hipMemcpyHostToDevice, st));
+    const uint32_t root = (uint32_t)remap(root_h), total = n_nodes + n_upper;
+    // the tree level by level, as lists of node numbers
+    SAH_TRY(d_list.alloc((size_t)total * 4 + 16)); SAH_TRY(d_cnt.alloc(16));
+    SAH_TRY(hipMemcpyAsync(d_list.p, &root, 4, hipMemcpyHostToDevice, st));
+    const uint32_t one = 1;
+    SAH_TRY(hipMemcpyAsync(d_cnt.p, &one, 4, hipMemcpyHostToDevice, st));
+    std::vector<std::pair<uint32_t, uint32_t>> levels;
+    uint32_t begin = 0, count = 1;
+    while (count > 0) {
+        if (levels.size() > 4096) return 1;
+        levels.push_back({begin, count});
+        k_sc_next_level<<<(count + 255u) / 256u, 256, 0, st>>>(d_bn.as<LbvhNode>(), d_list.as<uint32_t>(), begin, count, d_cnt.as<uint32_t>());
+        SAH_TRY(hipGetLastError());
+        uint32_t filled = 0;
+        SAH_TRY(hipMemcpyAsync(&filled, d_cnt.p, 4, hipMemcpyDeviceToHost, st));
+        SAH_TRY(hipStreamSynchronize(st));
+        begin += count;
+        count = filled - begin;
+    }
+    const double t2 = now();
+    const int frc = finish_scene(st, d_bn.as<LbvhNode>(), total, root, levels, d_list.as<uint32_t>(), d_order.as<uint32_t>(), d_P.as<float>(), d_idx.as<uint32_t>(), d_tmesh.as<uint32_t>(),
+                                 d_mtab.as<uint32_t>(), in.n_meshes, n, out, err);
+    if (trace && frc == 0) std::fprintf(stderr, "[bvh] device scene (hlbvh): %u items, %u + %u binary nodes in %zu levels -> %u 4-wide nodes (top %u renumbered), %u leaves: upload + lower half %.2f upper + levels %.2f records + collapse %.2f ms\n",
+                                        n, n_nodes, n_upper, levels.size(), out->n_nodes4, out->n_top, out->n_leaves, t1 - t0, t2 - t1, now() - t2);
+    return frc;
 }
 void SceneOut::free_all() {
     if (d_nodes) (void)hipFree(d_nodes);

@@ -34,11 +34,12 @@ def _digests(sd, expect_device=True):
 @pytest.mark.parametrize("n,leaf", [(12, 4), (13, 1), (1024, 4), (1025, 5), (4000, 4), (70001, 4), (300000, 8), (300000, 255)])
 def test_device_build_matches_host_build(n, leaf):
     """Sizes around the sort tile (1024 keys) and the wave (64); leaf sizes 1 .. 255.  The enclosure's ceiling and light quads are
-    four triangles whose boxes share one centre, so below four primitives per leaf emit_lbvh needs the median fallback: host build."""
+    four triangles whose boxes share one centre, so below four primitives per leaf emit_lbvh runs out of code bits and goes on by
+    centroid medians (split_node) -- on the device as well since round 3."""
     sd = scenes.rt1m(n, res=16, spp=1, max_depth=1)
     sd.desc.split_method = 1
     sd.desc.max_node_prims = leaf
-    host, dev = _digests(sd, expect_device=leaf >= 4)
+    host, dev = _digests(sd, expect_device=True)
     assert host == dev
 
 
@@ -59,10 +60,15 @@ def test_device_build_clustered_geometry():
     assert host == dev
 
 
-def test_device_build_gives_way_to_host_for_median_fallback():
-    """A Morton cell with more than maxnodeprims primitives needs split_node's re-sort: the device reports it, the host builds,
-    and the scene uploads as if the device had never been asked."""
-    host, dev = _digests(fs.scene_hlbvh_cluster(), expect_device=False)
+def test_device_build_median_fallback_on_the_device():
+    """More primitives than a leaf may hold inside one Morton cell (a cluster of 60 within 1e-5, 40 exact duplicates): split_node's
+    centroid medians (hlbvh.rs:102-157) run on the device -- stable order along the cycling axis, cut in the middle -- and give the
+    host builder's arrays."""
+    host, dev = _digests(fs.scene_hlbvh_cluster(), expect_device=True)
+    assert host == dev
+    sd = fs.scene_hlbvh_cluster()
+    sd.desc.max_node_prims = 1
+    host, dev = _digests(sd, expect_device=True)
     assert host == dev
 
 

@@ -7,12 +7,14 @@ PBRTGPU_BUILD_TRACE=1 python3 - > gpurun_out/r03f/build_trace.txt 2>&1 <<'PY'
 import importlib, sys, os
 sys.path.insert(0, os.getcwd())
 pkg = importlib.import_module("pbrt-r3_amd")
-for n in (1000000, 3500000, 16000000):
+for split in (0, 1):
+  for n in (1000000, 3500000, 16000000):
     sd = pkg.scenes.rt1m(n, res=64, spp=1)
+    sd.desc.split_method = split
     ctx = pkg.Context(0)
     for k in range(3):
         info = ctx.upload(sd)
-        print("n=%d upload %d: bvh_build_ms %.1f upload_ms %.1f on_device %d nodes %d" % (n, k, info.bvh_build_ms, info.upload_ms, info.bvh_on_device, info.n_nodes), flush=True)
+        print("split=%s n=%d upload %d: bvh_build_ms %.1f upload_ms %.1f on_device %d nodes %d" % ("sah" if split == 0 else "hlbvh", n, k, info.bvh_build_ms, info.upload_ms, info.bvh_on_device, info.n_nodes), flush=True)
     ctx.close()
 PY
-grep -E "n=|device scene|lights \+|device scene \(" gpurun_out/r03f/build_trace.txt | cut -c1-260
+grep -E "n=|device scene \(" gpurun_out/r03f/build_trace.txt | cut -c1-260
