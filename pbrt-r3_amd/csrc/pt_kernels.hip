@@ -16,6 +16,7 @@
 //   camera     src/cameras/perspective.rs:121-183, src/core/transform/transform.rs:184-282
 //   film       src/core/film/film_tile.rs:84-183, film.rs:219-241, :440-484
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "pt_device.h"
 #include "pt_device_math.h"
 #include "pt_bxdf.h"
@@ -2578,6 +2579,15 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_TEX_WAVES) k_sha
     shade_body<true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
 }
 
+// Every material through the lobe-list path in PATH order, no material sort (experiment switch PBRTGPU_SHADE_UNSORTED=1: sorted queues make
+// a wave see one material but walk the path pool with gaps; this form keeps the pool accesses dense and lets the lobe dispatch diverge)
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_GEN_WAVES) k_shade_all(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, false>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[PT_Q_CUR], &Q.counts[PT_Q_TICKET]);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_TEX_WAVES) k_shade_all_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, true, true>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[PT_Q_CUR], &Q.counts[PT_Q_TICKET]);
+}
+
 // ============================================================ film
 PT_DEV V3 validate_radiance(V3 l) {    // sampler.rs:151-176
     if (!finite3(l)) return mk3(0.0f, 0.0f, 0.0f);
@@ -3515,6 +3525,12 @@ hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode) {
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt) {
+    static const int unsorted = [] { const char* e = std::getenv("PBRTGPU_SHADE_UNSORTED"); return e ? std::atoi(e) : 0; }();
+    if (sc.general_materials && unsorted && !sc.n_instances && (!sc.n_spheres || sc.textured)) {
+        if (sc.textured) hipLaunchKernelGGL(k_shade_all_tex, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        else hipLaunchKernelGGL(k_shade_all, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        return PT_LAUNCH_CHECK();
+    }
     if (sc.general_materials) {
         hipLaunchKernelGGL(k_sort_count, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(PT_SORT_BINS), 0, st, Q);
