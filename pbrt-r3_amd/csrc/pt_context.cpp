@@ -1371,7 +1371,6 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     }
     // Continuation rays in origin order as well, where it pays: once nodes + leaf records outgrow the 256 MiB Infinity Cache the traversal
     // kernel waits on HBM, and rays that start in one cell miss the caches together instead of one by one.
-    Q.next_key = nullptr;
     int sort_cont = ctx->sort_cont;
     if (sort_cont < 0) sort_cont = (ctx->n_nodes_up * sizeof(PtNode) + ctx->n_tris_up * sizeof(PtTri) > ((size_t)256 << 20)) ? 1 : 0;
     if (sc.integrator != PT_INTEGRATOR_PATH) sort_cont = 0;
@@ -1385,7 +1384,6 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
             PT_HIP(ctx->d_csort_temp.alloc(tb));
             ctx->csort_cap = ctx->pool_paths;
         }
-        Q.next_key = ctx->d_csort_keys[0].as<uint32_t>();
     }
     PtCounters* cnt = ctx->d_counters.as<PtCounters>();
     uint32_t* err = ctx->d_err.as<uint32_t>();
@@ -1512,13 +1510,14 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 };
                 // after a bounce's shading: order its shadow rays by where they start (pt_raysort.hip); costs one counter read-back
                 auto sort_shadow = [&]() -> pt_status {
-                    if (!Q.shadow_key && !Q.next_key) return PT_OK;
+                    if (!Q.shadow_key && !sort_cont) return PT_OK;
                     uint32_t qc[PT_Q_SHADOW + 1];             // one read-back: the next bounce's continuation rays (prep has moved next to cur) and its shadow rays
                     PT_HIP(hipMemcpyAsync(qc, Q.counts, sizeof(qc), hipMemcpyDeviceToHost, ctx->stream));
                     PT_HIP(hipStreamSynchronize(ctx->stream));
                     const uint32_t n_sh = qc[PT_Q_SHADOW], n_next = qc[PT_Q_CUR];
-                    if (Q.next_key && n_next >= (uint32_t)std::max(ctx->sort_shadow_min, 1)) {
-                        // Q.next holds the list k_shade has just written; the ordered copy goes to the spare list
+                    if (sort_cont && n_next >= (uint32_t)std::max(ctx->sort_shadow_min, 1)) {
+                        // Q.next holds the list k_shade has just written: its rays' keys, then the ordered copy into the spare list
+                        PT_HIP(ptk_cont_keys(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q.next, n_next, ctx->d_csort_keys[0].as<uint32_t>()));
                         PT_HIP(ptk_sort_rays_keep(ctx->stream, Q.next, cont_spare, ctx->d_csort_keys[0].as<uint32_t>(), ctx->d_csort_keys[1].as<uint32_t>(),
                                                   ctx->d_csort_temp.p, ctx->d_csort_temp.bytes, n_next));
                         if (sort_cont == 2) std::swap(Q.next, cont_spare);      // shading walks the ordered list too; the old list is the spare now
@@ -1836,7 +1835,7 @@ pt_status pt_trace_wavefront(pt_context* ctx, uint32_t n, const float* o, const 
     PtQueues Q;
     Q.cur = ctx->d_qa.as<uint32_t>(); Q.next = ctx->d_qb.as<uint32_t>();
     Q.nee = ctx->d_qnee.as<uint32_t>(); Q.counts = ctx->d_counts.as<uint32_t>(); Q.sorted = ctx->d_qsorted.as<uint32_t>();
-    Q.shadow = ctx->d_qshadow.as<uint32_t>(); Q.probe = ctx->d_qprobe.as<uint32_t>(); Q.shadow_key = nullptr; Q.next_key = nullptr; Q.bin = nullptr;
+    Q.shadow = ctx->d_qshadow.as<uint32_t>(); Q.probe = ctx->d_qprobe.as<uint32_t>(); Q.shadow_key = nullptr; Q.bin = nullptr;
     uint32_t* const dst_q[3] = {Q.cur, Q.shadow, Q.probe};
     for (int k = 0; k < 3; k++)
         if (!ids[k].empty()) PT_HIP(hipMemcpyAsync(dst_q[k], ids[k].data(), ids[k].size() * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -335,7 +335,6 @@ struct PtQueues {
     uint32_t* sorted;    // cur re-ordered by material bin, misses dropped (scenes with non-Matte materials)
     uint16_t* bin;       // per entry of cur: its material bin (0xffff: a miss), written by k_sort_count for k_sort_scatter; nullptr: recomputed there
     uint32_t* shadow_key;// per entry of shadow: the sort key of its ray (origin cell | direction octant, pt_raysort.hip); nullptr: not wanted
-    uint32_t* next_key;  // per entry of next: the same key for the continuation ray (scenes larger than the Infinity Cache); nullptr: not wanted
 };
 #define PT_Q_CUR 0u          // items in cur
 #define PT_Q_MATTE_END 1u    // material sort: end of the Matte segment of sorted

@@ -41,6 +41,7 @@ int ptk_shade_prof_read(unsigned long long* out16);
 size_t ptk_sort_rays_temp_bytes(uint32_t cap);
 hipError_t ptk_sort_shadow_rays(hipStream_t st, uint32_t* ids, uint32_t* ids_alt, uint32_t* keys, uint32_t* keys_alt, void* temp, size_t temp_bytes, uint32_t n,
                                 uint32_t** sorted);
+hipError_t ptk_cont_keys(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* list, uint32_t n, uint32_t* keys);
 size_t ptk_sort_rays_keep_temp_bytes(uint32_t cap);
 hipError_t ptk_sort_rays_keep(hipStream_t st, const uint32_t* ids, uint32_t* ids_out, const uint32_t* keys, uint32_t* keys_out, void* temp, size_t temp_bytes, uint32_t n);
 int ptk_trace_dist_blocks_per_cu();      // blocks per CU the pooled-leaf traversal kernels were built for (LDS budget)

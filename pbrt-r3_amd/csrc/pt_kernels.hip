@@ -2181,7 +2181,6 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     __shared__ float4 s_stage[7][PT_BLOCK];
     __shared__ uint32_t s_pend[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: path ids of the iterations not yet queued (their queue bits: `pend_want`)
     __shared__ uint32_t s_pkey[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: the sort key of those iterations' shadow rays
-    __shared__ uint32_t s_ckey[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: the sort key of their continuation rays (Q.next_key)
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
     uint32_t n_vert = 0;
@@ -2223,10 +2222,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             if (j < n_batch) {
                 const uint32_t e = pend_want >> (4u * j), ep = s_pend[j][threadIdx.x];
                 const unsigned long long mc = __ballot((e & 1u) != 0), mn = __ballot((e & 2u) != 0), ms = __ballot((e & 4u) != 0), mp = __ballot((e & 8u) != 0);
-                if (e & 1u) {
-                    Q.next[bc + (uint32_t)__popcll(mc & below)] = ep;
-                    if (Q.next_key) Q.next_key[bc + (uint32_t)__popcll(mc & below)] = s_ckey[j][threadIdx.x];
-                }
+                if (e & 1u) Q.next[bc + (uint32_t)__popcll(mc & below)] = ep;
                 if (e & 2u) Q.nee[bn + (uint32_t)__popcll(mn & below)] = ep;
                 if (e & 4u) {
                     Q.shadow[bs + (uint32_t)__popcll(ms & below)] = ep;
@@ -2366,7 +2362,6 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     // no BSDF: continue through the surface, same bounce count (path.rs:108-111)
                     V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
                     o_ray_o = make_float4(no.x, no.y, no.z, PT_INF); wr |= 1u;
-                    if (Q.next_key) s_ckey[n_batch][threadIdx.x] = ray_sort_key(sc, no, rd);
                     cont = true; PT_COMMIT_NOW(0);
                 } else {
                     n_vert++;
@@ -2522,7 +2517,6 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                             // roulette continued with direction z = 0 (profiles/r03_deferred_store_miscompile.md)
                             o_ray_d = make_float4(wi.x, wi.y, wi.z, opaque_zero());
                             o_beta = make_float4(beta.x, beta.y, beta.z, eta_scale);
-                            if (Q.next_key) s_ckey[n_batch][threadIdx.x] = ray_sort_key(sc, no, wi);
                             wr |= 3u; PT_COMMIT_NOW(4);
                             bounces++;
                             cont = true;
@@ -2577,6 +2571,17 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_s
 // scenes with textured materials (and possibly spheres): lobes are built per hit for the textured ones
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_TEX_WAVES) k_shade_general_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
+}
+
+// Sort keys of a bounce's continuation rays, for scenes larger than the Infinity Cache (pt_context.cpp sort_cont): a pass of its own over the
+// list k_shade has just written -- inside the shading kernels the key arithmetic cost the general kernel registers it does not have
+// (mixed materials 857 -> 832 Mrays/s with the sort off), here it is 32 bytes read per ray where traversal is 96 % of the frame
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_cont_keys(PtScene sc, PtPaths P, const uint32_t* list, uint32_t n, uint32_t* keys) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = list[i];
+        const float4 o = P.ray_o[p], d = P.ray_d[p];
+        keys[i] = ray_sort_key(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z));
+    }
 }
 
 // Every material through the lobe-list path in PATH order, no material sort (experiment switch PBRTGPU_SHADE_UNSORTED=1: sorted queues make
@@ -3556,6 +3561,10 @@ hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths&
     } else {
         hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
     }
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_cont_keys(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* list, uint32_t n, uint32_t* keys) {
+    hipLaunchKernelGGL(k_cont_keys, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, list, n, keys);
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,
