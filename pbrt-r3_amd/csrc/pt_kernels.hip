@@ -1000,7 +1000,7 @@ PT_DEV void flush_counters(PtCounters* g, unsigned long long* s_cnt, unsigned lo
 PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
     uint32_t base = 0;
     if ((threadIdx.x & 63) == 0) base = atomicAdd(ticket, 64u);
-    return __shfl(base, 0, 64);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)base);      // lane 0 holds it; uniform for the compiler too (scalar loop state in the callers)
 }
 
 // ============================================================ K_TRACE (wavefront)
@@ -1042,6 +1042,11 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 
 #ifndef PT_LEAF_TRIS_MIN
 #define PT_LEAF_TRIS_MIN 56          // distributed leaf phase on its own (general visit in the wave): once this many triangle tests are parked
+#endif
+#ifndef PT_LEAF_LANES_MIN
+#define PT_LEAF_LANES_MIN 18         // > 0: a leaf round once this many LANES are parked on a leaf, instead of PT_LEAF_TRIS_MIN parked tests (0).  The exact
+                                     // test count costs four ballots + popcounts in EVERY iteration's phase decision; RT1M at 64 spp, k_trace ms per launch:
+                                     // tests >= 56: 39.66; lanes >= 12 / 16 / 18 / 20 / 22 / 24 / 28 / 32: 40.88 / 39.39 / 39.34 / 39.43 / 40.00 / 40.52 / 41.79 / 43.50
 #endif
 #ifndef PT_LEAF_TRIS_FUSED
 #define PT_LEAF_TRIS_FUSED 0         // > 0: a leaf round rides along a staged node round once this many tests are parked (experiment)
@@ -1144,7 +1149,9 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             // the XCDs round-robin), so each L2 sees one contiguous, pixel-ordered slice of the rays; a wave whose
             // segment has run dry moves on to the next one.
             const uint32_t seg_lo = seg * seg_len, seg_hi = min(total, seg_lo + seg_len);
-            const uint32_t base = seg_lo + (uint32_t)__shfl((int)pf_raw, 0, 64);
+            // readfirstlane, not a shuffle: the compiler then KNOWS the ticket is wave-uniform, and with it the whole prefetch state machine
+            // (stage, segment, counts) lives in scalar registers and branches on the scalar unit instead of v_cmp + EXEC masking every iteration
+            const uint32_t base = seg_lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)pf_raw);
             if (seg_lo >= total || base >= seg_hi) {
                 seg = (seg + 1u) & 7u;
                 if (++seg_dry == 8u) more = false;
@@ -1218,9 +1225,16 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         if constexpr (DIST) {
             // triangles parked: the count rides in bits 28..30 of the leaf reference
             const uint32_t tcnt = w_tri ? ((r.top >> PT_LEAF_COUNT_SHIFT) & 7u) + 1u : 0u;
+#if PT_LEAF_LANES_MIN > 0
+            // the leaf-round trigger from the number of parked LANES (experiment: the exact count of parked tests costs four ballots and
+            // popcounts per iteration, needed by every iteration's phase decision; leaf_issue computes its own prefix sums when a round runs)
+            unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            const uint32_t n_parked = (uint32_t)__popcll(m_tri) >= (uint32_t)PT_LEAF_LANES_MIN ? (uint32_t)PT_LEAF_TRIS_MIN : 0u;
+#else
             const unsigned long long c0 = __ballot((tcnt & 1u) != 0), c1 = __ballot((tcnt & 2u) != 0), c2 = __ballot((tcnt & 4u) != 0),
                                      c3 = __ballot((tcnt & 8u) != 0);
             const uint32_t n_parked = (uint32_t)(__popcll(c0) + 2 * __popcll(c1) + 4 * __popcll(c2) + 8 * __popcll(c3));
+#endif
             // ---- distributed leaf round, in two halves so that its triangle loads can fly together with a node round's fetches.
             // issue: owners are served in lane order while their whole leaf fits (the others stay parked); lane w becomes the helper
             // of triangle k of owner o, takes the owner's ray constants by ds_bpermute and starts the 48-byte record's load.
@@ -1231,6 +1245,9 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             RayPre lf_rp;
             TriVerts lf_tv;
             auto leaf_issue = [&]() {
+#if PT_LEAF_LANES_MIN > 0
+                c0 = __ballot((tcnt & 1u) != 0); c1 = __ballot((tcnt & 2u) != 0); c2 = __ballot((tcnt & 4u) != 0); c3 = __ballot((tcnt & 8u) != 0);
+#endif
                 lf_pre = (uint32_t)(__popcll(c0 & below) + 2 * __popcll(c1 & below) + 4 * __popcll(c2 & below) + 8 * __popcll(c3 & below));
                 lf_served = w_tri && lf_pre + tcnt <= 64u;
                 const unsigned long long m_served = __ballot(lf_served);
@@ -2216,7 +2233,8 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             if (ts) bs = atomicAdd(&Q.counts[PT_Q_SHADOW], ts);
             if (tp) bp = atomicAdd(&Q.counts[PT_Q_PROBE], tp);
         }
-        bc = __shfl(bc, 0, 64); bn = __shfl(bn, 0, 64); bs = __shfl(bs, 0, 64); bp = __shfl(bp, 0, 64);
+        bc = (uint32_t)__builtin_amdgcn_readfirstlane((int)bc); bn = (uint32_t)__builtin_amdgcn_readfirstlane((int)bn);       // lane 0 made the reservations; uniform for the compiler too
+        bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs); bp = (uint32_t)__builtin_amdgcn_readfirstlane((int)bp);
 #pragma unroll
         for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++) {
             if (j < n_batch) {
@@ -2239,7 +2257,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         if (chunk_left == 0) {                 // one ticket atomic per PT_SHADE_TICKET x 64 items
             uint32_t t0 = 0;
             if (lane == 0) t0 = atomicAdd(ticket, 64u * PT_SHADE_TICKET);
-            next_base = begin + (uint32_t)__shfl((int)t0, 0, 64);
+            next_base = begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)t0);
             chunk_left = PT_SHADE_TICKET;
         }
         uint32_t base = next_base;
@@ -3214,7 +3232,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
             if (j < n_batch) tc += (uint32_t)__popcll(__ballot(((want >> j) & 1u) != 0));
         uint32_t bc = 0;
         if (lane == 0 && tc) bc = atomicAdd(&Q.counts[PT_Q_NEXT], tc);
-        bc = __shfl(bc, 0, 64);
+        bc = (uint32_t)__builtin_amdgcn_readfirstlane((int)bc);
 #pragma unroll
         for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++)
             if (j < n_batch) {
