@@ -2211,8 +2211,10 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     // (tools/ubench/atomic_rate.hip: 88 M/s however many waves ask), so one reservation per queue and 64 paths -- 540 k of them
     // for a 34 M-path bounce -- made the queue counter, not the shading, set this kernel's duration.
     uint32_t n_batch = 0, pend_want = 0;      // pend_want: four queue bits (next, nee, shadow, probe) per pending iteration
-    uint32_t pf_p = 0;                  // prefetched for the next iteration: path id, its hit record
+    uint32_t pf_p = 0;                  // prefetched for the next iteration: path id, its hit record, its state word, sampler index and pixel
     int32_t pf_rec = -1;
+    uint32_t pf_st = 0, pf_pk = 0;
+    uint64_t pf_idx = 0;
     bool pf_valid = false;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     auto flush_batch = [&]() {
@@ -2296,6 +2298,8 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         const bool had_pf = pf_valid;
         const uint32_t pf_p_now = pf_p;
         const int32_t pf_rec_now = pf_rec;
+        const uint32_t pf_st_now = pf_st, pf_pk_now = pf_pk;
+        const uint64_t pf_idx_now = pf_idx;
         pf_valid = chunk_left > 0;
         const bool pf_lane = pf_valid && next_base + lane < end;
         if (pf_lane) pf_p = list[next_base + lane];
@@ -2305,7 +2309,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             float4 ro4 = P.ray_o[p], rd4 = P.ray_d[p];
             V3 ro = f4_3(ro4), rd = f4_3(rd4);
             int32_t rec = had_pf ? pf_rec_now : P.hit_rec[p];
-            uint32_t st = P.state[p];
+            uint32_t st = had_pf ? pf_st_now : P.state[p];
             uint32_t dim = st & 0xffffu, bounces = (st >> 16) & 0xffu, flags = st >> 24;
             float4 beta4 = P.beta[p];
             V3 beta = f4_3(beta4);
@@ -2321,8 +2325,8 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             SamplerPre sm;
             sm.s.index = 0; sm.s.dim = dim; sm.s.px = 0; sm.s.py = 0; sm.dim0 = dim; sm.have = false;
             if (rec >= 0 && (int32_t)bounces < sc.max_depth) {
-                sm.s.index = P.sobol_index[p];
-                const uint32_t pk = P.pixel[p];
+                sm.s.index = had_pf ? pf_idx_now : P.sobol_index[p];
+                const uint32_t pk = had_pf ? pf_pk_now : P.pixel[p];
                 sm.s.px = (int32_t)(pk & 0xffffu) + sc.film.sample_bounds[0];
                 sm.s.py = (int32_t)(pk >> 16) + sc.film.sample_bounds[1];
                 PT_SHP_SYNC(15);
@@ -2335,7 +2339,10 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             if constexpr (INST) found = rec >= 0 && make_surf_inst<SPH>(sc, ro, rd, (uint32_t)rec, P.hit_inst[p], s, &thit);
             else found = rec >= 0 && make_surf_any_rec<SPH>(sc, ro, rd, (uint32_t)rec, rec_a, rec_b, rec_c, s, &thit);
             PT_SHP(0);
-            if (pf_lane) pf_rec = P.hit_rec[pf_p];          // pf_p has long arrived
+            if (pf_lane) {                                   // pf_p has long arrived: the head of the next iteration's dependent chain, one iteration early
+                pf_rec = P.hit_rec[pf_p];
+                pf_st = P.state[pf_p]; pf_idx = P.sobol_index[pf_p]; pf_pk = P.pixel[pf_p];
+            }
             // emitted radiance at the first vertex / after a specular bounce (path.rs:87-98)
             if (found && (bounces == 0 || (flags & PT_ST_SPECULAR))) {
                 int32_t li = s.light;

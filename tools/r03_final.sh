@@ -2,8 +2,8 @@
 # Round-3 end-of-round evidence, run on the GPU box: tools/r03_final.sh [a|b|c]
 #   a  the default bench line (driver's command), the same under rocprofv3 --kernel-trace --stats, FETCH_SIZE / WRITE_SIZE of the default
 #      workload (one frame each, separate counter-only passes), SQ and TCP counter passes on the final build
-#   b  the regime lines: crown-class (3.5 M triangles, textured, 1024 spp), 16 M dense, 16 M sparse -- with the traffic file in place -- and
-#      the secondary lines of round 2's table
+#   b  the regime lines: crown-class (3.5 M triangles, textured, 1024 spp), 16 M dense, 16 M sparse -- with the traffic file in place --, the
+#      killeroo-class stand-in for config 4 (mixed materials, sphere light, Halton, 512 spp) and the secondary lines of round 2's table
 #   c  the whole -m gpu suite
 cd "$(dirname "$0")/.."
 part="${1:-a}"
@@ -23,7 +23,8 @@ elif [ "$part" = b ]; then
   timeout -k 10 600 python3 bench.py --triangles 3500000 --materials textured --spp 1024 --steps 1 --warmup 1 --no-spp1024 --cpu-tiles 16 > "$out/bench_crown_class.json" 2> "$out/bench_crown_class.err"
   timeout -k 10 600 python3 bench.py --triangles 16000000 --steps 1 --warmup 1 --no-spp1024 --cpu-tiles 16 > "$out/bench_16m.json" 2> "$out/bench_16m.err"
   timeout -k 10 600 python3 bench.py --triangles 16000000 --tri-size 0.00125 --steps 1 --warmup 1 --no-spp1024 --cpu-tiles 16 > "$out/bench_16m_sparse.json" 2> "$out/bench_16m_sparse.err"
-  for f in crown_class 16m 16m_sparse; do python3 -c "import json,sys; d=json.load(open('$out/bench_$f.json')); r=d['roofline']; print('%-12s %8.1f Mrays/s  bound %s frac %.3f | l1 %.3f hbm %s | parity %.1e' % ('$f', d['value'], r['bound'], r['frac'], r['l1_req']['frac'], r['hbm'] and r['hbm']['frac'], d['parity']['rel_l2']))"; done
+  timeout -k 10 600 python3 bench.py --materials mixed --light sphere --sampler halton --spp 512 --steps 1 --warmup 1 --no-spp1024 --cpu-tiles 16 > "$out/bench_killeroo_class.json" 2> "$out/bench_killeroo_class.err"
+  for f in crown_class 16m 16m_sparse killeroo_class; do python3 -c "import json,sys; d=json.load(open('$out/bench_$f.json')); r=d['roofline']; print('%-12s %8.1f Mrays/s  bound %s frac %.3f | l1 %.3f hbm %s | parity %.1e' % ('$f', d['value'], r['bound'], r['frac'], r['l1_req']['frac'], r['hbm'] and r['hbm']['frac'], d['parity']['rel_l2']))"; done
   for v in "--integrator ao" "--materials mixed --spp 64" "--sampler halton --spp 64" "--integrator directlighting --spp 64" "--integrator whitted --spp 64" "--light sphere --spp 64" "--materials textured --spp 64"; do
     name=$(echo "$v" | tr -d '-' | tr ' ' '_')
     timeout -k 10 300 python3 bench.py $v --no-cpu-baseline --no-spp1024 > "$out/bench_$name.json" 2> "$out/bench_$name.err" || { echo "bench $v failed"; tail -3 "$out/bench_$name.err"; exit 1; }
