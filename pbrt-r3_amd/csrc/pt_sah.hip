@@ -78,37 +78,59 @@ __global__ void k_sah_root(SNodes N, uint32_t n, uint32_t* counters) {
     }
 }
 // bounds of the new nodes
-__global__ __launch_bounds__(256) void k_sah_bounds(const SItem* __restrict__ items, const uint32_t* __restrict__ node_of, uint32_t n, SNodes N) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int kBoundsT = 1024;
+__global__ __launch_bounds__(kBoundsT) void k_sah_bounds(const SItem* __restrict__ items, const uint32_t* __restrict__ node_of, uint32_t n, SNodes N) {
+    __shared__ uint32_t s_v[12];
+    __shared__ uint32_t s_node;
+    const uint32_t i = blockIdx.x * kBoundsT + threadIdx.x;
+    if (threadIdx.x < 12) s_v[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
+    if (threadIdx.x == 0) s_node = node_of[blockIdx.x * kBoundsT];
+    __syncthreads();
+    const uint32_t first = s_node;
     const bool in = i < n;
     const uint32_t nd = in ? node_of[i] : 0xffffffffu;
     const bool act = in && N.state[nd] == ST_NEW;
-    uint32_t v[12];
-    if (act) {
-        const SItem it = items[i];
-        for (int a = 0; a < 3; a++) { v[a] = f2ord(it.lo[a]); v[3 + a] = f2ord(it.hi[a]); v[6 + a] = f2ord(it.c[a]); v[9 + a] = v[6 + a]; }
-    } else {
-        for (int a = 0; a < 3; a++) { v[a] = 0xffffffffu; v[3 + a] = 0u; v[6 + a] = 0xffffffffu; v[9 + a] = 0u; }
-    }
-    if (__ballot(act) == 0ull) return;
-    // Items of one node are consecutive, so a wave holds a few runs of equal node ids: a segmented scan (min / max are exact in any
-    // order) leaves each run's reduction in its last lane, which alone goes to memory -- 12 atomics per run and wave, not per item.
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t key = act ? nd : 0xffffffffu;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t ko = (uint32_t)__shfl_up((int)key, off, 64);
-        const bool take = lane >= (uint32_t)off && ko == key;
-        for (int k = 0; k < 12; k++) {
-            const uint32_t o = (uint32_t)__shfl_up((int)v[k], off, 64);
-            if (take) v[k] = (k % 6) < 3 ? min(v[k], o) : max(v[k], o);
+    if (__ballot(act) != 0ull) {
+        uint32_t v[12];
+        if (act) {
+            const SItem it = items[i];
+            for (int a = 0; a < 3; a++) { v[a] = f2ord(it.lo[a]); v[3 + a] = f2ord(it.hi[a]); v[6 + a] = f2ord(it.c[a]); v[9 + a] = v[6 + a]; }
+        } else {
+            for (int a = 0; a < 3; a++) { v[a] = 0xffffffffu; v[3 + a] = 0u; v[6 + a] = 0xffffffffu; v[9 + a] = 0u; }
+        }
+        // Items of one node are consecutive, so a wave holds a few runs of equal node ids: a segmented scan (min / max are exact in any
+        // order) leaves each run's reduction in its last lane.  Near the root every wave of the launch would then queue on the same twelve
+        // words (187 us a level at a million items), so the runs of the group's FIRST node meet in LDS and go out once per group.
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t key = act ? nd : 0xffffffffu;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t ko = (uint32_t)__shfl_up((int)key, off, 64);
+            const bool take = lane >= (uint32_t)off && ko == key;
+            for (int k = 0; k < 12; k++) {
+                const uint32_t o = (uint32_t)__shfl_up((int)v[k], off, 64);
+                if (take) v[k] = (k % 6) < 3 ? min(v[k], o) : max(v[k], o);
+            }
+        }
+        const uint32_t kn = (uint32_t)__shfl_down((int)key, 1, 64);
+        if (act && (lane == 63 || kn != key)) {
+            if (nd == first) {
+                for (int k = 0; k < 12; k++) {
+                    if ((k % 6) < 3) atomicMin(&s_v[k], v[k]);
+                    else atomicMax(&s_v[k], v[k]);
+                }
+            } else {
+                for (int k = 0; k < 12; k++) {
+                    if ((k % 6) < 3) atomicMin(&N.nb[(size_t)k * N.cap + nd], v[k]);
+                    else atomicMax(&N.nb[(size_t)k * N.cap + nd], v[k]);
+                }
+            }
         }
     }
-    const uint32_t kn = (uint32_t)__shfl_down((int)key, 1, 64);
-    if (act && (lane == 63 || kn != key)) {
-        for (int k = 0; k < 12; k++) {
-            if ((k % 6) < 3) atomicMin(&N.nb[(size_t)k * N.cap + nd], v[k]);
-            else atomicMax(&N.nb[(size_t)k * N.cap + nd], v[k]);
-        }
+    __syncthreads();
+    if (threadIdx.x < 12 && N.state[first] == ST_NEW) {
+        const uint32_t k = threadIdx.x;
+        if ((k % 6) < 3) atomicMin(&N.nb[(size_t)k * N.cap + first], s_v[k]);
+        else atomicMax(&N.nb[(size_t)k * N.cap + first], s_v[k]);
     }
 }
 __device__ inline int max_extent(const float* lo, const float* hi) {
@@ -118,9 +140,9 @@ __device__ inline int max_extent(const float* lo, const float* hi) {
     return 2;
 }
 // per new node: leaf or split axis; splitting nodes get a slot of the bucket arrays
-__global__ __launch_bounds__(256) void k_sah_decide(SNodes N, const uint32_t* act, uint32_t n_act, uint32_t max_prims, uint32_t* bcnt, uint32_t* bbox, uint32_t* counters) {
+__global__ __launch_bounds__(256) void k_sah_decide(SNodes N, const uint32_t* act, uint32_t max_prims, uint32_t* bcnt, uint32_t* bbox, uint32_t* counters) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_act) return;
+    if (k >= counters[5]) return;             // this level's new nodes (k_sah_roll): the host launches an upper bound and does not wait for the count
     const uint32_t nd = act[k];
     const uint32_t n = N.hi[nd] - N.lo[nd];
     float clo[3], chi[3];
@@ -144,47 +166,65 @@ __device__ inline int bucket_of(const float* clo, const float* chi, const float*
     if (b < 0) b = 0;
     return b;
 }
-// Bucket counts and boxes.  At the top of the tree a million items would queue on 84 words; a workgroup therefore gathers the items of
-// ITS FIRST node (near the root: all of them) in LDS and sends one atomic per used word, the others go straight to memory (deep in
-// the tree the nodes are small and the words many).
-__global__ __launch_bounds__(256) void k_sah_buckets(const SItem* __restrict__ items, const uint32_t* __restrict__ node_of, uint32_t n, SNodes N, uint32_t* bcnt, uint32_t* bbox,
-                                                    uint8_t* bucket) {
-    __shared__ uint32_t s_cnt[kB];
-    __shared__ uint32_t s_box[kB * 6];
-    __shared__ uint32_t s_node;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (threadIdx.x < kB) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x < kB * 6) s_box[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u;
-    if (threadIdx.x == 0) s_node = node_of[blockIdx.x * blockDim.x];
+// Bucket counts and boxes: 7 words per item.  Sent straight to memory they queue on 84 words near the root, and deep in the tree -- every
+// item its own atomics, across the fabric -- they took 0.2 ms a level at a million items.  A workgroup therefore keeps a table per RUN of
+// items of one splitting node (a node's items are consecutive, so a node is one run of a group) in LDS, up to R of them, and writes each
+// table out once: with plain stores when the whole node lies inside the group (k_sah_decide left the words at their identities), with
+// atomics for the first and last run, which may continue in the neighbours.  Runs beyond R go to memory item by item.
+template <int T, int R>
+__global__ __launch_bounds__(T) void k_sah_buckets(const SItem* __restrict__ items, const uint32_t* __restrict__ node_of, uint32_t n, SNodes N, uint32_t* bcnt, uint32_t* bbox,
+                                                  uint8_t* bucket) {
+    constexpr int W = kB * 7;                      // words per table: kB counts, then kB boxes of 6
+    __shared__ uint32_t s_tab[R * W];
+    __shared__ uint32_t s_run_node[R];
+    __shared__ uint32_t s_wruns[T / 64];
+    const uint32_t i = blockIdx.x * T + threadIdx.x;
+    for (uint32_t e = threadIdx.x; e < (uint32_t)(R * W); e += T) { const uint32_t w = e % W; s_tab[e] = w < (uint32_t)kB ? 0u : (((w - kB) % 6) < 3 ? 0xffffffffu : 0u); }
+    const bool in = i < n;
+    const uint32_t nd = in ? node_of[i] : 0xffffffffu;
+    const bool split = in && N.state[nd] == ST_SPLIT;
+    const bool head = split && (threadIdx.x == 0 || node_of[i - 1] != nd);
+    const uint64_t hb = __ballot(head);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_wruns[wave] = (uint32_t)__popcll(hb);
     __syncthreads();
-    const uint32_t first = s_node;
-    const bool first_splits = N.state[first] == ST_SPLIT;
-    if (i < n) {
-        const uint32_t nd = node_of[i];
-        if (N.state[nd] == ST_SPLIT) {
-            const SItem it = items[i];
-            const int dim = (int)N.axis[nd];
-            float clo[3], chi[3];
-            for (int a = 0; a < 3; a++) { clo[a] = ord2f(N.nb[(size_t)(6 + a) * N.cap + nd]); chi[a] = ord2f(N.nb[(size_t)(9 + a) * N.cap + nd]); }
-            const int b = bucket_of(clo, chi, it.c, dim);
-            bucket[i] = (uint8_t)b;
-            if (nd == first) {
-                atomicAdd(&s_cnt[b], 1u);
-                for (int a = 0; a < 3; a++) { atomicMin(&s_box[b * 6 + a], f2ord(it.lo[a])); atomicMax(&s_box[b * 6 + 3 + a], f2ord(it.hi[a])); }
-            } else {
-                const size_t s = (size_t)N.slot[nd] * kB + b;
-                atomicAdd(&bcnt[s], 1u);
-                for (int a = 0; a < 3; a++) { atomicMin(&bbox[s * 6 + a], f2ord(it.lo[a])); atomicMax(&bbox[s * 6 + 3 + a], f2ord(it.hi[a])); }
-            }
+    uint32_t rbase = 0, total = 0;
+    for (uint32_t w = 0; w < (uint32_t)(T / 64); w++) { const uint32_t c = s_wruns[w]; if (w < wave) rbase += c; total += c; }
+    const uint32_t r = rbase + (uint32_t)__popcll(hb & ((2ull << lane) - 1ull)) - 1u;        // the run of this item, if its node splits
+    if (head && r < (uint32_t)R) s_run_node[r] = nd;
+    if (split) {
+        const SItem it = items[i];
+        const int dim = (int)N.axis[nd];
+        float clo[3], chi[3];
+        for (int a = 0; a < 3; a++) { clo[a] = ord2f(N.nb[(size_t)(6 + a) * N.cap + nd]); chi[a] = ord2f(N.nb[(size_t)(9 + a) * N.cap + nd]); }
+        const int b = bucket_of(clo, chi, it.c, dim);
+        bucket[i] = (uint8_t)b;
+        if (r < (uint32_t)R) {
+            uint32_t* t = s_tab + r * W;
+            atomicAdd(&t[b], 1u);
+            for (int a = 0; a < 3; a++) { atomicMin(&t[kB + b * 6 + a], f2ord(it.lo[a])); atomicMax(&t[kB + b * 6 + 3 + a], f2ord(it.hi[a])); }
+        } else {
+            const size_t s = (size_t)N.slot[nd] * kB + b;
+            atomicAdd(&bcnt[s], 1u);
+            for (int a = 0; a < 3; a++) { atomicMin(&bbox[s * 6 + a], f2ord(it.lo[a])); atomicMax(&bbox[s * 6 + 3 + a], f2ord(it.hi[a])); }
         }
     }
     __syncthreads();
-    if (first_splits) {
-        const size_t s0 = (size_t)N.slot[first] * kB;
-        if (threadIdx.x < kB && s_cnt[threadIdx.x]) atomicAdd(&bcnt[s0 + threadIdx.x], s_cnt[threadIdx.x]);
-        if (threadIdx.x < kB * 6 && s_cnt[threadIdx.x / 6]) {
-            if ((threadIdx.x % 6) < 3) atomicMin(&bbox[s0 * 6 + threadIdx.x], s_box[threadIdx.x]);
-            else atomicMax(&bbox[s0 * 6 + threadIdx.x], s_box[threadIdx.x]);
+    const uint32_t n_runs = total < (uint32_t)R ? total : (uint32_t)R;
+    for (uint32_t e = threadIdx.x; e < n_runs * W; e += T) {
+        const uint32_t q = e / W, w = e % W;
+        const uint32_t bk = w < (uint32_t)kB ? w : (w - kB) / 6;
+        if (s_tab[q * W + bk] == 0) continue;                    // an empty bucket keeps its identities
+        const size_t s0 = (size_t)N.slot[s_run_node[q]] * kB;
+        const uint32_t v = s_tab[e];
+        const bool own = q > 0 && q + 1 < total;                 // the node's items all lie in this group
+        if (w < (uint32_t)kB) {
+            if (own) bcnt[s0 + w] = v; else atomicAdd(&bcnt[s0 + w], v);
+        } else {
+            uint32_t* dst = &bbox[s0 * 6 + (w - kB)];
+            if (own) *dst = v;
+            else if (((w - kB) % 6) < 3) atomicMin(dst, v);
+            else atomicMax(dst, v);
         }
     }
 }
@@ -195,10 +235,10 @@ __device__ inline float box_area(const Box& b) {
     return 2.0f * (dx * dy + dx * dz + dy * dz);
 }
 // per splitting node: the SAH costs in the host's order of operations, the split, the children
-__global__ __launch_bounds__(64) void k_sah_split(SNodes N, const uint32_t* act, uint32_t n_act, const uint32_t* bcnt, const uint32_t* bbox, uint32_t* next_act, uint32_t* counters,
+__global__ __launch_bounds__(64) void k_sah_split(SNodes N, const uint32_t* act, const uint32_t* bcnt, const uint32_t* bbox, uint32_t* next_act, uint32_t* counters,
                                                  uint32_t* flags, uint32_t* eq_list) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_act) return;
+    if (k >= counters[5]) return;
     const uint32_t nd = act[k];
     if (N.state[nd] != ST_SPLIT) return;
     const size_t s = (size_t)N.slot[nd] * kB;
@@ -257,12 +297,6 @@ __global__ __launch_bounds__(64) void k_sah_split(SNodes N, const uint32_t* act,
     const uint32_t a = atomicAdd(&counters[2], 2u);
     next_act[a] = c; next_act[a + 1] = c + 1u;
 }
-__global__ __launch_bounds__(256) void k_sah_flags(const uint32_t* __restrict__ node_of, const uint8_t* __restrict__ bucket, uint32_t n, SNodes N, uint32_t* flag) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t nd = node_of[i];
-    flag[i] = (N.state[nd] == ST_SPLIT && N.minb[nd] != kEqualMode && (uint32_t)bucket[i] <= N.minb[nd]) ? 1u : 0u;
-}
 // split_equal_counts: one workgroup per such node ranks its items by (centroid along the split axis, position) -- the order std::stable_sort
 // leaves -- and k_sah_scatter sends item i to lo + rank
 __global__ __launch_bounds__(256) void k_sah_equal_rank(const SItem* __restrict__ items, SNodes N, const uint32_t* __restrict__ eq_list, const uint32_t* __restrict__ counters,
@@ -284,12 +318,21 @@ __global__ __launch_bounds__(256) void k_sah_equal_rank(const SItem* __restrict_
         }
     }
 }
-// exclusive prefix sum of flag[] in three steps: 1024-item blocks, the block totals by one workgroup, add back
-__global__ __launch_bounds__(256) void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t n, uint32_t* out, uint32_t* totals) {
+// Which items go left, and the exclusive prefix sum of that flag in three steps: 1024-item blocks, the block totals by one workgroup, add back
+__global__ __launch_bounds__(256) void k_sah_flagscan(const uint32_t* __restrict__ node_of, const uint8_t* __restrict__ bucket, uint32_t n, SNodes N, uint32_t* flag, uint32_t* out,
+                                                     uint32_t* totals) {
     __shared__ uint32_t s_w[4];
     const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
     uint32_t v[4], sum = 0;
-    for (int k = 0; k < 4; k++) { v[k] = base + k < n ? in[base + k] : 0u; sum += v[k]; }
+    for (int k = 0; k < 4; k++) {
+        v[k] = 0u;
+        if (base + k < n) {
+            const uint32_t nd = node_of[base + k];
+            v[k] = (N.state[nd] == ST_SPLIT && N.minb[nd] != kEqualMode && (uint32_t)bucket[base + k] <= N.minb[nd]) ? 1u : 0u;
+            flag[base + k] = v[k];
+        }
+        sum += v[k];
+    }
     uint32_t inc = sum;
     const uint32_t lane = threadIdx.x & 63;
     for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= (uint32_t)off) inc += o; }
@@ -301,10 +344,19 @@ __global__ __launch_bounds__(256) void k_scan_blocks(const uint32_t* __restrict_
     for (int k = 0; k < 4; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
     if (threadIdx.x == 255) totals[blockIdx.x] = wbase + inc;
 }
-__global__ __launch_bounds__(1024) void k_scan_totals(uint32_t* totals, uint32_t n_blocks) {
+// Between two levels, on the device: the next-active count becomes the coming level's node count, the node total is noted (level l's
+// nodes are numbered [lvl_totals[l - 1], lvl_totals[l])), the per-level counters start at zero.  The host launches a level's kernels over
+// an upper bound of the count and looks at the counters only every few levels.
+__device__ inline void sah_roll(uint32_t* counters, uint32_t* lvl_totals, uint32_t level) {
+    lvl_totals[level] = counters[0];
+    counters[5] = level == 0 ? 1u : counters[2];
+    counters[1] = 0; counters[2] = 0; counters[4] = 0;
+}
+__global__ void k_sah_roll(uint32_t* counters, uint32_t* lvl_totals, uint32_t level) { sah_roll(counters, lvl_totals, level); }
+__global__ __launch_bounds__(1024) void k_scan_totals(uint32_t* totals, uint32_t n_blocks, uint32_t* counters, uint32_t* lvl_totals, uint32_t next_level) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
+    if (threadIdx.x == 0) { s_carry = 0; sah_roll(counters, lvl_totals, next_level); }       // this level's k_sah_split is done: roll for the next one
     __syncthreads();
     for (uint32_t base = 0; base < n_blocks; base += 1024u) {
         const uint32_t i = base + threadIdx.x;
@@ -406,10 +458,15 @@ __global__ __launch_bounds__(256) void k_sc_leafmark(const LbvhNode* __restrict_
     const bool leaf = k < n_nodes && nodes[k].count > 0;
     uint32_t cnt = 0;
     if (leaf) { cnt = nodes[k].count; tris[nodes[k].first + cnt - 1u].flags |= PT_TRI_LAST; }
+    __shared__ uint32_t s_n, s_mx;
+    if (threadIdx.x == 0) { s_n = 0; s_mx = 0; }
+    __syncthreads();
     const unsigned long long m = __ballot(leaf);
     uint32_t mx = cnt;
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) { atomicAdd(&small[0], (uint32_t)__popcll(m)); atomicMax(&small[1], mx); }
+    if ((threadIdx.x & 63) == 0 && m) { atomicAdd(&s_n, (uint32_t)__popcll(m)); atomicMax(&s_mx, mx); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) { atomicAdd(&small[0], s_n); atomicMax(&small[1], s_mx); }
 }
 // the (up to four) binary nodes that fill the slots of the 4-wide node made from binary node b (Collapser::slots_of)
 __device__ inline void sc_slots(const LbvhNode* __restrict__ nodes, uint32_t b, int32_t s[4]) {
@@ -765,41 +822,54 @@ static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32
     SAH_TRY(hipMemcpyAsync(d_act[0].p, &root_act, 4, hipMemcpyHostToDevice, st));
     const double t1 = now();
     int cur = 0, acur = 0;
-    uint32_t n_act = 1, levels = 0;
+    uint32_t levels = 0;
     uint32_t host_small[12];
-    std::vector<uint32_t> level_begin(1, 0u);          // binary nodes of level l: [level_begin[l], level_begin[l + 1]) -- node numbers come from one counter, level by level
-    level_begin.push_back(1u);
-    while (n_act > 0) {
-        if (++levels > 512u) return 1;
+    Scratch d_totals;
+    SAH_TRY(d_totals.alloc(520 * 4));
+    uint64_t bound = 1;                                 // upper bound of a level's node count: twice the level before, never more than the nodes there can be
+    k_sah_roll<<<1, 1, 0, st>>>(counters, d_totals.as<uint32_t>(), 0u);      // later rolls ride on k_scan_totals
+    for (;;) {
+        if (levels >= 512u) return 1;
+        // a look at the counters every fourth level (every second one deep in the tree, where levels are short): a level launched after the
+        // last one finds no new node and moves nothing, so looking late costs little and looking every time cost a round trip per level
+        if (levels > 0 && (levels % 4u == 0u || (levels > 16u && levels % 2u == 0u))) {
+            SAH_TRY(hipMemcpyAsync(host_small, counters, 48, hipMemcpyDeviceToHost, st));
+            SAH_TRY(hipStreamSynchronize(st));
+            if (host_small[8] != 0) {
+                if (trace) std::fprintf(stderr, "[bvh] device SAH gives up near level %u: flags %u (1 non-finite bounds, 2 an equal-counts range too long, 4 node capacity)\n", levels, host_small[8]);
+                return 1;
+            }
+            if (host_small[5] == 0) break;
+        }
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(bound, cap);
         SItem* items = d_items[cur].as<SItem>();
         uint32_t* node_of = d_nodeof[cur].as<uint32_t>();
         const uint32_t* act = d_act[acur].as<uint32_t>();
         uint32_t* next_act = d_act[acur ^ 1].as<uint32_t>();
-        SAH_TRY(hipMemsetAsync(counters + 1, 0, 8, st));         // splitting / next-active counts of this level
-        SAH_TRY(hipMemsetAsync(counters + 4, 0, 4, st));         // ... and its equal-counts nodes
-        k_sah_bounds<<<blocks, 256, 0, st>>>(items, node_of, n, N);
-        k_sah_decide<<<(n_act + 255u) / 256u, 256, 0, st>>>(N, act, n_act, max_prims, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), counters);
-        k_sah_buckets<<<blocks, 256, 0, st>>>(items, node_of, n, N, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), d_bucket.as<uint8_t>());
-        k_sah_split<<<(n_act + 63u) / 64u, 64, 0, st>>>(N, act, n_act, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), next_act, counters, flags, d_eqlist.as<uint32_t>());
+        const bool wide = (uint64_t)n >= bound * 64u;         // nodes of 64 items and more on average: few runs in a wide group
+        k_sah_bounds<<<(n + kBoundsT - 1u) / kBoundsT, kBoundsT, 0, st>>>(items, node_of, n, N);
+        k_sah_decide<<<(nb + 255u) / 256u, 256, 0, st>>>(N, act, max_prims, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), counters);
+        if (wide) k_sah_buckets<1024, 32><<<(n + 1023u) / 1024u, 1024, 0, st>>>(items, node_of, n, N, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), d_bucket.as<uint8_t>());
+        else k_sah_buckets<256, 56><<<blocks, 256, 0, st>>>(items, node_of, n, N, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), d_bucket.as<uint8_t>());
+        k_sah_split<<<(nb + 63u) / 64u, 64, 0, st>>>(N, act, d_bcnt.as<uint32_t>(), d_bbox.as<uint32_t>(), next_act, counters, flags, d_eqlist.as<uint32_t>());
         k_sah_equal_rank<<<kEqualGrid, 256, 0, st>>>(items, N, d_eqlist.as<uint32_t>(), counters, d_eqrank.as<uint32_t>());
-        k_sah_flags<<<blocks, 256, 0, st>>>(node_of, d_bucket.as<uint8_t>(), n, N, d_flag.as<uint32_t>());
-        k_scan_blocks<<<n_sblocks, 256, 0, st>>>(d_flag.as<uint32_t>(), n, d_pre.as<uint32_t>(), d_tot.as<uint32_t>());
-        k_scan_totals<<<1, 1024, 0, st>>>(d_tot.as<uint32_t>(), n_sblocks);
+        k_sah_flagscan<<<n_sblocks, 256, 0, st>>>(node_of, d_bucket.as<uint8_t>(), n, N, d_flag.as<uint32_t>(), d_pre.as<uint32_t>(), d_tot.as<uint32_t>());
+        k_scan_totals<<<1, 1024, 0, st>>>(d_tot.as<uint32_t>(), n_sblocks, counters, d_totals.as<uint32_t>(), levels + 1u);
         k_sah_scatter<<<blocks, 256, 0, st>>>(items, node_of, d_flag.as<uint32_t>(), d_pre.as<uint32_t>(), d_tot.as<uint32_t>(), n, N, d_items[cur ^ 1].as<SItem>(),
                                               d_nodeof[cur ^ 1].as<uint32_t>(), d_eqrank.as<uint32_t>());
         SAH_TRY(hipGetLastError());
-        SAH_TRY(hipMemcpyAsync(host_small, counters, 48, hipMemcpyDeviceToHost, st));
-        SAH_TRY(hipStreamSynchronize(st));
-        if (host_small[8] != 0) {
-            if (trace) std::fprintf(stderr, "[bvh] device SAH gives up at level %u: flags %u (1 non-finite bounds, 2 a split left one side empty, 4 node capacity)\n", levels, host_small[8]);
-            return 1;
-        }
-        n_act = host_small[2];
+        levels++;
         cur ^= 1; acur ^= 1;
-        if (host_small[0] > level_begin.back()) level_begin.push_back(host_small[0]);
+        bound *= 2;
     }
+    // the node totals per level (totals[l] = nodes numbered before level l's were made; the loop's last rolls saw no growth)
+    std::vector<uint32_t> totals(levels + 1);
+    SAH_TRY(hipMemcpyAsync(totals.data(), d_totals.p, (size_t)(levels + 1) * 4, hipMemcpyDeviceToHost, st));
+    SAH_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> level_begin(1, 0u);          // binary nodes of level l: [level_begin[l], level_begin[l + 1])
+    for (uint32_t l = 0; l <= levels; l++) if (totals[l] > level_begin.back()) level_begin.push_back(totals[l]);
     const double t2 = now();
-    const uint32_t n_nodes = host_small[0];
+    const uint32_t n_nodes = totals[levels];
     SAH_TRY(d_export.alloc((size_t)n_nodes * sizeof(LbvhNode)));
     SAH_TRY(d_order.alloc((size_t)n * 4));
     k_sah_export<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(N, n_nodes, d_export.as<LbvhNode>());
