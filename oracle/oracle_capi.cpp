@@ -71,6 +71,9 @@ void orc_depth_hist(orc_scene* s, int enable, uint64_t* out32) {
     for (int i = 0; i < 32; i++) out32[i] = g_depth_hist[i];
 }
 
+// bits of orc::reference_panics() since the last reset (see orc_sampling.hpp)
+uint32_t orc_reference_panics(int reset) { return reset ? reference_panics().exchange(0u) : reference_panics().load(); }
+
 static void fill_counters(const RayCounters& rc, pt_counters* c) {
     if (!c) return;
     c->camera_rays += rc.camera; c->regular_rays += rc.regular; c->shadow_rays += rc.shadow;

@@ -6,6 +6,7 @@
 #pragma once
 #include "orc_math.hpp"
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -78,6 +79,9 @@ inline Float radical_inverse(uint32_t base_index, uint64_t a) {
 }
 
 // ---- Halton machinery (core/lowdiscrepancy/radical_inverse.rs:60-109, primes.rs, sampling.rs:4-15)
+// Places where the reference would have panicked and this restatement went on instead (bit 0: a Halton dimension past the prime
+// tables).  A test reads and clears it through orc_reference_panics: the HIP path must report the same condition.
+inline std::atomic<uint32_t>& reference_panics() { static std::atomic<uint32_t> v{0}; return v; }
 struct HaltonTables {
     std::vector<uint64_t> primes;        // PRIMES: the first 1000 primes (primes.rs:1)
     std::vector<uint64_t> prime_sums;    // prefix sums (primes.rs:68 PRIME_SUMS)
@@ -277,6 +281,10 @@ struct SobolSampler {
             if (dim == 0) return radical_inverse(0, (uint64_t)(index >> base_exponents[0]));
             if (dim == 1) return radical_inverse(1, (uint64_t)(index / base_scales[1]));
             const HaltonTables& H = HaltonTables::get();
+            if (dim >= (uint32_t)H.primes.size()) {          // the reference panics here (PRIME_SUMS holds 1000 entries; halton.rs:103-108):
+                reference_panics().fetch_or(1u);               // noted (orc_reference_panics), and the render goes on with the last dimension
+                dim = (uint32_t)H.primes.size() - 1u;
+            }
             return scrambled_radical_inverse(H.primes[dim], &H.perms[H.prime_sums[dim]], (uint64_t)index);
         }
         Float s = sobol_sample_float(*T, index, dim, 0);

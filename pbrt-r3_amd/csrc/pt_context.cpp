@@ -350,6 +350,11 @@ pt_status setup_halton(pt_context* ctx, PtSobol& sb, int32_t res_x, int32_t res_
     sb.h_dims = ctx->d_hdims.as<uint4>();
     sb.h_perms = ctx->d_hperms.as<uint16_t>();
     sb.h_n_dims = kDims;
+    if (!ctx->d_err.p) {                         // (the first upload reaches this before the counters are made)
+        PT_HIP(ctx->d_err.alloc(16));
+        PT_HIP(hipMemsetAsync(ctx->d_err.p, 0, 16, ctx->stream));
+    }
+    sb.h_panic = ctx->d_err.as<uint32_t>();
     sb.h_center = at_center ? 1u : 0u;
     const int32_t res[2] = {res_x, res_y}, bases[2] = {2, 3};
     int32_t scale[2], exp[2];
@@ -1212,8 +1217,10 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     if (!ctx->d_counters.p) {
         PT_HIP(ctx->d_counters.alloc(sizeof(PtCounters)));
         PT_HIP(hipMemsetAsync(ctx->d_counters.p, 0, sizeof(PtCounters), ctx->stream));
-        PT_HIP(ctx->d_err.alloc(16));
-        PT_HIP(hipMemsetAsync(ctx->d_err.p, 0, 16, ctx->stream));
+        if (!ctx->d_err.p) {
+            PT_HIP(ctx->d_err.alloc(16));
+            PT_HIP(hipMemsetAsync(ctx->d_err.p, 0, 16, ctx->stream));
+        }
         PT_HIP(ctx->d_ticket.alloc(16));
         PT_HIP(ctx->d_counts.alloc(PT_COUNTS_WORDS * 4));
         PT_HIP(hipMemsetAsync(ctx->d_counts.p, 0, PT_COUNTS_WORDS * 4, ctx->stream));
@@ -1331,6 +1338,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
         if (ctx->d_tiles.bytes < (size_t)n_tiles * 20) PT_HIP(ctx->d_tiles.alloc((size_t)n_tiles * 20));
         uint32_t* d_off = reinterpret_cast<uint32_t*>(ctx->d_tiles.as<char>() + (size_t)n_tiles * 16);
         PT_HIP(hipMemsetAsync(ctx->d_tilebits.p, 0, bm_bytes, ctx->stream));
+        PT_HIP(hipMemsetAsync(ctx->d_err.p, 0, 4, ctx->stream));          // this call's errors only (a sampler hook may have left the Halton bit behind)
         PT_HIP(hipMemcpyAsync(ctx->d_tiles.p, tiles, (size_t)n_tiles * 16, hipMemcpyHostToDevice, ctx->stream));
         PT_HIP(hipMemcpyAsync(d_off, tile_off.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, ctx->stream));
         PT_HIP(ptk_expand_tiles(ctx->stream, ctx->d_tiles.as<int4>(), d_off, n_tiles, sbnd[0], sbnd[1], (uint32_t)sb_w, ctx->d_pixels.as<uint32_t>(),
@@ -1587,7 +1595,9 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     if (herr) {
         PT_HIP(hipMemsetAsync(err, 0, 4, ctx->stream));
         PT_HIP(hipStreamSynchronize(ctx->stream));
-        return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow (BVH deeper than the computed bound)");
+        if (herr & 1u) return ctx->fail(PT_ERR_DEVICE, "traversal stack overflow (BVH deeper than the computed bound)");
+        return ctx->fail(PT_ERR_UNSUPPORTED, "a path asked the Halton sampler for more than its 1000 dimensions: the reference panics there (halton.rs:103-107); "
+                                             "lower maxdepth or use the Sobol' sampler");
     }
 #ifdef PT_STACK_HIST
     {   // diagnostic build: histogram of the traversal stack depth at node visits (k_trace's lean visit)

@@ -218,6 +218,8 @@ struct PtSobol {
     const uint16_t* h_perms;     // radical-inverse digit permutations (halton.rs:12-20)
     uint32_t h_n_dims;
     uint32_t pad2;
+    uint32_t* h_panic;           // the context's error word: bit 2 (4) is set when a sample asks for a Halton dimension past the table, where
+                                 // the reference panics (halton.rs:103-107); the value is then taken from the last dimension so the launch finishes
 };
 
 struct PtLightGrid {

@@ -131,7 +131,10 @@ PT_DEV float halton_sample_dimension(const PtSobol& sb, uint64_t index, uint32_t
         if (dim == 0) return (float)__brevll(index >> sb.h_exp[0]) * 5.4210108624275222e-20f;
         return halton_radical_inverse(3u, 0x5555555555555556ull, nullptr, index / sb.h_scale1);
     }
-    if (dim >= sb.h_n_dims) dim = sb.h_n_dims - 1;   // the reference indexes PRIMES out of bounds here (panic)
+    if (dim >= sb.h_n_dims) {                        // the reference panics here ("HaltonSampler can only sample 1000 dimensions", halton.rs:103-107):
+        if (sb.h_panic) atomicOr(sb.h_panic, 4u);     // reported by pt_render / the hooks as PT_ERR_UNSUPPORTED; the launch itself finishes
+        dim = sb.h_n_dims - 1;
+    }
     uint4 e = sb.h_dims[dim];
     return halton_radical_inverse(e.x, (uint64_t)e.z | ((uint64_t)e.w << 32), sb.h_perms + e.y, index);
 }

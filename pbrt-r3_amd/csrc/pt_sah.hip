@@ -860,7 +860,7 @@ static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32
         SAH_TRY(hipGetLastError());
         levels++;
         cur ^= 1; acur ^= 1;
-        bound *= 2;
+        if (bound < cap) bound *= 2;                      // (deep, thin trees run to hundreds of levels)
     }
     // the node totals per level (totals[l] = nodes numbered before level l's were made; the loop's last rolls saw no growth)
     std::vector<uint32_t> totals(levels + 1);

@@ -38,6 +38,8 @@ class Oracle:
         lib.orc_resolve_rgb.restype = None
         lib.orc_radiance_samples.argtypes = [vp, C.POINTER(capi.pt_tile), vp]
         lib.orc_radiance_samples.restype = None
+        lib.orc_reference_panics.argtypes = [C.c_int]
+        lib.orc_reference_panics.restype = u32
         for name in ("orc_trace_closest", "orc_trace_any"):
             getattr(lib, name).argtypes = [vp, u32, vp, vp, vp, vp, C.POINTER(capi.pt_counters)]
             getattr(lib, name).restype = None
@@ -81,6 +83,11 @@ class Oracle:
         lib.orc_sobol_interval_to_index.argtypes = [u32, C.c_uint64, C.c_int32, C.c_int32]
         lib.orc_sobol_interval_to_index.restype = C.c_uint64
         assert lib.orc_sobol_load(DATA_DIR.encode()) == 0
+
+    def reference_panics(self, reset=True):
+        """Bits noted since the last reset where the reference would have panicked and the restatement went on (1: a Halton dimension
+        past the prime tables, halton.rs:103-108)."""
+        return int(self.lib.orc_reference_panics(1 if reset else 0))
 
     def scene(self, scene_desc):
         return OracleScene(self, scene_desc)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _compare(ctx, osc, exact_film, frac_limit=0.0):
+def _compare(ctx, osc, exact_film, frac_limit=0.0, weight_tol=None):
     info = ctx.info
     o, d, tmax = random_rays(info, 30000, 21)
     g = ctx.trace_closest(o, d, tmax)
@@ -33,15 +33,25 @@ def _compare(ctx, osc, exact_film, frac_limit=0.0):
     gx, grgb, gc = ctx.film_xyzw(), ctx.film_rgb(), ctx.counters()
     ox, oc, _ = osc.render(threads=8)
     orgb = osc.resolve_rgb(ox)
-    err = rel_l2(grgb, orgb)
+    if weight_tol is not None and not exact_film:
+        # negative-lobed filters leave pixels whose weights cancel to almost nothing; their colour is a quotient of two rounding residues and
+        # moves with the order of the film's float atomics (as it does with the reference's tile merge order): the image is compared where
+        # it is conditioned, the weighted sums everywhere
+        ok = np.abs(ox[..., 3]) > 1e-2 * np.abs(ox[..., 3]).max()
+        err = rel_l2(grgb[ok], orgb[ok])
+        assert np.abs(gx[..., :3] - ox[..., :3]).max() <= weight_tol * np.abs(ox[..., :3]).max()
+    else:
+        err = rel_l2(grgb, orgb)
     assert err <= 1e-3, err            # north_star tolerance; observed ~1e-7
     assert gc["camera_rays"] == oc["camera_rays"]
     for k in ("regular_rays", "shadow_rays", "path_vertices", "nodes_visited", "tris_tested"):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     if exact_film:
         assert np.array_equal(bits(gx[..., 3]), bits(ox[..., 3]))
-    else:      # wide filters: float atomics, summation order differs in the last bits
+    elif weight_tol is None:      # wide filters: float atomics, summation order differs in the last bits
         assert np.allclose(gx[..., 3], ox[..., 3], rtol=1e-5, atol=1e-6)
+    else:      # ... and with negative lobes (Mitchell, sinc) a pixel's weights cancel: the order shows relative to the largest weight, not to the sum
+        assert np.abs(gx[..., 3] - ox[..., 3]).max() <= weight_tol * np.abs(ox[..., 3]).max()
     return err, frac
 
 

@@ -14,7 +14,9 @@ if [ "$part" = a ]; then
   timeout -k 10 600 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; exit 1; }
   cut -c1-400 "$out/bench.json"
   timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$out/prof" --output-format csv -- python3 bench.py --no-cpu-baseline --no-spp1024 > "$out/bench_under_rocprof.json" 2> "$out/bench_under_rocprof.err" || { echo "rocprof run failed"; tail -5 "$out/bench_under_rocprof.err"; exit 1; }
-  find "$out/prof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$out/kernel_stats.csv"; rm -rf "$out/prof"
+  find "$out/prof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$out/kernel_stats.csv"
+  # the last frame's launches one by one (bounce by bounce): what the late, small bounces cost
+  find "$out/prof" -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/per_bounce.py {} > "$out/per_bounce.txt"; rm -rf "$out/prof"
   head -10 "$out/kernel_stats.csv" | cut -c1-140
   bash tools/pmc_traffic_workload.sh r03_default && cp gpurun_out/pmc_r03_default/traffic_entry.json "$out/traffic_entry_default.json" && cp gpurun_out/pmc_r03_default/summary.txt "$out/pmc_fetch_write_default.txt"
   SPP=52 bash tools/pmc_sq.sh r03 > "$out/sq_summary.txt" 2>&1; tail -32 "$out/sq_summary.txt"
