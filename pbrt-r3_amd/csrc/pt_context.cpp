@@ -350,11 +350,7 @@ pt_status setup_halton(pt_context* ctx, PtSobol& sb, int32_t res_x, int32_t res_
     sb.h_dims = ctx->d_hdims.as<uint4>();
     sb.h_perms = ctx->d_hperms.as<uint16_t>();
     sb.h_n_dims = kDims;
-    if (!ctx->d_err.p) {                         // (the first upload reaches this before the counters are made)
-        PT_HIP(ctx->d_err.alloc(16));
-        PT_HIP(hipMemsetAsync(ctx->d_err.p, 0, 16, ctx->stream));
-    }
-    sb.h_panic = ctx->d_err.as<uint32_t>();
+
     sb.h_center = at_center ? 1u : 0u;
     const int32_t res[2] = {res_x, res_y}, bases[2] = {2, 3};
     int32_t scale[2], exp[2];
@@ -496,6 +492,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         }
     }
     // integrator-specific refusals come after the index range checks above (they dereference materials[])
+    if (d->integrator == PT_INTEGRATOR_PATH && d->sampler == PT_SAMPLER_HALTON && d->max_depth > 124)
+        return ctx->fail(PT_ERR_UNSUPPORTED, "path with the Halton sampler and maxdepth above 124: a path that long asks for more than the sampler's 1000 "
+                                             "dimensions (5 for the camera, 8 per vertex), where the reference panics (halton.rs:103-108)");
     if (d->integrator == PT_INTEGRATOR_AO) {
         if (d->ao_samples < 1 || d->ao_samples > 4096) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "ao: nsamples outside [1, 4096]");
         for (uint32_t i = 0; i < d->n_meshes; i++)
@@ -1470,6 +1469,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 R.frames = (float4*)take(np * (size_t)rec_depth * PT_REC_FRAME_F4 * 16);
                 R.sh_o = (float4*)take(ne * 16); R.sh_d = (float4*)take(ne * 16); R.pr_o = (float4*)take(ne * 16); R.pr_d = (float4*)take(ne * 16);
                 R.A = (float4*)take(ne * 16); R.B = (float4*)take(ne * 16);
+                R.panic = err;
                 R.prec = (int32_t*)take(ne * 4); R.flags = (uint32_t*)take(ne * 4);
                 uint32_t* nl_shadow = (uint32_t*)take(ne * 4);
                 uint32_t* nl_probe = (uint32_t*)take(ne * 4);

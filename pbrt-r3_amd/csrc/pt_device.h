@@ -218,8 +218,6 @@ struct PtSobol {
     const uint16_t* h_perms;     // radical-inverse digit permutations (halton.rs:12-20)
     uint32_t h_n_dims;
     uint32_t pad2;
-    uint32_t* h_panic;           // the context's error word: bit 2 (4) is set when a sample asks for a Halton dimension past the table, where
-                                 // the reference panics (halton.rs:103-107); the value is then taken from the last dimension so the launch finishes
 };
 
 struct PtLightGrid {
@@ -315,6 +313,8 @@ struct PtRec {
     uint32_t n_paths, max_depth, epp, n_arrays;      // epp: entries per path ("all": the lights' sample counts added up); n_arrays: 2-D sample arrays
                                                      // requested per pixel ("all": two per light and depth)
     uint32_t s0, n_pix;                              // of the pass: path p is sample number s0 + p / n_pix of its pixel (the arrays are indexed by it)
+    uint32_t* panic;                                 // the context's error word: bit 2 (4) = a node asked the Halton sampler for a dimension past its
+                                                     // table, where the reference panics (halton.rs:103-108)
 };
 #define PT_REC_OUT_FRAME 0u      // k_rec_enter outcomes (bits 2..3 of the state's flag byte): a frame was pushed, next-event rays may be pending
 #define PT_REC_OUT_RETURN0 1u    // the ray left the scene (or Whitted met a surface without BSDF): the node returns zero

@@ -131,10 +131,11 @@ PT_DEV float halton_sample_dimension(const PtSobol& sb, uint64_t index, uint32_t
         if (dim == 0) return (float)__brevll(index >> sb.h_exp[0]) * 5.4210108624275222e-20f;
         return halton_radical_inverse(3u, 0x5555555555555556ull, nullptr, index / sb.h_scale1);
     }
-    if (dim >= sb.h_n_dims) {                        // the reference panics here ("HaltonSampler can only sample 1000 dimensions", halton.rs:103-107):
-        if (sb.h_panic) atomicOr(sb.h_panic, 4u);     // reported by pt_render / the hooks as PT_ERR_UNSUPPORTED; the launch itself finishes
-        dim = sb.h_n_dims - 1;
-    }
+    // The reference panics here (PRIME_SUMS holds 1000 entries, halton.rs:103-108).  The launch finishes on the last dimension; the condition
+    // itself is caught where a sampler's dimension count is written back (k_rec_enter / k_rec_next: PtRec::panic) and, for the path
+    // integrator -- 5 + 8 dimensions per vertex --, by the upload refusing maxdepth > 123 under this sampler: a check in here costs every
+    // shading kernel two or three registers at its tightest point (k_shade_general went from 256 to 258 and lost its second wave).
+    if (dim >= sb.h_n_dims) dim = sb.h_n_dims - 1;
     uint4 e = sb.h_dims[dim];
     return halton_radical_inverse(e.x, (uint64_t)e.z | ((uint64_t)e.w << 32), sb.h_perms + e.y, index);
 }
@@ -3130,6 +3131,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
                 }
             }
             dim = sm.dim;
+            if (sc.sobol.kind == PT_SAMPLER_HALTON && dim > sc.sobol.h_n_dims) atomicOr(R.panic, 4u);       // a dimension past the table was asked for
             // the frame: what a later visit needs to rebuild this interaction, and the node's radiance so far
             *rec_frame(R, depth, 0, p) = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)rec));
             *rec_frame(R, depth, 1, p) = make_float4(rd.x, rd.y, rd.z, __uint_as_float(inst | (has_diff ? 0x80000000u : 0u)));
@@ -3399,6 +3401,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
                     v = l; returning = true; d--;      // no (further) child: the node returns its radiance
                 }
                 dim = sm.dim;
+                if (sc.sobol.kind == PT_SAMPLER_HALTON && dim > sc.sobol.h_n_dims) atomicOr(R.panic, 4u);
                 P.state[p] = (dim & 0xffffu) | (depth << 16) | (flags << 24);
             }
             if (outcome == PT_REC_OUT_RETRACE) P.state[p] = st & ~(3u << 26);

@@ -170,3 +170,27 @@ def test_rust_ffi_block_matches_header(tmp_path):
         assert "pub struct %s " % n in block
     assert {f[0] for f in h.functions} == set(pkg_symbols())
     assert "(ABI %d)" % PT_ABI in block and "pub struct pt_material {      // 164 bytes" in block
+
+
+def test_kernel_register_budgets():
+    """The occupancy steps the measured numbers rest on, read from the built library's own code-object metadata (tools/kernel_resources.py):
+    a change elsewhere in pt_kernels.hip that costs a hot kernel a wave per SIMD or makes it spill shows here, on the CPU, instead of as a
+    few per cent in the next bench run.  (Waves per SIMD by allocated registers: <= 128 -> 4, <= 168 -> 3, <= 256 -> 2.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    ks = kernel_resources.kernels(pkg.capi.LIB_PATH)
+    budgets = {                      # kernel: (registers at most, spilled registers at most, LDS bytes at most)
+        "k_trace": (128, 0, 40960),              # four waves per SIMD, four blocks per CU (4 x 40 KB of the CU's 160 KB)
+        "k_trace_seq": (128, 0, 40960),
+        "k_shade": (256, 0, 40960),              # two waves per SIMD, nothing in scratch
+        "k_shade_matte_sorted": (256, 0, 40960),
+        "k_shade_general": (256, 0, 40960),
+        "k_shade_general_tex": (256, 130, 40960),    # spills: what round 3 measured with (DESIGN.md section 9)
+        "k_nee_resolve": (64, 0, 0),
+        "k_gen": (128, 0, 0),
+    }
+    for name, (vgpr, spill, lds) in budgets.items():
+        k = ks[name]
+        assert k[".vgpr_count"] <= vgpr, (name, "registers", k[".vgpr_count"])
+        assert k.get(".vgpr_spill_count", 0) <= spill, (name, "spilled registers", k.get(".vgpr_spill_count", 0))
+        assert k[".group_segment_fixed_size"] <= lds, (name, "LDS", k[".group_segment_fixed_size"])
