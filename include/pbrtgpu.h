@@ -366,7 +366,10 @@ pt_status pt_film_clear(pt_context* ctx);
  * must lie inside the sample bounds and be pairwise disjoint (overlapping tiles
  * are rejected with PT_ERR_INVALID_ARGUMENT: a pixel's samples are folded by one
  * thread in sample order).  n_tiles == 0 with tiles == NULL renders
- * every 16x16 tile of the sample bounds (the reference's decomposition). */
+ * every 16x16 tile of the sample bounds (the reference's decomposition).
+ * PT_ERR_UNSUPPORTED after the frame has been rendered: a node of the directlighting / whitted recursion asked the
+ * Halton sampler for a dimension past its 1000 (every vertex draws two per light), where the reference panics
+ * (samplers/halton.rs:103-108); the film then holds values taken from the last dimension and the context stays usable. */
 pt_status pt_render(pt_context* ctx, const pt_tile* tiles, uint32_t n_tiles);
 /* Film as {X,Y,Z,weight} float4 per cropped pixel: the quantity
  * Film::merge_film_tile accumulates and the unit of the multi-GPU sum-reduce. */
