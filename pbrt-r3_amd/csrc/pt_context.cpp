@@ -74,14 +74,14 @@ struct pt_context {
     size_t n_nodes_up = 0, n_tris_up = 0;
 
     // ---- traversal scratch
-    DevBuf d_spill, d_err, d_counters, d_ticket;
+    DevBuf d_spill, d_err, d_counters, d_ticket, d_tex_res;
     uint32_t spill_depth = 0;
     int grid_trace = 1024, grid_trace_dist = 768, grid_shade = 512, grid_wide = 2048;
 
     // ---- path pool
     size_t pool_paths = 0;
     DevBuf d_pool;          // one slab carved into the SoA arrays of PtPaths
-    PtPaths paths;
+    PtPaths paths{};
     DevBuf d_qa, d_qb, d_qnee, d_qshadow, d_qprobe, d_qsorted, d_counts, d_pixels, d_tiles, d_tilebits;
     ptbvh::Result host_bvh;                       // upload scratch: the world tree's arrays
     std::unique_ptr<ptbvh::Prim[]> host_prims;    // upload scratch (see pt_scene_upload); released when it exceeds 4 M primitives
@@ -159,6 +159,10 @@ pt_status ensure_pool(pt_context* ctx, size_t n_paths) {
     if (ctx->sc.n_instances && ctx->d_hit_inst.bytes < std::max(n_paths, ctx->pool_paths) * 4) {      // scenes with object instances only
         PT_HIP(ctx->d_hit_inst.alloc(std::max(n_paths, ctx->pool_paths) * 4));
         ctx->paths.hit_inst = ctx->d_hit_inst.as<uint32_t>();
+    }
+    if (ctx->sc.textured && !ctx->sc.n_instances && ctx->d_tex_res.bytes < std::max(n_paths, ctx->pool_paths) * (size_t)(PT_TEX_RES_F4 * 16)) {      // scenes with textured materials only
+        PT_HIP(ctx->d_tex_res.alloc(std::max(n_paths, ctx->pool_paths) * (size_t)(PT_TEX_RES_F4 * 16)));
+        ctx->paths.tex_res = ctx->d_tex_res.as<float4>();
     }
     if (ctx->pool_paths >= n_paths && ctx->d_pool.p) return PT_OK;
     // 11 float4 + float2 + u64 + 6 x 4-byte + 1 byte per path

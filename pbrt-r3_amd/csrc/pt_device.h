@@ -295,7 +295,10 @@ struct PtPaths {
     uint8_t* occluded;
     int32_t* probe_rec;
     uint32_t* hit_inst;  // instance index + 1 of the closest hit (0 = a world primitive); allocated for scenes with instances only
+    float4* tex_res;     // [n_paths][PT_TEX_RES_F4]: what k_tex_resolve evaluated at a textured hit (parameter values, alphas, the bump-mapped
+                         // shading frame), read by k_shade_general_res; allocated for scenes with textured materials only
 };
+#define PT_TEX_RES_F4 9u
 
 // ---- DirectLightingIntegrator / WhittedIntegrator on the wavefront (pt_kernels.hip, "recursive integrators"): the per-camera-sample
 // state of the depth-first walk over the specular_reflect / specular_transmit tree

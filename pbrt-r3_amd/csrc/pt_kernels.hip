@@ -2133,43 +2133,71 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
 // build_lobes (pt_lobes.h, shared with the host) as a call: inlined into textured_lobes it made that function the register peak of
 // the textured shading kernel
 __device__ __noinline__ void build_lobes_call(const pt_material& in, float a_r, float a_u, float a_v, PtMaterial& m) { build_lobes(in, a_r, a_u, a_v, m); }
+// textured_params: the per-hit half -- the bump map bends the frame, every programmed parameter is evaluated into `mp`, the roughness
+// values are remapped into a3 = {a_r, a_u, a_v}.  k_tex_resolve stops here and hands the values to k_shade_general_res (PtTexRes).
+template <bool INL>
+PT_DEV void textured_params_t(const PtScene& sc, int32_t material, const TexHit& th, PtMatParams& mp, float* a3, V3 n, V2 uv, V3* sh_n, V3* sh_dpdu,
+                              V3 sh_dpdv, V3 sh_dndu, V3 sh_dndv) {
+    mp = sc.mat_params[material];
+    // One call site for every texture program of the hit (the evaluations are independent of one another, so their order is free): jobs 0-2
+    // are the bump map's displacement at p + du * dpdu, p + dv * dpdv and p (core/material.rs:31-72), jobs 3-10 the parameters Kd Ks Kr Kt
+    // opacity sigma metal-eta metal-k, jobs 11-14 roughness uroughness vroughness eta.
+    float du = 0.0f, dv = 0.0f, disp[3] = {0.0f, 0.0f, 0.0f};
+    if (mp.prog[8]) {
+        du = 0.5f * (fabsf(th.dudx) + fabsf(th.dudy));
+        if (du == 0.0f) du = 0.0005f;
+        dv = 0.5f * (fabsf(th.dvdx) + fabsf(th.dvdy));
+        if (dv == 0.0f) dv = 0.0005f;
+    }
+    float a_r = mp.a_r, a_u = mp.a_u, a_v = mp.a_v;
+    for (int j = 0; j < 15; j++) {
+        const int k = j < 3 ? 8 : (j < 11 ? j - 3 : j - 2);          // index into PtMatParams::prog
+        const uint32_t pr = mp.prog[k];
+        if (!pr) continue;
+        TexHit ev = th;
+        if (j == 0) { ev.p = th.p + du * *sh_dpdu; ev.uv = mk2(uv.x + du, uv.y + 0.0f); }
+        else if (j == 1) { ev.p = th.p + dv * sh_dpdv; ev.uv = mk2(uv.x + 0.0f, uv.y + dv); }
+        V3 v;
+        if constexpr (INL) v = tex_eval_inl(sc.textures, sc.tex_prog + pr, ev, sc.images);       // k_tex_resolve: the whole texture code inline (pt_texture_calls.inc)
+        else v = tex_eval(sc.textures, sc.tex_prog + pr, ev, sc.images);
+        switch (j) {
+            case 0: case 1: disp[j] = v.x; break;
+            case 2: {
+                const float displace = v.x;
+                V3 dpdu = *sh_dpdu + (disp[0] - displace) / du * *sh_n + displace * sh_dndu;
+                V3 dpdv = sh_dpdv + (disp[1] - displace) / dv * *sh_n + displace * sh_dndv;
+                *sh_n = face_forward(normalize(cross(dpdu, dpdv)), n);       // set_shading_geometry(.., false) (surface_interaction.rs:140-161)
+                *sh_dpdu = dpdu;
+                break;
+            }
+            case 3: mp.m.kd[0] = v.x; mp.m.kd[1] = v.y; mp.m.kd[2] = v.z; break;
+            case 4: mp.m.ks[0] = v.x; mp.m.ks[1] = v.y; mp.m.ks[2] = v.z; break;
+            case 5: mp.m.kr[0] = v.x; mp.m.kr[1] = v.y; mp.m.kr[2] = v.z; break;
+            case 6: mp.m.kt[0] = v.x; mp.m.kt[1] = v.y; mp.m.kt[2] = v.z; break;
+            case 7: mp.m.opacity[0] = v.x; mp.m.opacity[1] = v.y; mp.m.opacity[2] = v.z; break;
+            case 8: mp.m.sigma = v.x; break;
+            case 9: mp.m.metal_eta[0] = v.x; mp.m.metal_eta[1] = v.y; mp.m.metal_eta[2] = v.z; break;
+            case 10: mp.m.metal_k[0] = v.x; mp.m.metal_k[1] = v.y; mp.m.metal_k[2] = v.z; break;
+            // float parameters behind textures: "roughness" / "uroughness" / "vroughness" (then roughness_to_alpha, unless "remaproughness"
+            // is off) and "eta"; the constant ones keep the values the host remapped at upload
+            case 11: mp.m.roughness = v.x; a_r = mp.m.remap_roughness ? pt_roughness_to_alpha(v.x) : v.x; break;
+            case 12: mp.m.uroughness = v.x; a_u = mp.m.remap_roughness ? pt_roughness_to_alpha(v.x) : v.x; break;
+            case 13: mp.m.vroughness = v.x; a_v = mp.m.remap_roughness ? pt_roughness_to_alpha(v.x) : v.x; break;
+            default: mp.m.eta = v.x; break;
+        }
+    }
+    a3[0] = a_r; a3[1] = a_u; a3[2] = a_v;
+}
+__device__ __noinline__ void textured_params(const PtScene& sc, int32_t material, const TexHit& th, PtMatParams& mp, float* a3, V3 n, V2 uv, V3* sh_n, V3* sh_dpdu,
+                                             V3 sh_dpdv, V3 sh_dndu, V3 sh_dndv) {
+    textured_params_t<false>(sc, material, th, mp, a3, n, uv, sh_n, sh_dpdu, sh_dpdv, sh_dndu, sh_dndv);
+}
 __device__ __noinline__ void textured_lobes(const PtScene& sc, int32_t material, const TexHit& th, PtMaterial* out, V3 n, V2 uv, V3* sh_n, V3* sh_dpdu,
                                             V3 sh_dpdv, V3 sh_dndu, V3 sh_dndv) {
-    PtMatParams mp = sc.mat_params[material];
-    if (mp.prog[8]) {
-        const uint32_t* prog = sc.tex_prog + mp.prog[8];
-        float du = 0.5f * (fabsf(th.dudx) + fabsf(th.dudy));
-        if (du == 0.0f) du = 0.0005f;
-        TexHit ev = th;
-        ev.p = th.p + du * *sh_dpdu;
-        ev.uv = mk2(uv.x + du, uv.y + 0.0f);
-        float u_displace = tex_eval(sc.textures, prog, ev, sc.images).x;
-        float dv = 0.5f * (fabsf(th.dvdx) + fabsf(th.dvdy));
-        if (dv == 0.0f) dv = 0.0005f;
-        ev.p = th.p + dv * sh_dpdv;
-        ev.uv = mk2(uv.x + 0.0f, uv.y + dv);
-        float v_displace = tex_eval(sc.textures, prog, ev, sc.images).x;
-        float displace = tex_eval(sc.textures, prog, th, sc.images).x;
-        V3 dpdu = *sh_dpdu + (u_displace - displace) / du * *sh_n + displace * sh_dndu;
-        V3 dpdv = sh_dpdv + (v_displace - displace) / dv * *sh_n + displace * sh_dndv;
-        *sh_n = face_forward(normalize(cross(dpdu, dpdv)), n);       // set_shading_geometry(.., false) (surface_interaction.rs:140-161)
-        *sh_dpdu = dpdu;
-    }
-    float* dst[8] = {mp.m.kd, mp.m.ks, mp.m.kr, mp.m.kt, mp.m.opacity, nullptr, mp.m.metal_eta, mp.m.metal_k};
-    for (int k = 0; k < 8; k++) {
-        if (!mp.prog[k]) continue;
-        V3 v = tex_eval(sc.textures, sc.tex_prog + mp.prog[k], th, sc.images);
-        if (k == 5) mp.m.sigma = v.x;
-        else { dst[k][0] = v.x; dst[k][1] = v.y; dst[k][2] = v.z; }
-    }
-    // float parameters behind textures: "roughness" / "uroughness" / "vroughness" (then roughness_to_alpha, unless "remaproughness"
-    // is off) and "eta"; the constant ones keep the values the host remapped at upload
-    float a_r = mp.a_r, a_u = mp.a_u, a_v = mp.a_v;
-    if (mp.prog[9]) { mp.m.roughness = tex_eval(sc.textures, sc.tex_prog + mp.prog[9], th, sc.images).x; a_r = mp.m.remap_roughness ? pt_roughness_to_alpha(mp.m.roughness) : mp.m.roughness; }
-    if (mp.prog[10]) { mp.m.uroughness = tex_eval(sc.textures, sc.tex_prog + mp.prog[10], th, sc.images).x; a_u = mp.m.remap_roughness ? pt_roughness_to_alpha(mp.m.uroughness) : mp.m.uroughness; }
-    if (mp.prog[11]) { mp.m.vroughness = tex_eval(sc.textures, sc.tex_prog + mp.prog[11], th, sc.images).x; a_v = mp.m.remap_roughness ? pt_roughness_to_alpha(mp.m.vroughness) : mp.m.vroughness; }
-    if (mp.prog[12]) mp.m.eta = tex_eval(sc.textures, sc.tex_prog + mp.prog[12], th, sc.images).x;
-    build_lobes_call(mp.m, a_r, a_u, a_v, *out);
+    PtMatParams mp;
+    float a3[3];
+    textured_params(sc, material, th, mp, a3, n, uv, sh_n, sh_dpdu, sh_dpdv, sh_dndu, sh_dndv);
+    build_lobes_call(mp.m, a3[0], a3[1], a3[2], *out);
 }
 // Sort key of a ray for pt_raysort.hip: Morton code of the cell of its origin inside the world bound (2^PT_SORT_CELL_BITS cells per axis), direction octant on top
 PT_DEV uint32_t ray_sort_key(const PtScene& sc, V3 o, V3 d) {
@@ -2192,7 +2220,7 @@ __device__ unsigned long long g_shade_prof[16];
 #endif
 // 0.0f the optimiser cannot see through (one v_mov): see the continuation store in shade_body
 PT_DEV float opaque_zero() { float z = 0.0f; asm volatile("" : "+v"(z)); return z; }
-template <bool GENERAL, bool SPH, bool TEX = false, bool INST = false>
+template <bool GENERAL, bool SPH, bool TEX = false, bool INST = false, bool RES = false>
 PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, const uint32_t* list, uint32_t begin, uint32_t end,
                        uint32_t* ticket) {
     __shared__ unsigned long long s_vert;
@@ -2360,9 +2388,17 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             }
             if (found && (int32_t)bounces < sc.max_depth) {
                 bool no_bsdf = s.material < 0;
-                PtMaterial tm;                     // TEX: this hit's lobes
+                PtMaterial tm;                     // TEX / RES: this hit's lobes
                 bool use_tm = false;
                 if constexpr (TEX) {
+#if PT_TEX_EXP == 4          // timing experiment: what the second half of a split kernel would cost -- lobes built from the unevaluated parameter block
+                    if (!no_bsdf && sc.materials[s.material].textured) {
+                        PtMatParams mp = sc.mat_params[s.material];
+                        build_lobes_call(mp.m, mp.a_r, mp.a_u, mp.a_v, tm);
+                        use_tm = true;
+                        no_bsdf = tm.has_bsdf == 0;
+                    }
+#else
                     if (!no_bsdf && sc.materials[s.material].textured) {
                         TexHit th;
                         th.p = s.p; th.uv = s.uv;
@@ -2382,6 +2418,23 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                         }
                         compute_differentials(th, s.p, s.n, s.dpdu, s.dpdv, has_diff, rdf);
                         textured_lobes(sc, s.material, th, &tm, s.n, s.uv, &s.sh_n, &s.sh_dpdu, s.sh_dpdv, s.sh_dndu, s.sh_dndv);
+                        use_tm = true;
+                        no_bsdf = tm.has_bsdf == 0;
+                    }
+#endif
+                }
+                if constexpr (RES) {          // k_tex_resolve has evaluated this hit's textures: the values, the alphas and the bump-mapped frame come from P.tex_res
+                    if (!no_bsdf && sc.materials[s.material].textured) {
+                        const float4* r = P.tex_res + (size_t)p * PT_TEX_RES_F4;
+                        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
+                        PtMatParams mp = sc.mat_params[s.material];
+                        mp.m.kd[0] = r0.x; mp.m.kd[1] = r0.y; mp.m.kd[2] = r0.z; mp.m.ks[0] = r0.w; mp.m.ks[1] = r1.x; mp.m.ks[2] = r1.y;
+                        mp.m.kr[0] = r1.z; mp.m.kr[1] = r1.w; mp.m.kr[2] = r2.x; mp.m.kt[0] = r2.y; mp.m.kt[1] = r2.z; mp.m.kt[2] = r2.w;
+                        mp.m.opacity[0] = r3.x; mp.m.opacity[1] = r3.y; mp.m.opacity[2] = r3.z; mp.m.sigma = r3.w;
+                        mp.m.metal_eta[0] = r4.x; mp.m.metal_eta[1] = r4.y; mp.m.metal_eta[2] = r4.z; mp.m.metal_k[0] = r4.w; mp.m.metal_k[1] = r5.x; mp.m.metal_k[2] = r5.y;
+                        mp.m.uroughness = r5.z; mp.m.vroughness = r5.w; mp.m.eta = r6.x;
+                        build_lobes_call(mp.m, r6.y, r6.z, r6.w, tm);
+                        s.sh_n = mk3(r7.x, r7.y, r7.z); s.sh_dpdu = mk3(r7.w, r8.x, r8.y);
                         use_tm = true;
                         no_bsdf = tm.has_bsdf == 0;
                     }
@@ -2600,6 +2653,72 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_s
 // scenes with textured materials (and possibly spheres): lobes are built per hit for the textured ones
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_TEX_WAVES) k_shade_general_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
+}
+
+// The textured segment in two kernels (PBRTGPU_TEX_SPLIT, default on; scenes without instances).  k_shade_general_tex carries the texture
+// interpreter, the MIP lookups and the lobe builder next to next-event estimation: 256 registers, 130 spilled, 3 KB of scratch per lane, and
+// everything AFTER the textures runs 1.6x slower than in k_shade_general for it (profiles/r03_q_tex_kernel_experiments.txt).  k_tex_resolve
+// does the per-hit half of Material::compute_scattering_functions alone -- surface, ray differentials, bump map, every programmed
+// parameter -- and leaves 36 floats per path (PtPaths::tex_res); k_shade_general_res is k_shade_general with the lobe list built from them.
+template <bool SPH>
+PT_DEV void tex_resolve_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q) {
+    const uint32_t begin = Q.counts[PT_Q_TEX_BEGIN], end = Q.counts[PT_Q_GENERAL_END];
+    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        const uint32_t p = Q.sorted[i];
+        const int32_t rec = P.hit_rec[p];
+        const uint32_t st = P.state[p];
+        const uint32_t bounces = (st >> 16) & 0xffu, flags = st >> 24;
+        if (rec < 0 || (int32_t)bounces >= sc.max_depth) continue;         // shade_body builds no BSDF there either
+        const float4 ro4 = P.ray_o[p], rd4 = P.ray_d[p];
+        const V3 ro = f4_3(ro4), rd = f4_3(rd4);
+        const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)(uint32_t)rec * 3;
+        const float4 rec_a = q[0], rec_b = q[1], rec_c = q[2];
+        Surf s;
+        float thit;
+        if (!make_surf_any_rec<SPH>(sc, ro, rd, (uint32_t)rec, rec_a, rec_b, rec_c, s, &thit)) continue;
+        if (s.material < 0 || !sc.materials[s.material].textured) continue;
+        TexHit th;
+        th.p = s.p; th.uv = s.uv;
+        RayDiffs rdf;
+        const bool has_diff = (flags & PT_ST_CAMERA) != 0;
+        if (has_diff) {             // rebuild the camera ray's offset rays from its camera sample (as shade_body does)
+            Sampler sl;
+            sl.index = P.sobol_index[p];
+            sl.dim = 2;
+            const uint32_t pk2 = P.pixel[p];
+            sl.px = (int32_t)(pk2 & 0xffffu) + sc.film.sample_bounds[0];
+            sl.py = (int32_t)(pk2 >> 16) + sc.film.sample_bounds[1];
+            V2 u_lens = mk2(0.0f, 0.0f);
+            if (sc.cam.lens_radius > 0.0f) u_lens = sl.get_2d(sc);
+            const float2 pf = P.p_film[p];
+            camera_differentials(sc, mk2(pf.x, pf.y), u_lens, ro, rd, rdf);
+        }
+        compute_differentials(th, s.p, s.n, s.dpdu, s.dpdv, has_diff, rdf);
+        PtMatParams mp;
+        float a3[3];
+        textured_params_t<true>(sc, s.material, th, mp, a3, s.n, s.uv, &s.sh_n, &s.sh_dpdu, s.sh_dpdv, s.sh_dndu, s.sh_dndv);
+        float4* o = P.tex_res + (size_t)p * PT_TEX_RES_F4;
+        o[0] = make_float4(mp.m.kd[0], mp.m.kd[1], mp.m.kd[2], mp.m.ks[0]);
+        o[1] = make_float4(mp.m.ks[1], mp.m.ks[2], mp.m.kr[0], mp.m.kr[1]);
+        o[2] = make_float4(mp.m.kr[2], mp.m.kt[0], mp.m.kt[1], mp.m.kt[2]);
+        o[3] = make_float4(mp.m.opacity[0], mp.m.opacity[1], mp.m.opacity[2], mp.m.sigma);
+        o[4] = make_float4(mp.m.metal_eta[0], mp.m.metal_eta[1], mp.m.metal_eta[2], mp.m.metal_k[0]);
+        o[5] = make_float4(mp.m.metal_k[1], mp.m.metal_k[2], mp.m.uroughness, mp.m.vroughness);
+        o[6] = make_float4(mp.m.eta, a3[0], a3[1], a3[2]);
+        o[7] = make_float4(s.sh_n.x, s.sh_n.y, s.sh_n.z, s.sh_dpdu.x);
+        o[8] = make_float4(s.sh_dpdu.y, s.sh_dpdu.z, 0.0f, 0.0f);
+    }
+}
+#ifndef PT_TEX_RESOLVE_WAVES
+#define PT_TEX_RESOLVE_WAVES 2
+#endif
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TEX_RESOLVE_WAVES) k_tex_resolve(PtScene sc, PtPaths P, PtQueues Q) { tex_resolve_body<false>(sc, P, Q); }
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TEX_RESOLVE_WAVES) k_tex_resolve_sph(PtScene sc, PtPaths P, PtQueues Q) { tex_resolve_body<true>(sc, P, Q); }
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_GEN_WAVES) k_shade_general_res(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, false, false, false, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_shade_general_res_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, true, false, false, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
 }
 
 // Sort keys of a bounce's continuation rays, for scenes larger than the Infinity Cache (pt_context.cpp sort_cont): a pass of its own over the
@@ -3618,7 +3737,18 @@ hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths&
                 hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
                 hipLaunchKernelGGL(k_shade_general, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
             }
-            hipLaunchKernelGGL(k_shade_general_tex, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            static const int split = [] { const char* e = std::getenv("PBRTGPU_TEX_SPLIT"); return e ? std::atoi(e) : 1; }();
+            if (split && P.tex_res) {
+                if (sc.n_spheres) {
+                    hipLaunchKernelGGL(k_tex_resolve_sph, dim3(4096), dim3(PT_BLOCK), 0, st, sc, P, Q);
+                    hipLaunchKernelGGL(k_shade_general_res_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+                } else {
+                    hipLaunchKernelGGL(k_tex_resolve, dim3(4096), dim3(PT_BLOCK), 0, st, sc, P, Q);
+                    hipLaunchKernelGGL(k_shade_general_res, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+                }
+            } else {
+                hipLaunchKernelGGL(k_shade_general_tex, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            }
         } else if (sc.n_spheres) {
             hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
             hipLaunchKernelGGL(k_shade_general_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
