@@ -160,9 +160,13 @@ pt_status ensure_pool(pt_context* ctx, size_t n_paths) {
         PT_HIP(ctx->d_hit_inst.alloc(std::max(n_paths, ctx->pool_paths) * 4));
         ctx->paths.hit_inst = ctx->d_hit_inst.as<uint32_t>();
     }
-    if (ctx->sc.textured && !ctx->sc.n_instances && ctx->d_tex_res.bytes < std::max(n_paths, ctx->pool_paths) * (size_t)(PT_TEX_RES_F4 * 16)) {      // scenes with textured materials only
+    const bool tex_split = ctx->sc.textured && !ctx->sc.n_instances;      // k_tex_resolve -> k_shade_general_res: 144 bytes per path, for such scenes only
+    if (tex_split && ctx->d_tex_res.bytes < std::max(n_paths, ctx->pool_paths) * (size_t)(PT_TEX_RES_F4 * 16)) {
         PT_HIP(ctx->d_tex_res.alloc(std::max(n_paths, ctx->pool_paths) * (size_t)(PT_TEX_RES_F4 * 16)));
         ctx->paths.tex_res = ctx->d_tex_res.as<float4>();
+    } else if (!tex_split && ctx->d_tex_res.p) {
+        ctx->d_tex_res.release();
+        ctx->paths.tex_res = nullptr;
     }
     if (ctx->pool_paths >= n_paths && ctx->d_pool.p) return PT_OK;
     // 11 float4 + float2 + u64 + 6 x 4-byte + 1 byte per path
