@@ -1052,6 +1052,9 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
                                      // test count costs four ballots + popcounts in EVERY iteration's phase decision; RT1M at 64 spp, k_trace ms per launch:
                                      // tests >= 56: 39.66; lanes >= 12 / 16 / 18 / 20 / 22 / 24 / 28 / 32: 40.88 / 39.39 / 39.34 / 39.43 / 40.00 / 40.52 / 41.79 / 43.50
 #endif
+#ifndef PT_SPH_LANES_MIN
+#define PT_SPH_LANES_MIN 16          // scenes with spheres: a sphere round once this many lanes are parked on a leaf that holds a sphere
+#endif
 #ifndef PT_LEAF_TRIS_FUSED
 #define PT_LEAF_TRIS_FUSED 0         // > 0: a leaf round rides along a staged node round once this many tests are parked (experiment)
 #endif
@@ -1121,6 +1124,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     r.sa = c.lane_base; r.sa_limit = 0;
     r.top = PT_EMPTY_REF;
     bool more = total > 0;
+    bool sph_wait = false;      // SPH pooled-leaf kernels: this lane's parked leaf holds a sphere and waits for a sphere round (see the phase decision)
     // prefetch reservation (see the loop): stage, ticket result (lane 0), rays reserved / handed out, one ray per lane
     int pf_stage = 0, pf_kind = 0;
     uint32_t pf_raw = 0, pf_count = 0, pf_used = 0, pf_p = 0;
@@ -1228,12 +1232,28 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #endif
         if constexpr (DIST) {
             // triangles parked: the count rides in bits 28..30 of the leaf reference
+            // Scenes with spheres: a leaf that holds a sphere waits for a round of its own.  The sphere test is ~600 instructions of interval
+            // arithmetic against ~80 for a triangle, and in a pooled round the whole wave walks through it for the one or two lanes that
+            // have a sphere (with a sphere LIGHT every shadow ray ends in its leaf: k_trace +23 %).  A normal round therefore only finds
+            // out that a leaf holds a sphere (its records are loaded anyway) and leaves it parked with `sph_wait` set; once PT_SPH_LANES_MIN
+            // lanes wait like that -- or nothing else can run -- a sphere round serves exactly those leaves, spheres and triangles alike.
+            // Every leaf is still tested whole, by its owner, in leaf order: results and counters do not change.
+            constexpr bool SPHDEF = SPH && !PT_NODE_STAGED && PT_LEAF_LANES_MIN > 0;      // (the experiment builds test spheres in every round, as before)
+            bool sround = SPH && !SPHDEF;              // this iteration's leaf round is a sphere round
+            unsigned long long m_tri_s = 0;
+            if constexpr (SPHDEF) {
+                m_tri_s = __ballot(w_tri && sph_wait);
+                m_tri &= ~m_tri_s;
+            }
+            const bool sph_go = SPHDEF && (uint32_t)__popcll(m_tri_s) >= (uint32_t)PT_SPH_LANES_MIN;
             const uint32_t tcnt = w_tri ? ((r.top >> PT_LEAF_COUNT_SHIFT) & 7u) + 1u : 0u;
+            uint32_t tcnt_r = tcnt;                    // ... of the lanes the coming round serves (0 for the others)
+            bool w_serve = w_tri;
 #if PT_LEAF_LANES_MIN > 0
             // the leaf-round trigger from the number of parked LANES (experiment: the exact count of parked tests costs four ballots and
             // popcounts per iteration, needed by every iteration's phase decision; leaf_issue computes its own prefix sums when a round runs)
             unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            const uint32_t n_parked = (uint32_t)__popcll(m_tri) >= (uint32_t)PT_LEAF_LANES_MIN ? (uint32_t)PT_LEAF_TRIS_MIN : 0u;
+            const uint32_t n_parked = (sph_go || (uint32_t)__popcll(m_tri) >= (uint32_t)PT_LEAF_LANES_MIN) ? (uint32_t)PT_LEAF_TRIS_MIN : 0u;
 #else
             const unsigned long long c0 = __ballot((tcnt & 1u) != 0), c1 = __ballot((tcnt & 2u) != 0), c2 = __ballot((tcnt & 4u) != 0),
                                      c3 = __ballot((tcnt & 8u) != 0);
@@ -1250,15 +1270,15 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             TriVerts lf_tv;
             auto leaf_issue = [&]() {
 #if PT_LEAF_LANES_MIN > 0
-                c0 = __ballot((tcnt & 1u) != 0); c1 = __ballot((tcnt & 2u) != 0); c2 = __ballot((tcnt & 4u) != 0); c3 = __ballot((tcnt & 8u) != 0);
+                c0 = __ballot((tcnt_r & 1u) != 0); c1 = __ballot((tcnt_r & 2u) != 0); c2 = __ballot((tcnt_r & 4u) != 0); c3 = __ballot((tcnt_r & 8u) != 0);
 #endif
                 lf_pre = (uint32_t)(__popcll(c0 & below) + 2 * __popcll(c1 & below) + 4 * __popcll(c2 & below) + 8 * __popcll(c3 & below));
-                lf_served = w_tri && lf_pre + tcnt <= 64u;
+                lf_served = w_serve && lf_pre + tcnt_r <= 64u;
                 const unsigned long long m_served = __ballot(lf_served);
                 const int last = 63 - __clzll(m_served);                      // m_served != 0: the first parked lane always fits
-                lf_items = (uint32_t)__shfl((int)(lf_pre + tcnt), last, 64);
+                lf_items = (uint32_t)__shfl((int)(lf_pre + tcnt_r), last, 64);
                 if (lf_served)
-                    for (uint32_t k = 0; k < tcnt; k++) s_map[wbase + lf_pre + k] = (unsigned char)lane;
+                    for (uint32_t k = 0; k < tcnt_r; k++) s_map[wbase + lf_pre + k] = (unsigned char)lane;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1268,7 +1288,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 const uint32_t first = (uint32_t)__shfl((int)(r.top & PT_LEAF_FIRST_MASK), o, 64);
                 lf_rp.o = mk3(__shfl(r.rp.o.x, o, 64), __shfl(r.rp.o.y, o, 64), __shfl(r.rp.o.z, o, 64));
                 lf_rp.d = mk3(0.0f, 0.0f, 0.0f);        // only the one-sided test (and a sphere) reads the direction
-                if (SPH || sc.any_one_sided) lf_rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));
+                if ((SPH && sround) || sc.any_one_sided) lf_rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));     // (no sphere is tested outside a sphere round)
                 lf_kk = __shfl(r.rp.kx | (r.rp.ky << 2) | (r.rp.kz << 4) | ((kind == 2 ? 1 : 0) << 6), o, 64);
                 lf_rp.kx = lf_kk & 3; lf_rp.ky = (lf_kk >> 2) & 3; lf_rp.kz = (lf_kk >> 4) & 3;
                 lf_rp.sx = __shfl(r.rp.sx, o, 64); lf_rp.sy = __shfl(r.rp.sy, o, 64); lf_rp.sz = __shfl(r.rp.sz, o, 64);
@@ -1279,24 +1299,36 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             // finish: every helper runs its (ray, triangle) test, results go to LDS, the owner walks its leaf's results in leaf order
             // and applies the one comparison that depends on the ray's shrinking t_max with the t_max each triangle would have seen
             auto leaf_finish = [&]() {
+                bool sphere_rec = false;
+                if constexpr (SPH) sphere_rec = lf_valid && (lf_tv.flags & PT_TRI_SPHERE) != 0;
+                unsigned long long m_sitems = 0;            // normal round: the items that are spheres (item i is helper lane i)
+                if constexpr (SPHDEF) { if (!sround) { m_sitems = __ballot(sphere_rec); } }
                 if (lf_valid) {
-                    bool sphere_rec = false;
-                    if constexpr (SPH) sphere_rec = (lf_tv.flags & PT_TRI_SPHERE) != 0;
-                    if (sphere_rec) {       // Sphere::intersect(_p) against t_max = +inf; the owner applies the t_max tests
+                    // The triangle test runs for EVERY item, a sphere's record included (its fields are not vertices: the result is thrown
+                    // away).  With the test behind `if (!sphere)` the compiler moved the record's loads into the two branches, behind the
+                    // load of the flags they depend on: a second memory round trip in every leaf round of the sphere-capable kernel
+                    // (5 760 against 4 340 clocks per round on a scene WITHOUT spheres, -DPT_PROFILE_PHASES).
+                    TriCore tc;
+                    const bool tri_ok = tri_core(lf_rp, lf_tv.p0, lf_tv.p1, lf_tv.p2, lf_tv.flags, tc);
+                    float4 res = make_float4(tri_ok ? 1.0f : 0.0f, tc.t_scaled, tc.det, tc.t);
+                    if (sphere_rec && sround) {       // Sphere::intersect(_p) against t_max = +inf; the owner applies the t_max tests
                         SphHit sh;
                         sh.t = 0.0f; sh.a_hi = 0.0f; sh.b_hi = 0.0f;
-                        bool ok = sph_hit_test(sc.spheres[__float_as_uint(lf_tv.p0.x)], lf_rp.o, lf_rp.d, PT_INF, (lf_kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
-                        s_res[wbase + lane] = make_float4(ok ? 2.0f : 0.0f, sh.a_hi, sh.b_hi, sh.t);
-                    } else {
-                        TriCore tc;
-                        bool ok = tri_core(lf_rp, lf_tv.p0, lf_tv.p1, lf_tv.p2, lf_tv.flags, tc);
-                        s_res[wbase + lane] = make_float4(ok ? 1.0f : 0.0f, tc.t_scaled, tc.det, tc.t);
+                        const bool ok = sph_hit_test(sc.spheres[__float_as_uint(lf_tv.p0.x)], lf_rp.o, lf_rp.d, PT_INF, (lf_kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
+                        res = make_float4(ok ? 2.0f : 0.0f, sh.a_hi, sh.b_hi, sh.t);
                     }
+                    // (a sphere in a normal round: the owner sees the item in m_sitems and leaves its leaf parked for a sphere round)
+                    s_res[wbase + lane] = res;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lf_served) {
+                bool walk = lf_served;
+                if constexpr (SPHDEF) {
+                    if (lf_served && !sround && ((m_sitems >> lf_pre) & ((1ull << tcnt_r) - 1ull)) != 0ull) { sph_wait = true; walk = false; }     // a sphere among this leaf's items
+                    if (lf_served && sround) sph_wait = false;
+                }
+                if (walk) {
                     const uint32_t rec0 = fs_pop(c, r.sa, r.top) & PT_LEAF_FIRST_MASK;
                     const bool any_hit = kind == 2;
                     bool leaf_hit = false;
@@ -1304,7 +1336,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     for (uint32_t k = 0; k < tcnt; k++) {
                         const float4 v = s_res[wbase + lf_pre + k];
                         bool acc;
-                        if (SPH && v.x == 2.0f) acc = !(v.y > r.ray_tmax) && !(v.z > r.ray_tmax);
+                        if (SPH && sround && v.x == 2.0f) acc = !(v.y > r.ray_tmax) && !(v.z > r.ray_tmax);      // (a sphere's result: only a sphere round makes one)
                         else acc = v.x != 0.0f && tri_accept(v.y, v.z, r.ray_tmax);
                         if (acc) {
                             r.best = (int32_t)(rec0 + k); leaf_hit = true;
@@ -1388,13 +1420,24 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #ifdef PT_PROFILE_PHASES
                 prof[12] += t1 - t0; prof[13] += 1; prof[4] += (unsigned long long)__popcll(m_node);
 #endif
-            } else if (m_tri != 0) {
+            } else if ((m_tri | m_tri_s) != 0) {
+                if constexpr (SPHDEF) {
+                    sround = sph_go || m_tri == 0;          // the sphere leaves' turn: enough of them wait, or nothing else can run
+                    w_serve = w_tri && (sph_wait == sround);
+                    tcnt_r = w_serve ? tcnt : 0u;
+                }
                 PT_PROF_T(t0);
                 leaf_issue();
+#ifdef PT_PROFILE_PHASES
+                PT_PROF_T(t0b);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PT_PROF_T(t0c);
+                prof[5] += t0b - t0; prof[6] += t0c - t0b;
+#endif
                 leaf_finish();
                 PT_PROF_T(t1);
 #ifdef PT_PROFILE_PHASES
-                prof[7] += t1 - t0; prof[8] += 1; prof[9] += (unsigned long long)lf_items;
+                prof[7] += t1 - t0c; prof[8] += 1; prof[9] += (unsigned long long)lf_items;
 #endif
             }
         } else {
@@ -3563,9 +3606,10 @@ int ptk_shade_prof_read(unsigned long long* out16) {       // 1 when the library
 }
 hipError_t ptk_trace(hipStream_t st, int grid, int grid_dist, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
                      uint32_t spill_depth, uint32_t* err) {
+    static const bool force_sph = std::getenv("PBRTGPU_FORCE_SPH_TRACE") != nullptr;      // diagnosis: what the sphere-capable kernel costs a scene without spheres
     if (sc.dist_leaves && !sc.n_instances) grid = grid_dist;      // the pooled-leaf kernels fit three blocks per CU, the others four
     if (sc.n_instances) hipLaunchKernelGGL(k_trace_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
-    else if (sc.n_spheres && sc.dist_leaves) hipLaunchKernelGGL(k_trace_sph_dist, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    else if ((sc.n_spheres || force_sph) && sc.dist_leaves) hipLaunchKernelGGL(k_trace_sph_dist, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else if (sc.n_spheres) hipLaunchKernelGGL(k_trace_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else if (sc.dist_leaves) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else hipLaunchKernelGGL(k_trace_seq, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
