@@ -1629,6 +1629,8 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                      tot, pr[3], pr[3] + pr[13] ? (double)pr[4] / (double)(pr[3] + pr[13]) : 0.0, 100.0 * pr[0] / tot, 100.0 * pr[1] / tot, 100.0 * pr[2] / tot,
                      pr[3] ? (double)(pr[0] + pr[1] + pr[2]) / (double)pr[3] : 0.0, pr[8], pr[8] ? (double)pr[9] / (double)pr[8] : 0.0, 100.0 * pr[5] / tot, 100.0 * pr[6] / tot,
                      100.0 * pr[7] / tot, pr[8] ? (double)(pr[5] + pr[6] + pr[7]) / (double)pr[8] : 0.0, pr[13], 100.0 * pr[12] / tot, 100.0 * pr[10] / tot);
+        std::fprintf(stderr, "[phases] service in parts: prefetch state machine %.1f%%, retiring + handing out rays %.1f%% (%.0f + %.0f clocks per iteration)\n", 100.0 * pr[14] / tot,
+                     100.0 * pr[15] / tot, (double)pr[14] / (double)(pr[3] + pr[8] + pr[13] + 1), (double)pr[15] / (double)(pr[3] + pr[8] + pr[13] + 1));
     }
 #endif
     {   // diagnostic build -DPT_PROFILE_SHADE: where a shading wave's clocks go

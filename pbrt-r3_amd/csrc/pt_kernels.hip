@@ -1052,6 +1052,9 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
                                      // test count costs four ballots + popcounts in EVERY iteration's phase decision; RT1M at 64 spp, k_trace ms per launch:
                                      // tests >= 56: 39.66; lanes >= 12 / 16 / 18 / 20 / 22 / 24 / 28 / 32: 40.88 / 39.39 / 39.34 / 39.43 / 40.00 / 40.52 / 41.79 / 43.50
 #endif
+#ifndef PT_WALK_BATCH
+#define PT_WALK_BATCH 1              // 1: a leaf's owner reads its results from LDS four at a time instead of one per loop iteration
+#endif
 #ifndef PT_SPH_LANES_MIN
 #define PT_SPH_LANES_MIN 16          // scenes with spheres: a sphere round once this many lanes are parked on a leaf that holds a sphere
 #endif
@@ -1184,6 +1187,10 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             }
             pf_stage = 3;
         }
+#ifdef PT_PROFILE_PHASES
+        const long long pt_pf = __builtin_readcyclecounter();
+        prof[14] += (unsigned long long)(pt_pf - pt_iter);       // the prefetch state machine
+#endif
         // ---- retire finished rays: stores only
         if (kind != 0 && ray_done(r)) {
             if (kind == 1) { P.hit_t[p] = r.ray_tmax; P.hit_rec[p] = r.best; if (INST) P.hit_inst[p] = r.best_inst; }
@@ -1214,6 +1221,9 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 if (pf_used == pf_count) pf_stage = 0;
             }
         }
+#ifdef PT_PROFILE_PHASES
+        prof[15] += (unsigned long long)(__builtin_readcyclecounter() - pt_pf);       // retiring and handing out rays
+#endif
         if (__ballot(kind != 0) == 0) {
             if (!more && pf_stage == 0) break;
             continue;
@@ -1333,6 +1343,29 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     const bool any_hit = kind == 2;
                     bool leaf_hit = false;
                     uint32_t tested = tcnt;
+#if PT_WALK_BATCH
+                    // The results come four at a time: the loop's one LDS read per item was a round trip per item for the owner with the
+                    // fullest leaf, and the whole wave waits for that owner.  (Slots past the leaf's own are read and ignored: they lie in
+                    // the wave's 64 and hold other owners' results.)
+                    bool stop = false;
+                    for (uint32_t k0 = 0; k0 < tcnt && !stop; k0 += 4u) {
+                        const uint32_t b = wbase + lf_pre + k0;
+                        const float4 va = s_res[b], vb = s_res[wbase + min(lf_pre + k0 + 1u, 63u)], vc = s_res[wbase + min(lf_pre + k0 + 2u, 63u)],
+                                     vd = s_res[wbase + min(lf_pre + k0 + 3u, 63u)];
+                        auto step = [&](const float4 v, uint32_t k) {
+                            if (stop || k >= tcnt) return;
+                            bool acc;
+                            if (SPH && sround && v.x == 2.0f) acc = !(v.y > r.ray_tmax) && !(v.z > r.ray_tmax);      // (a sphere's result: only a sphere round makes one)
+                            else acc = v.x != 0.0f && tri_accept(v.y, v.z, r.ray_tmax);
+                            if (acc) {
+                                r.best = (int32_t)(rec0 + k); leaf_hit = true;
+                                if (any_hit) { r.sa = c.lane_base; r.top = PT_EMPTY_REF; tested = k + 1; stop = true; return; }
+                                r.ray_tmax = v.w;
+                            }
+                        };
+                        step(va, k0); step(vb, k0 + 1u); step(vc, k0 + 2u); step(vd, k0 + 3u);
+                    }
+#else
                     for (uint32_t k = 0; k < tcnt; k++) {
                         const float4 v = s_res[wbase + lf_pre + k];
                         bool acc;
@@ -1344,6 +1377,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                             r.ray_tmax = v.w;
                         }
                     }
+#endif
                     c.n_tris += tested;
                     if (leaf_hit && !any_hit) r.tmax = r.ray_tmax;
                 }
