@@ -22,6 +22,7 @@
 #include "pt_bxdf.h"
 #include "pt_sphere.h"
 #include "pt_texture.h"
+#include <type_traits>
 #include "pt_lobes.h"
 #include "pt_kernels.h"
 #include "../../include/pbrtgpu.h"
@@ -1056,7 +1057,8 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #define PT_WALK_BATCH 1              // 1: a leaf's owner reads its results from LDS four at a time instead of one per loop iteration
 #endif
 #ifndef PT_SPH_LANES_MIN
-#define PT_SPH_LANES_MIN 16          // scenes with spheres: a sphere round once this many lanes are parked on a leaf that holds a sphere
+#define PT_SPH_LANES_MIN 8           // scenes with spheres: a sphere round once this many lanes are parked on a leaf that holds a sphere (2 / 4 / 6 / 8 / 10 / 16 / 24 / 32:
+                                     // 46.9 / 45.2 / 44.6 / 44.4 / 44.5 / 44.9 / 48.6 / 54.2 ms per launch, RT1M lit by a sphere, 64 spp)
 #endif
 #ifndef PT_LEAF_TRIS_FUSED
 #define PT_LEAF_TRIS_FUSED 0         // > 0: a leaf round rides along a staged node round once this many tests are parked (experiment)
@@ -1278,7 +1280,9 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             int lf_kk = 0;
             RayPre lf_rp;
             TriVerts lf_tv;
-            auto leaf_issue = [&]() {
+            auto leaf_issue = [&](auto sr_tag) {
+                constexpr bool SR = decltype(sr_tag)::value;      // compile-time: this copy is the sphere round (two copies: the normal round carries no sphere code)
+                (void)SR;
 #if PT_LEAF_LANES_MIN > 0
                 c0 = __ballot((tcnt_r & 1u) != 0); c1 = __ballot((tcnt_r & 2u) != 0); c2 = __ballot((tcnt_r & 4u) != 0); c3 = __ballot((tcnt_r & 8u) != 0);
 #endif
@@ -1298,7 +1302,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 const uint32_t first = (uint32_t)__shfl((int)(r.top & PT_LEAF_FIRST_MASK), o, 64);
                 lf_rp.o = mk3(__shfl(r.rp.o.x, o, 64), __shfl(r.rp.o.y, o, 64), __shfl(r.rp.o.z, o, 64));
                 lf_rp.d = mk3(0.0f, 0.0f, 0.0f);        // only the one-sided test (and a sphere) reads the direction
-                if ((SPH && sround) || sc.any_one_sided) lf_rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));     // (no sphere is tested outside a sphere round)
+                if ((SPH && SR) || sc.any_one_sided) lf_rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));     // (no sphere is tested outside a sphere round)
                 lf_kk = __shfl(r.rp.kx | (r.rp.ky << 2) | (r.rp.kz << 4) | ((kind == 2 ? 1 : 0) << 6), o, 64);
                 lf_rp.kx = lf_kk & 3; lf_rp.ky = (lf_kk >> 2) & 3; lf_rp.kz = (lf_kk >> 4) & 3;
                 lf_rp.sx = __shfl(r.rp.sx, o, 64); lf_rp.sy = __shfl(r.rp.sy, o, 64); lf_rp.sz = __shfl(r.rp.sz, o, 64);
@@ -1308,11 +1312,13 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             };
             // finish: every helper runs its (ray, triangle) test, results go to LDS, the owner walks its leaf's results in leaf order
             // and applies the one comparison that depends on the ray's shrinking t_max with the t_max each triangle would have seen
-            auto leaf_finish = [&]() {
+            auto leaf_finish = [&](auto sr_tag) {
+                constexpr bool SR = decltype(sr_tag)::value;
+                (void)SR;
                 bool sphere_rec = false;
                 if constexpr (SPH) sphere_rec = lf_valid && (lf_tv.flags & PT_TRI_SPHERE) != 0;
                 unsigned long long m_sitems = 0;            // normal round: the items that are spheres (item i is helper lane i)
-                if constexpr (SPHDEF) { if (!sround) { m_sitems = __ballot(sphere_rec); } }
+                if constexpr (SPHDEF && !SR) { m_sitems = __ballot(sphere_rec); }
                 if (lf_valid) {
                     // The triangle test runs for EVERY item, a sphere's record included (its fields are not vertices: the result is thrown
                     // away).  With the test behind `if (!sphere)` the compiler moved the record's loads into the two branches, behind the
@@ -1321,7 +1327,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     TriCore tc;
                     const bool tri_ok = tri_core(lf_rp, lf_tv.p0, lf_tv.p1, lf_tv.p2, lf_tv.flags, tc);
                     float4 res = make_float4(tri_ok ? 1.0f : 0.0f, tc.t_scaled, tc.det, tc.t);
-                    if (sphere_rec && sround) {       // Sphere::intersect(_p) against t_max = +inf; the owner applies the t_max tests
+                    if (SR && sphere_rec) {       // Sphere::intersect(_p) against t_max = +inf; the owner applies the t_max tests
                         SphHit sh;
                         sh.t = 0.0f; sh.a_hi = 0.0f; sh.b_hi = 0.0f;
                         const bool ok = sph_hit_test(sc.spheres[__float_as_uint(lf_tv.p0.x)], lf_rp.o, lf_rp.d, PT_INF, (lf_kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
@@ -1335,8 +1341,8 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 bool walk = lf_served;
                 if constexpr (SPHDEF) {
-                    if (lf_served && !sround && ((m_sitems >> lf_pre) & ((1ull << tcnt_r) - 1ull)) != 0ull) { sph_wait = true; walk = false; }     // a sphere among this leaf's items
-                    if (lf_served && sround) sph_wait = false;
+                    if (!SR && lf_served && ((m_sitems >> lf_pre) & ((1ull << tcnt_r) - 1ull)) != 0ull) { sph_wait = true; walk = false; }     // a sphere among this leaf's items
+                    if (SR && lf_served) sph_wait = false;
                 }
                 if (walk) {
                     const uint32_t rec0 = fs_pop(c, r.sa, r.top) & PT_LEAF_FIRST_MASK;
@@ -1355,7 +1361,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                         auto step = [&](const float4 v, uint32_t k) {
                             if (stop || k >= tcnt) return;
                             bool acc;
-                            if (SPH && sround && v.x == 2.0f) acc = !(v.y > r.ray_tmax) && !(v.z > r.ray_tmax);      // (a sphere's result: only a sphere round makes one)
+                            if (SPH && SR && v.x == 2.0f) acc = !(v.y > r.ray_tmax) && !(v.z > r.ray_tmax);      // (a sphere's result: only a sphere round makes one)
                             else acc = v.x != 0.0f && tri_accept(v.y, v.z, r.ray_tmax);
                             if (acc) {
                                 r.best = (int32_t)(rec0 + k); leaf_hit = true;
@@ -1369,7 +1375,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     for (uint32_t k = 0; k < tcnt; k++) {
                         const float4 v = s_res[wbase + lf_pre + k];
                         bool acc;
-                        if (SPH && sround && v.x == 2.0f) acc = !(v.y > r.ray_tmax) && !(v.z > r.ray_tmax);      // (a sphere's result: only a sphere round makes one)
+                        if (SPH && SR && v.x == 2.0f) acc = !(v.y > r.ray_tmax) && !(v.z > r.ray_tmax);      // (a sphere's result: only a sphere round makes one)
                         else acc = v.x != 0.0f && tri_accept(v.y, v.z, r.ray_tmax);
                         if (acc) {
                             r.best = (int32_t)(rec0 + k); leaf_hit = true;
@@ -1408,14 +1414,14 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 PT_PROF_T(t0);
                 if (do_node) below_top = node_round_issue(sc, r, c, w_node);
                 PT_PROF_T(t1);
-                if (do_leaf) leaf_issue();
+                if (do_leaf) leaf_issue(std::integral_constant<bool, SPH>{});
                 PT_PROF_T(t2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA writes have landed (nothing else orders a ds_read behind them)
                 __builtin_amdgcn_wave_barrier();
                 PT_PROF_T(t3);
                 if (do_node) node_round_finish(r, c, w_node, below_top);
                 PT_PROF_T(t4);
-                if (do_leaf) leaf_finish();
+                if (do_leaf) leaf_finish(std::integral_constant<bool, SPH>{});
                 PT_PROF_T(t5);
 #else
                 unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
@@ -1431,13 +1437,13 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     PT_PROF_SET(t4); PT_PROF_SET(t5);
                 } else {
                     PT_PROF_SET(t1);
-                    leaf_issue();
+                    leaf_issue(std::integral_constant<bool, SPH>{});
                     PT_PROF_SET(t2);
 #ifdef PT_PROFILE_PHASES
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
                     PT_PROF_SET(t3); PT_PROF_SET(t4);
-                    leaf_finish();
+                    leaf_finish(std::integral_constant<bool, SPH>{});
                     PT_PROF_SET(t5);
                 }
 #endif
@@ -1461,14 +1467,14 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     tcnt_r = w_serve ? tcnt : 0u;
                 }
                 PT_PROF_T(t0);
-                leaf_issue();
+                if (SPHDEF && sround) leaf_issue(std::true_type{}); else leaf_issue(std::integral_constant<bool, SPH && !SPHDEF>{});
 #ifdef PT_PROFILE_PHASES
                 PT_PROF_T(t0b);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PT_PROF_T(t0c);
                 prof[5] += t0b - t0; prof[6] += t0c - t0b;
 #endif
-                leaf_finish();
+                if (SPHDEF && sround) leaf_finish(std::true_type{}); else leaf_finish(std::integral_constant<bool, SPH && !SPHDEF>{});
                 PT_PROF_T(t1);
 #ifdef PT_PROFILE_PHASES
                 prof[7] += t1 - t0c; prof[8] += 1; prof[9] += (unsigned long long)lf_items;
