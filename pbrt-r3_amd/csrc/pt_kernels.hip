@@ -1390,6 +1390,8 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             };
 #ifdef PT_FORCE_GENERAL_VISIT
             const bool lean = false;                                                // experiment: the first version's visit for everyone
+#elif defined(PT_EXP_NO_GENERAL_VISIT)
+            const bool lean = true;                                                 // timing experiment (wrong for NaN-exact lanes): the general visit compiled out
 #else
             const bool lean = __ballot(w_node && r.sa >= r.sa_limit) == 0ull;      // nobody NaN-exact, nobody near the LDS part's end
 #endif
