@@ -311,3 +311,18 @@ def test_halton_dimension_overflow_is_reported(fuzz_ctx, oracle):
         o2.close()
     finally:
         osc.close()
+
+
+def test_long_halton_paths_are_refused_at_upload(fuzz_ctx):
+    """path + Halton + maxdepth > 124: 5 dimensions for the camera and 8 per vertex run past the sampler's 1000 dimensions, where the reference
+    panics; the shading kernels do not check per sample (it cost them registers they do not have), so the upload refuses the combination."""
+    b = fs.base(res=16, spp=1)
+    b.sampler_halton(1)
+    fs.room(b)
+    b.integrator_path(maxdepth=124)
+    fuzz_ctx.upload(b.build())                  # 5 + 8 * 124 = 997: fine
+    b.integrator_path(maxdepth=125)
+    with pytest.raises(pkg.capi.PtError, match="1000"):
+        fuzz_ctx.upload(b.build())
+    b.sampler_sobol(1)
+    fuzz_ctx.upload(b.build())                  # Sobol' wraps instead (sobol.rs:39-56): no limit
