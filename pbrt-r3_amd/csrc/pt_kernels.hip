@@ -1330,7 +1330,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     if (SR && sphere_rec) {       // Sphere::intersect(_p) against t_max = +inf; the owner applies the t_max tests
                         SphHit sh;
                         sh.t = 0.0f; sh.a_hi = 0.0f; sh.b_hi = 0.0f;
-                        const bool ok = sph_hit_test(sc.spheres[__float_as_uint(lf_tv.p0.x)], lf_rp.o, lf_rp.d, PT_INF, (lf_kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
+                        const bool ok = sph_hit_test_inl(sc.spheres[__float_as_uint(lf_tv.p0.x)], lf_rp.o, lf_rp.d, PT_INF, (lf_kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
                         res = make_float4(ok ? 2.0f : 0.0f, sh.a_hi, sh.b_hi, sh.t);
                     }
                     // (a sphere in a normal round: the owner sees the item in m_sitems and leaves its leaf parked for a sphere round)

@@ -89,7 +89,9 @@ PT_DEV V3 sph_refine(const PtSphere& s, V3 o, V3 d, float t, float wrap, float* 
 }
 // Front of Sphere::intersect / intersect_p (sphere.rs:61-128, :200-263).  second_wrap: what the
 // retry at t1 adds to a negative phi -- PI in intersect (sphere.rs:121, as written), 2*PI in intersect_p.
-__device__ __noinline__ bool sph_hit_test(const PtSphere& s, V3 ro, V3 rd, float t_max, float second_wrap, SphHit* h) {
+// (inline: for the pooled-leaf traversal kernel's sphere round, which then needs no scratch frame -- k_trace_sph_dist 44.4 -> 43.5 ms per
+// launch on RT1M lit by a sphere; everybody else calls sph_hit_test below: inlined into the shading kernels it costs them 40 spilled registers)
+__device__ __forceinline__ bool sph_hit_test_inl(const PtSphere& s, V3 ro, V3 rd, float t_max, float second_wrap, SphHit* h) {
     // Transform::transform_ray with world_to_object (transform.rs:184-203, :245-282)
     const float* m = s.w2o;
     const float g3 = PT_GAMMA(3.0f);
@@ -133,6 +135,9 @@ __device__ __noinline__ bool sph_hit_test(const PtSphere& s, V3 ro, V3 rd, float
     h->a_hi = t0.hi;
     h->b_hi = ef_eq(th, t0) ? -PT_INF : t1.hi;
     return true;
+}
+__device__ __noinline__ bool sph_hit_test(const PtSphere& s, V3 ro, V3 rd, float t_max, float second_wrap, SphHit* h) {
+    return sph_hit_test_inl(s, ro, rd, t_max, second_wrap, h);
 }
 // World-space interaction of a hit (sphere.rs:130-198 + transform_surface_interaction, transform.rs:299-323).
 // Only what the path consumes: p, p_error, n, wo, shading n and dpdu (u, v, dndu, dndv feed textures).
