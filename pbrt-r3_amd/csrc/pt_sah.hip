@@ -476,13 +476,21 @@ __device__ inline void sc_slots(const LbvhNode* __restrict__ nodes, uint32_t b, 
     if (nodes[r].count > 0) s[2] = r; else { s[2] = nodes[r].left; s[3] = nodes[r].right; }
 }
 // the next level of a binary tree as a list of node numbers (HLBVH trees are not numbered level by level)
-__global__ __launch_bounds__(256) void k_sc_next_level(const LbvhNode* __restrict__ nodes, uint32_t* list, uint32_t begin, uint32_t count, uint32_t* counter) {
+// (begin, count) of level l sit in lv[2 l], lv[2 l + 1] on the device: k_sc_level_roll writes the next pair after each level, the host launches
+// over an upper bound of the count and reads the table back every few levels
+__global__ __launch_bounds__(256) void k_sc_next_level(const LbvhNode* __restrict__ nodes, uint32_t* list, const uint32_t* __restrict__ lv, uint32_t level, uint32_t* counter) {
+    const uint32_t begin = lv[2u * level], count = lv[2u * level + 1u];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const LbvhNode n = nodes[list[begin + i]];
     if (n.count > 0) return;
     const uint32_t at = atomicAdd(counter, 2u);
     list[at] = (uint32_t)n.left; list[at + 1] = (uint32_t)n.right;
+}
+__global__ void k_sc_level_roll(uint32_t* lv, uint32_t level, const uint32_t* counter) {
+    const uint32_t end = lv[2u * level] + lv[2u * level + 1u];
+    lv[2u * level + 2u] = end;
+    lv[2u * level + 3u] = counter[0] - end;
 }
 // bottom-up, one launch per even binary level: 4-wide nodes in the subtree of each interior node of the level (itself included)
 __global__ __launch_bounds__(256) void k_sc_size4(const LbvhNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t begin, uint32_t count, uint32_t* size4,
@@ -939,17 +947,31 @@ int device_hlbvh_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, Sc
     const uint32_t one = 1;
     SAH_TRY(hipMemcpyAsync(d_cnt.p, &one, 4, hipMemcpyHostToDevice, st));
     std::vector<std::pair<uint32_t, uint32_t>> levels;
-    uint32_t begin = 0, count = 1;
-    while (count > 0) {
-        if (levels.size() > 4096) return 1;
-        levels.push_back({begin, count});
-        k_sc_next_level<<<(count + 255u) / 256u, 256, 0, st>>>(d_bn.as<LbvhNode>(), d_list.as<uint32_t>(), begin, count, d_cnt.as<uint32_t>());
-        SAH_TRY(hipGetLastError());
-        uint32_t filled = 0;
-        SAH_TRY(hipMemcpyAsync(&filled, d_cnt.p, 4, hipMemcpyDeviceToHost, st));
-        SAH_TRY(hipStreamSynchronize(st));
-        begin += count;
-        count = filled - begin;
+    {
+        constexpr uint32_t kMaxLevels = 4096;
+        Scratch d_lv;
+        SAH_TRY(d_lv.alloc((size_t)(2 * kMaxLevels + 4) * 4));
+        const uint32_t lv0[2] = {0u, 1u};
+        SAH_TRY(hipMemcpyAsync(d_lv.p, lv0, 8, hipMemcpyHostToDevice, st));
+        std::vector<uint32_t> h_lv;
+        uint64_t bound = 1;
+        uint32_t l = 0;
+        for (;;) {
+            if (l >= kMaxLevels) return 1;
+            const uint32_t nb = (uint32_t)std::min<uint64_t>(bound, total);
+            k_sc_next_level<<<(nb + 255u) / 256u, 256, 0, st>>>(d_bn.as<LbvhNode>(), d_list.as<uint32_t>(), d_lv.as<uint32_t>(), l, d_cnt.as<uint32_t>());
+            k_sc_level_roll<<<1, 1, 0, st>>>(d_lv.as<uint32_t>(), l, d_cnt.as<uint32_t>());
+            SAH_TRY(hipGetLastError());
+            l++;
+            if (bound < total) bound *= 2;
+            if (l % 8u == 0u || l >= 40u) {             // a look at the table every eighth level (a level past the last one finds nothing to do)
+                h_lv.resize(2 * (size_t)l + 2);
+                SAH_TRY(hipMemcpyAsync(h_lv.data(), d_lv.p, h_lv.size() * 4, hipMemcpyDeviceToHost, st));
+                SAH_TRY(hipStreamSynchronize(st));
+                if (h_lv[2 * (size_t)l + 1] == 0) break;
+            }
+        }
+        for (uint32_t k = 0; k < l && h_lv[2 * (size_t)k + 1] > 0; k++) levels.push_back({h_lv[2 * (size_t)k], h_lv[2 * (size_t)k + 1]});
     }
     const double t2 = now();
     const int frc = finish_scene(st, d_bn.as<LbvhNode>(), total, root, levels, d_list.as<uint32_t>(), d_order.as<uint32_t>(), d_P.as<float>(), d_idx.as<uint32_t>(), d_tmesh.as<uint32_t>(),
