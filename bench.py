@@ -161,6 +161,35 @@ def main():
 
     t_render, t_reduce = [0.0], [0.0]      # this rank's host wall time inside render / inside the film reduce, over the timed steps
 
+    # Which reduce runs (stated in the line as `reduce`): BENCH_REDUCE=torch (default: torch.distributed all_reduce = RCCL, over a
+    # torch-owned staging copy), =in_place (RCCL on the library's own allocation), =library (the library's pt_film_allreduce on the
+    # library's stream, over an RCCL communicator this process creates from a unique id rank 0 broadcasts -- what a Rust host would call).
+    reduce_mode = os.environ.get("BENCH_REDUCE", "in_place" if os.environ.get("BENCH_REDUCE_IN_PLACE") == "1" else "torch")
+    lib_comm, rccl = None, None
+    if use_dist and not rehearse and reduce_mode == "library":
+        import ctypes as C
+
+        class NcclUniqueId(C.Structure):
+            _fields_ = [("internal", C.c_byte * 128)]
+        rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)        # the copy torch has already mapped
+        rccl.ncclGetUniqueId.argtypes = [C.POINTER(NcclUniqueId)]
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]
+        uid = NcclUniqueId()
+        if rank == 0:
+            assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+        box = [bytes(uid.internal) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        C.memmove(C.byref(uid), box[0], 128)
+        lib_comm = C.c_void_p()
+        rc = rccl.ncclCommInitRank(C.byref(lib_comm), world, uid, rank)
+        if rc != 0:
+            raise SystemExit("ncclCommInitRank failed: %d" % rc)
+    reduce_desc = (None if not use_dist else
+                   "gloo all_reduce of a host copy (BENCH_REHEARSE: several ranks on one GPU, never a judged number)" if rehearse else
+                   {"torch": "torch.distributed all_reduce (RCCL) over a torch-owned staging copy of the film",
+                    "in_place": "torch.distributed all_reduce (RCCL) on the library's own film allocation",
+                    "library": "pt_film_allreduce (the library's own RCCL call on its stream; communicator from ncclCommInitRank)"}[reduce_mode])
+
     def step():
         ctx.film_clear()
         ta = time.time()
@@ -177,8 +206,10 @@ def main():
                 t.copy_(h)
                 torch.cuda.synchronize()
                 ctx.film_commit_xyzw()
+            elif lib_comm is not None:
+                ctx.film_allreduce(lib_comm.value)
             else:
-                pkg.dist.reduce_film(ctx, local_rank, staged=os.environ.get("BENCH_REDUCE_IN_PLACE") != "1")
+                pkg.dist.reduce_film(ctx, local_rank, staged=reduce_mode != "in_place")
             t_reduce[0] += time.time() - tb      # includes the wait for the slowest rank's render
 
     def fence():
@@ -188,12 +219,16 @@ def main():
         torch.cuda.synchronize()
 
     def check_reduced_film():
-        # every camera sample of every rank's tiles must be in the reduced film exactly once (box filter: weight 1 each)
+        # every camera sample of every rank's tiles must be in the reduced film exactly once (box filter: weight 1 each, so every
+        # pixel's weight is spp up to the edge-split samples; a rank's tiles lost in the reduce would leave 16x16 holes of weight 0)
         x = ctx.film_xyzw()
         want = float(info.spp) * (info.cropped_bounds[2] - info.cropped_bounds[0]) * (info.cropped_bounds[3] - info.cropped_bounds[1])
         got = float(x[..., 3].astype(np.float64).sum())
-        log("reduced film: sum of weights %.1f, expected %.1f (%s)" % (got, want, "ok" if abs(got - want) <= 1e-6 * want else "MISMATCH"))
-        return abs(got - want) <= 1e-6 * want
+        holes = int((x[..., 3] < 0.5 * info.spp).sum())
+        # (samples that land exactly on a pixel edge split their weight, and on the film's border part of it falls outside: a handful of units)
+        ok = abs(got - want) <= max(1e-6 * want, 64.0) and holes == 0
+        log("reduced film: sum of weights %.1f, expected %.1f, pixels under half weight %d (%s)" % (got, want, holes, "ok" if ok else "MISMATCH"))
+        return {"ok": bool(ok), "weight_sum": got, "weight_sum_expected": want, "pixels_under_half_weight": holes}
 
     log("scene %d tris uploaded (gen %.1fs, bvh %.0f ms), %d tiles for this rank" % (sd.desc.n_triangles, t_scene, info.bvh_build_ms, len(my_tiles)))
     for i in range(args.warmup):
@@ -210,8 +245,12 @@ def main():
     elapsed = time.time() - t_start
     cnt = ctx.counters()
 
-    if use_dist and (rehearse or os.environ.get("BENCH_CHECK_FILM") == "1"):
-        check_reduced_film()
+    film_check = None
+    if use_dist and world > 1 and os.environ.get("BENCH_CHECK_FILM") != "0":      # a scaling line vouches for its own film (every rank holds the sum)
+        film_check = check_reduced_film()
+        flag = torch.tensor([1.0 if film_check["ok"] else 0.0], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        film_check["ok_on_every_rank"] = bool(float(flag[0]) > 0.5)
     stats = torch.tensor([elapsed, cnt["regular_rays"], cnt["shadow_rays"], cnt["nodes_visited"], cnt["tris_tested"],
                           cnt["path_vertices"], cnt["trace_ms"], cnt["trace_launches"], cnt["camera_rays"], cnt["shade_ms"]],
                          dtype=torch.float64, device="cpu" if rehearse else "cuda")
@@ -262,81 +301,135 @@ def main():
         if args.tri_size != 0.005:
             key["tri_size"] = args.tri_size
         import glob
+        import hashlib
+        # a PMC measurement describes the kernels it was taken on: entries carry sha256(pt_kernels.hip)[:16], and one taken on other
+        # kernel source is not quoted (traffic = null) until tools/pmc_traffic_workload.sh has been re-run
+        ksha = hashlib.sha256(open(os.path.join(ROOT, "pbrt-r3_amd", "csrc", "pt_kernels.hip"), "rb").read()).hexdigest()[:16]
+        stale = None
         for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):     # newest round first
             try:
                 tj = json.load(open(tp))
             except Exception:
                 continue
             for ent in (tj if isinstance(tj, list) else [tj]):
-                # measured on exactly this workload (passes of the same size), else null
+                # measured on exactly this workload (passes of the same size) and this kernel source, else null
                 if traffic is None and isinstance(ent, dict) and ent.get("workload") == key and ent.get("fabric_bytes_per_launch"):
-                    traffic, traffic_note = ent["fabric_bytes_per_launch"], ent.get("note", "") + " (%s)" % os.path.basename(tp)
+                    if ent.get("kernels_sha16") == ksha:
+                        traffic, traffic_note = ent["fabric_bytes_per_launch"], ent.get("note", "") + " (%s)" % os.path.basename(tp)
+                    elif stale is None:
+                        stale = os.path.basename(tp)
+        if traffic is None and stale:
+            traffic_note = "the PMC entry for this workload in %s was measured on other kernel source (pt_kernels.hip is now %s): re-run tools/pmc_traffic_workload.sh" % (stale, ksha)
         hbm_frac = (traffic / avg_launch_s / 8e12) if (traffic and avg_launch_s > 0) else None
         l1_frac = achieved / peak
+        alg_gbps = (alg_bytes / launches) / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         l1_blk = {"bound": "l1_req", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "Greq/s", "frac": round(l1_frac, 4)}
-        hbm_blk = ({"bound": "hbm", "achieved": round(traffic / avg_launch_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(hbm_frac, 4)}
+        hbm_blk = ({"bound": "hbm", "achieved": round(traffic / avg_launch_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(hbm_frac, 4),
+                    "what": "bytes that left L2 (FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits included) per launch / launch time"}
                    if hbm_frac is not None else None)
-        top = hbm_blk if (hbm_blk and hbm_frac > l1_frac) else l1_blk       # the bound that actually holds for this workload
-        roofline = dict(top)
+        # Top level: always the contract's form -- bound "hbm", achieved = SURVEY.md section 8d's ALGORITHMIC bytes per launch / the launch
+        # time measured here, against 8 TB/s.  While the scene is cache-resident those bytes are served by L2 and the Infinity Cache, so the
+        # fraction can exceed 1; `traffic` (and `hbm_measured`) is what the counters saw leave L2, `l1_req` the bound that holds then.
+        roofline = {"bound": "hbm", "achieved": round(alg_gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg_gbps / 8000.0, 4), "traffic": traffic}
         roofline.update({
-                    "kernel": "k_trace_sph_dist" if args.light == "sphere" else "k_trace", "traffic": traffic,
-                    "l1_req": l1_blk, "hbm": hbm_blk,
+                    "kernel": "k_trace_sph_dist" if args.light == "sphere" else "k_trace",
+                    "l1_req": l1_blk, "hbm_measured": hbm_blk, "kernels_sha16": ksha,
                     "requests_per_launch": round(reqs / launches, 1), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
+                    "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1),
                     "nodes_per_ray": round(cnt["nodes_visited"] / max(1.0, n_rays), 2), "tris_per_ray": round(cnt["tris_tested"] / max(1.0, n_rays), 2),
                     "node_visits_from_lds": round(cnt.get("nodes_from_lds", 0) / max(1.0, cnt["nodes_visited"]), 4),
                     "trace_share_of_render": round(cnt["trace_ms"] / max(1e-9, cnt["render_ms"]), 3),
                     "shade_share_of_render": round(cnt["shade_ms"] / max(1e-9, cnt["render_ms"]), 3),
-                    # informational: SURVEY.md section 8d's algorithmic bytes (cache-served, can exceed the HBM peak), what HBM must move at least,
-                    # and the measured L2-miss (fabric) traffic where profiles/ holds it for this workload
-                    "algorithmic_gbps": round((alg_bytes / launches) / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else 0.0,
                     "scene_bytes": scene_bytes, "infinity_cache_bytes": 256 * 2 ** 20,
                     "hbm_compulsory_bytes_per_launch": round(compulsory, 1),
                     "hbm_compulsory_frac_of_8TBps": round(compulsory / avg_launch_s / 8e12, 5) if avg_launch_s > 0 else 0.0,
                     "fabric_frac_of_8TBps": round(hbm_frac, 4) if hbm_frac is not None else None,
-                    "note": "l1_req = lane requests to the CU's vector L1 (one 16-byte request per clock per CU): "
-                            "%g per node visit that is not served from the LDS copy of the top of the tree, 3 per triangle test, 5 per ray; hbm / traffic = FETCH_SIZE x 2 + WRITE_SIZE bytes leaving L2 "
-                            "(Infinity Cache hits included) per launch: %s" % (per_visit, traffic_note)})
+                    "note": "top level = algorithmic bytes (48 B / closest-hit ray, 36 B / any-hit ray, 128 B / node visit, 48 B / triangle test; cache-served "
+                            "while the scene fits L2 + Infinity Cache) / k_trace's mean launch time / 8 TB/s.  l1_req = lane requests to the CU's vector L1 "
+                            "(one 16-byte request per clock per CU): %g per node visit that is not served from the LDS copy of the top of the tree, 3 per "
+                            "triangle test, 5 per ray.  traffic / hbm_measured = FETCH_SIZE x 2 + WRITE_SIZE bytes leaving L2 (Infinity Cache hits included) "
+                            "per launch: %s" % (per_visit, traffic_note)})
         cpu, parity, spp1024 = None, None, None
-        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only (rank 0 would keep the other ranks waiting)
-            import oracle_lib
-            osc = oracle_lib.load().scene(sd)
-            cores = min(effective_cores(), 16)      # a 1-GPU box grants 16 host CPUs; BENCH_CPU_THREADS overrides the probe
-            ntile = args.cpu_tiles
-            if ntile <= 0:
-                # calibrate on 2 tiles, then size the sample for ~15 s on all cores
-                probe = tiles[len(tiles) // 2: len(tiles) // 2 + 2]
-                log("cpu baseline: oracle scene built, calibrating on 2 tiles")
-                _, c0, s0 = osc.render(probe, threads=min(2, cores), want_image=False)
-                log("cpu baseline: 2 tiles took %.1f s" % s0)
-                per_tile = s0 / 2 * min(2, cores)
-                ntile = int(max(cores, min(len(tiles), 15.0 * cores / max(per_tile, 1e-3))))
-            stride = max(1, len(tiles) // ntile)
-            sample = tiles[::stride][:ntile]
-            log("cpu baseline: rendering %d tiles on %d threads" % (len(sample), cores))
-            oxyzw, ccnt, secs = osc.render(sample, threads=cores, want_image=True)
-            log("cpu baseline: done in %.1f s" % secs)
-            # parity of the benchmarked frame: the GPU film of the last timed step against the oracle on the sampled tiles
-            # (linear RGB after the division by the filter weight; north_star tolerance: 1e-3 relative L2)
+
+        def film_parity(osc_, oxyzw_, sample_, what):
+            # parity of the benchmarked frame: the GPU film of the last timed step (at N > 1: the REDUCED film) against the oracle on the
+            # sampled tiles (linear RGB after the division by the filter weight; north_star tolerance: 1e-3 relative L2)
             g_rgb = ctx.film_rgb().astype(np.float64)
-            o_rgb = osc.resolve_rgb(oxyzw).astype(np.float64)
+            o_rgb = osc_.resolve_rgb(oxyzw_).astype(np.float64)
             cb = list(info.cropped_bounds)
             mask = np.zeros(g_rgb.shape[:2], bool)
-            for (x0, y0, x1, y1) in sample:
+            for (x0, y0, x1, y1) in sample_:
                 # interior pixels of the tile only: a border pixel also receives the edge-split samples of the neighbouring tiles
                 # (normalised footprints, quirk Q1), which the full GPU frame has and the oracle's partial film has not
                 mask[max(y0 + 1, cb[1]) - cb[1]: max(min(y1 - 1, cb[3]) - cb[1], 0), max(x0 + 1, cb[0]) - cb[0]: max(min(x1 - 1, cb[2]) - cb[0], 0)] = True
             gd, od = g_rgb[mask], o_rgb[mask]
             den = np.maximum(np.abs(od), 1e-6)
-            parity = {"rel_l2": float(np.sqrt(((gd - od) ** 2).sum()) / max(np.sqrt((od ** 2).sum()), 1e-30)),
-                      "max_rel": float((np.abs(gd - od) / den).max()) if gd.size else 0.0,
-                      "pixels_over_1pct": int(((np.abs(gd - od) / den).max(axis=-1) > 0.01).sum()) if gd.size else 0,
-                      "n_pixels": int(mask.sum()), "tolerance_rel_l2": 1e-3,
-                      "reference": "oracle (CPU restatement), interior pixels of the %d sampled tiles at all %d spp" % (len(sample), info.spp)}
-            log("parity: rel-L2 %.3e over %d pixels" % (parity["rel_l2"], parity["n_pixels"]))
+            out_ = {"rel_l2": float(np.sqrt(((gd - od) ** 2).sum()) / max(np.sqrt((od ** 2).sum()), 1e-30)),
+                    "max_rel": float((np.abs(gd - od) / den).max()) if gd.size else 0.0,
+                    "pixels_over_1pct": int(((np.abs(gd - od) / den).max(axis=-1) > 0.01).sum()) if gd.size else 0,
+                    "n_pixels": int(mask.sum()), "tolerance_rel_l2": 1e-3, "reference": what}
+            log("parity: rel-L2 %.3e over %d pixels" % (out_["rel_l2"], out_["n_pixels"]))
+            return out_
+
+        if not args.no_cpu_baseline and world > 1:
+            # N > 1: no CPU timing leg (the other ranks would wait for it), but the line still vouches for its film -- the oracle renders four
+            # of RANK 0's tiles and four of the LAST rank's, and the reduced film must match on both
+            import oracle_lib
+            osc = oracle_lib.load().scene(sd)
+            mine0, last = tiles[0::world], tiles[world - 1::world]
+            sample = [mine0[(len(mine0) * k) // 5] for k in (1, 2, 3, 4)] + [last[(len(last) * k) // 5] for k in (1, 2, 3, 4)]
+            oxyzw, _, secs = osc.render(sample, threads=min(effective_cores(), 16), want_image=True)
+            parity = film_parity(osc, oxyzw, sample, "oracle (CPU restatement) on 4 tiles of rank 0 and 4 of rank %d against the REDUCED film, interior pixels, all %d spp (%.1f s)"
+                                 % (world - 1, info.spp, secs))
+            osc.close()
+        if not args.no_cpu_baseline and world == 1:      # the CPU timing leg runs at N=1 only (rank 0 would keep the other ranks waiting)
+            import oracle_lib
+            osc = oracle_lib.load().scene(sd)
+            cores = min(effective_cores(), 16)      # a 1-GPU box grants 16 host CPUs; BENCH_CPU_THREADS overrides the probe
+            # The timed build is compiled HERE, for this host's cores (-O3 -march=native, still -ffp-contract=off); the portable build that
+            # travels with the repo (-O2) stays the checker, and the native one must reproduce its film bit for bit before it is timed.
+            native, native_note = None, None
+            try:
+                native = oracle_lib.load_native()
+            except Exception as e:                   # no compiler on this host: time the portable build and say so
+                native_note = "native build unavailable (%s): the portable -O2 build was timed" % (str(e).splitlines()[-1][:120] if str(e) else type(e).__name__)
+                log("cpu baseline: " + native_note)
+            tsc = native.scene(sd) if native is not None else osc
+            ntile = args.cpu_tiles
+            if ntile <= 0:
+                # calibrate on 2 tiles, then size the sample for ~15 s on all cores
+                probe = tiles[len(tiles) // 2: len(tiles) // 2 + 2]
+                log("cpu baseline: oracle scene built, calibrating on 2 tiles")
+                _, c0, s0 = tsc.render(probe, threads=min(2, cores), want_image=False)
+                log("cpu baseline: 2 tiles took %.1f s" % s0)
+                per_tile = s0 / 2 * min(2, cores)
+                ntile = int(max(cores, min(len(tiles), 15.0 * cores / max(per_tile, 1e-3))))
+            stride = max(1, len(tiles) // ntile)
+            sample = tiles[::stride][:ntile]
+            log("cpu baseline: rendering %d tiles on %d threads (%s build)" % (len(sample), cores, "native" if native is not None else "portable"))
+            oxyzw, ccnt, secs = tsc.render(sample, threads=cores, want_image=True)
+            log("cpu baseline: done in %.1f s" % secs)
+            bit_equal = None
+            if native is not None:
+                sub = sample[:: max(1, len(sample) // 8)][:8]          # a bounded cross-check: eight of the sampled tiles through the portable build
+                pxyzw, pcnt, psecs = osc.render(sub, threads=cores, want_image=True)
+                nxyzw, ncnt, _ = tsc.render(sub, threads=cores, want_image=True)
+                bit_equal = bool(np.array_equal(pxyzw.view(np.uint32), nxyzw.view(np.uint32)) and all(pcnt[k] == ncnt[k] for k in ("regular_rays", "shadow_rays", "nodes_visited", "tris_tested", "path_vertices")))
+                log("cpu baseline: native film %s the portable build's on %d tiles" % ("bit-equal to" if bit_equal else "DIFFERS from", len(sub)))
+                if not bit_equal:
+                    raise SystemExit("the native oracle build does not reproduce the portable build: refusing to time it")
+            parity = film_parity(tsc, oxyzw, sample, "oracle (CPU restatement), interior pixels of the %d sampled tiles at all %d spp" % (len(sample), info.spp))
             crays = ccnt["regular_rays"] + ccnt["shadow_rays"]
             cpu = {"value": round(crays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "mrays_s_per_thread": round(crays / secs / 1e6 / max(1, cores), 4),
                    "sample": "%d of %d 16x16 tiles (every %dth), all %d spp, %.1f s" % (len(sample), len(tiles), stride, info.spp, secs),
-                   "note": "C++ restatement of the reference (oracle/), not the Rust binary"}
+                   "build": (oracle_lib.NATIVE_FLAGS + " (compiled on this host at bench time)") if native is not None else oracle_lib.PORTABLE_FLAGS,
+                   "bit_equal_to_portable_build": bit_equal,
+                   "note": "C++ restatement of the reference (oracle/), not the Rust binary: tile-parallel over %d host threads like the reference's rayon par_iter; "
+                           "a checker written for fidelity (per-call heap stacks, full interactions per candidate hit, as the reference has them), not a tuned renderer%s"
+                           % (cores, ("; " + native_note) if native_note else "")}
+            if native is not None:
+                tsc.close()
             osc.close()
         if world == 1 and not args.no_spp1024 and args.spp != 1024:
             # north_star's target sentence quotes 1024 spp for the same scene (BASELINE config 2 says 256; Mrays/s is spp-independent,
@@ -374,6 +467,10 @@ def main():
         if per_rank is not None:
             # reduce_ms of a rank = its wait for the slowest rank + the collective itself; min over ranks ~ the collective alone
             out["per_rank"] = per_rank
+            out["reduce"] = reduce_desc
+            out["reduced_film_ok"] = (film_check["ok"] and film_check["ok_on_every_rank"]) if film_check else None
+            out["reduced_film"] = film_check
+            out["tiles_total"] = len(tiles)
         if args.integrator in ("directlighting", "whitted"):
             out["config"]["workload"] = out["config"]["workload"].replace("path maxdepth %d" % args.max_depth, args.integrator + " maxdepth 5")
         if args.integrator == "ao":

@@ -91,6 +91,8 @@ struct pt_context {
     size_t sort_cap = 0;
     DevBuf d_csort_ids, d_csort_keys[2], d_csort_temp; // the continuation rays' key list, the ordered copy (ids + keys) and rocprim's scratch
     size_t csort_cap = 0;
+    uint32_t* h_live = nullptr;                        // page-locked: the recursive integrators' live-sample count, read one level behind
+    int nee_split = 0;                                 // PBRTGPU_NEE_SPLIT: kernel families that shade a vertex in two kernels (ptk_shade)
     int sort_cont = -1;                                // continuation rays of a bounce ordered like the shadow rays: 0 never, 1 for the traversal kernel only
                                                        // (shading keeps path order), 2 for both, -1 (default): mode 1 for scenes larger than the Infinity Cache
     int sort_shadow_min = 1 << 20;                     // shadow rays of a launch are ordered by origin cell from this many up (0: never)
@@ -248,6 +250,8 @@ pt_status pt_context_create(int device, pt_context** out) {
     if (const char* e = std::getenv("PBRTGPU_SHADE_BLOCKS_PER_CU")) ctx->grid_shade = ctx->n_cu * std::max(1, std::atoi(e));
     if (const char* e = std::getenv("PBRTGPU_SORT_SHADOW_MIN")) ctx->sort_shadow_min = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("PBRTGPU_SORT_CONT")) ctx->sort_cont = std::min(2, std::max(-1, std::atoi(e)));
+    ctx->nee_split = ptk_nee_split_default();
+    if (const char* e = std::getenv("PBRTGPU_NEE_SPLIT")) ctx->nee_split = std::atoi(e);
     ctx->grid_wide = ctx->n_cu * 8;
     // Sobol' tables: $PBRTGPU_DATA_DIR, else <directory of this shared library>/../data
     const char* dd = std::getenv("PBRTGPU_DATA_DIR");
@@ -269,6 +273,7 @@ void pt_context_destroy(pt_context* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->h_live) (void)hipHostFree(ctx->h_live);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1310,13 +1315,6 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
     size_t pool_target = (size_t)288 << 20;
     if (const char* e = std::getenv("PBRTGPU_POOL_PATHS")) pool_target = std::max<size_t>(65536, std::strtoull(e, nullptr, 10));
     pool_target = std::min<size_t>(pool_target, (size_t)1 << 30);      // 32-bit path ids and queue counters with room to spare
-    {   // never more than half of what the device has free
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ctx->pool_paths < pool_target) {
-            const size_t per_path = 11 * 16 + 8 + 8 + 6 * 4 + 4 + 6 * 4;
-            pool_target = std::min(pool_target, std::max<size_t>(ctx->pool_paths, std::max<size_t>(1u << 20, (free_b / 2) / per_path)));
-        }
-    }
     const bool ao = sc.integrator == PT_INTEGRATOR_AO;
     const bool rec = sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING || sc.integrator == PT_INTEGRATOR_WHITTED;
     // next-event entries per path: Whitted one per light, DirectLighting "one" a single one, "all" one per light sample
@@ -1324,7 +1322,28 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                              : sc.integrator == PT_INTEGRATOR_WHITTED ? std::max(1u, sc.n_lights) : std::max(1u, ctx->light_samples_total);
     const uint32_t rec_depth = (uint32_t)std::max(1, sc.max_depth);
     const size_t rec_per_path = 64 + (size_t)rec_depth * PT_REC_FRAME_F4 * 16 + (size_t)rec_epp * (6 * 16 + 1 + 4 + 4 + 8);
-    if (rec) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, ((size_t)6 << 30) / rec_per_path));
+    {   // never more than half of what the device has free (what this render still has to allocate: a pool or frame store that exists is not counted twice)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            // per path: the pool's eleven float4 and its words, five queues + the sort's lists; textured scenes: the evaluated parameters; large scenes: the
+            // continuation sort's lists; the recursive integrators: their frames and next-event entries
+            size_t per_path = 11 * 16 + 8 + 8 + 6 * 4 + 4 + 6 * 4 + 4 * 4;
+            if (sc.textured && !sc.n_instances) per_path += PT_TEX_RES_F4 * 16;
+            if (ctx->sort_cont != 0) per_path += 4 * 4;
+            if (rec) {
+                // The frame store used to be held under 6 GB whatever the device had: a 64-spp directlighting frame of RT1M then ran as 22 passes of
+                // 3 M camera samples, each ending in the traversal kernel's drain tail (5.9 ms launches: 687 Mrays/s where the same kernel does
+                // 1 070 on launches of 150 ms).  Now it takes what the pool takes: up to half of the free memory together.
+                const size_t have = ctx->pool_paths * per_path + ctx->rec_paths * rec_per_path;      // already allocated: comes back to the budget
+                const size_t budget = (free_b + have) / 2;
+                pool_target = std::min(pool_target, std::max<size_t>(65536, budget / (per_path + rec_per_path)));
+            } else if (ctx->pool_paths < pool_target) {
+                pool_target = std::min(pool_target, std::max<size_t>(ctx->pool_paths, std::max<size_t>(1u << 20, (free_b / 2) / per_path)));
+            }
+        }
+    }
+    if (rec) pool_target = std::min<size_t>(pool_target, ((size_t)1 << 31) / std::max(1u, rec_epp));      // next-event entries are numbered path x entries-per-path in 32 bits
+    if (rec) if (const char* e = std::getenv("PBRTGPU_REC_POOL_BYTES")) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, std::strtoull(e, nullptr, 10) / rec_per_path));
     if (ao) pool_target = std::max<size_t>(65536, std::min<size_t>(pool_target, ((size_t)128 << 20) / (size_t)sc.ao_samples));      // <= 128 M occlusion rays (4.4 GB) per pass: big launches amortise the drain tail
     size_t chunk_pix = std::min(n_pixels_total, pool_target);
     uint32_t S = (uint32_t)std::max<size_t>(1, std::min<size_t>(spp, pool_target / chunk_pix));
@@ -1372,15 +1391,19 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
         Q.bin = ctx->d_qbin.as<uint16_t>();
     }
     Q.shadow_key = nullptr;
-    if (ctx->sort_shadow_min > 0 && sc.integrator == PT_INTEGRATOR_PATH) {       // pt_raysort.hip: k_shade writes a key per shadow ray, each bounce's list is sorted by it
-        if (ctx->sort_cap < ctx->pool_paths) {
-            const size_t tb = ptk_sort_rays_temp_bytes((uint32_t)ctx->pool_paths);
+    // pt_raysort.hip: a key per shadow ray beside the list (k_shade writes it; k_rec_nee_lists for the recursive integrators, whose lists hold
+    // next-event ENTRIES, rec_epp per camera sample), each launch's list is sorted by it
+    const bool rec_i = sc.integrator == PT_INTEGRATOR_DIRECTLIGHTING || sc.integrator == PT_INTEGRATOR_WHITTED;
+    if (ctx->sort_shadow_min > 0 && (sc.integrator == PT_INTEGRATOR_PATH || rec_i)) {
+        const size_t want_cap = rec_i ? chunk_pix * (size_t)S * std::max(1u, rec_epp) : ctx->pool_paths;
+        if (ctx->sort_cap < want_cap) {
+            const size_t tb = ptk_sort_rays_temp_bytes((uint32_t)want_cap);
             if (tb == 0) return ctx->fail(PT_ERR_DEVICE, "radix sort scratch size query failed");
-            PT_HIP(ctx->d_sort_ids.alloc(ctx->pool_paths * 4));
-            PT_HIP(ctx->d_sort_keys[0].alloc(ctx->pool_paths * 4));
-            PT_HIP(ctx->d_sort_keys[1].alloc(ctx->pool_paths * 4));
+            PT_HIP(ctx->d_sort_ids.alloc(want_cap * 4));
+            PT_HIP(ctx->d_sort_keys[0].alloc(want_cap * 4));
+            PT_HIP(ctx->d_sort_keys[1].alloc(want_cap * 4));
             PT_HIP(ctx->d_sort_temp.alloc(tb));
-            ctx->sort_cap = ctx->pool_paths;
+            ctx->sort_cap = want_cap;
         }
         Q.shadow_key = ctx->d_sort_keys[0].as<uint32_t>();
     }
@@ -1491,6 +1514,13 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 PtQueues Qn = Q;
                 Qn.counts = ctx->d_counts2.as<uint32_t>(); Qn.shadow = nl_shadow; Qn.probe = nl_probe;
                 PT_HIP(ptk_rec_init(ctx->stream, ctx->grid_wide, sc, ctx->paths, R, n_paths));
+                // The walk ends when no camera sample is live.  That count comes back through page-locked memory ONE LEVEL BEHIND: level i + 1 is
+                // queued before the host looks at level i's count, so the device never waits for the host (a level launched after the last one
+                // finds empty lists and does nothing).
+                if (!ctx->h_live) PT_HIP(hipHostMalloc((void**)&ctx->h_live, 64));
+                hipEvent_t rb_ev[2] = {get_event(ctx, ev_i), get_event(ctx, ev_i + 1)};
+                if (!rb_ev[0] || !rb_ev[1]) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
+                ev_i += 2;
                 for (uint32_t iter = 0; iter < 100000u; iter++) {
                     hipEvent_t a = get_event(ctx, ev_i), b = get_event(ctx, ev_i + 1), c = get_event(ctx, ev_i + 2);
                     if (!a || !b || !c) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
@@ -1500,17 +1530,34 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                     PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Q, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
                     PT_HIP(ptk_prep(ctx->stream, Qn, 0));
                     PT_HIP(ptk_rec_enter(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, Qn, R, cnt, rec_epp));
-                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, NP, Qn, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
+                    PtQueues Qt = Qn;
+                    if (Qn.shadow_key) {
+                        // The node's shadow rays start at the hit points of this level -- scattered through a scene of small triangles -- and head for the
+                        // lights: ordered by origin cell and direction octant like the path integrator's (pt_raysort.hip).  Costs this level one
+                        // counter read-back; only the work list moves (results are written per entry).
+                        uint32_t n_sh = 0;
+                        PT_HIP(hipMemcpyAsync(&n_sh, Qn.counts + PT_Q_SHADOW, 4, hipMemcpyDeviceToHost, ctx->stream));
+                        PT_HIP(hipStreamSynchronize(ctx->stream));
+                        if (n_sh >= (uint32_t)ctx->sort_shadow_min) {
+                            uint32_t* sorted = nullptr;
+                            PT_HIP(ptk_sort_shadow_rays(ctx->stream, Qn.shadow, ctx->d_sort_ids.as<uint32_t>(), ctx->d_sort_keys[0].as<uint32_t>(),
+                                                        ctx->d_sort_keys[1].as<uint32_t>(), ctx->d_sort_temp.p, ctx->d_sort_temp.bytes, n_sh, &sorted));
+                            Qt.shadow = sorted;
+                        }
+                    }
+                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, NP, Qt, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err));
                     ctx->trace_launches += 2;
                     PT_HIP(hipEventRecord(b, ctx->stream));
                     PT_HIP(ptk_rec_next(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, R));
                     PT_HIP(ptk_prep(ctx->stream, Q, 1));
                     PT_HIP(hipEventRecord(c, ctx->stream));
                     std::swap(Q.cur, Q.next);
-                    uint32_t n_live = 0;
-                    PT_HIP(hipMemcpyAsync(&n_live, Q.counts + PT_Q_CUR, 4, hipMemcpyDeviceToHost, ctx->stream));
-                    PT_HIP(hipStreamSynchronize(ctx->stream));
-                    if (n_live == 0) break;
+                    PT_HIP(hipMemcpyAsync(&ctx->h_live[iter & 1u], Q.counts + PT_Q_CUR, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    PT_HIP(hipEventRecord(rb_ev[iter & 1u], ctx->stream));
+                    if (iter >= 1u) {
+                        PT_HIP(hipEventSynchronize(rb_ev[(iter - 1u) & 1u]));
+                        if (ctx->h_live[(iter - 1u) & 1u] == 0) { ctx->trace_launches -= 2; break; }      // the level just queued is an empty one
+                    }
                 }
             } else if (sc.n_lights > 0) {          // no lights: li() returns zero immediately (path.rs:71-74)
                 uint32_t* shadow_sorted = nullptr;          // the ordered shadow list for the next traversal launch, if one was made
@@ -1565,7 +1612,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                     PT_HIP(ptk_nee_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q));
                     ctx->trace_launches++;
                     PT_HIP(ptk_prep(ctx->stream, Q, 0));
-                    PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, cnt));
+                    PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, cnt, ctx->nee_split));
                     PT_HIP(ptk_prep(ctx->stream, Q, 1));
                     {
                         const pt_status ss = sort_shadow();

@@ -328,6 +328,7 @@ struct PtRec {
 #define PT_ST_CAMERA 2u         // the ray is still the camera ray: it has differentials (textures filter with them)
 #define PT_NEE_SHADOW 1u
 #define PT_NEE_PROBE 2u
+#define PT_NEE_DIMS5 4u          // split shading (part 1 -> part 2): the vertex drew all five next-event dimensions (light choice, u_light, u_scattering), not just the light choice
 
 struct PtQueues {
     uint32_t* cur;       // path ids to shade / whose continuation ray is traced
@@ -358,4 +359,7 @@ struct PtQueues {
 #define PT_SORT_COUNT0 256u                       // [+256) bin counts
 #define PT_SORT_CURSOR0 (256u + 256u)             // [+256) bin cursors
 #define PT_Q_SEG_TICKET0 768u                     // k_trace: one ticket per queue segment (8 segments, 128 B apart)
-#define PT_COUNTS_WORDS (768u + 8u * 32u)
+#define PT_Q_TICKET_N1 1024u                      // work tickets of the next-event halves of the split shading kernels (Matte / general / textured segment)
+#define PT_Q_TICKET_N2 1056u
+#define PT_Q_TICKET_N3 1088u
+#define PT_COUNTS_WORDS (768u + 8u * 32u + 3u * 32u)

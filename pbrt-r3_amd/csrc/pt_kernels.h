@@ -12,7 +12,8 @@ hipError_t ptk_gen(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P
                    uint32_t s0, uint32_t n_samples, PtCounters* cnt);
 hipError_t ptk_nee_resolve(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q);
 hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode);
-hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt);
+hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, int nee_split);
+int ptk_nee_split_default();
 hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,
                     float4* own, float4* spill, float* radiance_out, uint32_t s0, uint32_t spp_total);
 hipError_t ptk_film_xyzw(hipStream_t st, const float4* own, const float4* spill, float4* xyzw, uint32_t n);

@@ -27,6 +27,13 @@
 #include "pt_kernels.h"
 #include "../../include/pbrtgpu.h"
 
+#ifndef PT_SHADE_PF_DEEP
+#define PT_SHADE_PF_DEEP 0       // 1: k_shade's one-iteration-ahead prefetch also covers the ray, the throughput and the leaf record
+#endif
+#ifndef PT_TOUCH_PUSHED
+#define PT_TOUCH_PUSHED 0        // 1: node_step_lean touches the pushed children that are not the next visit (experiment, see there)
+#endif
+
 // ============================================================ Sobol' sampler
 PT_DEV uint64_t sobol_interval_to_index(const PtSobol& sb, uint64_t frame, int32_t px, int32_t py) {
     const uint32_t m = sb.log2_resolution;
@@ -962,6 +969,26 @@ PT_DEV void node_step_lean(const PtScene& sc, LaneRay& r, TravCtx& c) {
     const unsigned long long y1 = Tm & (el1 ^ er1), e1 = er1 ^ y1, e3 = el1 ^ y1;
     fs_push4_exec(r.sa, top, c0, c1, c2, c3, e0, e1, e2, e3);
     r.top = top;
+#if PT_TOUCH_PUSHED
+    // Experiment (scenes beyond the Infinity Cache): every reference pushed here IS visited later (the reference's stack holds no distances), so
+    // the children that are pushed but are not the next visit -- c0 when anything is pushed after it, c1 when c2 or c3 is, c2 when c3 is -- are
+    // touched now: one 4-byte load of the node's (or the leaf's first record's) first word into a register nobody reads.  Loads return in order,
+    // so the touch is paid for by this lane's NEXT fetch waiting behind it; what it buys is that the miss overlaps that fetch instead of
+    // standing alone in a later round.
+    {
+        const unsigned long long p0 = e0 & (e1 | e2 | e3), p1 = e1 & (e2 | e3), p2 = e2 & e3;
+        const unsigned long long me = 1ull << (threadIdx.x & 63u);
+        const char* tb = reinterpret_cast<const char*>(sc.tris);
+        auto touch = [&](uint32_t cref) {
+            const char* a = (cref & PT_LEAF_BIT) ? tb + (size_t)(cref & PT_LEAF_FIRST_MASK) * 48u : nb + (size_t)(cref << 7);
+            uint32_t v = *reinterpret_cast<const uint32_t*>(a);
+            asm volatile("" :: "v"(v));
+        };
+        if (p0 & me) touch(c0);
+        if (p1 & me) touch(c1);
+        if (p2 & me) touch(c2);
+    }
+#endif
 }
 
 // intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
@@ -1700,6 +1727,7 @@ extern "C" __global__ void k_prep(PtQueues Q, int mode) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (mode == 0) {            // before SHADE: nee and next start empty
             Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_NEE] = 0; Q.counts[PT_Q_TICKET] = 0; Q.counts[PT_Q_TICKET2] = 0; Q.counts[PT_Q_TICKET3] = 0; Q.counts[PT_Q_SHADOW] = 0; Q.counts[PT_Q_PROBE] = 0;
+            Q.counts[PT_Q_TICKET_N1] = 0; Q.counts[PT_Q_TICKET_N2] = 0; Q.counts[PT_Q_TICKET_N3] = 0;
             for (uint32_t k = 0; k < 8u; k++) Q.counts[PT_Q_SEG_TICKET0 + 32u * k] = 0;
         } else {                    // after SHADE: next becomes cur (host swaps the pointers)
             Q.counts[PT_Q_CUR] = Q.counts[PT_Q_NEXT]; Q.counts[PT_Q_NEXT] = 0; Q.counts[PT_Q_TICKET] = 0;
@@ -2305,14 +2333,18 @@ __device__ unsigned long long g_shade_prof[16];
 #endif
 // 0.0f the optimiser cannot see through (one v_mov): see the continuation store in shade_body
 PT_DEV float opaque_zero() { float z = 0.0f; asm volatile("" : "+v"(z)); return z; }
-template <bool GENERAL, bool SPH, bool TEX = false, bool INST = false, bool RES = false>
+// PART: 0 = the whole vertex in one kernel.  1 = next-event estimation only (light pick, light sample, BSDF sample for MIS; writes the
+// shadow / probe rays, the pending terms and -- for every vertex with a BSDF -- the nee word, whose PT_NEE_DIMS bits tell part 2 how many
+// sample dimensions were drawn); 2 = everything else (emission, pass-through, continuation, Russian roulette), run AFTER part 1 on the same
+// list because it overwrites the ray.  Both halves rebuild the interaction from (ray, record): the split trades that for register room.
+template <bool GENERAL, bool SPH, bool TEX = false, bool INST = false, bool RES = false, int PART = 0>
 PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, const uint32_t* list, uint32_t begin, uint32_t end,
                        uint32_t* ticket) {
     __shared__ unsigned long long s_vert;
     // A vertex's next-event outputs wait here (28 KB per block) until every load of the iteration has come back: on this ISA loads and
     // stores share one in-order counter (vmcnt), so a store issued in the middle of the dependent chain grid -> light table -> light
     // makes each later wait sit out the store's round trip as well.
-    __shared__ float4 s_stage[7][PT_BLOCK];
+    __shared__ float4 s_stage[PART == 2 ? 1 : 7][PT_BLOCK];
     __shared__ uint32_t s_pend[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: path ids of the iterations not yet queued (their queue bits: `pend_want`)
     __shared__ uint32_t s_pkey[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: the sort key of those iterations' shadow rays
     if (threadIdx.x == 0) s_vert = 0;
@@ -2333,6 +2365,10 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     uint32_t pf_st = 0, pf_pk = 0;
     uint64_t pf_idx = 0;
     bool pf_valid = false;
+    // PT_SHADE_PF_DEEP: the next iteration's ray, throughput and leaf record come one iteration ahead as well, so that an iteration starts with
+    // everything its surface needs and its dependent chain is grid -> light instead of path state -> record -> grid -> light
+    constexpr bool DEEP = PT_SHADE_PF_DEEP && !GENERAL && !SPH && !INST && PART == 0;      // the Matte kernels have the 21 registers it takes (232 -> 253); the lobe-list kernels sit at 256
+    float4 pf_ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf_rd = pf_ro, pf_beta = pf_ro, pf_ra = pf_ro, pf_rb = pf_ro, pf_rc = pf_ro;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     auto flush_batch = [&]() {
         if (n_batch == 0) return;
@@ -2392,9 +2428,11 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         uint32_t wr = 0, o_nee = 0, o_state = 0;     // outputs held back to the end of the iteration: 1 ray_o, 2 ray_d + beta, 4 shadow ray, 8 probe ray, 16 pending NEE, 32 state
         float4 o_ray_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), o_ray_d = o_ray_o, o_beta = o_ray_o;
         auto commit = [&]() {
-            if (wr & 4u) { P.sh_o[p] = s_stage[0][threadIdx.x]; P.sh_d[p] = s_stage[1][threadIdx.x]; }
-            if (wr & 8u) { P.pr_o[p] = s_stage[2][threadIdx.x]; P.pr_d[p] = s_stage[3][threadIdx.x]; }
-            if (wr & 16u) { P.pendA[p] = s_stage[4][threadIdx.x]; P.pendB[p] = s_stage[5][threadIdx.x]; P.pbeta[p] = s_stage[6][threadIdx.x]; P.nee[p] = o_nee; }
+            if constexpr (PART != 2) {
+                if (wr & 4u) { P.sh_o[p] = s_stage[0][threadIdx.x]; P.sh_d[p] = s_stage[1][threadIdx.x]; }
+                if (wr & 8u) { P.pr_o[p] = s_stage[2][threadIdx.x]; P.pr_d[p] = s_stage[3][threadIdx.x]; }
+                if (wr & 16u) { P.pendA[p] = s_stage[4][threadIdx.x]; P.pendB[p] = s_stage[5][threadIdx.x]; P.pbeta[p] = s_stage[6][threadIdx.x]; P.nee[p] = o_nee; }
+            }
             if (wr & 1u) P.ray_o[p] = o_ray_o;
             if (wr & 2u) { P.ray_d[p] = o_ray_d; P.beta[p] = o_beta; }
             if (wr & 32u) P.state[p] = o_state;
@@ -2417,24 +2455,27 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         const int32_t pf_rec_now = pf_rec;
         const uint32_t pf_st_now = pf_st, pf_pk_now = pf_pk;
         const uint64_t pf_idx_now = pf_idx;
+        const float4 pf_ro_now = pf_ro, pf_rd_now = pf_rd, pf_beta_now = pf_beta, pf_ra_now = pf_ra, pf_rb_now = pf_rb, pf_rc_now = pf_rc;
         pf_valid = chunk_left > 0;
         const bool pf_lane = pf_valid && next_base + lane < end;
         if (pf_lane) pf_p = list[next_base + lane];
         if (active) {
             p = had_pf ? pf_p_now : list[item];
             PT_SHP_SYNC(13);
-            float4 ro4 = P.ray_o[p], rd4 = P.ray_d[p];
+            float4 ro4, rd4, beta4;
+            if (DEEP && had_pf) { ro4 = pf_ro_now; rd4 = pf_rd_now; beta4 = pf_beta_now; }
+            else { ro4 = P.ray_o[p]; rd4 = P.ray_d[p]; beta4 = P.beta[p]; }
             V3 ro = f4_3(ro4), rd = f4_3(rd4);
             int32_t rec = had_pf ? pf_rec_now : P.hit_rec[p];
             uint32_t st = had_pf ? pf_st_now : P.state[p];
             uint32_t dim = st & 0xffffu, bounces = (st >> 16) & 0xffu, flags = st >> 24;
-            float4 beta4 = P.beta[p];
             V3 beta = f4_3(beta4);
             float eta_scale = beta4.w;
             PT_SHP_SYNC(14);
             // the hit's leaf record: asked for first, so that it travels while the sample tables are read
             float4 rec_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rec_b = rec_a, rec_c = rec_a;
-            if (rec >= 0) {
+            if (DEEP && had_pf) { rec_a = pf_ra_now; rec_b = pf_rb_now; rec_c = pf_rc_now; }
+            else if (rec >= 0) {
                 const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)(uint32_t)rec * 3;
                 rec_a = q[0]; rec_b = q[1]; rec_c = q[2];
             }
@@ -2459,9 +2500,10 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             if (pf_lane) {                                   // pf_p has long arrived: the head of the next iteration's dependent chain, one iteration early
                 pf_rec = P.hit_rec[pf_p];
                 pf_st = P.state[pf_p]; pf_idx = P.sobol_index[pf_p]; pf_pk = P.pixel[pf_p];
+                if constexpr (DEEP) { pf_ro = P.ray_o[pf_p]; pf_rd = P.ray_d[pf_p]; pf_beta = P.beta[pf_p]; }
             }
             // emitted radiance at the first vertex / after a specular bounce (path.rs:87-98)
-            if (found && (bounces == 0 || (flags & PT_ST_SPECULAR))) {
+            if (PART != 1 && found && (bounces == 0 || (flags & PT_ST_SPECULAR))) {
                 int32_t li = s.light;
                 if (li >= 0) {
                     V3 le = light_L(sc.lights[li], s.n, -rd);
@@ -2527,11 +2569,13 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 if constexpr (GENERAL) { if (!no_bsdf && !use_tm) no_bsdf = sc.materials[s.material].has_bsdf == 0; }
                 if (no_bsdf) {
                     // no BSDF: continue through the surface, same bounce count (path.rs:108-111)
-                    V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
-                    o_ray_o = make_float4(no.x, no.y, no.z, PT_INF); wr |= 1u;
-                    cont = true; PT_COMMIT_NOW(0);
+                    if constexpr (PART != 1) {
+                        V3 no = offset_ray_origin(s.p, s.p_error, s.n, rd);
+                        o_ray_o = make_float4(no.x, no.y, no.z, PT_INF); wr |= 1u;
+                        cont = true; PT_COMMIT_NOW(0);
+                    }
                 } else {
-                    n_vert++;
+                    if constexpr (PART != 1) n_vert++;
                     Bsdf b;
                     GBsdf gb;
                     bool nonspecular;
@@ -2568,7 +2612,10 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     };
                     PT_SHP(1);
                     // ---- next-event estimation (uniform_sample_one_light_surface, sample_lights.rs:129-176)
-                    if (nonspecular && sc.n_lights > 0) {
+                    if constexpr (PART == 2) {           // part 1 drew this vertex's next-event dimensions and noted how many
+                        if (nonspecular && sc.n_lights > 0) sm.s.dim += (P.nee[p] & PT_NEE_DIMS5) ? 5u : 1u;
+                    }
+                    if (PART != 2 && nonspecular && sc.n_lights > 0) {
                         const float* tab = grid_lookup(sc.grid, s.p);
                         float light_pdf;
                         uint32_t light_num = sample_discrete(tab, sc.n_lights, sm.get_1d(sc), &light_pdf);
@@ -2578,7 +2625,7 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                             V2 u_scat = sm.get_2d(sc);
                             PT_SHP(3);
                             const PtLight& lt = sc.lights[light_num];
-                            uint32_t nee = light_num << 8;
+                            uint32_t nee = (light_num << 8) | (PART == 1 ? PT_NEE_DIMS5 : 0u);
                             V3 A = mk3(0.0f, 0.0f, 0.0f), B = mk3(0.0f, 0.0f, 0.0f);
                             V3 li, wi, lp, lperr, ln;
                             float lpdf;
@@ -2649,11 +2696,12 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                                 want_nee = true;
                                 want_sh = (nee & PT_NEE_SHADOW) != 0;
                                 want_pr = (nee & PT_NEE_PROBE) != 0;
-                            }
-                        }
+                            } else if constexpr (PART == 1) { P.nee[p] = nee; }        // nothing pending, but part 2 reads the dimension count
+                        } else if constexpr (PART == 1) { P.nee[p] = 0u; }              // light_pdf == 0: one dimension drawn
                     }
                     PT_SHP(6);
                     // ---- continuation (path.rs:139-233)
+                    if constexpr (PART != 1) {
                     V2 u = sm.get_2d(sc);
                     PT_SHP(7);
                     V3 f, wi;
@@ -2689,9 +2737,16 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                             cont = true;
                         }
                     }
+                    }
                     dim = sm.s.dim;
                 }
                 if (cont) { o_state = (dim & 0xffffu) | ((bounces & 0xffu) << 16) | ((flags & ~PT_ST_CAMERA) << 24); wr |= 32u; } PT_COMMIT_NOW(5);     // later rays are plain Rays
+            }
+        }
+        if constexpr (DEEP) {          // the next iteration's leaf record: its index has arrived by now (asked for at the top of this iteration's work)
+            if (pf_lane && pf_rec >= 0) {
+                const float4* q = reinterpret_cast<const float4*>(sc.tris) + (size_t)(uint32_t)pf_rec * 3;
+                pf_ra = q[0]; pf_rb = q[1]; pf_rc = q[2];
             }
         }
         PT_SHP(8);
@@ -2805,6 +2860,42 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_GEN_WAVES) k_sha
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_shade_general_res_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true, false, false, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
 }
+
+// ---- the vertex in two kernels (shade_body PART 1 / PART 2; PBRTGPU_NEE_SPLIT selects the kernel families that run this way).  Next-event
+// estimation is the register peak of every shading kernel and, in scenes with sphere lights, the only place where Sphere::sample_from and the
+// EFloat quadratic of Shape::pdf_from are needed: on its own it leaves the continuation half lean, and the sphere code out of it.
+#ifndef PT_NEE_WAVES
+#define PT_NEE_WAVES 2
+#endif
+#ifndef PT_CONT_WAVES
+#define PT_CONT_WAVES 3
+#endif
+#ifndef PT_NEE_GEN_WAVES
+#define PT_NEE_GEN_WAVES 2
+#endif
+#ifndef PT_CONT_GEN_WAVES
+#define PT_CONT_GEN_WAVES 3
+#endif
+#ifndef PT_CONT_SPH_WAVES
+#define PT_CONT_SPH_WAVES 2      // the sphere-capable continuation halves rebuild hits on spheres (Sphere::intersect + its interaction): 185-200 registers
+#endif
+#ifndef PT_NEE_SPLIT_DEFAULT
+#define PT_NEE_SPLIT_DEFAULT 0
+#endif
+#define PT_SPLIT_KERNELS(NAME, WN, WC, LIST, BEGIN, END, TN, TC, ...)                                                                              \
+    extern "C" __global__ void __launch_bounds__(PT_BLOCK, WN) NAME##_nee(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {                     \
+        shade_body<__VA_ARGS__, 1>(sc, P, Q, cnt, LIST, BEGIN, END, &Q.counts[TN]);                                                                \
+    }                                                                                                                                              \
+    extern "C" __global__ void __launch_bounds__(PT_BLOCK, WC) NAME##_cont(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {                    \
+        shade_body<__VA_ARGS__, 2>(sc, P, Q, cnt, LIST, BEGIN, END, &Q.counts[TC]);                                                                \
+    }
+PT_SPLIT_KERNELS(k_shade, PT_NEE_WAVES, PT_CONT_WAVES, Q.cur, 0u, Q.counts[PT_Q_CUR], PT_Q_TICKET_N1, PT_Q_TICKET, false, false, false, false, false)
+PT_SPLIT_KERNELS(k_shade_matte_sorted, PT_NEE_WAVES, PT_CONT_WAVES, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], PT_Q_TICKET_N1, PT_Q_TICKET, false, false, false, false, false)
+PT_SPLIT_KERNELS(k_shade_general, PT_NEE_GEN_WAVES, PT_CONT_GEN_WAVES, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_TEX_BEGIN], PT_Q_TICKET_N2, PT_Q_TICKET2, true, false, false, false, false)
+PT_SPLIT_KERNELS(k_shade_matte_sorted_sph, PT_NEE_WAVES, PT_CONT_SPH_WAVES, Q.sorted, 0u, Q.counts[PT_Q_MATTE_END], PT_Q_TICKET_N1, PT_Q_TICKET, false, true, false, false, false)
+PT_SPLIT_KERNELS(k_shade_general_sph, PT_NEE_GEN_WAVES, PT_CONT_SPH_WAVES, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_TEX_BEGIN], PT_Q_TICKET_N2, PT_Q_TICKET2, true, true, false, false, false)
+PT_SPLIT_KERNELS(k_shade_general_res, PT_NEE_GEN_WAVES, PT_CONT_GEN_WAVES, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], PT_Q_TICKET_N3, PT_Q_TICKET3, true, false, false, false, true)
+PT_SPLIT_KERNELS(k_shade_general_res_sph, PT_NEE_GEN_WAVES, PT_CONT_SPH_WAVES, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], PT_Q_TICKET_N3, PT_Q_TICKET3, true, true, false, false, true)
 
 // Sort keys of a bounce's continuation rays, for scenes larger than the Infinity Cache (pt_context.cpp sort_cont): a pass of its own over the
 // list k_shade has just written -- inside the shading kernels the key arithmetic cost the general kernel registers it does not have
@@ -3119,9 +3210,13 @@ struct RecNode {
     float bsdf_eta;
     bool found, has_bsdf;
 };
+// FULL = false: the instantiation for scenes without spheres, instances and textured materials (the triangle-only test, no texture programs, no
+// per-hit lobe list in scratch): what `directlighting` / `whitted` run on BASELINE's scenes.  FULL = true: everything compiled in.
+template <bool FULL>
 PT_DEV void rec_build(const PtScene& sc, V3 ro, V3 rd, int32_t rec, uint32_t inst, bool has_diff, const RayDiffs& rdf, RecNode& nd) {
     float thit;
-    nd.found = rec >= 0 && make_surf_inst<true>(sc, ro, rd, (uint32_t)rec, inst, nd.s, &thit);
+    if constexpr (FULL) nd.found = rec >= 0 && make_surf_inst<true>(sc, ro, rd, (uint32_t)rec, inst, nd.s, &thit);
+    else nd.found = rec >= 0 && make_surf_any<false>(sc, ro, rd, (uint32_t)rec, nd.s, &thit);
     nd.has_bsdf = false;
     nd.bsdf_eta = 1.0f;
     if (!nd.found) return;
@@ -3130,9 +3225,11 @@ PT_DEV void rec_build(const PtScene& sc, V3 ro, V3 rd, int32_t rec, uint32_t ins
     compute_differentials(nd.th, nd.s.p, nd.s.n, nd.s.dpdu, nd.s.dpdv, has_diff, rdf);
     if (nd.s.material < 0) return;
     const PtMaterial* m = &sc.materials[nd.s.material];
-    if (m->textured) {
-        textured_lobes(sc, nd.s.material, nd.th, &nd.tm, nd.s.n, nd.s.uv, &nd.s.sh_n, &nd.s.sh_dpdu, nd.s.sh_dpdv, nd.s.sh_dndu, nd.s.sh_dndv);
-        m = &nd.tm;
+    if constexpr (FULL) {
+        if (m->textured) {
+            textured_lobes(sc, nd.s.material, nd.th, &nd.tm, nd.s.n, nd.s.uv, &nd.s.sh_n, &nd.s.sh_dpdu, nd.s.sh_dpdv, nd.s.sh_dndu, nd.s.sh_dndv);
+            m = &nd.tm;
+        }
     }
     if (!m->has_bsdf) return;
     nd.has_bsdf = true;
@@ -3145,6 +3242,7 @@ PT_DEV void rec_build(const PtScene& sc, V3 ro, V3 rd, int32_t rec, uint32_t ins
 PT_DEV float4* rec_frame(const PtRec& R, uint32_t depth, uint32_t k, uint32_t p) { return R.frames + ((size_t)depth * PT_REC_FRAME_F4 + k) * R.n_paths + p; }
 // estimate_direct (sample_lights.rs:178-328) for light `light_num`: the two MIS terms and their rays go to entry e, the rays' results
 // are combined by k_rec_next.  Returns the PT_NEE_* flags of the entry.
+template <bool FULL>
 PT_DEV uint32_t rec_estimate_direct(const PtScene& sc, const PtRec& R, const RecNode& nd, uint32_t light_num, V2 u_light, V2 u_scat, uint32_t e, float divisor = 1.0f) {
     const Surf& s = nd.s;
     const PtLight& lt = sc.lights[light_num];
@@ -3153,7 +3251,7 @@ PT_DEV uint32_t rec_estimate_direct(const PtScene& sc, const PtRec& R, const Rec
     V3 A = mk3(0.0f, 0.0f, 0.0f), B = A;
     V3 li, wi, lp, lperr, ln;
     float lpdf;
-    if (light_sample_any<true>(sc, lt, s.p, s.p_error, s.n, u_light, &li, &wi, &lpdf, &lp, &lperr, &ln)) {
+    if (light_sample_any<FULL>(sc, lt, s.p, s.p_error, s.n, u_light, &li, &wi, &lpdf, &lp, &lperr, &ln)) {
         if (lpdf > 0.0f && !is_black(li)) {
             V3 f = gbsdf_f(nd.gb, s.wo, wi, kNoSpec) * abs_dot(wi, s.sh_n);
             float spdf = gbsdf_pdf(nd.gb, s.wo, wi, kNoSpec);
@@ -3178,7 +3276,7 @@ PT_DEV uint32_t rec_estimate_direct(const PtScene& sc, const PtRec& R, const Rec
             V3 po = offset_ray_origin(s.p, s.p_error, s.n, wi2);
             Surf ls;
             float lt_t;
-            if (make_surf_any<true>(sc, po, wi2, lt.tri_rec, ls, &lt_t)) {          // light.pdf_li -> Shape::pdf_from (shape.rs:40-54)
+            if (make_surf_any<FULL>(sc, po, wi2, lt.tri_rec, ls, &lt_t)) {          // light.pdf_li -> Shape::pdf_from (shape.rs:40-54)
                 float lp2 = distance_squared(s.p, ls.p) / (abs_dot(ls.n, -wi2) * lt.area);
                 if (isinf(lp2)) lp2 = 0.0f;
                 if (lp2 != 0.0f) {
@@ -3226,7 +3324,8 @@ PT_DEV RayDiffs rec_load_diff(const PtRec& R, uint32_t p) {
     d.rx_d = f4_3(R.diff[2 * (size_t)R.n_paths + p]); d.ry_d = f4_3(R.diff[3 * (size_t)R.n_paths + p]);
     return d;
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_enter(PtScene sc, PtPaths P, PtQueues Q, PtRec R, PtCounters* cnt) {
+template <bool FULL>
+PT_DEV void rec_enter_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtRec& R, PtCounters* cnt) {
     const uint32_t n = Q.counts[PT_Q_CUR];
     const uint32_t lane = threadIdx.x & 63;
     const bool whitted = sc.integrator == PT_INTEGRATOR_WHITTED;
@@ -3245,7 +3344,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
         rdf.rx_o = rdf.ry_o = rdf.rx_d = rdf.ry_d = mk3(0.0f, 0.0f, 0.0f);
         if (has_diff) rdf = rec_load_diff(R, p);
         RecNode nd;
-        rec_build(sc, ro, rd, rec, inst, has_diff, rdf, nd);
+        rec_build<FULL>(sc, ro, rd, rec, inst, has_diff, rdf, nd);
         uint32_t outcome = PT_REC_OUT_FRAME;
         if (!nd.found) outcome = PT_REC_OUT_RETURN0;              // the lights' le(ray) sum: zero for area lights
         else if (!nd.has_bsdf) {
@@ -3276,7 +3375,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
                     V3 A = mk3(0.0f, 0.0f, 0.0f);
                     V3 li, wi, lp, lperr, ln;
                     float lpdf;
-                    if (light_sample_any<true>(sc, lt, nd.s.p, nd.s.p_error, nd.s.n, u, &li, &wi, &lpdf, &lp, &lperr, &ln) && !(lpdf <= 0.0f || is_black(li))) {
+                    if (light_sample_any<FULL>(sc, lt, nd.s.p, nd.s.p_error, nd.s.n, u, &li, &wi, &lpdf, &lp, &lperr, &ln) && !(lpdf <= 0.0f || is_black(li))) {
                         V3 f = gbsdf_f(nd.gb, nd.s.wo, wi, PT_BSDF_ALL);
                         if (!is_black(f)) {
                             V3 origin = offset_ray_origin(nd.s.p, nd.s.p_error, nd.s.n, lp - nd.s.p);
@@ -3308,13 +3407,13 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
                                 for (uint32_t k = 0; k < n; k++) {
                                     const uint64_t idx = n == 1u ? sm.index : sampler_index(sc, sample_num * n + k, sm.px, sm.py);
                                     const V2 u = mk2(sample_dimension(sc, idx, 5u, sm.px, sm.py), sample_dimension(sc, idx, 6u, sm.px, sm.py));
-                                    rec_estimate_direct(sc, R, nd, j, u, u, e0 + off + k, (float)n);
+                                    rec_estimate_direct<FULL>(sc, R, nd, j, u, u, e0 + off + k, (float)n);
                                 }
                             } else {
                                 arr = R.n_arrays;
                                 const V2 u_light = sm.get_2d(sc);
                                 const V2 u_scat = sm.get_2d(sc);
-                                rec_estimate_direct(sc, R, nd, j, u_light, u_scat, e0 + off, 1.0f);
+                                rec_estimate_direct<FULL>(sc, R, nd, j, u_light, u_scat, e0 + off, 1.0f);
                                 for (uint32_t k = 1; k < n; k++) R.flags[e0 + off + k] = 0u;
                             }
                             off += n;
@@ -3327,7 +3426,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
                         const float light_pdf = 1.0f / (float)sc.n_lights;
                         const V2 u_light = sm.get_2d(sc);
                         const V2 u_scat = sm.get_2d(sc);
-                        rec_estimate_direct(sc, R, nd, light_num, u_light, u_scat, e0);
+                        rec_estimate_direct<FULL>(sc, R, nd, light_num, u_light, u_scat, e0);
                         float4 a = R.A[e0];
                         a.w = light_pdf;
                         R.A[e0] = a;
@@ -3355,9 +3454,16 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
     __syncthreads();
     if (threadIdx.x == 0 && s_vert) atomicAdd(&cnt->vertices, s_vert);
 }
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_enter(PtScene sc, PtPaths P, PtQueues Q, PtRec R, PtCounters* cnt) {
+    rec_enter_body<true>(sc, P, Q, R, cnt);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_enter_plain(PtScene sc, PtPaths P, PtQueues Q, PtRec R, PtCounters* cnt) {
+    rec_enter_body<false>(sc, P, Q, R, cnt);
+}
 // compaction of the entries with live rays into the shadow / probe work lists of the next traversal launch
-extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_nee_lists(PtPaths P, PtQueues Q, PtQueues Qn, PtRec R, uint32_t n_lights_per_node) {
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_nee_lists(PtScene sc, PtPaths P, PtQueues Q, PtQueues Qn, PtRec R, uint32_t n_lights_per_node) {
     __shared__ uint32_t s_e[PT_SHADE_FLUSH][PT_BLOCK];       // entries of the iterations not yet queued (one reservation per PT_SHADE_FLUSH iterations, see shade_body)
+    __shared__ uint32_t s_k[PT_SHADE_FLUSH][PT_BLOCK];       // their shadow rays' sort keys (origin cell | direction octant), when the list is to be ordered (Qn.shadow_key)
     const uint32_t n = Q.counts[PT_Q_CUR];
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -3381,7 +3487,10 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_nee_lists(PtPaths P
                 const bool ws = ((want >> (2u * j)) & 1u) != 0, wp = ((want >> (2u * j)) & 2u) != 0;
                 const unsigned long long ms = __ballot(ws), mp = __ballot(wp);
                 const uint32_t e = s_e[j][threadIdx.x];
-                if (ws) Qn.shadow[bs + (uint32_t)__popcll(ms & below)] = e;
+                if (ws) {
+                    Qn.shadow[bs + (uint32_t)__popcll(ms & below)] = e;
+                    if (Qn.shadow_key) Qn.shadow_key[bs + (uint32_t)__popcll(ms & below)] = s_k[j][threadIdx.x];
+                }
                 if (wp) Qn.probe[bp + (uint32_t)__popcll(mp & below)] = e;
                 bs += (uint32_t)__popcll(ms); bp += (uint32_t)__popcll(mp);
             }
@@ -3397,6 +3506,10 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_nee_lists(PtPaths P
                 e = p * R.epp + i % n_lights_per_node;
                 const uint32_t fl = R.flags[e];
                 want_sh = (fl & PT_NEE_SHADOW) != 0; want_pr = (fl & PT_NEE_PROBE) != 0;
+                if (want_sh && Qn.shadow_key) {
+                    const float4 o = R.sh_o[e], d = R.sh_d[e];
+                    s_k[n_batch][threadIdx.x] = ray_sort_key(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z));
+                }
             }
         }
         s_e[n_batch][threadIdx.x] = e;
@@ -3406,6 +3519,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_nee_lists(PtPaths P
     flush();
 }
 // specular_reflect / specular_transmit at the frame `depth` (sampler.rs:37-143): true = a child ray was set up (cur ray, differentials, pending f / scale)
+template <bool FULL>
 PT_DEV bool rec_sample_child(const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t p, uint32_t depth, bool transmit, Sampler& sm, V3* pend_f, float* pend_scale, uint32_t* child_flags) {
     const float4 f0 = *rec_frame(R, depth, 0, p), f1 = *rec_frame(R, depth, 1, p);
     const V3 ro = f4_3(f0), rd = f4_3(f1);
@@ -3416,7 +3530,7 @@ PT_DEV bool rec_sample_child(const PtScene& sc, const PtPaths& P, const PtRec& R
     rdf.rx_o = f4_3(*rec_frame(R, depth, 2, p)); rdf.ry_o = f4_3(*rec_frame(R, depth, 3, p));
     rdf.rx_d = f4_3(*rec_frame(R, depth, 4, p)); rdf.ry_d = f4_3(*rec_frame(R, depth, 5, p));
     RecNode nd;
-    rec_build(sc, ro, rd, rec, iw & 0x7fffffffu, has_diff, rdf, nd);
+    rec_build<FULL>(sc, ro, rd, rec, iw & 0x7fffffffu, has_diff, rdf, nd);
     const V2 u = sm.get_2d(sc);
     V3 f, wi;
     float pdf;
@@ -3470,7 +3584,8 @@ PT_DEV bool rec_sample_child(const PtScene& sc, const PtPaths& P, const PtRec& R
     *pend_scale = wi_ns / pdf;
     return true;
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_next(PtScene sc, PtPaths P, PtQueues Q, PtRec R) {
+template <bool FULL>
+PT_DEV void rec_next_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtRec& R) {
     const uint32_t n = Q.counts[PT_Q_CUR];
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -3578,11 +3693,11 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
                         uint32_t cflags;
                         bool child = false;
                         if (phase == 0) {
-                            child = rec_sample_child(sc, P, R, p, (uint32_t)d, false, sm, &pend_f, &pend_scale, &cflags);
+                            child = rec_sample_child<FULL>(sc, P, R, p, (uint32_t)d, false, sm, &pend_f, &pend_scale, &cflags);
                             if (!child) { l = l + mk3(0.0f, 0.0f, 0.0f); phase = 1; }
                         }
                         if (!child && phase == 1) {
-                            child = rec_sample_child(sc, P, R, p, (uint32_t)d, true, sm, &pend_f, &pend_scale, &cflags);
+                            child = rec_sample_child<FULL>(sc, P, R, p, (uint32_t)d, true, sm, &pend_f, &pend_scale, &cflags);
                             if (child) phase = 2;
                             else l = l + mk3(0.0f, 0.0f, 0.0f);
                         } else if (child) phase = 1;
@@ -3616,18 +3731,22 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_r
     }
     flush();
 }
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_next(PtScene sc, PtPaths P, PtQueues Q, PtRec R) { rec_next_body<true>(sc, P, Q, R); }
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_next_plain(PtScene sc, PtPaths P, PtQueues Q, PtRec R) { rec_next_body<false>(sc, P, Q, R); }
 hipError_t ptk_rec_init(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t n) {
     hipLaunchKernelGGL(k_rec_init, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, R, n);
     return hipGetLastError();
 }
 hipError_t ptk_rec_enter(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtQueues& Qn, const PtRec& R, PtCounters* cnt,
                          uint32_t lights_per_node) {
-    hipLaunchKernelGGL(k_rec_enter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R, cnt);
-    hipLaunchKernelGGL(k_rec_nee_lists, dim3(grid), dim3(PT_BLOCK), 0, st, P, Q, Qn, R, lights_per_node);
+    if (sc.n_spheres || sc.n_instances || sc.textured) hipLaunchKernelGGL(k_rec_enter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R, cnt);
+    else hipLaunchKernelGGL(k_rec_enter_plain, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R, cnt);
+    hipLaunchKernelGGL(k_rec_nee_lists, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, Qn, R, lights_per_node);
     return hipGetLastError();
 }
 hipError_t ptk_rec_next(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtRec& R) {
-    hipLaunchKernelGGL(k_rec_next, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R);
+    if (sc.n_spheres || sc.n_instances || sc.textured) hipLaunchKernelGGL(k_rec_next, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R);
+    else hipLaunchKernelGGL(k_rec_next_plain, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R);
     return hipGetLastError();
 }
 
@@ -3802,49 +3921,58 @@ hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode) {
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, st, Q, mode);
     return PT_LAUNCH_CHECK();
 }
-hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt) {
+int ptk_nee_split_default() { return PT_NEE_SPLIT_DEFAULT; }
+hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, int nsplit) {
     static const int unsorted = [] { const char* e = std::getenv("PBRTGPU_SHADE_UNSORTED"); return e ? std::atoi(e) : 0; }();
     if (sc.general_materials && unsorted && !sc.n_instances && (!sc.n_spheres || sc.textured)) {
         if (sc.textured) hipLaunchKernelGGL(k_shade_all_tex, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
         else hipLaunchKernelGGL(k_shade_all, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
         return PT_LAUNCH_CHECK();
     }
+    // nsplit (the context's PBRTGPU_NEE_SPLIT): which kernel families run a vertex as two kernels (next-event estimation, then everything else):
+    // 1 the Matte kernels, 2 the lobe-list kernels, 4 the sphere-capable kernels (Matte and lobe-list), 8 the textured segment's second half
+    const int per_cu = grid / 2;          // grid = two blocks per CU (the whole-vertex kernels' occupancy)
+#define PT_RUN(K) hipLaunchKernelGGL(K, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt)
+#define PT_RUN2(K, WN, WC) do { hipLaunchKernelGGL(K##_nee, dim3(per_cu * (WN)), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt); \
+                                hipLaunchKernelGGL(K##_cont, dim3(per_cu * (WC)), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt); } while (0)
+    auto matte_sorted = [&]() {
+        if (sc.n_spheres) { if (nsplit & 4) PT_RUN2(k_shade_matte_sorted_sph, PT_NEE_WAVES, PT_CONT_SPH_WAVES); else PT_RUN(k_shade_matte_sorted_sph); }
+        else { if (nsplit & 1) PT_RUN2(k_shade_matte_sorted, PT_NEE_WAVES, PT_CONT_WAVES); else PT_RUN(k_shade_matte_sorted); }
+    };
+    auto general = [&]() {
+        if (sc.n_spheres) { if (nsplit & 4) PT_RUN2(k_shade_general_sph, PT_NEE_GEN_WAVES, PT_CONT_SPH_WAVES); else PT_RUN(k_shade_general_sph); }
+        else { if (nsplit & 2) PT_RUN2(k_shade_general, PT_NEE_GEN_WAVES, PT_CONT_GEN_WAVES); else PT_RUN(k_shade_general); }
+    };
     if (sc.general_materials) {
         hipLaunchKernelGGL(k_sort_count, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(PT_SORT_BINS), 0, st, Q);
         hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
         if (sc.n_instances) {
-            hipLaunchKernelGGL(k_shade_general_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            PT_RUN(k_shade_general_inst);
         } else if (sc.textured) {       // three segments: Matte | other constant materials | textured materials
-            if (sc.n_spheres) {
-                hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-                hipLaunchKernelGGL(k_shade_general_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-            } else {
-                hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-                hipLaunchKernelGGL(k_shade_general, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-            }
+            matte_sorted();
+            general();
             static const int split = [] { const char* e = std::getenv("PBRTGPU_TEX_SPLIT"); return e ? std::atoi(e) : 1; }();
             if (split && P.tex_res) {
                 if (sc.n_spheres) {
                     hipLaunchKernelGGL(k_tex_resolve_sph, dim3(4096), dim3(PT_BLOCK), 0, st, sc, P, Q);
-                    hipLaunchKernelGGL(k_shade_general_res_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+                    if (nsplit & 4) PT_RUN2(k_shade_general_res_sph, PT_NEE_GEN_WAVES, PT_CONT_SPH_WAVES); else PT_RUN(k_shade_general_res_sph);
                 } else {
                     hipLaunchKernelGGL(k_tex_resolve, dim3(4096), dim3(PT_BLOCK), 0, st, sc, P, Q);
-                    hipLaunchKernelGGL(k_shade_general_res, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+                    if (nsplit & 8) PT_RUN2(k_shade_general_res, PT_NEE_GEN_WAVES, PT_CONT_GEN_WAVES); else PT_RUN(k_shade_general_res);
                 }
             } else {
-                hipLaunchKernelGGL(k_shade_general_tex, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+                PT_RUN(k_shade_general_tex);
             }
-        } else if (sc.n_spheres) {
-            hipLaunchKernelGGL(k_shade_matte_sorted_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-            hipLaunchKernelGGL(k_shade_general_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
         } else {
-            hipLaunchKernelGGL(k_shade_matte_sorted, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
-            hipLaunchKernelGGL(k_shade_general, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+            matte_sorted();
+            general();
         }
     } else {
-        hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
+        if (nsplit & 1) PT_RUN2(k_shade, PT_NEE_WAVES, PT_CONT_WAVES); else PT_RUN(k_shade);
     }
+#undef PT_RUN
+#undef PT_RUN2
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_cont_keys(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* list, uint32_t n, uint32_t* keys) {

@@ -10,6 +10,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+LIB_NATIVE = os.path.join(ORACLE_DIR, "liboracle_native.so")      # bench.py's CPU timing leg only: built on the host that times it (oracle/Makefile `native`)
+PORTABLE_FLAGS = "g++ -O2 -ffp-contract=off -fno-fast-math"
+NATIVE_FLAGS = "g++ -O3 -march=native -ffp-contract=off -fno-fast-math"
 KAT = os.path.join(ORACLE_DIR, "orc_kat")
 
 pkg = importlib.import_module("pbrt-r3_amd")
@@ -208,6 +211,17 @@ class OracleScene:
 
 
 _oracle = None
+_native = None
+
+
+def load_native():
+    """The same restatement compiled for THIS host's cores (-O3 -march=native, still without fused multiply-add): always rebuilt here, a
+    library built elsewhere with -march=native may not run on this CPU."""
+    global _native
+    if _native is None:
+        subprocess.check_call(["make", "-s", "-B", "-C", ORACLE_DIR, "native"])
+        _native = Oracle(C.CDLL(LIB_NATIVE))
+    return _native
 
 
 def load():

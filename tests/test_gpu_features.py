@@ -539,6 +539,36 @@ def test_crown_class_3p5m_triangles(gpu_ctx, oracle, split):
     osc.close()
 
 
+def test_crown_class_3p5m_textured_tiles(gpu_ctx, oracle):
+    """BASELINE config 5's CONTENT at its scale, not only its size: the 3.5 M-triangle stand-in with the textured material split of the
+    crown-class bench line (`bench.py --triangles 3500000 --materials textured`: image-mapped Matte under a bump map, a checkerboard-driven
+    plastic, metal, glass, a bump-mapped mirror, an fbm-mixed substrate) -- k_tex_resolve + k_shade_general_res next to the Matte and
+    lobe-list kernels over a material-sorted queue.  Three 16x16 tiles of per-sample radiance bit-identical to the oracle, every ray /
+    node / triangle / vertex counter of a four-tile render equal, film weights bit-equal."""
+    sd = scenes.rt1m(3500000, res=256, spp=8, max_depth=8, materials="textured")
+    gpu_ctx.upload(sd)
+    osc = oracle.scene(sd)
+    info = gpu_ctx.info
+    assert (osc.info.n_nodes, osc.info.n_leaves) == (info.n_nodes, info.n_leaves)
+    sb = list(info.sample_bounds)
+    tiles = [(sb[0] + 16 * i, sb[1] + 16 * j, sb[0] + 16 * i + 16, sb[1] + 16 * j + 16) for i, j in ((7, 7), (3, 11), (12, 5))]
+    lit = 0.0
+    for tile in tiles:
+        g, r = gpu_ctx.radiance_samples(tile), osc.radiance_samples(tile)
+        lit += float(r.sum())
+        assert np.array_equal(bits(g), bits(r)), tile
+    assert lit > 0
+    four = tiles + [(sb[0] + 128, sb[1] + 128, sb[0] + 144, sb[1] + 144)]
+    gpu_ctx.film_clear(); gpu_ctx.reset_counters()
+    gpu_ctx.render(four)
+    gx, gc = gpu_ctx.film_xyzw(), gpu_ctx.counters()
+    ox, oc, _ = osc.render(four, threads=8)
+    for k in ("camera_rays", "regular_rays", "shadow_rays", "nodes_visited", "tris_tested", "path_vertices"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    assert np.array_equal(bits(gx[..., 3]), bits(ox[..., 3])) and rel_l2(gx, ox) < 1e-6
+    osc.close()
+
+
 @pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("name,make", [("cornell", lambda: scenes.cornell_box(res=64, spp=16)), ("materials", lambda: fs.scene_materials_lights("spatial")),
                                        ("spheres", lambda: fs.scene_spheres()), ("instances", lambda: fs.scene_instances()),

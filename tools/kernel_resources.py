@@ -28,7 +28,23 @@ def _sections(elf):
 def code_objects(path, arch="gfx950"):
     """The device ELF images for `arch` embedded in the shared library (one per translation unit with kernels)."""
     lib = open(path, "rb").read()
+    if lib.startswith(MAGIC) or lib[:4] != b"\x7fELF":      # a bare offload bundle (hipcc --cuda-device-only -c): the bundle walk below, over the whole file
+        images = []
+        at = lib.find(MAGIC)
+        while at >= 0:
+            n, = struct.unpack_from("<Q", lib, at + len(MAGIC))
+            p = at + len(MAGIC) + 8
+            for _ in range(n):
+                eoff, esize, tlen = struct.unpack_from("<QQQ", lib, p)
+                triple = lib[p + 24:p + 24 + tlen].decode()
+                p += 24 + tlen
+                if arch in triple and esize:
+                    images.append(lib[at + eoff:at + eoff + esize])
+            at = lib.find(MAGIC, at + len(MAGIC))
+        return images
     fat = [(off, size) for name, _t, off, size in _sections(lib) if name == ".hip_fatbin"]
+    if not fat and struct.unpack_from("<H", lib, 0x12)[0] == 224:     # EM_AMDGPU: a device code object itself (hipcc --cuda-device-only -c)
+        return [lib]
     assert fat, "no .hip_fatbin section in %s" % path
     images = []
     for off, size in fat:
