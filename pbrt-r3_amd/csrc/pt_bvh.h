@@ -106,6 +106,11 @@ struct SceneIn {
     const float* P; uint32_t n_vertices;
     const uint32_t* indices; const uint32_t* tri_mesh; uint32_t n_tris;
     const uint32_t* mesh_triflags; const int32_t* mesh_material; const uint32_t* mesh_flags; uint32_t n_meshes;
+    // Analytic spheres of the world list (round 4), in list order: sphere j is primitive sph_prim[j] of the merged list (ascending; triangle t is
+    // primitive t + the number of spheres listed before it), sph_bounds[6 j ..] its Sphere::world_bound, sph_rec[4 j ..] = {index into the scene's
+    // sphere array, record flags (PT_TRI_SPHERE | material field), material, 0}.  n_spheres == 0: a triangle-only list, as before.
+    const uint32_t* sph_prim = nullptr; const float* sph_bounds = nullptr; const uint32_t* sph_rec = nullptr; uint32_t n_spheres = 0;
+    uint32_t n_prims() const { return n_tris + n_spheres; }
 };
 struct SceneOut {
     void *d_nodes = nullptr, *d_tris = nullptr, *d_tinfo = nullptr, *d_rec_of_prim = nullptr;

@@ -552,11 +552,15 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     {
         uint32_t any_object = 0;
         for (uint32_t i = 0; i < d->n_meshes; i++) any_object |= d->meshes[i].object;
+        for (uint32_t i = 0; i < d->n_spheres; i++) any_object |= d->spheres[i].object;
         const int mnp = std::min(std::max(max_node_prims, 0), 255);
         const bool sah = d->split_method == PT_SPLIT_SAH && mnp >= 2, hl = d->split_method == PT_SPLIT_HLBVH && mnp >= 1;
-        if (d->n_spheres == 0 && d->n_instances == 0 && any_object == 0 && (sah || hl) && d->n_triangles >= 2 &&
-            d->n_triangles < PT_LEAF_FIRST_MASK - 16u && ctx->bvh_build_where != PT_BVH_BUILD_HOST &&
-            (ctx->bvh_build_where == PT_BVH_BUILD_DEVICE || d->n_triangles >= ptbvh::kDeviceMinPrims) && !std::getenv("PBRTGPU_HOST_FINISH")) {
+        const uint64_t n_world = (uint64_t)d->n_triangles + d->n_spheres;
+        // (round 4: analytic spheres of the world list ride along -- a handful of them among the triangles, killeroo-simple's two sphere lights --;
+        // objects and instances still take the host path)
+        if (d->n_instances == 0 && any_object == 0 && (sah || hl) && n_world >= 2 &&
+            n_world < PT_LEAF_FIRST_MASK - 16u && ctx->bvh_build_where != PT_BVH_BUILD_HOST &&
+            (ctx->bvh_build_where == PT_BVH_BUILD_DEVICE || n_world >= ptbvh::kDeviceMinPrims) && !std::getenv("PBRTGPU_HOST_FINISH")) {
             std::vector<uint32_t> m_triflags(d->n_meshes), m_flags(d->n_meshes);
             std::vector<int32_t> m_material(d->n_meshes);
             for (uint32_t i = 0; i < d->n_meshes; i++) {
@@ -573,7 +577,26 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                 m_flags[i] = mf;
                 m_material[i] = mat;
             }
+            // the world list's spheres in list order (spliced in before triangle `before_triangle`, ties in creation order: make_list below)
+            std::vector<ptbvh::SpherePrim> sprims;
+            std::vector<uint32_t> s_order(d->n_spheres), s_prim(d->n_spheres), s_rec(4 * (size_t)d->n_spheres);
+            std::vector<float> s_bounds(6 * (size_t)d->n_spheres);
+            if (d->n_spheres) {
+                build_spheres(d, sph, sprims);
+                for (uint32_t i = 0; i < d->n_spheres; i++) s_order[i] = i;
+                std::stable_sort(s_order.begin(), s_order.end(), [&](uint32_t x, uint32_t y) {
+                    return d->spheres[x].before_triangle != d->spheres[y].before_triangle ? d->spheres[x].before_triangle < d->spheres[y].before_triangle
+                                                                                         : d->spheres[x].order < d->spheres[y].order;
+                });
+                for (uint32_t j = 0; j < d->n_spheres; j++) {
+                    const uint32_t i = s_order[j];
+                    s_prim[j] = d->spheres[i].before_triangle + j;          // the triangles before it and the j spheres listed before it
+                    std::memcpy(&s_bounds[6 * (size_t)j], sprims[i].lo, 12); std::memcpy(&s_bounds[6 * (size_t)j + 3], sprims[i].hi, 12);
+                    s_rec[4 * (size_t)j] = i; s_rec[4 * (size_t)j + 1] = sprims[i].flags; s_rec[4 * (size_t)j + 2] = (uint32_t)d->spheres[i].material; s_rec[4 * (size_t)j + 3] = 0;
+                }
+            }
             ptbvh::SceneIn in{d->P, d->n_vertices, d->indices, d->tri_mesh, d->n_triangles, m_triflags.data(), m_material.data(), m_flags.data(), d->n_meshes};
+            in.sph_prim = s_prim.data(); in.sph_bounds = s_bounds.data(); in.sph_rec = s_rec.data(); in.n_spheres = d->n_spheres;
             ptbvh::SceneOut out;
             hipError_t herr = hipSuccess;
             const int rc = sah ? ptbvh::device_sah_scene(ctx->stream, in, (uint32_t)mnp, &out, &herr) : ptbvh::device_hlbvh_scene(ctx->stream, in, (uint32_t)mnp, &out, &herr);
@@ -581,8 +604,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             if (rc < 0) return ctx->hip_fail(herr, "scene build on the device");
             mark("device scene (bounds, SAH, records, collapse)");
             if (rc == 0) {
-                // light i = the i-th emissive triangle in primitive order (scene_context.rs:1218-1231)
-                std::vector<uint32_t> lit;
+                // light i = the i-th emissive primitive in primitive order (scene_context.rs:1218-1231); `lit` holds primitive numbers of the merged list,
+                // `lit_src` what each stands for (bit 31: a sphere, else the triangle)
+                std::vector<uint32_t> lit, lit_src;
                 bool any_light_mesh = false;
                 for (uint32_t i = 0; i < d->n_meshes; i++) any_light_mesh |= d->meshes[i].area_light >= 0;
                 if (any_light_mesh) {                     // the host's threads scan their share of the triangles; the shares are joined in order
@@ -592,17 +616,48 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                         const size_t a = c * step, b = std::min((size_t)d->n_triangles, a + step);
                         for (size_t t = a; t < b; t++) if (d->meshes[d->tri_mesh[t]].area_light >= 0) part[c].push_back((uint32_t)t);
                     });
-                    for (const auto& v : part) lit.insert(lit.end(), v.begin(), v.end());
+                    for (const auto& v : part) lit_src.insert(lit_src.end(), v.begin(), v.end());
+                }
+                if (d->n_spheres) {                       // triangle numbers -> primitive numbers, the emissive spheres merged in at their places
+                    std::vector<uint32_t> tri_lit;
+                    tri_lit.swap(lit_src);
+                    size_t ti = 0;
+                    uint32_t j = 0;                       // spheres listed so far
+                    auto flush_tris = [&](uint32_t before) {          // emissive triangles t < before: primitive t + j
+                        while (ti < tri_lit.size() && tri_lit[ti] < before) { lit.push_back(tri_lit[ti] + j); lit_src.push_back(tri_lit[ti]); ti++; }
+                    };
+                    for (; j < d->n_spheres; j++) {
+                        const uint32_t i = s_order[j];
+                        flush_tris(d->spheres[i].before_triangle);
+                        if (d->spheres[i].area_light >= 0) { lit.push_back(s_prim[j]); lit_src.push_back(0x80000000u | i); }
+                    }
+                    flush_tris(0xffffffffu);
+                } else {
+                    lit = lit_src;
                 }
                 if (lit.size() >= (1u << 24)) { out.free_all(); return ctx->fail(PT_ERR_UNSUPPORTED, "more than 2^24 emissive primitives"); }
                 std::vector<uint32_t> lit_rec(lit.size());
                 if (ptbvh::device_scene_lights(ctx->stream, &out, lit.data(), (uint32_t)lit.size(), lit_rec.data(), &herr) < 0) { out.free_all(); return ctx->hip_fail(herr, "light records on the device"); }
                 for (size_t i = 0; i < lit.size(); i++) {
-                    const uint32_t t = lit[i];
-                    const pt_mesh& m = d->meshes[d->tri_mesh[t]];
-                    const pt_area_light& al = d->area_lights[m.area_light];
                     PtLight L;
                     std::memset(&L, 0, sizeof(L));
+                    if (lit_src[i] & 0x80000000u) {       // a sphere: the host path's record for one (below)
+                        const uint32_t si = lit_src[i] & 0x7fffffffu;
+                        const pt_area_light& al = d->area_lights[d->spheres[si].area_light];
+                        std::memcpy(&L.p0[0], &si, 4);
+                        L.area = sph[si].area;
+                        L.mesh_flags = PT_LIGHT_SPHERE;
+                        L.two_sided = al.two_sided;
+                        L.n_samples = (uint32_t)std::max(1, al.n_samples);
+                        std::memcpy(L.L, al.L, 12);
+                        L.tri_rec = lit_rec[i];
+                        L.prim = lit[i];
+                        lights.push_back(L);
+                        continue;
+                    }
+                    const uint32_t t = lit_src[i];
+                    const pt_mesh& m = d->meshes[d->tri_mesh[t]];
+                    const pt_area_light& al = d->area_lights[m.area_light];
                     const uint32_t v0 = d->indices[3 * (size_t)t], v1 = d->indices[3 * (size_t)t + 1], v2 = d->indices[3 * (size_t)t + 2];
                     const float* p0 = d->P + 3 * (size_t)v0; const float* p1 = d->P + 3 * (size_t)v1; const float* p2 = d->P + 3 * (size_t)v2;
                     std::memcpy(L.p0, p0, 12); std::memcpy(L.p1, p1, 12); std::memcpy(L.p2, p2, 12);
@@ -616,7 +671,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                     L.n_samples = (uint32_t)std::max(1, al.n_samples);
                     std::memcpy(L.L, al.L, 12);
                     L.tri_rec = lit_rec[i];
-                    L.prim = t;
+                    L.prim = lit[i];
                     if (L.mesh_flags & PT_MESH_HAS_N) { std::memcpy(L.n0, d->N + 3 * (size_t)v0, 12); std::memcpy(L.n1, d->N + 3 * (size_t)v1, 12); std::memcpy(L.n2, d->N + 3 * (size_t)v2, 12); }
                     lights.push_back(L);
                 }
@@ -625,9 +680,9 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                 // the context's buffers take the blocks over
                 ctx->d_nodes.release(); ctx->d_tris.release(); ctx->d_tri_info.release();
                 ctx->d_nodes.p = out.d_nodes; ctx->d_nodes.bytes = (size_t)out.n_nodes4 * sizeof(PtNode);
-                ctx->d_tris.p = out.d_tris; ctx->d_tris.bytes = ((size_t)d->n_triangles + 1) * sizeof(PtTri);
-                ctx->d_tri_info.p = out.d_tinfo; ctx->d_tri_info.bytes = (size_t)d->n_triangles * sizeof(PtTriInfo);
-                up_n_nodes = out.n_nodes4; up_n_tris = (size_t)d->n_triangles + 1;
+                ctx->d_tris.p = out.d_tris; ctx->d_tris.bytes = ((size_t)n_world + 1) * sizeof(PtTri);
+                ctx->d_tri_info.p = out.d_tinfo; ctx->d_tri_info.bytes = (size_t)n_world * sizeof(PtTriInfo);
+                up_n_nodes = out.n_nodes4; up_n_tris = (size_t)n_world + 1;
                 n_world_nodes = out.n_nodes4; n_top = out.n_top;
                 up_root_ref = 0; up_max_leaf = out.max_leaf; up_n_leaves = out.n_leaves;
                 std::memcpy(up_root_lo, out.root_lo, 12); std::memcpy(up_root_hi, out.root_hi, 12);

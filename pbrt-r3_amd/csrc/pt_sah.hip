@@ -413,21 +413,38 @@ __global__ __launch_bounds__(256) void k_sah_order(const SItem* __restrict__ ite
 // order, the collapse of the binary tree into 128-byte 4-wide nodes in the reference's depth-first numbering (qbvh_x86.rs:93-176, the host
 // version is Collapser in pt_bvh.cpp), the breadth-first renumbering of the top of the tree and the finishing pass of pt_context.cpp --
 // so that neither the tree nor the primitive order ever crosses PCIe.  Byte for byte the arrays the host path uploads.
-__global__ __launch_bounds__(256) void k_sc_bounds(const float* __restrict__ P, const uint32_t* __restrict__ idx, uint32_t n, float* raw) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+// A world list with analytic spheres spliced in: sphere j is primitive sph_prim[j] (ascending).  Returns the number of spheres listed before
+// primitive q and whether q is one of them; a triangle's index is q minus that count.  (A handful of spheres: a binary search per primitive.)
+__device__ inline uint32_t sc_spheres_before(const uint32_t* __restrict__ sph_prim, uint32_t n_s, uint32_t q, bool* is_sphere) {
+    uint32_t lo = 0, hi = n_s;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sph_prim[mid] < q) lo = mid + 1u; else hi = mid; }
+    *is_sphere = lo < n_s && sph_prim[lo] == q;
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_sc_bounds(const float* __restrict__ P, const uint32_t* __restrict__ idx, uint32_t n, float* raw, const uint32_t* __restrict__ sph_prim,
+                                                  const float* __restrict__ sph_bounds, uint32_t n_s) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    uint32_t t = q;
+    if (n_s) {
+        bool sphere;
+        const uint32_t before = sc_spheres_before(sph_prim, n_s, q, &sphere);
+        if (sphere) { for (int a = 0; a < 6; a++) raw[(size_t)q * 6 + a] = sph_bounds[(size_t)before * 6 + a]; return; }      // Sphere::world_bound, from the host
+        t = q - before;
+    }
     const float* p0 = P + 3 * (size_t)idx[3 * (size_t)t];
     const float* p1 = P + 3 * (size_t)idx[3 * (size_t)t + 1];
     const float* p2 = P + 3 * (size_t)idx[3 * (size_t)t + 2];
     for (int a = 0; a < 3; a++) {                        // union3 (triangle.rs:189-200)
-        raw[(size_t)t * 6 + a] = fminf(fminf(p0[a], p1[a]), p2[a]);
-        raw[(size_t)t * 6 + 3 + a] = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
+        raw[(size_t)q * 6 + a] = fminf(fminf(p0[a], p1[a]), p2[a]);
+        raw[(size_t)q * 6 + 3 + a] = fmaxf(fmaxf(p0[a], p1[a]), p2[a]);
     }
 }
 // record r = primitive order[r]: the 48-byte leaf record, the 32-byte shading record, the primitive -> record map
 __global__ __launch_bounds__(256) void k_sc_records(const uint32_t* __restrict__ order, const float* __restrict__ P, const uint32_t* __restrict__ idx,
                                                    const uint32_t* __restrict__ tri_mesh, const uint32_t* __restrict__ mesh_triflags, const int32_t* __restrict__ mesh_material,
-                                                   const uint32_t* __restrict__ mesh_flags, uint32_t n, PtTri* tris, PtTriInfo* tinfo, uint32_t* rec_of_prim, uint32_t* small) {
+                                                   const uint32_t* __restrict__ mesh_flags, uint32_t n, PtTri* tris, PtTriInfo* tinfo, uint32_t* rec_of_prim, uint32_t* small,
+                                                   const uint32_t* __restrict__ sph_prim, const uint32_t* __restrict__ sph_rec, uint32_t n_s) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n) return;
     if (r == n) {                                        // one zero pad record: the kernels fetch triangle records two at a time
@@ -437,19 +454,39 @@ __global__ __launch_bounds__(256) void k_sc_records(const uint32_t* __restrict__
         tris[n] = pad;
         return;
     }
-    const uint32_t t = order[r];
+    const uint32_t q = order[r];
+    uint32_t t = q;
+    if (n_s) {
+        bool sphere;
+        const uint32_t before = sc_spheres_before(sph_prim, n_s, q, &sphere);
+        if (sphere) {                                    // ptbvh::sphere_record + the shading record of the host path's `tinfo` loop
+            PtTri tr;
+            tr.p0[0] = __uint_as_float(sph_rec[4 * (size_t)before]); tr.p0[1] = tr.p0[2] = 0.0f;
+            tr.p1[0] = tr.p1[1] = tr.p1[2] = 0.0f; tr.p2[0] = tr.p2[1] = tr.p2[2] = 0.0f;
+            tr.prim = q;
+            tr.flags = (sph_rec[4 * (size_t)before + 1] | PT_TRI_SPHERE) & ~PT_TRI_LAST;
+            tr.light1 = 0;
+            tris[r] = tr;
+            PtTriInfo ti;
+            ti.v[0] = ti.v[1] = ti.v[2] = 0; ti.mesh = 0; ti.light = -1; ti.material = (int32_t)sph_rec[4 * (size_t)before + 2]; ti.mesh_flags = 0; ti.pad = 0;
+            tinfo[r] = ti;
+            rec_of_prim[q] = r;
+            return;
+        }
+        t = q - before;
+    }
     const uint32_t v0 = idx[3 * (size_t)t], v1 = idx[3 * (size_t)t + 1], v2 = idx[3 * (size_t)t + 2], m = tri_mesh[t];
     PtTri tr;
     for (int a = 0; a < 3; a++) { tr.p0[a] = P[3 * (size_t)v0 + a]; tr.p1[a] = P[3 * (size_t)v1 + a]; tr.p2[a] = P[3 * (size_t)v2 + a]; }
     const uint32_t f = mesh_triflags[m];
-    tr.prim = t;
+    tr.prim = q;
     tr.flags = f & ~(PT_TRI_LAST | PT_TRI_SPHERE | PT_TRI_INSTANCE);
     tr.light1 = 0;
     tris[r] = tr;
     PtTriInfo ti;
     ti.v[0] = v0; ti.v[1] = v1; ti.v[2] = v2; ti.mesh = m; ti.light = -1; ti.material = mesh_material[m]; ti.mesh_flags = mesh_flags[m]; ti.pad = 0;
     tinfo[r] = ti;
-    rec_of_prim[t] = r;
+    rec_of_prim[q] = r;
     if (f & PT_TRI_ONE_SIDED) small[4] = 1u;             // PtScene::any_one_sided
 }
 // PT_TRI_LAST closes each leaf; leaves and the largest leaf are counted
@@ -708,11 +745,12 @@ static float* scene_staging(size_t bytes) {
 // -1: HIP error.
 // The scene's arrays go up through page-locked staging filled by the host's threads (from pageable memory the runtime stages the copy itself at
 // a few GB/s); the per-mesh tables are tiny.  Then the triangles' bounds, on the device.
-static int upload_scene_arrays(hipStream_t st, const SceneIn& sc, Scratch& d_P, Scratch& d_idx, Scratch& d_tmesh, Scratch& d_mtab, float* d_raw, hipError_t* err) {
-    const uint32_t n = sc.n_tris;
+static int upload_scene_arrays(hipStream_t st, const SceneIn& sc, Scratch& d_P, Scratch& d_idx, Scratch& d_tmesh, Scratch& d_mtab, Scratch& d_sph, float* d_raw, hipError_t* err) {
+    const uint32_t n = sc.n_tris, ns = sc.n_spheres;
     const size_t nP = 3 * (size_t)sc.n_vertices, nI = 3 * (size_t)n, nm = sc.n_meshes;
     SAH_TRY(d_P.alloc(nP * 4)); SAH_TRY(d_idx.alloc(nI * 4)); SAH_TRY(d_tmesh.alloc((size_t)n * 4)); SAH_TRY(d_mtab.alloc(nm * 12 + 16));
-    float* stage = scene_staging((nP + nI + n + 3 * nm) * 4);
+    SAH_TRY(d_sph.alloc((size_t)ns * 44 + 16));          // per sphere: primitive number, bound (6 floats), record words (4)
+    float* stage = scene_staging((nP + nI + n + 3 * nm + 11 * (size_t)ns) * 4);
     if (!stage) return 1;
     uint32_t* su = reinterpret_cast<uint32_t*>(stage);
     parallel_for(nP, [&](size_t a, size_t b) { std::memcpy(stage + a, sc.P + a, (b - a) * 4); });
@@ -721,11 +759,19 @@ static int upload_scene_arrays(hipStream_t st, const SceneIn& sc, Scratch& d_P, 
     std::memcpy(su + nP + nI + n, sc.mesh_triflags, nm * 4);
     std::memcpy(su + nP + nI + n + nm, sc.mesh_material, nm * 4);
     std::memcpy(su + nP + nI + n + 2 * nm, sc.mesh_flags, nm * 4);
-    SAH_TRY(hipMemcpyAsync(d_P.p, stage, nP * 4, hipMemcpyHostToDevice, st));
-    SAH_TRY(hipMemcpyAsync(d_idx.p, su + nP, nI * 4, hipMemcpyHostToDevice, st));
-    SAH_TRY(hipMemcpyAsync(d_tmesh.p, su + nP + nI, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    SAH_TRY(hipMemcpyAsync(d_mtab.p, su + nP + nI + n, nm * 12, hipMemcpyHostToDevice, st));
-    k_sc_bounds<<<(n + 255u) / 256u, 256, 0, st>>>(d_P.as<float>(), d_idx.as<uint32_t>(), n, d_raw);
+    uint32_t* ssph = su + nP + nI + n + 3 * nm;          // [ns] primitive numbers, [6 ns] bounds, [4 ns] record words
+    if (ns) {
+        std::memcpy(ssph, sc.sph_prim, (size_t)ns * 4);
+        std::memcpy(ssph + ns, sc.sph_bounds, (size_t)ns * 24);
+        std::memcpy(ssph + 7 * (size_t)ns, sc.sph_rec, (size_t)ns * 16);
+    }
+    if (nP) SAH_TRY(hipMemcpyAsync(d_P.p, stage, nP * 4, hipMemcpyHostToDevice, st));
+    if (nI) SAH_TRY(hipMemcpyAsync(d_idx.p, su + nP, nI * 4, hipMemcpyHostToDevice, st));
+    if (n) SAH_TRY(hipMemcpyAsync(d_tmesh.p, su + nP + nI, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (nm) SAH_TRY(hipMemcpyAsync(d_mtab.p, su + nP + nI + n, nm * 12, hipMemcpyHostToDevice, st));
+    if (ns) SAH_TRY(hipMemcpyAsync(d_sph.p, ssph, (size_t)ns * 44, hipMemcpyHostToDevice, st));
+    const uint32_t np = n + ns;
+    k_sc_bounds<<<(np + 255u) / 256u, 256, 0, st>>>(d_P.as<float>(), d_idx.as<uint32_t>(), np, d_raw, d_sph.as<uint32_t>(), d_sph.as<float>() + ns, ns);
     SAH_TRY(hipGetLastError());
     return 0;
 }
@@ -734,7 +780,7 @@ static int upload_scene_arrays(hipStream_t st, const SceneIn& sc, Scratch& d_P, 
 // ranges of `list`, or of the node numbers themselves when `list` is null).  The blocks of `sout` belong to the caller afterwards.
 static int finish_scene(hipStream_t st, const LbvhNode* bn, uint32_t n_nodes, uint32_t root, const std::vector<std::pair<uint32_t, uint32_t>>& levels, const uint32_t* list,
                         const uint32_t* d_order, const float* d_P, const uint32_t* d_idx, const uint32_t* d_tmesh, const uint32_t* mtab, uint32_t nm, uint32_t n, SceneOut* sout,
-                        hipError_t* err) {
+                        hipError_t* err, const uint32_t* d_sph = nullptr, uint32_t n_s = 0) {          // n: primitives of the merged list (triangles + spheres)
         struct Owned { void* p = nullptr; ~Owned() { if (p) (void)hipFree(p); } void* release() { void* q = p; p = nullptr; return q; } };
         Owned o_tris, o_tinfo, o_rop, o_nodes;
         SAH_TRY(hipMalloc(&o_tris.p, ((size_t)n + 1) * sizeof(PtTri)));
@@ -748,7 +794,8 @@ static int finish_scene(hipStream_t st, const LbvhNode* bn, uint32_t n_nodes, ui
         SAH_TRY(hipMemsetAsync(d_size4.p, 0, (size_t)n_nodes * 4, st));
         SAH_TRY(hipMemsetAsync(d_idx4.p, 0xff, (size_t)n_nodes * 4, st));
         k_sc_records<<<(n + 1u + 255u) / 256u, 256, 0, st>>>(d_order, d_P, d_idx, d_tmesh, mtab,
-                                                           reinterpret_cast<const int32_t*>(mtab + nm), mtab + 2 * nm, n, (PtTri*)o_tris.p, (PtTriInfo*)o_tinfo.p, (uint32_t*)o_rop.p, small);
+                                                           reinterpret_cast<const int32_t*>(mtab + nm), mtab + 2 * nm, n, (PtTri*)o_tris.p, (PtTriInfo*)o_tinfo.p, (uint32_t*)o_rop.p, small,
+                                                           d_sph, d_sph ? d_sph + 7 * (size_t)n_s : nullptr, n_s);
         k_sc_leafmark<<<(n_nodes + 255u) / 256u, 256, 0, st>>>(bn, n_nodes, (PtTri*)o_tris.p, small);
         const size_t n_lv = levels.size();
         for (size_t l = n_lv; l-- > 0;)
@@ -815,9 +862,9 @@ static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32
     uint32_t* flags = counters + 8;
     SAH_TRY(hipMemsetAsync(d_small.p, 0, 64, st));
     const uint32_t blocks = (n + 255u) / 256u;
-    Scratch d_P, d_idx, d_tmesh, d_mtab;
+    Scratch d_P, d_idx, d_tmesh, d_mtab, d_sph;
     if (scene) {
-        const int urc = upload_scene_arrays(st, *scene, d_P, d_idx, d_tmesh, d_mtab, d_raw.as<float>(), err);
+        const int urc = upload_scene_arrays(st, *scene, d_P, d_idx, d_tmesh, d_mtab, d_sph, d_raw.as<float>(), err);
         if (urc != 0) return urc;
         if (trace) { const double ta = now(); (void)hipStreamSynchronize(st); std::fprintf(stderr, "[bvh] device scene: vertices + indices staged and uploaded, bounds on the device: %.2f ms since entry, %.2f ms waiting\n", now() - t0, now() - ta); }
     } else {
@@ -887,7 +934,7 @@ static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32
         std::vector<std::pair<uint32_t, uint32_t>> lv;
         for (size_t l = 0; l + 1 < level_begin.size(); l++) lv.push_back({level_begin[l], level_begin[l + 1] - level_begin[l]});
         const int frc = finish_scene(st, d_export.as<LbvhNode>(), n_nodes, 0u, lv, nullptr, d_order.as<uint32_t>(), d_P.as<float>(), d_idx.as<uint32_t>(), d_tmesh.as<uint32_t>(),
-                                     d_mtab.as<uint32_t>(), scene->n_meshes, n, sout, err);
+                                     d_mtab.as<uint32_t>(), scene->n_meshes, n, sout, err, d_sph.as<uint32_t>(), scene->n_spheres);
         if (trace && frc == 0) std::fprintf(stderr, "[bvh] device scene (sah): %u items, %u binary nodes in %zu levels -> %u 4-wide nodes (top %u renumbered), %u leaves: setup %.2f levels %.2f records + collapse %.2f ms\n", n,
                                             n_nodes, lv.size(), sout->n_nodes4, sout->n_top, sout->n_leaves, t1 - t0, t2 - t1, now() - t2);
         return frc;
@@ -905,7 +952,7 @@ int device_sah(hipStream_t st, const float* raw_bounds, uint32_t n, uint32_t max
     return sah_build(st, raw_bounds, n, max_prims, order, nodes, err, nullptr, nullptr);
 }
 int device_sah_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, SceneOut* out, hipError_t* err) {
-    return sah_build(st, nullptr, in.n_tris, max_prims, nullptr, nullptr, err, &in, out);
+    return sah_build(st, nullptr, in.n_prims(), max_prims, nullptr, nullptr, err, &in, out);
 }
 // "splitmethod" "hlbvh" the same way: bounds from the vertices on the device, Morton sort / treelets / emit_lbvh (pt_hlbvh.hip) with the tree
 // and the order kept there, the upper SAH over the <= 4096 treelet roots on the host (their boxes come back, the joining nodes go up behind
@@ -916,15 +963,15 @@ int device_hlbvh_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, Sc
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     if (err) *err = hipSuccess;
-    const uint32_t n = in.n_tris;
+    const uint32_t n = in.n_prims();
     if (n < 2 || n > (1u << 26)) return 1;
     const uint32_t node_cap = 2u * n + 2u * 4096u + 8u;
     t_arena.reserve((size_t)n * 200 + (size_t)in.n_vertices * 12 + ((size_t)2 << 20));
-    Scratch d_raw, d_P, d_idx, d_tmesh, d_mtab, d_bn, d_order, d_list, d_cnt;
+    Scratch d_raw, d_P, d_idx, d_tmesh, d_mtab, d_sph, d_bn, d_order, d_list, d_cnt;
     SAH_TRY(d_raw.alloc((size_t)n * 24));
     SAH_TRY(d_bn.alloc((size_t)node_cap * sizeof(LbvhNode)));
     SAH_TRY(d_order.alloc((size_t)n * 4));
-    const int urc = upload_scene_arrays(st, in, d_P, d_idx, d_tmesh, d_mtab, d_raw.as<float>(), err);
+    const int urc = upload_scene_arrays(st, in, d_P, d_idx, d_tmesh, d_mtab, d_sph, d_raw.as<float>(), err);
     if (urc != 0) return urc;
     uint32_t n_nodes = 0, n_roots = 0;
     std::vector<LbvhNode> roots;
@@ -975,7 +1022,7 @@ int device_hlbvh_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, Sc
     }
     const double t2 = now();
     const int frc = finish_scene(st, d_bn.as<LbvhNode>(), total, root, levels, d_list.as<uint32_t>(), d_order.as<uint32_t>(), d_P.as<float>(), d_idx.as<uint32_t>(), d_tmesh.as<uint32_t>(),
-                                 d_mtab.as<uint32_t>(), in.n_meshes, n, out, err);
+                                 d_mtab.as<uint32_t>(), in.n_meshes, n, out, err, d_sph.as<uint32_t>(), in.n_spheres);
     if (trace && frc == 0) std::fprintf(stderr, "[bvh] device scene (hlbvh): %u items, %u + %u binary nodes in %zu levels -> %u 4-wide nodes (top %u renumbered), %u leaves: upload + lower half %.2f upper + levels %.2f records + collapse %.2f ms\n",
                                         n, n_nodes, n_upper, levels.size(), out->n_nodes4, out->n_top, out->n_leaves, t1 - t0, t2 - t1, now() - t2);
     return frc;

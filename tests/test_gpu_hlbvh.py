@@ -223,3 +223,40 @@ def test_device_scene_path_equals_host_finish(monkeypatch):
         finally:
             ctx.close()
     assert got[0] == got[1]
+
+
+def test_device_scene_path_with_world_spheres(oracle):
+    """Round 4: analytic spheres of the WORLD list ride along the device upload (killeroo-simple's lights are spheres: config 4 used to take the
+    host builder for that alone).  A sphere is one primitive of the merged list -- spliced in before triangle `before_triangle` --, its world
+    bound comes from the host, its leaf record, shading record and light number are written by the same kernels as the triangles'.  Node and
+    record arrays byte-identical to the host path's (SAH and HLBVH, sphere objects and sphere lights, a sphere as the very first and the very
+    last primitive), then per-sample radiance, film and counters against the oracle on the device-built scene."""
+    from test_gpu_features import _compare
+
+    def rt_sphere(n, split):
+        sd = scenes.rt1m(n, res=32, spp=4, max_depth=4, light="sphere")
+        sd.desc.split_method = split
+        return sd
+    makes = [lambda: fs.scene_spheres("spatial"), lambda: fs.scene_spheres("power", split="hlbvh"), lambda: fs.scene_spheres("spatial", lights_only=True),
+             lambda: rt_sphere(70001, 0), lambda: rt_sphere(70001, 1)]
+    ran = 0
+    for make in makes:
+        sd = make()
+        d = sd.desc
+        if d.n_spheres == 0 or d.n_instances or d.split_method not in (0, 1) or any(d.meshes[i].object for i in range(d.n_meshes)) or any(d.spheres[i].object for i in range(d.n_spheres)):
+            continue
+        host, dev = _digests(sd)
+        assert host == dev
+        ctx = pkg.Context(0)
+        try:
+            ctx.set_bvh_build(DEVICE)
+            info = ctx.upload(sd)
+            assert info.bvh_on_device == 1
+            osc = oracle.scene(sd)
+            assert (osc.info.n_nodes, osc.info.n_leaves, osc.info.n_lights) == (info.n_nodes, info.n_leaves, info.n_lights)
+            _compare(ctx, osc, exact_film=True)
+            osc.close()
+            ran += 1
+        finally:
+            ctx.close()
+    assert ran >= 3
