@@ -91,6 +91,10 @@ struct pt_context {
     size_t sort_cap = 0;
     DevBuf d_csort_ids, d_csort_keys[2], d_csort_temp; // the continuation rays' key list, the ordered copy (ids + keys) and rocprim's scratch
     size_t csort_cap = 0;
+    // the lazily filled light grid (PtLightGrid::row_of): voxel -> row table, the list of voxels a bounce touched first, rows in use / allocated
+    DevBuf d_grid_rows, d_grid_todo;
+    size_t grid_rows_used = 0, grid_rows_cap = 0, grid_nvox = 0;
+    bool grid_lazy = false;
     uint32_t* h_live = nullptr;                        // page-locked: the recursive integrators' live-sample count, read one level behind
     int nee_split = 0;                                 // PBRTGPU_NEE_SPLIT: kernel families that shade a vertex in two kernels (ptk_shade)
     int sort_cont = -1;                                // continuation rays of a bounce ordered like the shadow rays: 0 never, 1 for the traversal kernel only
@@ -1222,6 +1226,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     std::memcpy(g.wb_max, sc.wb_max, 12);
     int strategy = d->light_strategy;
     if (strategy == PT_LIGHTS_UNIFORM && sc.n_lights != 1) strategy = PT_LIGHTS_SPATIAL;
+    ctx->grid_lazy = false;
     if (sc.n_lights > 0) {
         if (strategy == PT_LIGHTS_SPATIAL) {
             const uint32_t max_voxels = 64;
@@ -1238,11 +1243,32 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             }
             g.single = 0;
             size_t bytes = nvox * g.stride * sizeof(float);
-            if (bytes > ((size_t)16 << 30)) return ctx->fail(PT_ERR_UNSUPPORTED, "dense light grid would exceed 16 GiB; lazy per-voxel fill is not implemented yet");
-            PT_HIP(ctx->d_grid.alloc(bytes + 64));
-            g.data = ctx->d_grid.as<float>();
-            PT_HIP(ptk_light_grid(ctx->stream, sc, ctx->d_grid.as<float>(), (uint32_t)nvox));
-            PT_HIP(hipStreamSynchronize(ctx->stream));
+            // Dense while it is small (every voxel's tables made here, at upload: 0.6 ms for RT1M's 262 144 voxels x 2 lights); from
+            // PBRTGPU_LIGHT_GRID_DENSE_MAX bytes on (default 2 GiB: about a thousand lights) the grid is filled as the reference fills its hash table
+            // (spatial.rs:199-260), voxel by voxel on first touch -- render_tiles lists the voxels each bounce's hits fall in (k_grid_mark) and makes
+            // their rows before the bounce is shaded.  A mesh light of ten thousand triangles is 80 KB per voxel: 21 GB dense, a few hundred MB for
+            // the voxels a frame actually visits.
+            size_t dense_max = (size_t)2 << 30;
+            if (const char* e = std::getenv("PBRTGPU_LIGHT_GRID_DENSE_MAX")) dense_max = std::strtoull(e, nullptr, 10);
+            ctx->grid_lazy = bytes > dense_max;
+            ctx->grid_nvox = nvox;
+            if (!ctx->grid_lazy) {
+                PT_HIP(ctx->d_grid.alloc(bytes + 64));
+                g.data = ctx->d_grid.as<float>();
+                PT_HIP(ptk_light_grid(ctx->stream, sc, ctx->d_grid.as<float>(), (uint32_t)nvox));
+                PT_HIP(hipStreamSynchronize(ctx->stream));
+            } else {
+                const size_t row_bytes = (size_t)g.stride * sizeof(float);
+                ctx->grid_rows_cap = std::min<size_t>(nvox, std::max<size_t>(256, ((size_t)256 << 20) / row_bytes));
+                ctx->grid_rows_used = 0;
+                PT_HIP(ctx->d_grid.alloc(ctx->grid_rows_cap * row_bytes + 64));
+                PT_HIP(ctx->d_grid_rows.alloc(nvox * 4));
+                PT_HIP(ctx->d_grid_todo.alloc(nvox * 4 + 64));          // the voxel list, then its counter
+                PT_HIP(hipMemsetAsync(ctx->d_grid_rows.p, 0xff, nvox * 4, ctx->stream));
+                PT_HIP(hipMemsetAsync(ctx->d_grid_todo.as<uint32_t>() + nvox, 0, 64, ctx->stream));
+                g.data = ctx->d_grid.as<float>();
+                g.row_of = ctx->d_grid_rows.as<int32_t>();
+            }
         } else {
             // uniform / power: one Distribution1D (lightdistrib/uniform.rs, power.rs:9-17)
             g.voxels[0] = g.voxels[1] = g.voxels[2] = 1;
@@ -1334,6 +1360,41 @@ pt_status pt_film_clear(pt_context* ctx) {
 }
 
 // Renders the listed tiles; radiance_out (device, optional) receives per-sample radiance.
+// The lazily filled light grid, before a bounce is shaded: the voxels this bounce's hits fall in and nobody has asked for yet get their rows.
+// One counter read-back per bounce (scenes with thousands of lights only: the dense grid needs none of this).
+static pt_status fill_light_grid(pt_context* ctx, const PtQueues& Q) {
+    PtScene& sc = ctx->sc;
+    uint32_t* todo = ctx->d_grid_todo.as<uint32_t>();
+    uint32_t* todo_count = todo + ctx->grid_nvox;
+    PT_HIP(ptk_grid_mark(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q, ctx->d_grid_rows.as<int32_t>(), todo, todo_count));
+    uint32_t n = 0;
+    PT_HIP(hipMemcpyAsync(&n, todo_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(hipStreamSynchronize(ctx->stream));
+    if (n == 0) return PT_OK;
+    const size_t row_bytes = (size_t)sc.grid.stride * sizeof(float);
+    if (ctx->grid_rows_used + n > ctx->grid_rows_cap) {          // grow the row store (doubling, never past one row per voxel) and move the rows made so far
+        size_t cap = ctx->grid_rows_cap;
+        while (cap < ctx->grid_rows_used + n) cap *= 2;
+        cap = std::min(cap, ctx->grid_nvox);
+        void* bigger = nullptr;
+        if (hipMalloc(&bigger, cap * row_bytes + 64) != hipSuccess)
+            return ctx->fail(PT_ERR_DEVICE, "light grid: no memory for the tables of the voxels this frame visits (" + std::to_string(cap * row_bytes >> 20) + " MiB)");
+        PT_HIP(hipMemcpyAsync(bigger, ctx->d_grid.p, ctx->grid_rows_used * row_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        PT_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->d_grid.release();
+        ctx->d_grid.p = bigger; ctx->d_grid.bytes = cap * row_bytes + 64;
+        ctx->grid_rows_cap = cap;
+        sc.grid.data = ctx->d_grid.as<float>();
+    }
+    float* rows = ctx->d_grid.as<float>() + ctx->grid_rows_used * (size_t)sc.grid.stride;
+    PT_HIP(ptk_light_grid(ctx->stream, sc, rows, n, todo));
+    PT_HIP(ptk_grid_assign(ctx->stream, ctx->d_grid_rows.as<int32_t>(), todo, n, (uint32_t)ctx->grid_rows_used, todo_count));
+    ctx->grid_rows_used += n;
+    if (std::getenv("PBRTGPU_BUILD_TRACE")) std::fprintf(stderr, "[light grid] %u voxels filled on first touch (%zu of %zu so far, %zu MiB of rows)\n", n, ctx->grid_rows_used, ctx->grid_nvox,
+                                                         ctx->grid_rows_used * row_bytes >> 20);
+    return PT_OK;
+}
+
 static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_tiles, float* d_radiance_out) {
     const PtScene& sc = ctx->sc;
     const int32_t* sbnd = sc.film.sample_bounds;
@@ -1667,7 +1728,11 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                     PT_HIP(ptk_nee_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q));
                     ctx->trace_launches++;
                     PT_HIP(ptk_prep(ctx->stream, Q, 0));
-                    PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, sc, ctx->paths, Q, cnt, ctx->nee_split));
+                    if (ctx->grid_lazy) {
+                        const pt_status gs = fill_light_grid(ctx, Q);
+                        if (gs != PT_OK) return gs;
+                    }
+                    PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, ctx->sc, ctx->paths, Q, cnt, ctx->nee_split));
                     PT_HIP(ptk_prep(ctx->stream, Q, 1));
                     {
                         const pt_status ss = sort_shadow();

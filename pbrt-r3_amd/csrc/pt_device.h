@@ -229,6 +229,9 @@ struct PtLightGrid {
     uint32_t stride;
     uint32_t single;             // 1: uniform / power strategy, one table for every point
     float wb_min[3], wb_max[3];
+    // Lazy fill (scenes whose dense grid would not fit: thousands of lights): row_of[voxel] = the row of `data` that holds the voxel's tables, or
+    // a negative number while nobody has asked for it (spatial.rs:199-260 fills on first touch as well).  nullptr: dense, row = voxel.
+    const int32_t* row_of;
 };
 
 struct PtCounters {

@@ -19,7 +19,9 @@ hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& 
 hipError_t ptk_film_xyzw(hipStream_t st, const float4* own, const float4* spill, float4* xyzw, uint32_t n);
 hipError_t ptk_film_add(hipStream_t st, float4* xyzw, const float4* other, uint32_t n);
 hipError_t ptk_film_rgb(hipStream_t st, const float4* xyzw, float* rgb, uint32_t n, float scale);
-hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32_t n_vox);
+hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32_t n_vox, const uint32_t* vox_list = nullptr);
+hipError_t ptk_grid_mark(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, int32_t* row_of, uint32_t* todo, uint32_t* todo_count);
+hipError_t ptk_grid_assign(hipStream_t st, int32_t* row_of, const uint32_t* todo, uint32_t n, uint32_t row0, uint32_t* todo_count);
 hipError_t ptk_camera_rays(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* o, float* d,
                            float* pf);
 hipError_t ptk_bsdf_eval(hipStream_t st, const PtScene& sc, uint32_t material, uint32_t n, const float* wo, const float* wi, uint32_t flags, float* f,

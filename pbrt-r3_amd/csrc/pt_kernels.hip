@@ -2043,6 +2043,7 @@ PT_DEV const float* grid_lookup(const PtLightGrid& g, V3 p) {
         pi[i] = v;
     }
     size_t vox = ((size_t)pi[2] * g.voxels[1] + pi[1]) * g.voxels[0] + pi[0];
+    if (g.row_of) vox = (size_t)(uint32_t)g.row_of[vox];          // lazily filled grid: k_grid_mark + k_light_grid_rows have made the row before this bounce is shaded
     return g.data + vox * g.stride;
 }
 PT_DEV uint32_t sample_discrete(const float* tab, uint32_t n, float u, float* pdf) {
@@ -3061,8 +3062,10 @@ PT_DEV void light_grid_voxel(const PtLightGrid& g, uint32_t v, V3* vmin, V3* vma
     *vmax = mk3(a.x >= b.x ? a.x : b.x, a.y >= b.y ? a.y : b.y, a.z >= b.z ? a.z : b.z);
 }
 constexpr int kGridBatch = 64;            // (voxel, light) pairs a workgroup takes at a time
+// vox_list: the voxels whose tables rows 0 .. n_vox-1 of `data` receive (the lazily filled grid: the voxels a bounce has touched for the first time);
+// nullptr: row k is voxel k (the dense grid, filled at upload).
 template <bool SPH>
-PT_DEV void light_grid_sums(const PtScene& sc, float* data, uint32_t n_vox) {
+PT_DEV void light_grid_sums(const PtScene& sc, float* data, uint32_t n_vox, const uint32_t* vox_list) {
     __shared__ float s_term[kGridBatch][129];
     __shared__ float s_box[kGridBatch][6];
     const PtLightGrid& g = sc.grid;
@@ -3076,7 +3079,8 @@ PT_DEV void light_grid_sums(const PtScene& sc, float* data, uint32_t n_vox) {
         // skipped addition does (the sum starts at +0 and no addition of these terms can make it -0).
         if (i < (uint32_t)kGridBatch && batch * kGridBatch + i < n_jobs) {          // the voxel of pair i, once
             V3 vmin, vmax;
-            light_grid_voxel(g, (uint32_t)((batch * kGridBatch + i) / nl), &vmin, &vmax);
+            const uint32_t row = (uint32_t)((batch * kGridBatch + i) / nl);
+            light_grid_voxel(g, vox_list ? vox_list[row] : row, &vmin, &vmax);
             s_box[i][0] = vmin.x; s_box[i][1] = vmin.y; s_box[i][2] = vmin.z; s_box[i][3] = vmax.x; s_box[i][4] = vmax.y; s_box[i][5] = vmax.z;
         }
         __syncthreads();
@@ -3123,8 +3127,58 @@ PT_DEV void light_grid_cdf(const PtScene& sc, float* data, uint32_t n_vox) {
         cdf[nl + 1] = func_int;
     }
 }
-extern "C" __global__ __launch_bounds__(128) void k_light_grid(PtScene sc, float* data, uint32_t n_vox) { light_grid_sums<false>(sc, data, n_vox); }
-extern "C" __global__ __launch_bounds__(128) void k_light_grid_sph(PtScene sc, float* data, uint32_t n_vox) { light_grid_sums<true>(sc, data, n_vox); }
+extern "C" __global__ __launch_bounds__(128) void k_light_grid(PtScene sc, float* data, uint32_t n_vox, const uint32_t* vox_list) { light_grid_sums<false>(sc, data, n_vox, vox_list); }
+extern "C" __global__ __launch_bounds__(128) void k_light_grid_sph(PtScene sc, float* data, uint32_t n_vox, const uint32_t* vox_list) { light_grid_sums<true>(sc, data, n_vox, vox_list); }
+// ---- the lazily filled grid (PtLightGrid::row_of; SpatialLightDistribution::lookup, spatial.rs:199-260, fills a voxel on its first touch).
+// Before a bounce is shaded, k_grid_mark rebuilds every hit of the bounce's queue exactly as the shading kernels will (same interaction point,
+// same voxel arithmetic) and lists the voxels nobody has asked for yet; the host gives them rows, k_light_grid fills those, k_grid_assign
+// publishes them.  A voxel's tables depend on the voxel alone, so filling more voxels than the shading ends up reading changes nothing.
+PT_DEV uint32_t grid_voxel_of(const PtLightGrid& g, V3 p) {
+    uint32_t pi[3];
+    float pc[3] = {p.x, p.y, p.z};
+    for (int i = 0; i < 3; i++) {
+        float o = pc[i] - g.wb_min[i];
+        if (g.wb_max[i] > g.wb_min[i]) o = o / (g.wb_max[i] - g.wb_min[i]);
+        o = clampf(o, 0.0f, 1.0f);
+        float f = o * (float)g.voxels[i];
+        uint32_t v = f > 0.0f ? (uint32_t)f : 0u;
+        if (v > g.voxels[i] - 1) v = g.voxels[i] - 1;
+        pi[i] = v;
+    }
+    return (pi[2] * g.voxels[1] + pi[1]) * g.voxels[0] + pi[0];
+}
+template <bool SPH, bool INST>
+PT_DEV void grid_mark_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, int32_t* row_of, uint32_t* todo, uint32_t* todo_count) {
+    const uint32_t n = Q.counts[PT_Q_CUR];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = Q.cur[i];
+        const int32_t rec = P.hit_rec[p];
+        if (rec < 0) continue;
+        const V3 ro = f4_3(P.ray_o[p]), rd = f4_3(P.ray_d[p]);
+        Surf s;
+        float thit;
+        bool found;
+        if constexpr (INST) found = make_surf_inst<SPH>(sc, ro, rd, (uint32_t)rec, P.hit_inst[p], s, &thit);
+        else found = make_surf_any<SPH>(sc, ro, rd, (uint32_t)rec, s, &thit);
+        if (!found) continue;
+        const uint32_t vox = grid_voxel_of(sc.grid, s.p);
+        if (row_of[vox] == -1 && atomicCAS(&row_of[vox], -1, -2) == -1) todo[atomicAdd(todo_count, 1u)] = vox;      // -2: listed, row pending
+    }
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_grid_mark(PtScene sc, PtPaths P, PtQueues Q, int32_t* row_of, uint32_t* todo, uint32_t* todo_count) {
+    grid_mark_body<false, false>(sc, P, Q, row_of, todo, todo_count);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_grid_mark_sph(PtScene sc, PtPaths P, PtQueues Q, int32_t* row_of, uint32_t* todo, uint32_t* todo_count) {
+    grid_mark_body<true, false>(sc, P, Q, row_of, todo, todo_count);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_grid_mark_inst(PtScene sc, PtPaths P, PtQueues Q, int32_t* row_of, uint32_t* todo, uint32_t* todo_count) {
+    grid_mark_body<true, true>(sc, P, Q, row_of, todo, todo_count);
+}
+extern "C" __global__ void k_grid_assign(int32_t* row_of, const uint32_t* todo, uint32_t n, uint32_t row0, uint32_t* todo_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) row_of[todo[i]] = (int32_t)(row0 + i);
+    if (i == 0) *todo_count = 0;
+}
 extern "C" __global__ void k_light_grid_cdf(PtScene sc, float* data, uint32_t n_vox) { light_grid_cdf(sc, data, n_vox); }
 
 // ============================================================ hooks: sampler / camera
@@ -3996,14 +4050,24 @@ hipError_t ptk_film_rgb(hipStream_t st, const float4* xyzw, float* rgb, uint32_t
     hipLaunchKernelGGL(k_film_rgb, dim3(1024), dim3(PT_BLOCK), 0, st, xyzw, rgb, n, scale);
     return PT_LAUNCH_CHECK();
 }
-hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32_t n_vox) {
+hipError_t ptk_light_grid(hipStream_t st, const PtScene& sc, float* data, uint32_t n_vox, const uint32_t* vox_list) {
     const uint64_t jobs = (uint64_t)n_vox * sc.grid.n_lights;
     if (jobs == 0) return hipSuccess;
     const uint64_t batches = (jobs + 63) / 64;          // kGridBatch pairs each
     const uint32_t grid = (uint32_t)(batches < 2048u ? batches : 2048u);
-    if (sc.n_spheres) hipLaunchKernelGGL(k_light_grid_sph, dim3(grid), dim3(128), 0, st, sc, data, n_vox);
-    else hipLaunchKernelGGL(k_light_grid, dim3(grid), dim3(128), 0, st, sc, data, n_vox);
+    if (sc.n_spheres) hipLaunchKernelGGL(k_light_grid_sph, dim3(grid), dim3(128), 0, st, sc, data, n_vox, vox_list);
+    else hipLaunchKernelGGL(k_light_grid, dim3(grid), dim3(128), 0, st, sc, data, n_vox, vox_list);
     hipLaunchKernelGGL(k_light_grid_cdf, dim3((n_vox + 63) / 64), dim3(64), 0, st, sc, data, n_vox);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_grid_mark(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, int32_t* row_of, uint32_t* todo, uint32_t* todo_count) {
+    if (sc.n_instances) hipLaunchKernelGGL(k_grid_mark_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, row_of, todo, todo_count);
+    else if (sc.n_spheres) hipLaunchKernelGGL(k_grid_mark_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, row_of, todo, todo_count);
+    else hipLaunchKernelGGL(k_grid_mark, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, row_of, todo, todo_count);
+    return PT_LAUNCH_CHECK();
+}
+hipError_t ptk_grid_assign(hipStream_t st, int32_t* row_of, const uint32_t* todo, uint32_t n, uint32_t row0, uint32_t* todo_count) {
+    hipLaunchKernelGGL(k_grid_assign, dim3((n + 255u) / 256u), dim3(256), 0, st, row_of, todo, n, row0, todo_count);
     return PT_LAUNCH_CHECK();
 }
 hipError_t ptk_camera_rays(hipStream_t st, const PtScene& sc, uint32_t n, const int32_t* pixel_xy, const uint32_t* sample_index, float* o, float* d,

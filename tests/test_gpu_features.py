@@ -539,6 +539,67 @@ def test_crown_class_3p5m_triangles(gpu_ctx, oracle, split):
     osc.close()
 
 
+def _mesh_light_scene(n_side=32, res=12, spp=1, depth=2):
+    """A room lit by ONE emissive mesh of 2 n_side^2 triangles -- 2 048 lights: the dense 64^3 light grid would be 4.3 GB of tables."""
+    b = fs.base(res=res, spp=spp, depth=depth)
+    b.integrator_path(maxdepth=depth, lightsamplestrategy="spatial")
+    fs.room(b)
+    b.material_matte((0.5, 0.5, 0.5))
+    b.area_light_source_diffuse(L=(3, 3, 2.5))
+    xs = np.linspace(-1.5, 1.5, n_side + 1, dtype=np.float32)
+    P = [(float(x), 1.9, float(z)) for z in xs for x in xs]
+    idx = []
+    for j in range(n_side):
+        for i in range(n_side):
+            a = j * (n_side + 1) + i
+            idx += [a, a + 1, a + n_side + 2, a, a + n_side + 2, a + n_side + 1]
+    b.shape_trianglemesh(P, idx)
+    b.no_area_light()
+    return b.build()
+
+
+@pytest.mark.parametrize("name,make", [("cornell", lambda: scenes.cornell_box(res=48, spp=8)), ("materials", lambda: fs.scene_materials_lights("spatial")),
+                                       ("spheres", lambda: fs.scene_spheres("spatial")), ("instances", lambda: fs.scene_instances())])
+def test_lazy_light_grid_is_the_dense_grid(oracle, monkeypatch, name, make):
+    """The light grid filled voxel by voxel on first touch, as the reference fills its hash table (spatial.rs:199-260) -- what scenes with
+    thousands of lights get instead of the dense grid -- forced on for small scenes (PBRTGPU_LIGHT_GRID_DENSE_MAX=0): per-sample radiance, film
+    and every counter are still the oracle's, bit for bit (a voxel's tables depend on the voxel alone)."""
+    monkeypatch.setenv("PBRTGPU_LIGHT_GRID_DENSE_MAX", "0")
+    sd = make()
+    ctx = pkg.Context(0)
+    try:
+        ctx.upload(sd)
+        osc = oracle.scene(sd)
+        _compare(ctx, osc, exact_film=True)
+        osc.close()
+    finally:
+        ctx.close()
+
+
+def test_mesh_light_of_two_thousand_triangles_uses_the_lazy_grid(oracle):
+    """2 048 emissive triangles: the dense grid (64 x 64 x 64 voxels x 16 KB) would be 4.3 GB and is not made; rows appear for the voxels the
+    frame's hits fall in.  Per-sample radiance of the whole (small) film bit-identical to the oracle, counters equal."""
+    sd = _mesh_light_scene()
+    ctx = pkg.Context(0)
+    try:
+        info = ctx.upload(sd)
+        assert info.n_lights == 2050          # the mesh + the room's own quad
+        osc = oracle.scene(sd)
+        sb = list(info.sample_bounds)
+        tile = (sb[0], sb[1], sb[2], sb[3])
+        g, r = ctx.radiance_samples(tile), osc.radiance_samples(tile)
+        assert r.sum() > 0 and np.array_equal(bits(g), bits(r))
+        ctx.film_clear(); ctx.reset_counters(); ctx.render()
+        gc = ctx.counters()
+        ox, oc, _ = osc.render(threads=8)
+        for k in ("camera_rays", "regular_rays", "shadow_rays", "nodes_visited", "tris_tested", "path_vertices"):
+            assert gc[k] == oc[k], (k, gc[k], oc[k])
+        assert rel_l2(ctx.film_xyzw(), ox) < 1e-6
+        osc.close()
+    finally:
+        ctx.close()
+
+
 def test_crown_class_3p5m_textured_tiles(gpu_ctx, oracle):
     """BASELINE config 5's CONTENT at its scale, not only its size: the 3.5 M-triangle stand-in with the textured material split of the
     crown-class bench line (`bench.py --triangles 3500000 --materials textured`: image-mapped Matte under a bump map, a checkerboard-driven
