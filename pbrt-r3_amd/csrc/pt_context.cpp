@@ -99,6 +99,7 @@ struct pt_context {
     int nee_split = 0;                                 // PBRTGPU_NEE_SPLIT: kernel families that shade a vertex in two kernels (ptk_shade)
     int sort_cont = -1;                                // continuation rays of a bounce ordered like the shadow rays: 0 never, 1 for the traversal kernel only
                                                        // (shading keeps path order), 2 for both, -1 (default): mode 1 for scenes larger than the Infinity Cache
+    int sort_cont_min = 1 << 20;                       // ... and the continuation rays (when sort_cont is on) from this many up: its own threshold (PBRTGPU_SORT_CONT_MIN)
     int sort_shadow_min = 1 << 20;                     // shadow rays of a launch are ordered by origin cell from this many up (0: never)
     DevBuf d_rec, d_counts2; // recursive integrators (directlighting, whitted): frames, differentials, next-event entries and lists; the second counter block
     size_t rec_paths = 0;
@@ -253,6 +254,7 @@ pt_status pt_context_create(int device, pt_context** out) {
     ctx->grid_shade = ctx->n_cu * 2;
     if (const char* e = std::getenv("PBRTGPU_SHADE_BLOCKS_PER_CU")) ctx->grid_shade = ctx->n_cu * std::max(1, std::atoi(e));
     if (const char* e = std::getenv("PBRTGPU_SORT_SHADOW_MIN")) ctx->sort_shadow_min = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("PBRTGPU_SORT_CONT_MIN")) ctx->sort_cont_min = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("PBRTGPU_SORT_CONT")) ctx->sort_cont = std::min(2, std::max(-1, std::atoi(e)));
     ctx->nee_split = ptk_nee_split_default();
     if (const char* e = std::getenv("PBRTGPU_NEE_SPLIT")) ctx->nee_split = std::atoi(e);
@@ -1691,10 +1693,11 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 auto sort_shadow = [&]() -> pt_status {
                     if (!Q.shadow_key && !sort_cont) return PT_OK;
                     uint32_t qc[PT_Q_SHADOW + 1];             // one read-back: the next bounce's continuation rays (prep has moved next to cur) and its shadow rays
-                    PT_HIP(hipMemcpyAsync(qc, Q.counts, sizeof(qc), hipMemcpyDeviceToHost, ctx->stream));
+                    qc[PT_Q_SHADOW] = 0;
+                    PT_HIP(hipMemcpyAsync(qc, Q.counts, Q.shadow_key ? sizeof(qc) : 4 * (PT_Q_CUR + 1u), hipMemcpyDeviceToHost, ctx->stream));      // (the shadow list unsorted: the first word alone)
                     PT_HIP(hipStreamSynchronize(ctx->stream));
                     const uint32_t n_sh = qc[PT_Q_SHADOW], n_next = qc[PT_Q_CUR];
-                    if (sort_cont && n_next >= (uint32_t)std::max(ctx->sort_shadow_min, 1)) {
+                    if (sort_cont && n_next >= (uint32_t)ctx->sort_cont_min) {
                         // Q.next holds the list k_shade has just written: its rays' keys, then the ordered copy into the spare list
                         PT_HIP(ptk_cont_keys(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q.next, n_next, ctx->d_csort_keys[0].as<uint32_t>()));
                         PT_HIP(ptk_sort_rays_keep(ctx->stream, Q.next, cont_spare, ctx->d_csort_keys[0].as<uint32_t>(), ctx->d_csort_keys[1].as<uint32_t>(),

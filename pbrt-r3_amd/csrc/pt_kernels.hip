@@ -141,7 +141,7 @@ PT_DEV float halton_sample_dimension(const PtSobol& sb, uint64_t index, uint32_t
     }
     // The reference panics here (PRIME_SUMS holds 1000 entries, halton.rs:103-108).  The launch finishes on the last dimension; the condition
     // itself is caught where a sampler's dimension count is written back (k_rec_enter / k_rec_next: PtRec::panic) and, for the path
-    // integrator -- 5 + 8 dimensions per vertex --, by the upload refusing maxdepth > 123 under this sampler: a check in here costs every
+    // integrator -- 5 + 8 dimensions per vertex --, by the upload refusing maxdepth > 124 under this sampler (5 + 8 x 124 - 4 = 993 < 1000; 125 reaches 1001): a check in here costs every
     // shading kernel two or three registers at its tightest point (k_shade_general went from 256 to 258 and lost its second wave).
     if (dim >= sb.h_n_dims) dim = sb.h_n_dims - 1;
     uint4 e = sb.h_dims[dim];

@@ -676,6 +676,8 @@ __global__ __launch_bounds__(256) void k_sc_light_recs(const uint32_t* __restric
 // Device scratch for one build.  The blocks come out of an arena the calling thread keeps per device (one hipMalloc, reused by every
 // later build: the 14 hipMalloc / hipFree pairs cost 7 ms per build, more than the build's kernels); what does not fit -- the first
 // build, or a bigger scene -- is allocated the slow way and the arena is regrown to the high-water mark afterwards.
+constexpr size_t kArenaKeepBytes = (size_t)1 << 30;          // device scratch a thread keeps between builds
+constexpr size_t kStagingKeepBytes = (size_t)256 << 20;      // page-locked staging a thread keeps between uploads
 struct ScratchArena {
     char* base = nullptr;
     size_t cap = 0, used = 0, wanted = 0;
@@ -690,14 +692,17 @@ struct ScratchArena {
     }
     // a first build knows roughly what it will ask for: one block now instead of two dozen separate allocations (0.3-0.5 ms each)
     void reserve(size_t bytes) {
-        if (used != 0 || cap >= bytes || bytes > ((size_t)4 << 30)) return;
+        if (used != 0 || cap >= bytes || bytes > kArenaKeepBytes) return;
         if (base) (void)hipFree(base);
         base = nullptr; cap = 0;
         void* q = nullptr;
         if (hipMalloc(&q, bytes) == hipSuccess) { base = (char*)q; cap = bytes; }
     }
     void end() {                                                   // every block handed out has been returned (Scratch destructors ran)
-        if (wanted > cap && wanted <= ((size_t)4 << 30)) {
+        // kept between uploads while it is small: a 16 M-triangle build leaves ~3 GB here, which no later 1 M-triangle rebuild needs (the arena is a
+        // 7 ms saving per build, not worth gigabytes of an idle thread's device memory)
+        if (cap > kArenaKeepBytes && wanted <= kArenaKeepBytes) { (void)hipFree(base); base = nullptr; cap = 0; }
+        if (wanted > cap && wanted <= kArenaKeepBytes) {
             if (base) (void)hipFree(base);
             base = nullptr; cap = 0;
             void* q = nullptr;
@@ -728,6 +733,10 @@ static float* scene_staging(size_t bytes) {
         ~Holder() { if (buf && getpid() != (pid_t)syscall(SYS_gettid)) (void)hipHostFree(buf); }
     };
     static thread_local Holder h;
+    if (bytes == 0) {                          // trim request (after an upload): a big scene's staging does not stay pinned for the thread's life
+        if (h.cap > kStagingKeepBytes) { (void)hipHostFree(h.buf); h.buf = nullptr; h.cap = 0; }
+        return nullptr;
+    }
     if (bytes > h.cap) {
         if (h.buf) (void)hipHostFree(h.buf);
         h.buf = nullptr; h.cap = 0;
@@ -935,6 +944,7 @@ static int sah_build(hipStream_t st, const float* raw_bounds, uint32_t n, uint32
         for (size_t l = 0; l + 1 < level_begin.size(); l++) lv.push_back({level_begin[l], level_begin[l + 1] - level_begin[l]});
         const int frc = finish_scene(st, d_export.as<LbvhNode>(), n_nodes, 0u, lv, nullptr, d_order.as<uint32_t>(), d_P.as<float>(), d_idx.as<uint32_t>(), d_tmesh.as<uint32_t>(),
                                      d_mtab.as<uint32_t>(), scene->n_meshes, n, sout, err, d_sph.as<uint32_t>(), scene->n_spheres);
+        (void)scene_staging(0);
         if (trace && frc == 0) std::fprintf(stderr, "[bvh] device scene (sah): %u items, %u binary nodes in %zu levels -> %u 4-wide nodes (top %u renumbered), %u leaves: setup %.2f levels %.2f records + collapse %.2f ms\n", n,
                                             n_nodes, lv.size(), sout->n_nodes4, sout->n_top, sout->n_leaves, t1 - t0, t2 - t1, now() - t2);
         return frc;
@@ -1023,6 +1033,7 @@ int device_hlbvh_scene(hipStream_t st, const SceneIn& in, uint32_t max_prims, Sc
     const double t2 = now();
     const int frc = finish_scene(st, d_bn.as<LbvhNode>(), total, root, levels, d_list.as<uint32_t>(), d_order.as<uint32_t>(), d_P.as<float>(), d_idx.as<uint32_t>(), d_tmesh.as<uint32_t>(),
                                  d_mtab.as<uint32_t>(), in.n_meshes, n, out, err, d_sph.as<uint32_t>(), in.n_spheres);
+    (void)scene_staging(0);
     if (trace && frc == 0) std::fprintf(stderr, "[bvh] device scene (hlbvh): %u items, %u + %u binary nodes in %zu levels -> %u 4-wide nodes (top %u renumbered), %u leaves: upload + lower half %.2f upper + levels %.2f records + collapse %.2f ms\n",
                                         n, n_nodes, n_upper, levels.size(), out->n_nodes4, out->n_top, out->n_leaves, t1 - t0, t2 - t1, now() - t2);
     return frc;
