@@ -96,6 +96,10 @@ struct pt_context {
     size_t grid_rows_used = 0, grid_rows_cap = 0, grid_nvox = 0;
     bool grid_lazy = false;
     uint32_t* h_live = nullptr;                        // page-locked: the recursive integrators' live-sample count, read one level behind
+    // k_trace_far (pushed leaves touched: scenes whose rays miss the caches): PBRTGPU_TRACE_FAR 0 never, 1 always, default -1 = decided per scene by
+    // a timed trial on the scene's own rays -- the first incoherent bounce after an upload is traced twice, once by each kernel
+    int trace_far = -1, trace_far_choice = -1;
+    DevBuf d_cnt_save;
     int nee_split = 0;                                 // PBRTGPU_NEE_SPLIT: kernel families that shade a vertex in two kernels (ptk_shade)
     int sort_cont = -1;                                // continuation rays of a bounce ordered like the shadow rays: 0 never, 1 for the traversal kernel only
                                                        // (shading keeps path order), 2 for both, -1 (default): mode 1 for scenes larger than the Infinity Cache
@@ -250,12 +254,16 @@ pt_status pt_context_create(int device, pt_context** out) {
     // occupancy-sized persistent grids: blocks per CU from register/LDS use x CU count
     ctx->grid_trace = ctx->n_cu * 4;
     ctx->grid_trace_dist = ctx->n_cu * ptk_trace_dist_blocks_per_cu();
-    if (const char* e = std::getenv("PBRTGPU_TRACE_BLOCKS_PER_CU")) ctx->grid_trace = ctx->grid_trace_dist = ctx->n_cu * std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("PBRTGPU_TRACE_BLOCKS_PER_CU")) {
+        ctx->grid_trace = ctx->n_cu * std::max(1, std::atoi(e));
+        if (!ptk_trace_wide()) ctx->grid_trace_dist = ctx->grid_trace;          // (a PT_TRACE_WIDE build runs one 1024-thread block per CU: sixteen waves, all a CU holds)
+    }
     ctx->grid_shade = ctx->n_cu * 2;
     if (const char* e = std::getenv("PBRTGPU_SHADE_BLOCKS_PER_CU")) ctx->grid_shade = ctx->n_cu * std::max(1, std::atoi(e));
     if (const char* e = std::getenv("PBRTGPU_SORT_SHADOW_MIN")) ctx->sort_shadow_min = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("PBRTGPU_SORT_CONT_MIN")) ctx->sort_cont_min = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("PBRTGPU_SORT_CONT")) ctx->sort_cont = std::min(2, std::max(-1, std::atoi(e)));
+    if (const char* e = std::getenv("PBRTGPU_TRACE_FAR")) ctx->trace_far = std::atoi(e);
     ctx->nee_split = ptk_nee_split_default();
     if (const char* e = std::getenv("PBRTGPU_NEE_SPLIT")) ctx->nee_split = std::atoi(e);
     ctx->grid_wide = ctx->n_cu * 8;
@@ -1229,6 +1237,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     int strategy = d->light_strategy;
     if (strategy == PT_LIGHTS_UNIFORM && sc.n_lights != 1) strategy = PT_LIGHTS_SPATIAL;
     ctx->grid_lazy = false;
+    ctx->trace_far_choice = -1;          // a new scene: the trial runs again
     if (sc.n_lights > 0) {
         if (strategy == PT_LIGHTS_SPATIAL) {
             const uint32_t max_voxels = 64;
@@ -1681,13 +1690,44 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 uint32_t* shadow_sorted = nullptr;          // the ordered shadow list for the next traversal launch, if one was made
                 uint32_t* cont_sorted = nullptr;            // the ordered copy of cur for the next traversal launch (sort_cont == 1)
                 uint32_t* cont_spare = ctx->d_csort_ids.as<uint32_t>();
+                // Which traversal kernel: k_trace_far only pays where rays miss the caches -- 16 M sparse triangles +17 %, but a 16 M-triangle scene whose
+                // rays end early -12 %, 3.5 M triangles -7 % -- and neither the scene's size nor its depth tells the two apart.  So a scene larger than
+                // the Infinity Cache decides by trial: its first incoherent bounce after an upload (bounce 1 of the first pass: the largest one) is
+                // traced twice, by each kernel, on the same lists; results are identical (the second launch rewrites them), the counters are put back.
+                const char* far_min_env = std::getenv("PBRTGPU_TRACE_FAR_MIN_BYTES");          // (tests: the trial on small scenes)
+                const size_t far_min_bytes = far_min_env ? (size_t)std::strtoull(far_min_env, nullptr, 10) : ((size_t)256 << 20);
+                const bool far_able = ptk_trace_has_far(sc) && ctx->n_nodes_up * sizeof(PtNode) + ctx->n_tris_up * sizeof(PtTri) > far_min_bytes;
+                if (ctx->trace_far >= 0 || !far_able) ctx->trace_far_choice = (ctx->trace_far > 0 && ptk_trace_has_far(sc)) ? 1 : 0;
+                int bounce_i = 0;
+                PtQueues Q_last_trace = Q;
                 auto trace = [&]() -> hipError_t {
                     PtQueues Qt = Q;
                     if (shadow_sorted) Qt.shadow = shadow_sorted;
                     shadow_sorted = nullptr;
                     if (cont_sorted) Qt.cur = cont_sorted;
                     cont_sorted = nullptr;
-                    return ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Qt, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err);
+                    Q_last_trace = Qt;
+                    return ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Qt, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err,
+                                     ctx->trace_far_choice > 0 ? 1 : 0);
+                };
+                auto far_trial = [&](hipEvent_t near_a, hipEvent_t near_b) -> pt_status {      // right after bounce 1's launch by k_trace (timed by near_a .. near_b)
+                    hipEvent_t fa = get_event(ctx, ev_i), fb = get_event(ctx, ev_i + 1);
+                    if (!fa || !fb) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
+                    ev_i += 2;
+                    if (!ctx->d_cnt_save.p) PT_HIP(ctx->d_cnt_save.alloc(sizeof(PtCounters)));
+                    PT_HIP(hipMemcpyAsync(ctx->d_cnt_save.p, cnt, sizeof(PtCounters), hipMemcpyDeviceToDevice, ctx->stream));
+                    PT_HIP(hipMemsetAsync(Q.counts + PT_Q_SEG_TICKET0, 0, 8u * 32u * 4u, ctx->stream));          // the launch's work tickets
+                    PT_HIP(hipEventRecord(fa, ctx->stream));
+                    PT_HIP(ptk_trace(ctx->stream, ctx->grid_trace, ctx->grid_trace_dist, sc, ctx->paths, Q_last_trace, cnt, ctx->d_spill.as<uint32_t>(), ctx->spill_depth, err, 1));
+                    PT_HIP(hipEventRecord(fb, ctx->stream));
+                    PT_HIP(hipMemcpyAsync(cnt, ctx->d_cnt_save.p, sizeof(PtCounters), hipMemcpyDeviceToDevice, ctx->stream));
+                    PT_HIP(hipStreamSynchronize(ctx->stream));
+                    float near_ms = 0, far_ms = 0;
+                    PT_HIP(hipEventElapsedTime(&near_ms, near_a, near_b));
+                    PT_HIP(hipEventElapsedTime(&far_ms, fa, fb));
+                    ctx->trace_far_choice = far_ms < 0.97f * near_ms ? 1 : 0;          // (a tie stays with the kernel everybody else runs)
+                    if (std::getenv("PBRTGPU_BUILD_TRACE")) std::fprintf(stderr, "[trace] trial on bounce 1: k_trace %.2f ms, k_trace_far %.2f ms -> %s\n", near_ms, far_ms, ctx->trace_far_choice ? "k_trace_far" : "k_trace");
+                    return PT_OK;
                 };
                 // after a bounce's shading: order its shadow rays by where they start (pt_raysort.hip); costs one counter read-back
                 auto sort_shadow = [&]() -> pt_status {
@@ -1726,8 +1766,21 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                         ev_i += 3;
                         PT_HIP(hipEventRecord(a, ctx->stream));
                     }
+                    const bool trial = ctx->trace_far_choice < 0 && bounce_i == 1;
+                    hipEvent_t ta = a, tb = b;
+                    if (trial && !timed) {
+                        ta = get_event(ctx, ev_i); tb = get_event(ctx, ev_i + 1);
+                        if (!ta || !tb) return ctx->fail(PT_ERR_DEVICE, "hipEventCreate failed");
+                        ev_i += 2;
+                        PT_HIP(hipEventRecord(ta, ctx->stream));
+                    }
                     PT_HIP(trace());
-                    if (timed) PT_HIP(hipEventRecord(b, ctx->stream));
+                    if (timed || trial) PT_HIP(hipEventRecord(tb, ctx->stream));
+                    if (trial) {
+                        const pt_status ts = far_trial(ta, tb);
+                        if (ts != PT_OK) return ts;
+                    }
+                    bounce_i++;
                     PT_HIP(ptk_nee_resolve(ctx->stream, ctx->grid_wide, sc, ctx->paths, Q));
                     ctx->trace_launches++;
                     PT_HIP(ptk_prep(ctx->stream, Q, 0));

@@ -10,7 +10,14 @@
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 32          // per-lane traversal stack entries kept in LDS
 #endif
-#define PT_SLOT (PT_BLOCK * 4u)    // bytes between two entries of a lane's LDS traversal stack ([entry][lane] layout)
+// PT_TRACE_WIDE 1: the pooled-leaf traversal kernels (k_trace, k_trace_sph_dist) run as ONE 1024-thread block per CU instead of four 256-thread
+// blocks: same sixteen waves, same registers, but the LDS copy of the top of the tree is shared by all of them -- one copy of 341 nodes
+// (levels 0..4) instead of four copies of 85 (levels 0..3).
+#ifndef PT_TRACE_WIDE
+#define PT_TRACE_WIDE 1
+#endif
+#define PT_TBLOCK (PT_TRACE_WIDE ? 1024 : PT_BLOCK)      // threads per block of the pooled-leaf traversal kernels
+#define PT_SLOT (PT_TBLOCK * 4u)   // bytes between two entries of a lane's LDS traversal stack ([entry][lane] layout; pooled-leaf kernels)
 // PT_NODE_STAGED 1: the pooled-leaf traversal kernels fetch a round's nodes cooperatively through LDS (global_load_lds_dwordx4;
 // a quarter of the L1 requests, but 49 KB of LDS per block = three blocks per CU and a longer round); 0: every lane loads its
 // own node (four blocks per CU).  Measured on RT1M: 0 is the faster one.
@@ -21,7 +28,7 @@
 // of the tree breadth-first, so these are its top levels: 85 = levels 0..3) in LDS, 112 bytes each, and visits to them read LDS instead
 // of going through the vector L1, whose request rate bounds the kernel.  Paid for with 8 of the 32 stack slots.
 #ifndef PT_TOP_NODES
-#define PT_TOP_NODES 85
+#define PT_TOP_NODES (PT_TRACE_WIDE ? 341 : 85)
 #endif
 #ifndef PT_SORT_CELL_BITS
 #define PT_SORT_CELL_BITS 4      // shadow-ray sort key (pt_raysort.hip): bits per axis of the origin's cell; the key is 3 x this + 3 octant bits wide.

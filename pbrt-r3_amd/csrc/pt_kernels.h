@@ -5,7 +5,8 @@
 #include "../../include/pbrtgpu.h"
 
 hipError_t ptk_trace(hipStream_t st, int grid, int grid_dist, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
-                     uint32_t spill_depth, uint32_t* err);
+                     uint32_t spill_depth, uint32_t* err, int far = 0);
+bool ptk_trace_has_far(const PtScene& sc);
 hipError_t ptk_trace_batch(hipStream_t st, int grid, const PtScene& sc, uint32_t n, const float* o, const float* d, const float* tmax, pt_hit* out,
                            uint8_t* occ, int any_hit, uint32_t* ticket, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err);
 hipError_t ptk_gen(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const uint32_t* pixels, uint32_t n_pix,
@@ -14,6 +15,7 @@ hipError_t ptk_nee_resolve(hipStream_t st, int grid, const PtScene& sc, const Pt
 hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode);
 hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, int nee_split);
 int ptk_nee_split_default();
+int ptk_trace_wide();
 hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,
                     float4* own, float4* spill, float* radiance_out, uint32_t s0, uint32_t spp_total);
 hipError_t ptk_film_xyzw(hipStream_t st, const float4* own, const float4* spill, float4* xyzw, uint32_t n);

@@ -30,8 +30,8 @@
 #ifndef PT_SHADE_PF_DEEP
 #define PT_SHADE_PF_DEEP 0       // 1: k_shade's one-iteration-ahead prefetch also covers the ray, the throughput and the leaf record
 #endif
-#ifndef PT_TOUCH_PUSHED
-#define PT_TOUCH_PUSHED 0        // 1: node_step_lean touches the pushed children that are not the next visit (experiment, see there)
+#ifndef PT_TOUCH_VARIANT
+#define PT_TOUCH_VARIANT 3       // k_trace_far: which pushed children node_step_lean touches (see there; 3 = leaves that are not the next visit)
 #endif
 
 // ============================================================ Sobol' sampler
@@ -924,6 +924,7 @@ PT_DEV void node_round_finish(LaneRay& r, TravCtx& c, bool w_node, uint32_t top)
 // The lean visit with per-lane loads (PT_NODE_STAGED == 0): every lane fetches its own node, SGPR base + 32-bit offset with the
 // sign-dependent row offsets hoisted per ray.  Keeps the 32-slot LDS stack and four blocks per CU; bound by the vector L1's
 // request rate (eight requests per lane and visit).
+template <int TOUCH>
 PT_DEV void node_step_lean(const PtScene& sc, LaneRay& r, TravCtx& c) {
     const uint32_t ref = r.top;
     r.sa -= PT_SLOT;
@@ -969,26 +970,36 @@ PT_DEV void node_step_lean(const PtScene& sc, LaneRay& r, TravCtx& c) {
     const unsigned long long y1 = Tm & (el1 ^ er1), e1 = er1 ^ y1, e3 = el1 ^ y1;
     fs_push4_exec(r.sa, top, c0, c1, c2, c3, e0, e1, e2, e3);
     r.top = top;
-#if PT_TOUCH_PUSHED
-    // Experiment (scenes beyond the Infinity Cache): every reference pushed here IS visited later (the reference's stack holds no distances), so
-    // the children that are pushed but are not the next visit -- c0 when anything is pushed after it, c1 when c2 or c3 is, c2 when c3 is -- are
-    // touched now: one 4-byte load of the node's (or the leaf's first record's) first word into a register nobody reads.  Loads return in order,
-    // so the touch is paid for by this lane's NEXT fetch waiting behind it; what it buys is that the miss overlaps that fetch instead of
-    // standing alone in a later round.
-    {
-        const unsigned long long p0 = e0 & (e1 | e2 | e3), p1 = e1 & (e2 | e3), p2 = e2 & e3;
+    if constexpr (TOUCH != 0) {
+        // k_trace_far, for scenes whose rays miss the caches (chosen per scene by a timed trial, pt_context.cpp).  Every reference pushed here IS
+        // visited later -- the reference's stack holds no distances --, so a pushed LEAF that is not the next visit has its first record's line
+        // touched now: one 4-byte load into a register nobody reads.  A leaf round waits for the slowest of up to 64 record fetches, each the
+        // first access to a line of its own; touched at push time the line is on its way (or in L2) when the round comes.  Loads return in
+        // order, so the touch is paid for by this lane's next fetch waiting behind it -- which is why it loses wherever the records hit the
+        // caches anyway (RT1M -20 %, a 3.5 M-triangle scene -7 %) and is not the default.  Measured variants (16 M sparse triangles, 130 node visits
+        // per ray, Mrays/s at 64 spp; TOUCH = the variant number): none 361; 3 not-next leaves 421; 2 not-next interior nodes 356; 1 both 353;
+        // 4 every pushed leaf, the next visit too 352; 5 = 4 + the second line of leaves of three records and more 284.
+        unsigned long long p0, p1, p2, p3 = 0ull;
+        if (TOUCH >= 4) { p0 = e0; p1 = e1; p2 = e2; p3 = e3; }
+        else { p0 = e0 & (e1 | e2 | e3); p1 = e1 & (e2 | e3); p2 = e2 & e3; }
         const unsigned long long me = 1ull << (threadIdx.x & 63u);
         const char* tb = reinterpret_cast<const char*>(sc.tris);
         auto touch = [&](uint32_t cref) {
+            if (TOUCH == 2 && (cref & PT_LEAF_BIT)) return;
+            if (TOUCH >= 3 && !(cref & PT_LEAF_BIT)) return;
             const char* a = (cref & PT_LEAF_BIT) ? tb + (size_t)(cref & PT_LEAF_FIRST_MASK) * 48u : nb + (size_t)(cref << 7);
             uint32_t v = *reinterpret_cast<const uint32_t*>(a);
             asm volatile("" :: "v"(v));
+            if (TOUCH == 5 && ((cref >> PT_LEAF_COUNT_SHIFT) & 7u) >= 2u) {
+                uint32_t w = *reinterpret_cast<const uint32_t*>(a + 128);
+                asm volatile("" :: "v"(w));
+            }
         };
         if (p0 & me) touch(c0);
         if (p1 & me) touch(c1);
         if (p2 & me) touch(c2);
+        if (p3 & me) touch(c3);
     }
-#endif
 }
 
 // intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
@@ -1092,12 +1103,13 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #endif
 // DIST: every leaf holds at most 8 triangles and its reference carries the count, so a leaf phase can pool the
 // triangles of all parked lanes and hand one (ray, triangle) test to each lane of the wave.
-template <bool DIST, bool SPH, bool INST = false>
+template <bool DIST, bool SPH, bool INST = false, int TOUCH = 0>
 PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill, uint32_t spill_depth, uint32_t* err) {
     // LDS per block.  Pooled-leaf kernels: 16 stack slots x 1 KB + 8 KB node staging per wave + node-index exchange = 49 KB, three
     // blocks per CU (RT1M: 99.98 % of node visits find the stack at 13 entries or fewer; deeper lanes spill to HBM); a leaf round's
     // 64 test results and owner map live in the wave's staging area, which a node round of the same wave never uses at the same time.
-    __shared__ uint32_t s_stack[(DIST ? PT_FS_SLOTS : PT_LDS_STACK) * PT_BLOCK];
+    constexpr uint32_t TB = DIST ? PT_TBLOCK : PT_BLOCK;          // threads per block (PT_TRACE_WIDE: the pooled-leaf kernels run 1024)
+    __shared__ uint32_t s_stack[(DIST ? PT_FS_SLOTS : PT_LDS_STACK) * TB];
     __shared__ unsigned long long s_cnt[4];
 #if PT_NODE_STAGED
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[DIST ? (PT_BLOCK / 64) * 8192 : 16];
@@ -1105,8 +1117,8 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     float4* const s_res = reinterpret_cast<float4*>(s_stage + (threadIdx.x >> 6) * 8192u) - (threadIdx.x & ~63u);            // indexed [wbase + k]
     unsigned char* const s_map = reinterpret_cast<unsigned char*>(&s_idx[(threadIdx.x >> 6) * 80u + 64u]) - (threadIdx.x & ~63u);
 #else
-    __shared__ float4 s_res[DIST ? PT_BLOCK : 1];          // per wave: 64 test results (ok, t_scaled, det, t)
-    __shared__ unsigned char s_map[DIST ? PT_BLOCK : 1];   // per wave: work item -> owner lane
+    __shared__ float4 s_res[DIST ? TB : 1];          // per wave: 64 test results (ok, t_scaled, det, t)
+    __shared__ unsigned char s_map[DIST ? TB : 1];   // per wave: work item -> owner lane
 #endif
 #if PT_TOP_NODES > 0 && !PT_NODE_STAGED
     __shared__ float4 s_top[DIST ? PT_TOP_NODES * 7 : 1];      // rows 0..6 (six plane rows, child references) of the first nodes of the tree
@@ -1114,8 +1126,8 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     TravCtx c;
     c.lds = &s_stack[threadIdx.x];
     c.top_lds = 0; c.top_bytes = 0; c.n_nodes_lds = 0;
-    c.spill_stride = gridDim.x * PT_BLOCK;
-    c.spill = spill + PT_DIAG_WORDS + (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;      // the buffer's first PT_DIAG_WORDS words belong to the diagnostic builds
+    c.spill_stride = gridDim.x * TB;
+    c.spill = spill + PT_DIAG_WORDS + (size_t)blockIdx.x * TB + threadIdx.x;      // the buffer's first PT_DIAG_WORDS words belong to the diagnostic builds
     c.spill_depth = spill_depth;
     c.n_nodes = 0; c.n_tris = 0; c.overflow = 0;
     c.lane_base = 0; c.stage_wave = 0; c.stage_own = 0; c.idx_pub = 0; c.idx_ld = 0;
@@ -1134,7 +1146,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     if constexpr (DIST) {
         const uint32_t n_top = min(sc.n_top, (uint32_t)PT_TOP_NODES);
         const float4* src = reinterpret_cast<const float4*>(sc.nodes);
-        for (uint32_t k = threadIdx.x; k < n_top * 7u; k += PT_BLOCK) { const uint32_t nd = k / 7u; s_top[k] = src[nd * 8u + (k - nd * 7u)]; }
+        for (uint32_t k = threadIdx.x; k < n_top * 7u; k += TB) { const uint32_t nd = k / 7u; s_top[k] = src[nd * 8u + (k - nd * 7u)]; }
         c.top_lds = lds_addr_of(reinterpret_cast<const uint32_t*>(s_top));
         c.top_bytes = n_top << 7;
         __syncthreads();
@@ -1425,7 +1437,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #if !PT_NODE_STAGED
             if (lean && m_node != 0 && n_parked < PT_LEAF_TRIS_MIN) {
                 PT_PROF_T(t0);
-                if (w_node) node_step_lean(sc, r, c);
+                if (w_node) node_step_lean<TOUCH>(sc, r, c);
                 PT_PROF_T(t1);
 #ifdef PT_PROFILE_PHASES
                 prof[2] += t1 - t0; prof[3] += 1; prof[4] += (unsigned long long)__popcll(m_node);
@@ -1535,9 +1547,14 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt->nodes_lds, v);
     }
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_DIST_WAVES) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+extern "C" __global__ void __launch_bounds__(PT_TBLOCK, PT_TRACE_DIST_WAVES) k_trace(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                               uint32_t spill_depth, uint32_t* err) {
     trace_body<true, false>(sc, P, Q, cnt, spill, spill_depth, err);
+}
+// the same with pushed leaves touched (node_step_lean<TOUCH>): scenes whose rays miss the caches, chosen per scene by a timed trial (pt_context.cpp)
+extern "C" __global__ void __launch_bounds__(PT_TBLOCK, PT_TRACE_DIST_WAVES) k_trace_far(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+                                                                   uint32_t spill_depth, uint32_t* err) {
+    trace_body<true, false, false, PT_TOUCH_VARIANT>(sc, P, Q, cnt, spill, spill_depth, err);
 }
 // leaves of more than 8 triangles ("maxnodeprims" > 8): every lane walks its own leaf
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace_seq(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
@@ -1550,7 +1567,7 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, 2) k_trace_inst(PtScene s
     trace_body<false, true, true>(sc, P, Q, cnt, spill, spill_depth, err);
 }
 // scenes with spheres: a leaf record may stand for a sphere
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_DIST_WAVES) k_trace_sph_dist(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+extern "C" __global__ void __launch_bounds__(PT_TBLOCK, PT_TRACE_DIST_WAVES) k_trace_sph_dist(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                                            uint32_t spill_depth, uint32_t* err) {
     trace_body<true, true>(sc, P, Q, cnt, spill, spill_depth, err);
 }
@@ -3807,7 +3824,8 @@ hipError_t ptk_rec_next(hipStream_t st, int grid, const PtScene& sc, const PtPat
 // ============================================================ launch wrappers (host side of this TU)
 #define PT_LAUNCH_CHECK() hipGetLastError()
 
-int ptk_trace_dist_blocks_per_cu() { return PT_TRACE_DIST_WAVES; }
+int ptk_trace_dist_blocks_per_cu() { return PT_TRACE_WIDE ? 1 : PT_TRACE_DIST_WAVES; }      // PT_TRACE_WIDE: one 1024-thread block per CU
+int ptk_trace_wide() { return PT_TRACE_WIDE; }
 int ptk_shade_prof_read(unsigned long long* out16) {       // 1 when the library is the -DPT_PROFILE_SHADE diagnostic build (reads and clears)
 #ifdef PT_PROFILE_SHADE
     unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -3819,14 +3837,16 @@ int ptk_shade_prof_read(unsigned long long* out16) {       // 1 when the library
     return 0;
 #endif
 }
+bool ptk_trace_has_far(const PtScene& sc) { return sc.dist_leaves && !sc.n_instances && !sc.n_spheres; }
 hipError_t ptk_trace(hipStream_t st, int grid, int grid_dist, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, uint32_t* spill,
-                     uint32_t spill_depth, uint32_t* err) {
+                     uint32_t spill_depth, uint32_t* err, int far) {
     static const bool force_sph = std::getenv("PBRTGPU_FORCE_SPH_TRACE") != nullptr;      // diagnosis: what the sphere-capable kernel costs a scene without spheres
     if (sc.dist_leaves && !sc.n_instances) grid = grid_dist;      // the pooled-leaf kernels fit three blocks per CU, the others four
     if (sc.n_instances) hipLaunchKernelGGL(k_trace_inst, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
-    else if ((sc.n_spheres || force_sph) && sc.dist_leaves) hipLaunchKernelGGL(k_trace_sph_dist, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    else if ((sc.n_spheres || force_sph) && sc.dist_leaves) hipLaunchKernelGGL(k_trace_sph_dist, dim3(grid), dim3(PT_TBLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else if (sc.n_spheres) hipLaunchKernelGGL(k_trace_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
-    else if (sc.dist_leaves) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    else if (sc.dist_leaves && far) hipLaunchKernelGGL(k_trace_far, dim3(grid), dim3(PT_TBLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
+    else if (sc.dist_leaves) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PT_TBLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     else hipLaunchKernelGGL(k_trace_seq, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt, spill, spill_depth, err);
     return PT_LAUNCH_CHECK();
 }

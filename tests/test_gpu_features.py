@@ -600,6 +600,28 @@ def test_mesh_light_of_two_thousand_triangles_uses_the_lazy_grid(oracle):
         ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["always", "trial"])
+@pytest.mark.parametrize("name,make", [("cornell", lambda: scenes.cornell_box(res=64, spp=16)), ("materials", lambda: fs.scene_materials_lights("spatial")),
+                                       ("rt20k", lambda: scenes.rt1m(20000, res=48, spp=8, max_depth=6)), ("textures", lambda: fs.scene_textures())])
+def test_far_traversal_kernel_changes_nothing(oracle, monkeypatch, name, make, mode):
+    """k_trace_far -- pushed leaves touched ahead of their visit, for scenes whose rays miss the caches -- forced on (PBRTGPU_TRACE_FAR=1), and the
+    timed trial that picks it per scene (forced to run on these small scenes: bounce 1 of the first pass traced twice, once by each kernel,
+    counters put back): per-sample radiance, film and every counter are the oracle's either way -- touching a line changes no result."""
+    if mode == "always":
+        monkeypatch.setenv("PBRTGPU_TRACE_FAR", "1")
+    else:
+        monkeypatch.setenv("PBRTGPU_TRACE_FAR_MIN_BYTES", "0")
+    sd = make()
+    ctx = pkg.Context(0)
+    try:
+        ctx.upload(sd)
+        osc = oracle.scene(sd)
+        _compare(ctx, osc, exact_film=True)
+        osc.close()
+    finally:
+        ctx.close()
+
+
 def test_crown_class_3p5m_textured_tiles(gpu_ctx, oracle):
     """BASELINE config 5's CONTENT at its scale, not only its size: the 3.5 M-triangle stand-in with the textured material split of the
     crown-class bench line (`bench.py --triangles 3500000 --materials textured`: image-mapped Matte under a bump map, a checkerboard-driven

@@ -12,6 +12,11 @@ W[crown]="--triangles 3500000 --materials textured"
 W[textured]="--materials textured"
 W[sphere]="--light sphere"
 W[sparse16]="--triangles 16000000 --tri-size 0.00125"
+W[t4m]="--triangles 4000000"
+W[t8m]="--triangles 8000000"
+W[dense16]="--triangles 16000000"
+W[sparse8]="--triangles 8000000 --tri-size 0.00177"
+W[sparse4]="--triangles 4000000 --tri-size 0.0025"
 W[direct]="--integrator directlighting"
 W[whitted]="--integrator whitted"
 for spec in "$@"; do
