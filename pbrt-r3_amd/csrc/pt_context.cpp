@@ -100,6 +100,12 @@ struct pt_context {
     // a timed trial on the scene's own rays -- the first incoherent bounce after an upload is traced twice, once by each kernel
     int trace_far = -1, trace_far_choice = -1;
     DevBuf d_cnt_save;
+    // PBRTGPU_SHADE_LOCAL: the material sort inside runs of 4 096 queue entries + one lobe-list kernel (k_sort_local) instead of the global sort and a
+    // kernel per class: 0 never, 1 wherever possible, default -1 = scenes that have lobe-list (non-Matte) constant materials, no textured ones and no
+    // instances (mixed materials 889 -> 916 Mrays/s, with a sphere light as well 834 -> 843; a Matte scene lit by a sphere, where the sorted queue exists
+    // only to select the sphere-capable kernels, loses 1.4 % and keeps the global sort)
+    int shade_local = -1;
+    bool scene_has_lobe_materials = false;
     int nee_split = 0;                                 // PBRTGPU_NEE_SPLIT: kernel families that shade a vertex in two kernels (ptk_shade)
     int sort_cont = -1;                                // continuation rays of a bounce ordered like the shadow rays: 0 never, 1 for the traversal kernel only
                                                        // (shading keeps path order), 2 for both, -1 (default): mode 1 for scenes larger than the Infinity Cache
@@ -264,6 +270,7 @@ pt_status pt_context_create(int device, pt_context** out) {
     if (const char* e = std::getenv("PBRTGPU_SORT_CONT_MIN")) ctx->sort_cont_min = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("PBRTGPU_SORT_CONT")) ctx->sort_cont = std::min(2, std::max(-1, std::atoi(e)));
     if (const char* e = std::getenv("PBRTGPU_TRACE_FAR")) ctx->trace_far = std::atoi(e);
+    if (const char* e = std::getenv("PBRTGPU_SHADE_LOCAL")) ctx->shade_local = std::atoi(e);
     ctx->nee_split = ptk_nee_split_default();
     if (const char* e = std::getenv("PBRTGPU_NEE_SPLIT")) ctx->nee_split = std::atoi(e);
     ctx->grid_wide = ctx->n_cu * 8;
@@ -1127,6 +1134,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     sc.UV = d->UV ? ctx->d_UV.as<float>() : nullptr;
     sc.materials = ctx->d_materials.as<PtMaterial>();
     sc.general_materials = general_materials ? 1u : 0u;
+    ctx->scene_has_lobe_materials = general_materials;          // (before spheres / instances force the sorted queue on)
     sc.any_one_sided = any_one_sided ? 1u : 0u;
     sc.dist_leaves = (up_max_leaf <= 8 && !std::getenv("PBRTGPU_SEQ_LEAVES")) ? 1u : 0u;
     ctx->n_materials = d->n_materials;
@@ -1788,7 +1796,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                         const pt_status gs = fill_light_grid(ctx, Q);
                         if (gs != PT_OK) return gs;
                     }
-                    PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, ctx->sc, ctx->paths, Q, cnt, ctx->nee_split));
+                    PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, ctx->sc, ctx->paths, Q, cnt, ctx->nee_split, ctx->shade_local < 0 ? (ctx->scene_has_lobe_materials ? 1 : 0) : ctx->shade_local));
                     PT_HIP(ptk_prep(ctx->stream, Q, 1));
                     {
                         const pt_status ss = sort_shadow();

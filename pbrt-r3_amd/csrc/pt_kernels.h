@@ -13,7 +13,7 @@ hipError_t ptk_gen(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P
                    uint32_t s0, uint32_t n_samples, PtCounters* cnt);
 hipError_t ptk_nee_resolve(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q);
 hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode);
-hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, int nee_split);
+hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, int nee_split, int local_sort = 0);
 int ptk_nee_split_default();
 int ptk_trace_wide();
 hipError_t ptk_film(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const uint32_t* pixels, uint32_t n_pix, uint32_t n_samples,

@@ -2234,6 +2234,46 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_scatter(PtScene sc
     }
 }
 
+// The material sort kept LOCAL (round 4; scenes with constant non-Matte materials): every block orders one run of PT_LOCAL_CHUNK consecutive
+// entries of the shade queue by material bin, in place -- bins ascending, misses last -- and ONE lobe-list kernel (k_shade_all) walks the
+// result.  A wave still sees one material (a run holds 4 096 paths: hundreds per bin), but consecutive waves now work on neighbouring path
+// slots: the global sort hands each kernel a list that skips the other kernels' paths, so every 128-byte line of the eleven path-state arrays
+// is fetched for half its paths, once by each kernel (k_shade_matte_sorted took 33 % longer over 55 % of the vertices than k_shade takes over
+// all of them).
+#ifndef PT_LOCAL_CHUNK
+#define PT_LOCAL_CHUNK 4096u
+#endif
+extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_local(PtScene sc, PtPaths P, PtQueues Q) {
+    __shared__ uint32_t s_cnt[PT_SORT_BINS + 1];          // per bin (the last one: misses): count, then the bin's cursor inside the run
+    __shared__ uint32_t s_p[PT_LOCAL_CHUNK];
+    __shared__ uint16_t s_b[PT_LOCAL_CHUNK];
+    const uint32_t n = Q.counts[PT_Q_CUR];
+    const uint32_t n_runs = (n + PT_LOCAL_CHUNK - 1u) / PT_LOCAL_CHUNK;
+    for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
+        const uint32_t lo = run * PT_LOCAL_CHUNK, len = min(PT_LOCAL_CHUNK, n - lo);
+        for (uint32_t k = threadIdx.x; k <= PT_SORT_BINS; k += blockDim.x) s_cnt[k] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+            const uint32_t p = Q.cur[lo + i];
+            const uint32_t bin = path_sort_bin(sc, P, p);
+            const uint32_t b = bin == 0xffffffffu ? PT_SORT_BINS : bin;
+            s_p[i] = p; s_b[i] = (uint16_t)b;
+            atomicAdd(&s_cnt[b], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {                              // exclusive scan over 257 counters (a handful of them non-zero)
+            uint32_t acc = 0;
+            for (uint32_t k = 0; k <= PT_SORT_BINS; k++) { const uint32_t c = s_cnt[k]; s_cnt[k] = acc; acc += c; }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+            const uint32_t pos = atomicAdd(&s_cnt[s_b[i]], 1u);
+            Q.sorted[lo + pos] = s_p[i];
+        }
+        __syncthreads();
+    }
+}
+
 // ============================================================ K_SHADE
 // One bounce of PathIntegrator::li for every path in Q.cur (path.rs:85-234).
 #ifndef PT_SHADE_TICKET
@@ -2930,6 +2970,9 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_cont_keys(PtScene sc, P
 // a wave see one material but walk the path pool with gaps; this form keeps the pool accesses dense and lets the lobe dispatch diverge)
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_GEN_WAVES) k_shade_all(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, false>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[PT_Q_CUR], &Q.counts[PT_Q_TICKET]);
+}
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_shade_all_sph(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, true>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[PT_Q_CUR], &Q.counts[PT_Q_TICKET]);
 }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_TEX_WAVES) k_shade_all_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true, true>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[PT_Q_CUR], &Q.counts[PT_Q_TICKET]);
@@ -3996,7 +4039,16 @@ hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode) {
     return PT_LAUNCH_CHECK();
 }
 int ptk_nee_split_default() { return PT_NEE_SPLIT_DEFAULT; }
-hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, int nsplit) {
+hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, int nsplit, int local_sort) {
+    if (sc.general_materials && local_sort && !sc.n_instances && !sc.textured) {
+        // the shade queue ordered by material inside runs of 4 096 entries, one lobe-list kernel over all of it (see k_sort_local)
+        hipLaunchKernelGGL(k_sort_local, dim3(grid * 4), dim3(PT_BLOCK), 0, st, sc, P, Q);
+        PtQueues Ql = Q;
+        Ql.cur = Q.sorted;
+        if (sc.n_spheres) hipLaunchKernelGGL(k_shade_all_sph, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Ql, cnt);
+        else hipLaunchKernelGGL(k_shade_all, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Ql, cnt);
+        return PT_LAUNCH_CHECK();
+    }
     static const int unsorted = [] { const char* e = std::getenv("PBRTGPU_SHADE_UNSORTED"); return e ? std::atoi(e) : 0; }();
     if (sc.general_materials && unsorted && !sc.n_instances && (!sc.n_spheres || sc.textured)) {
         if (sc.textured) hipLaunchKernelGGL(k_shade_all_tex, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, cnt);
