@@ -1796,7 +1796,7 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                         const pt_status gs = fill_light_grid(ctx, Q);
                         if (gs != PT_OK) return gs;
                     }
-                    PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, ctx->sc, ctx->paths, Q, cnt, ctx->nee_split, ctx->shade_local < 0 ? (ctx->scene_has_lobe_materials ? 1 : 0) : ctx->shade_local));
+                    PT_HIP(ptk_shade(ctx->stream, ctx->grid_shade, ctx->sc, ctx->paths, Q, cnt, ctx->nee_split, ctx->shade_local < 0 ? ((ctx->scene_has_lobe_materials && !ctx->sc.textured) ? 1 : 0) : ctx->shade_local));
                     PT_HIP(ptk_prep(ctx->stream, Q, 1));
                     {
                         const pt_status ss = sort_shadow();

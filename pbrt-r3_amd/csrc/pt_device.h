@@ -126,7 +126,9 @@ struct PtMaterial {
     float bsdf_eta;              // BSDF::eta
     uint32_t sort_bin;           // shade-queue bin: [0,128) Matte materials, [128,256) the others
     uint32_t textured;           // 1: parameters come from textures at each hit (PtMatParams), the lobes below are unused
-    uint32_t pad[3];
+    uint32_t spec_mask;          // bit 0: some lobe matches BSDF_REFLECTION | BSDF_SPECULAR, bit 1: ... BSDF_TRANSMISSION | BSDF_SPECULAR (what specular_reflect /
+                                 // specular_transmit ask BSDF::sample_f for: with the bit clear the call returns None before it looks at anything)
+    uint32_t pad[2];
     PtLobe lobes[PT_MAX_LOBES];
 };
 // One MIP pyramid (core/texture/mipmap.rs) in HBM: all levels back to back, level l at texels + level_off[l] floats.

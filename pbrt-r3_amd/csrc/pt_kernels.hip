@@ -30,6 +30,9 @@
 #ifndef PT_SHADE_PF_DEEP
 #define PT_SHADE_PF_DEEP 0       // 1: k_shade's one-iteration-ahead prefetch also covers the ray, the throughput and the leaf record
 #endif
+#ifndef PT_TEX_NOUNROLL
+#define PT_TEX_NOUNROLL 0
+#endif
 #ifndef PT_TOUCH_VARIANT
 #define PT_TOUCH_VARIANT 3       // k_trace_far: which pushed children node_step_lean touches (see there; 3 = leaves that are not the next visit)
 #endif
@@ -2321,6 +2324,9 @@ PT_DEV void textured_params_t(const PtScene& sc, int32_t material, const TexHit&
         if (dv == 0.0f) dv = 0.0005f;
     }
     float a_r = mp.a_r, a_u = mp.a_u, a_v = mp.a_v;
+#if PT_TEX_NOUNROLL
+#pragma nounroll
+#endif
     for (int j = 0; j < 15; j++) {
         const int k = j < 3 ? 8 : (j < 11 ? j - 3 : j - 2);          // index into PtMatParams::prog
         const uint32_t pr = mp.prog[k];
@@ -2858,12 +2864,20 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_TEX_WAVES) k_sha
 // everything AFTER the textures runs 1.6x slower than in k_shade_general for it (profiles/r03_q_tex_kernel_experiments.txt).  k_tex_resolve
 // does the per-hit half of Material::compute_scattering_functions alone -- surface, ray differentials, bump map, every programmed
 // parameter -- and leaves 36 floats per path (PtPaths::tex_res); k_shade_general_res is k_shade_general with the lobe list built from them.
-template <bool SPH>
+// ALL: the locally sorted queue (k_sort_local) -- every entry of Q.cur is looked at, the ones whose material is not textured are passed over
+// after one look at the hit record's material field.
+template <bool SPH, bool ALL = false>
 PT_DEV void tex_resolve_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q) {
-    const uint32_t begin = Q.counts[PT_Q_TEX_BEGIN], end = Q.counts[PT_Q_GENERAL_END];
+    const uint32_t begin = ALL ? 0u : Q.counts[PT_Q_TEX_BEGIN], end = ALL ? Q.counts[PT_Q_CUR] : Q.counts[PT_Q_GENERAL_END];
+    const uint32_t* list = ALL ? Q.cur : Q.sorted;
     for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
-        const uint32_t p = Q.sorted[i];
+        const uint32_t p = list[i];
         const int32_t rec = P.hit_rec[p];
+        if constexpr (ALL) {
+            if (rec < 0) continue;
+            const uint32_t m1 = sc.tris[rec].flags >> PT_TRI_MATERIAL_SHIFT;
+            if (m1 == 0u || !sc.materials[m1 - 1u].textured) continue;
+        }
         const uint32_t st = P.state[p];
         const uint32_t bounces = (st >> 16) & 0xffu, flags = st >> 24;
         if (rec < 0 || (int32_t)bounces >= sc.max_depth) continue;         // shade_body builds no BSDF there either
@@ -2912,6 +2926,10 @@ PT_DEV void tex_resolve_body(const PtScene& sc, const PtPaths& P, const PtQueues
 #endif
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TEX_RESOLVE_WAVES) k_tex_resolve(PtScene sc, PtPaths P, PtQueues Q) { tex_resolve_body<false>(sc, P, Q); }
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TEX_RESOLVE_WAVES) k_tex_resolve_sph(PtScene sc, PtPaths P, PtQueues Q) { tex_resolve_body<true>(sc, P, Q); }
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TEX_RESOLVE_WAVES) k_tex_resolve_all(PtScene sc, PtPaths P, PtQueues Q) { tex_resolve_body<false, true>(sc, P, Q); }
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_GEN_WAVES) k_shade_all_res(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, false, false, false, true>(sc, P, Q, cnt, Q.cur, 0u, Q.counts[PT_Q_CUR], &Q.counts[PT_Q_TICKET]);
+}
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_GEN_WAVES) k_shade_general_res(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, false, false, false, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
 }
@@ -3322,6 +3340,7 @@ struct RecNode {
     TexHit th;
     V3 n_before;
     float bsdf_eta;
+    uint32_t spec_mask;          // PtMaterial::spec_mask of the node's BSDF
     bool found, has_bsdf;
 };
 // FULL = false: the instantiation for scenes without spheres, instances and textured materials (the triangle-only test, no texture programs, no
@@ -3333,6 +3352,7 @@ PT_DEV void rec_build(const PtScene& sc, V3 ro, V3 rd, int32_t rec, uint32_t ins
     else nd.found = rec >= 0 && make_surf_any<false>(sc, ro, rd, (uint32_t)rec, nd.s, &thit);
     nd.has_bsdf = false;
     nd.bsdf_eta = 1.0f;
+    nd.spec_mask = 0;
     if (!nd.found) return;
     nd.n_before = nd.s.sh_n;
     nd.th.p = nd.s.p; nd.th.uv = nd.s.uv;
@@ -3352,6 +3372,7 @@ PT_DEV void rec_build(const PtScene& sc, V3 ro, V3 rd, int32_t rec, uint32_t ins
     nd.gb.ts = normalize(cross(nd.gb.ns, nd.gb.ss));
     nd.gb.lobes = m->lobes; nd.gb.n_lobes = m->n_lobes;
     nd.bsdf_eta = m->bsdf_eta;
+    nd.spec_mask = m->spec_mask;
 }
 PT_DEV float4* rec_frame(const PtRec& R, uint32_t depth, uint32_t k, uint32_t p) { return R.frames + ((size_t)depth * PT_REC_FRAME_F4 + k) * R.n_paths + p; }
 // estimate_direct (sample_lights.rs:178-328) for light `light_num`: the two MIS terms and their rays go to entry e, the rays' results
@@ -3439,14 +3460,18 @@ PT_DEV RayDiffs rec_load_diff(const PtRec& R, uint32_t p) {
     return d;
 }
 template <bool FULL>
-PT_DEV void rec_enter_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtRec& R, PtCounters* cnt) {
+PT_DEV void rec_enter_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtQueues& Qn, const PtRec& R, PtCounters* cnt) {
     const uint32_t n = Q.counts[PT_Q_CUR];
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool whitted = sc.integrator == PT_INTEGRATOR_WHITTED;
     uint32_t n_vert = 0;
-    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + lane;
-        if (i >= n) continue;
+    __shared__ uint32_t s_ws[PT_BLOCK / 64], s_wp[PT_BLOCK / 64], s_qbase[2];
+    // block-uniform trips: the node's next-event entries are compacted into the shadow / probe work lists at the end of every trip, one
+    // reservation per list and BLOCK (a reservation per wave would queue on the two counters: 88 M atomics/s each)
+    for (uint32_t bbase = blockIdx.x * blockDim.x; bbase < n; bbase += gridDim.x * blockDim.x) {
+        const uint32_t i = bbase + threadIdx.x;
+        uint32_t ns = 0, np = 0, e_first = 0;             // this lane's live shadow / probe rays; its first entry
+        if (i < n) {
         const uint32_t p = Q.cur[i];
         const V3 ro = f4_3(P.ray_o[p]), rd = f4_3(P.ray_d[p]);
         const int32_t rec = P.hit_rec[p];
@@ -3553,14 +3578,47 @@ PT_DEV void rec_enter_body(const PtScene& sc, const PtPaths& P, const PtQueues& 
             *rec_frame(R, depth, 0, p) = make_float4(ro.x, ro.y, ro.z, __uint_as_float((uint32_t)rec));
             *rec_frame(R, depth, 1, p) = make_float4(rd.x, rd.y, rd.z, __uint_as_float(inst | (has_diff ? 0x80000000u : 0u)));
             *rec_frame(R, depth, 2, p) = make_float4(rdf.rx_o.x, rdf.rx_o.y, rdf.rx_o.z, 0.0f);
-            *rec_frame(R, depth, 3, p) = make_float4(rdf.ry_o.x, rdf.ry_o.y, rdf.ry_o.z, 0.0f);
+            *rec_frame(R, depth, 3, p) = make_float4(rdf.ry_o.x, rdf.ry_o.y, rdf.ry_o.z, __uint_as_float(nd.spec_mask));       // .w: which specular children this BSDF can have at all
             *rec_frame(R, depth, 4, p) = make_float4(rdf.rx_d.x, rdf.rx_d.y, rdf.rx_d.z, 0.0f);
             *rec_frame(R, depth, 5, p) = make_float4(rdf.ry_d.x, rdf.ry_d.y, rdf.ry_d.z, 0.0f);
             *rec_frame(R, depth, 6, p) = make_float4(l.x, l.y, l.z, 0.0f);
         }
         P.state[p] = (dim & 0xffffu) | (depth << 16) | ((flags | (outcome << 2)) << 24);
+        if (outcome == PT_REC_OUT_FRAME) {
+            e_first = p * R.epp;
+            for (uint32_t j = 0; j < R.epp; j++) { const uint32_t fl = R.flags[e_first + j]; ns += (fl & PT_NEE_SHADOW) ? 1u : 0u; np += (fl & PT_NEE_PROBE) ? 1u : 0u; }
+        }
+        }
+        // ---- this trip's entries with a live shadow / probe ray, in path and entry order, appended to the work lists of the next traversal launch
+        uint32_t is = ns, ip = np;                       // inclusive scan over the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = (uint32_t)__shfl_up((int)is, o, 64), b = (uint32_t)__shfl_up((int)ip, o, 64);
+            if ((int)lane >= o) { is += a; ip += b; }
+        }
+        if (lane == 63u) { s_ws[wave] = is; s_wp[wave] = ip; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t ts = 0, tp = 0;
+            for (uint32_t w = 0; w < PT_BLOCK / 64; w++) { ts += s_ws[w]; tp += s_wp[w]; }
+            s_qbase[0] = ts ? atomicAdd(&Qn.counts[PT_Q_SHADOW], ts) : 0u;
+            s_qbase[1] = tp ? atomicAdd(&Qn.counts[PT_Q_PROBE], tp) : 0u;
+        }
+        __syncthreads();
+        if (ns | np) {
+            uint32_t os = s_qbase[0] + (is - ns), op = s_qbase[1] + (ip - np);
+            for (uint32_t w = 0; w < wave; w++) { os += s_ws[w]; op += s_wp[w]; }
+            for (uint32_t j = 0; j < R.epp; j++) {
+                const uint32_t e = e_first + j, fl = R.flags[e];
+                if (fl & PT_NEE_SHADOW) {
+                    Qn.shadow[os] = e;
+                    if (Qn.shadow_key) { const float4 o4 = R.sh_o[e], d4 = R.sh_d[e]; Qn.shadow_key[os] = ray_sort_key(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z)); }
+                    os++;
+                }
+                if (fl & PT_NEE_PROBE) Qn.probe[op++] = e;
+            }
+        }
+        __syncthreads();                                 // s_ws / s_wp / s_qbase are rewritten by the next trip
     }
-    // the next-event rays of this launch: entries with a live shadow / probe ray, in entry order
     __shared__ unsigned long long s_vert;
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
@@ -3568,73 +3626,19 @@ PT_DEV void rec_enter_body(const PtScene& sc, const PtPaths& P, const PtQueues& 
     __syncthreads();
     if (threadIdx.x == 0 && s_vert) atomicAdd(&cnt->vertices, s_vert);
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_enter(PtScene sc, PtPaths P, PtQueues Q, PtRec R, PtCounters* cnt) {
-    rec_enter_body<true>(sc, P, Q, R, cnt);
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_enter(PtScene sc, PtPaths P, PtQueues Q, PtQueues Qn, PtRec R, PtCounters* cnt) {
+    rec_enter_body<true>(sc, P, Q, Qn, R, cnt);
 }
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_enter_plain(PtScene sc, PtPaths P, PtQueues Q, PtRec R, PtCounters* cnt) {
-    rec_enter_body<false>(sc, P, Q, R, cnt);
-}
-// compaction of the entries with live rays into the shadow / probe work lists of the next traversal launch
-extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_rec_nee_lists(PtScene sc, PtPaths P, PtQueues Q, PtQueues Qn, PtRec R, uint32_t n_lights_per_node) {
-    __shared__ uint32_t s_e[PT_SHADE_FLUSH][PT_BLOCK];       // entries of the iterations not yet queued (one reservation per PT_SHADE_FLUSH iterations, see shade_body)
-    __shared__ uint32_t s_k[PT_SHADE_FLUSH][PT_BLOCK];       // their shadow rays' sort keys (origin cell | direction octant), when the list is to be ordered (Qn.shadow_key)
-    const uint32_t n = Q.counts[PT_Q_CUR];
-    const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const uint32_t total = n * n_lights_per_node;
-    uint32_t n_batch = 0, want = 0;                           // want: bits 2 j / 2 j + 1 = entry j goes to the shadow / probe list
-    auto flush = [&]() {
-        if (n_batch == 0) return;
-        uint32_t ts = 0, tp = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++)
-            if (j < n_batch) { ts += (uint32_t)__popcll(__ballot(((want >> (2u * j)) & 1u) != 0)); tp += (uint32_t)__popcll(__ballot(((want >> (2u * j)) & 2u) != 0)); }
-        uint32_t bs = 0, bp = 0;
-        if (lane == 0) {
-            if (ts) bs = atomicAdd(&Qn.counts[PT_Q_SHADOW], ts);
-            if (tp) bp = atomicAdd(&Qn.counts[PT_Q_PROBE], tp);
-        }
-        bs = __shfl(bs, 0, 64); bp = __shfl(bp, 0, 64);
-#pragma unroll
-        for (uint32_t j = 0; j < PT_SHADE_FLUSH; j++)
-            if (j < n_batch) {
-                const bool ws = ((want >> (2u * j)) & 1u) != 0, wp = ((want >> (2u * j)) & 2u) != 0;
-                const unsigned long long ms = __ballot(ws), mp = __ballot(wp);
-                const uint32_t e = s_e[j][threadIdx.x];
-                if (ws) {
-                    Qn.shadow[bs + (uint32_t)__popcll(ms & below)] = e;
-                    if (Qn.shadow_key) Qn.shadow_key[bs + (uint32_t)__popcll(ms & below)] = s_k[j][threadIdx.x];
-                }
-                if (wp) Qn.probe[bp + (uint32_t)__popcll(mp & below)] = e;
-                bs += (uint32_t)__popcll(ms); bp += (uint32_t)__popcll(mp);
-            }
-        n_batch = 0; want = 0;
-    };
-    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) - lane; base < total; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + lane;
-        bool want_sh = false, want_pr = false;
-        uint32_t e = 0;
-        if (i < total) {
-            const uint32_t p = Q.cur[i / n_lights_per_node];
-            if (((P.state[p] >> 26) & 3u) == PT_REC_OUT_FRAME) {
-                e = p * R.epp + i % n_lights_per_node;
-                const uint32_t fl = R.flags[e];
-                want_sh = (fl & PT_NEE_SHADOW) != 0; want_pr = (fl & PT_NEE_PROBE) != 0;
-                if (want_sh && Qn.shadow_key) {
-                    const float4 o = R.sh_o[e], d = R.sh_d[e];
-                    s_k[n_batch][threadIdx.x] = ray_sort_key(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z));
-                }
-            }
-        }
-        s_e[n_batch][threadIdx.x] = e;
-        want |= ((want_sh ? 1u : 0u) | (want_pr ? 2u : 0u)) << (2u * n_batch);
-        if (++n_batch == PT_SHADE_FLUSH) flush();
-    }
-    flush();
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_rec_enter_plain(PtScene sc, PtPaths P, PtQueues Q, PtQueues Qn, PtRec R, PtCounters* cnt) {
+    rec_enter_body<false>(sc, P, Q, Qn, R, cnt);
 }
 // specular_reflect / specular_transmit at the frame `depth` (sampler.rs:37-143): true = a child ray was set up (cur ray, differentials, pending f / scale)
 template <bool FULL>
 PT_DEV bool rec_sample_child(const PtScene& sc, const PtPaths& P, const PtRec& R, uint32_t p, uint32_t depth, bool transmit, Sampler& sm, V3* pend_f, float* pend_scale, uint32_t* child_flags) {
+    // A BSDF without a lobe that matches (REFLECTION | SPECULAR) / (TRANSMISSION | SPECULAR): the reference draws its 2-D sample
+    // (sampler.rs:45, :92) and BSDF::sample_f returns None at `matching_comps == 0` (bsdf.rs:104-107) -- every Matte, Plastic, Metal or Substrate
+    // node.  The draw is a dimension count here, and nothing of the frame needs rebuilding (rec_build was 2/3 of k_rec_next on a diffuse scene).
+    if (!(__float_as_uint(rec_frame(R, depth, 3, p)->w) & (transmit ? 2u : 1u))) { sm.dim += 2; return false; }
     const float4 f0 = *rec_frame(R, depth, 0, p), f1 = *rec_frame(R, depth, 1, p);
     const V3 ro = f4_3(f0), rd = f4_3(f1);
     const int32_t rec = (int32_t)__float_as_uint(f0.w);
@@ -3853,9 +3857,9 @@ hipError_t ptk_rec_init(hipStream_t st, int grid, const PtScene& sc, const PtPat
 }
 hipError_t ptk_rec_enter(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtQueues& Qn, const PtRec& R, PtCounters* cnt,
                          uint32_t lights_per_node) {
-    if (sc.n_spheres || sc.n_instances || sc.textured) hipLaunchKernelGGL(k_rec_enter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R, cnt);
-    else hipLaunchKernelGGL(k_rec_enter_plain, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, R, cnt);
-    hipLaunchKernelGGL(k_rec_nee_lists, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, Qn, R, lights_per_node);
+    (void)lights_per_node;
+    if (sc.n_spheres || sc.n_instances || sc.textured) hipLaunchKernelGGL(k_rec_enter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, Qn, R, cnt);
+    else hipLaunchKernelGGL(k_rec_enter_plain, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q, Qn, R, cnt);
     return hipGetLastError();
 }
 hipError_t ptk_rec_next(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, const PtRec& R) {
@@ -4040,6 +4044,16 @@ hipError_t ptk_prep(hipStream_t st, const PtQueues& Q, int mode) {
 }
 int ptk_nee_split_default() { return PT_NEE_SPLIT_DEFAULT; }
 hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths& P, const PtQueues& Q, PtCounters* cnt, int nsplit, int local_sort) {
+    if (sc.general_materials && local_sort && !sc.n_instances && sc.textured && !sc.n_spheres && P.tex_res) {
+        // ... with textured materials: the texture half over the same list (it passes over the untextured entries), then the lobe-list kernel that
+        // takes a textured hit's parameters from what the texture half left
+        hipLaunchKernelGGL(k_sort_local, dim3(grid * 4), dim3(PT_BLOCK), 0, st, sc, P, Q);
+        PtQueues Ql = Q;
+        Ql.cur = Q.sorted;
+        hipLaunchKernelGGL(k_tex_resolve_all, dim3(4096), dim3(PT_BLOCK), 0, st, sc, P, Ql);
+        hipLaunchKernelGGL(k_shade_all_res, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Ql, cnt);
+        return PT_LAUNCH_CHECK();
+    }
     if (sc.general_materials && local_sort && !sc.n_instances && !sc.textured) {
         // the shade queue ordered by material inside runs of 4 096 entries, one lobe-list kernel over all of it (see k_sort_local)
         hipLaunchKernelGGL(k_sort_local, dim3(grid * 4), dim3(PT_BLOCK), 0, st, sc, P, Q);

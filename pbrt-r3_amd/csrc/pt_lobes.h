@@ -37,6 +37,7 @@ PT_HD inline void set_distribution(PtLobe* l, float ax, float ay) {             
 PT_HD inline void build_lobes(const pt_material& in, float a_r, float a_u, float a_v, PtMaterial& m) {
     m.type = in.type;
     m.n_lobes = 0; m.nonspecular = 0; m.oren_a = 0.0f; m.oren_b = 0.0f;      // every field read afterwards is written here
+    m.spec_mask = 0;
     m.kd[0] = in.kd[0]; m.kd[1] = in.kd[1]; m.kd[2] = in.kd[2];
     m.sigma = in.sigma;
     m.bsdf_eta = 1.0f;
@@ -145,7 +146,10 @@ PT_HD inline void build_lobes(const pt_material& in, float a_r, float a_u, float
         }
         default: break;
     }
-    for (uint32_t i = 0; i < m.n_lobes; i++)
+    for (uint32_t i = 0; i < m.n_lobes; i++) {
         if (!(m.lobes[i].type & kSpecular)) m.nonspecular++;
+        if ((m.lobes[i].type & (kRefl | kSpecular)) == m.lobes[i].type) m.spec_mask |= 1u;          // matches_flags (bxdf.rs:17-20) against what specular_reflect asks for
+        if ((m.lobes[i].type & (kTrans | kSpecular)) == m.lobes[i].type) m.spec_mask |= 2u;         // ... and specular_transmit
+    }
 }
 

@@ -209,7 +209,7 @@ def test_kernel_register_budgets():
         # the recursive integrators: the instantiation BASELINE's scenes run (no spheres, instances or textured materials) spills nothing;
         # the everything-compiled-in one keeps its per-hit lobe list in scratch
         "k_rec_enter_plain": (256, 0, 64), "k_rec_next_plain": (256, 0, 8192),
-        "k_rec_enter": (256, 180, 64), "k_rec_next": (256, 100, 8192),
+        "k_rec_enter": (256, 180, 64), "k_rec_next": (256, 110, 8192),
         "k_nee_resolve": (64, 0, 0),
         "k_gen": (128, 0, 0),
         "k_grid_mark": (128, 0, 0),
