@@ -30,6 +30,9 @@
 #ifndef PT_SHADE_PF_DEEP
 #define PT_SHADE_PF_DEEP 0       // 1: k_shade's one-iteration-ahead prefetch also covers the ray, the throughput and the leaf record
 #endif
+#ifndef PT_LOBES_IN_LDS
+#define PT_LOBES_IN_LDS 1       // the lobe-list kernels keep the lobes of the material a wave's lanes share in LDS (shade_body): mixed materials 927 -> 942 Mrays/s
+#endif
 #ifndef PT_TEX_NOUNROLL
 #define PT_TEX_NOUNROLL 0
 #endif
@@ -2289,7 +2292,8 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK) k_sort_local(PtScene sc, 
 #define PT_WIDE_KERNEL_WAVES 2   // the sphere / instance shading kernels and the recursive integrators' two kernels: compiled for this many waves per SIMD
 #endif
 #ifndef PT_SHADE_GEN_WAVES
-#define PT_SHADE_GEN_WAVES 1     // k_shade_general: 256 registers = two waves per SIMD; compiled for 3 (168 registers, 149 spilled): mixed bench 856 -> 835
+#define PT_SHADE_GEN_WAVES 2     // k_shade_general: 256 registers = two waves per SIMD (with the LDS lobe copy it wants 260 when left alone: bound to two waves it
+                                 // fits without spilling); compiled for 3 (168 registers, 149 spilled): mixed bench 856 -> 835
 #endif
 #ifndef PT_SHADE_TEX_WAVES
 #define PT_SHADE_TEX_WAVES 2     // waves per SIMD the textured shading kernel is compiled for: 256 registers and 112 spilled, against 300 and none
@@ -2410,6 +2414,9 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
     // makes each later wait sit out the store's round trip as well.
     __shared__ float4 s_stage[PART == 2 ? 1 : 7][PT_BLOCK];
     __shared__ uint32_t s_pend[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: path ids of the iterations not yet queued (their queue bits: `pend_want`)
+#if PT_LOBES_IN_LDS
+    __shared__ uint32_t s_lobes[GENERAL ? PT_BLOCK / 64 : 1][PT_MAX_LOBES * (sizeof(PtLobe) / 4)];      // per wave: the lobe list of the material its lanes share
+#endif
     __shared__ uint32_t s_pkey[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: the sort key of those iterations' shadow rays
     if (threadIdx.x == 0) s_vert = 0;
     __syncthreads();
@@ -2650,6 +2657,26 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                         gb.ss = normalize(s.sh_dpdu);
                         gb.ts = normalize(cross(gb.ns, gb.ss));
                         gb.lobes = m.lobes; gb.n_lobes = m.n_lobes;
+#if PT_LOBES_IN_LDS
+                        if constexpr (!INST && !TEX) {          // (the one-kernel textured form spills as it is: 109 registers, 171 with this)
+                            // The lobe evaluators walk the material's lobe list four times per vertex (f, pdf, two sample_f), a dependent chain of
+                            // small loads each time.  The queue is ordered by material, so the lanes that got here nearly always share one: then
+                            // the wave copies that material's lobes (<= 400 bytes) into LDS once and every walk reads them there.
+                            const int32_t mat0 = __builtin_amdgcn_readfirstlane(s.material);
+                            const unsigned long long here = __ballot(1);
+                            if (__ballot(use_tm || s.material != mat0) == 0ull) {
+                                const uint32_t nd = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.n_lobes) * (uint32_t)(sizeof(PtLobe) / 4);
+                                const uint32_t nact = (uint32_t)__popcll(here), rank = (uint32_t)__popcll(here & below);
+                                const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.materials[mat0].lobes);
+                                uint32_t* dst = &s_lobes[threadIdx.x >> 6][0];
+                                for (uint32_t k = rank; k < nd; k += nact) dst[k] = src[k];
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                                gb.lobes = reinterpret_cast<const PtLobe*>(dst);
+                            }
+                        }
+#endif
                         nonspecular = m.nonspecular > 0;
                         bsdf_eta = m.bsdf_eta;
                     } else {
