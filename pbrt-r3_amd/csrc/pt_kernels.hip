@@ -33,6 +33,9 @@
 #ifndef PT_LOBES_IN_LDS
 #define PT_LOBES_IN_LDS 1       // the lobe-list kernels keep the lobes of the material a wave's lanes share in LDS (shade_body): mixed materials 927 -> 942 Mrays/s
 #endif
+#ifndef PT_LIGHTS_IN_LDS
+#define PT_LIGHTS_IN_LDS 8       // the shading kernels keep the light records of scenes with at most this many lights in LDS (0: never); RT1M 1 075 -> 1 081 Mrays/s
+#endif
 #ifndef PT_TEX_NOUNROLL
 #define PT_TEX_NOUNROLL 0
 #endif
@@ -2419,6 +2422,18 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #endif
     __shared__ uint32_t s_pkey[PT_SHADE_FLUSH][PT_BLOCK];      // per lane: the sort key of those iterations' shadow rays
     if (threadIdx.x == 0) s_vert = 0;
+#if PT_LIGHTS_IN_LDS
+    // Scenes with a handful of lights (BASELINE's have two): the light records sit in LDS for the kernel's life, which takes one round trip out of
+    // every vertex's dependent chain grid row -> light number -> light record -> sample.
+    __shared__ PtLight s_lights[PT_LIGHTS_IN_LDS];
+    const bool lights_lds = sc.n_lights <= (uint32_t)PT_LIGHTS_IN_LDS && PART != 2;
+    if (lights_lds) {
+        const uint32_t nd = sc.n_lights * (uint32_t)(sizeof(PtLight) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.lights);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_lights);
+        for (uint32_t k = threadIdx.x; k < nd; k += PT_BLOCK) dst[k] = src[k];
+    }
+#endif
     __syncthreads();
     uint32_t n_vert = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -2715,7 +2730,11 @@ PT_DEV void shade_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                             V2 u_light = sm.get_2d(sc);
                             V2 u_scat = sm.get_2d(sc);
                             PT_SHP(3);
+#if PT_LIGHTS_IN_LDS
+                            const PtLight& lt = lights_lds ? s_lights[light_num] : sc.lights[light_num];
+#else
                             const PtLight& lt = sc.lights[light_num];
+#endif
                             uint32_t nee = (light_num << 8) | (PART == 1 ? PT_NEE_DIMS5 : 0u);
                             V3 A = mk3(0.0f, 0.0f, 0.0f), B = mk3(0.0f, 0.0f, 0.0f);
                             V3 li, wi, lp, lperr, ln;
