@@ -1326,6 +1326,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             uint32_t lf_pre = 0, lf_items = 0;
             bool lf_served = false, lf_valid = false;
             int lf_kk = 0;
+            float lf_tmax = PT_INF;             // sphere rounds: the owner's t_max when the round starts (an upper bound of what its leaf walk will compare with)
             RayPre lf_rp;
             TriVerts lf_tv;
             auto leaf_issue = [&](auto sr_tag) {
@@ -1351,6 +1352,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                 lf_rp.o = mk3(__shfl(r.rp.o.x, o, 64), __shfl(r.rp.o.y, o, 64), __shfl(r.rp.o.z, o, 64));
                 lf_rp.d = mk3(0.0f, 0.0f, 0.0f);        // only the one-sided test (and a sphere) reads the direction
                 if ((SPH && SR) || sc.any_one_sided) lf_rp.d = mk3(__shfl(r.rp.d.x, o, 64), __shfl(r.rp.d.y, o, 64), __shfl(r.rp.d.z, o, 64));     // (no sphere is tested outside a sphere round)
+                if constexpr (SPH && SR) lf_tmax = __shfl(r.ray_tmax, o, 64);
                 lf_kk = __shfl(r.rp.kx | (r.rp.ky << 2) | (r.rp.kz << 4) | ((kind == 2 ? 1 : 0) << 6), o, 64);
                 lf_rp.kx = lf_kk & 3; lf_rp.ky = (lf_kk >> 2) & 3; lf_rp.kz = (lf_kk >> 4) & 3;
                 lf_rp.sx = __shfl(r.rp.sx, o, 64); lf_rp.sy = __shfl(r.rp.sy, o, 64); lf_rp.sz = __shfl(r.rp.sz, o, 64);
@@ -1375,10 +1377,12 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
                     TriCore tc;
                     const bool tri_ok = tri_core(lf_rp, lf_tv.p0, lf_tv.p1, lf_tv.p2, lf_tv.flags, tc);
                     float4 res = make_float4(tri_ok ? 1.0f : 0.0f, tc.t_scaled, tc.det, tc.t);
-                    if (SR && sphere_rec) {       // Sphere::intersect(_p) against t_max = +inf; the owner applies the t_max tests
+                    if (SR && sphere_rec) {       // Sphere::intersect(_p) against the owner's t_max as the round starts; the owner applies the t_max tests again, in
+                        // leaf order, with the t_max each item would have seen (never larger: a test that fails here fails there, and the value-lane
+                        // reject inside sph_hit_test_inl ends nearly every shadow ray's test before the interval arithmetic starts)
                         SphHit sh;
                         sh.t = 0.0f; sh.a_hi = 0.0f; sh.b_hi = 0.0f;
-                        const bool ok = sph_hit_test_inl(sc.spheres[__float_as_uint(lf_tv.p0.x)], lf_rp.o, lf_rp.d, PT_INF, (lf_kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
+                        const bool ok = sph_hit_test_inl(sc.spheres[__float_as_uint(lf_tv.p0.x)], lf_rp.o, lf_rp.d, lf_tmax, (lf_kk & 64) ? 2.0f * PT_PI : PT_PI, &sh);
                         res = make_float4(ok ? 2.0f : 0.0f, sh.a_hi, sh.b_hi, sh.t);
                     }
                     // (a sphere in a normal round: the owner sees the item in m_sitems and leaves its leaf parked for a sphere round)

@@ -107,6 +107,22 @@ __device__ __forceinline__ bool sph_hit_test_inl(const PtSphere& s, V3 ro, V3 rd
         float dt = dot(vabs(d), oe) / ls;
         o = o + d * dt;
     }
+    {   // The value lane of the interval computation below, alone -- the same operations in the same order, a third of the work and none of the
+        // next_float_up / down calls: a miss IT proves is a miss of the whole test (every EFloat keeps lo <= v <= hi, so t0.v > t_max implies
+        // t0.hi > t_max; the discriminant and the infinity checks read the value lanes only).  Nearly every sphere test of a scene lit by a
+        // sphere ends here: shadow rays stop just short of the light's surface, BSDF-sampled directions miss a small light altogether.
+        const float av = (d.x * d.x + d.y * d.y) + d.z * d.z;
+        const float bv = ((d.x * o.x + d.y * o.y) + d.z * o.z) * 2.0f;
+        const float cv = ((o.x * o.x + o.y * o.y) + o.z * o.z) - s.radius * s.radius;
+        const double discrim = (double)bv * (double)bv - 4.0 * (double)av * (double)cv;
+        if (discrim < 0.0) return false;
+        const float fr = (float)sqrt(discrim);
+        const float qv = bv < 0.0f ? (bv - fr) * -0.5f : (bv + fr) * -0.5f;
+        const float r0 = qv / av, r1 = cv / qv;
+        const float t0v = r0 <= r1 ? r0 : r1, t1v = r0 <= r1 ? r1 : r0;
+        if (isinf(t0v) || isinf(t1v)) return false;
+        if (t0v > t_max) return false;
+    }
     PtEF ox = ef_make(o.x, oe.x), oy = ef_make(o.y, oe.y), oz = ef_make(o.z, oe.z);
     PtEF dx = ef_make(d.x, de.x), dy = ef_make(d.y, de.y), dz = ef_make(d.z, de.z);
     PtEF rad = ef_make(s.radius, 0.0f);
