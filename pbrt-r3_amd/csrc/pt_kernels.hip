@@ -101,6 +101,9 @@ PT_DEV float halton_radical_inverse(uint32_t base, uint64_t magic, const uint16_
         // multiply pairs of the general 64 x 64 product; the digit and the next quotient stay in one register each.
         uint32_t a32 = (uint32_t)a;
         const uint32_t mh = (uint32_t)(magic >> 32), ml = (uint32_t)magic;
+        // (Round 4 tried the digits first and all their permutation look-ups in one batch -- up to 14 loads in flight per dimension instead of
+        // one per trip of this loop: bit-identical, and 0.7 % SLOWER on RT1M under Halton, 1 036 -> 1 029 Mrays/s; the fixed 14-digit unroll costs
+        // more than the waits it removes.  Not kept.)
         while (a32 != 0) {
             const uint32_t lo = a32 * mh, carry_in = __umulhi(a32, ml);
             const uint32_t next = __umulhi(a32, mh) + ((lo + carry_in) < lo ? 1u : 0u);

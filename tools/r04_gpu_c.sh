@@ -17,6 +17,7 @@ W[t8m]="--triangles 8000000"
 W[dense16]="--triangles 16000000"
 W[sparse8]="--triangles 8000000 --tri-size 0.00177"
 W[sparse4]="--triangles 4000000 --tri-size 0.0025"
+W[halton]="--sampler halton"
 W[direct]="--integrator directlighting"
 W[whitted]="--integrator whitted"
 for spec in "$@"; do
