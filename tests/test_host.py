@@ -187,7 +187,7 @@ def test_kernel_register_budgets():
         "k_shade": (256, 0, 40960),              # two waves per SIMD, nothing in scratch
         "k_shade_matte_sorted": (256, 0, 40960),
         "k_shade_general": (256, 0, 40960),
-        "k_shade_general_tex": (256, 130, 40960),    # the one-kernel form of the textured segment (PBRTGPU_TEX_SPLIT=0, scenes with instances)
+        "k_shade_general_tex": (256, 140, 40960),    # the one-kernel form of the textured segment (PBRTGPU_TEX_SPLIT=0, scenes with instances)
         "k_shade_general_res": (256, 0, 40960),      # the textured segment's shading half: nothing spilled
         "k_tex_resolve": (256, 32, 0),               # ... and its texture half, the texture code inlined: 13 registers spilled, 448 B of scratch
         "k_tex_resolve_sph": (256, 32, 0),
@@ -195,7 +195,7 @@ def test_kernel_register_budgets():
         # middle of next-event estimation.  Round 4 built the spill-free form (the vertex in two kernels, below) and measured it 6 % SLOWER on
         # the killeroo-class line, so these stay the default; the budgets hold them where they are.
         "k_shade_matte_sorted_sph": (256, 90, 40960),
-        "k_shade_general_sph": (256, 50, 40960),
+        "k_shade_general_sph": (256, 64, 40960),
         "k_shade_general_res_sph": (256, 104, 40960),
         "k_shade_general_inst": (256, 150, 40960),   # scenes with object instances: one kernel shades everything (a breadth feature)
         # the vertex in two kernels (PBRTGPU_NEE_SPLIT): no kernel of the family spills; the continuation halves of the triangle-only families fit three waves per SIMD
