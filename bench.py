@@ -332,7 +332,10 @@ def main():
         # fraction can exceed 1; `traffic` (and `hbm_measured`) is what the counters saw leave L2, `l1_req` the bound that holds then.
         roofline = {"bound": "hbm", "achieved": round(alg_gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg_gbps / 8000.0, 4), "traffic": traffic}
         roofline.update({
-                    "kernel": "k_trace_sph_dist" if args.light == "sphere" else "k_trace",
+                    "kernel": ("k_trace_sph_dist" if args.light == "sphere" else
+                               "k_trace_far" if os.environ.get("PBRTGPU_TRACE_FAR") == "1" else
+                               "k_trace" if (os.environ.get("PBRTGPU_TRACE_FAR") == "0" or scene_bytes <= 256 * 2 ** 20) else
+                               "k_trace or k_trace_far (scenes beyond the Infinity Cache: the library's timed trial on the first incoherent bounce picks one)"),
                     "l1_req": l1_blk, "hbm_measured": hbm_blk, "kernels_sha16": ksha,
                     "requests_per_launch": round(reqs / launches, 1), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
                     "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1),

@@ -170,3 +170,27 @@ def test_bench_library_reduce_world1():
                     {"BENCH_FORCE_REDUCE": "1", "BENCH_REDUCE": "library", "MASTER_PORT": str(29900 + os.getpid() % 90)})
     assert d["n_gpus"] == 1 and "pt_film_allreduce" in d["reduce"] and len(d["per_rank"]) == 1
     assert d["per_rank"][0]["tiles"] == d["tiles_total"] and d["per_rank"][0]["reduce_ms"] > 0
+
+
+def test_cpp_driver_eight_ranks_deal_the_full_frame(tmp_path):
+    """BASELINE config 3's deal at its real size: a 1024 x 1024 film is 65 x 65 = 4 225 tiles of 16 x 16 (sampler.rs:271-289); eight ranks -- threads of
+    ONE process on this one GPU (a box allows six GPU processes, so bench.py's process-per-rank flow is rehearsed with four) -- take 529 or 528
+    each, render concurrently, meet, and the films are summed.  Weights bit-equal to the single-context frame: every camera sample exactly once."""
+    exe = os.path.join(ROOT, "pbrt-r3_amd", "csrc", "pbrt_gpu")
+    text = open(os.path.join(ROOT, "tests", "scenes", "cornell.pbrt")).read().replace('"integer xresolution" [64] "integer yresolution" [64]', '"integer xresolution" [1024] "integer yresolution" [1024]')
+    assert "[1024]" in text
+    scene = str(tmp_path / "cornell_1024.pbrt")
+    open(scene, "w").write(text)
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "scenes", "cornell_blocks.pbrt"), str(tmp_path / "cornell_blocks.pbrt"))          # the file it Includes
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one, eight = str(tmp_path / "one.xyzw"), str(tmp_path / "eight.xyzw")
+    subprocess.check_call([exe, scene, "-o", str(tmp_path / "one.pfm"), "--xyzw", one, "--pixelsamples", "4", "--quiet"], env=env)
+    r = subprocess.run([exe, scene, "-o", str(tmp_path / "eight.pfm"), "--xyzw", eight, "--pixelsamples", "4", "--devices", "0,0,0,0,0,0,0,0", "--stats"],
+                       env=env, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    want, got = np.fromfile(one, np.float32).reshape(-1, 4), np.fromfile(eight, np.float32).reshape(-1, 4)
+    assert want.shape[0] == 1024 * 1024 and np.array_equal(bits(got[:, 3]), bits(want[:, 3]))
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-7)
+    tiles = [int(ln.split("tiles")[1].split()[0]) for ln in r.stderr.splitlines() if ln.strip().startswith("rank ")]
+    assert len(tiles) == 8 and sum(tiles) == 65 * 65 and sorted(set(tiles)) == [528, 529]

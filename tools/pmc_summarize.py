@@ -2,6 +2,7 @@
 """Aggregate rocprofv3 --pmc CSVs per kernel: sum of each counter and per-launch mean."""
 import collections, csv, glob, json, os, sys
 root = sys.argv[1]
+kname = sys.argv[2] if len(sys.argv) > 2 else "k_trace"          # the traversal kernel the workload runs (k_trace, k_trace_far, k_trace_sph_dist)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -19,12 +20,12 @@ for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", agg[k].get("FET
         n = calls[k][c]
         print("   %-26s total %.6g   per launch %.6g   (%d launches)" % (c, agg[k][c], agg[k][c] / max(1, n), n))
 out = {}
-kt = agg.get("k_trace", {})
+kt = agg.get(kname, {})
 if "FETCH_SIZE" in kt:
-    n = calls["k_trace"]["FETCH_SIZE"]
+    n = calls[kname]["FETCH_SIZE"]
     # gfx950: FETCH_SIZE is in KiB and tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM) -> x2 for wide reads.
     out["fetch_kib_per_launch_raw"] = kt["FETCH_SIZE"] / n
 if "WRITE_SIZE" in kt:
-    out["write_kib_per_launch_raw"] = kt["WRITE_SIZE"] / calls["k_trace"]["WRITE_SIZE"]
+    out["write_kib_per_launch_raw"] = kt["WRITE_SIZE"] / calls[kname]["WRITE_SIZE"]
 json.dump(out, open(os.path.join(root, "k_trace_traffic_raw.json"), "w"))
 print(out)

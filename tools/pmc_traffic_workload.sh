@@ -13,14 +13,16 @@ for pass in fetch write; do
   timeout -k 10 ${PMC_TIMEOUT:-500} rocprofv3 --pmc $set --output-format csv -d "$out" -- python3 bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-spp1024 > "$out/bench.json" 2> "$out/bench.err" || { echo "pass $pass failed"; tail -5 "$out/bench.err"; exit 1; }
   echo "pass $pass done"
 done
-python3 tools/pmc_summarize.py "gpurun_out/pmc_$tag" > "gpurun_out/pmc_$tag/summary.txt"
+kname=$(python3 -c "import json; print(json.loads(open('gpurun_out/pmc_$tag/fetch/bench.json').read().strip().splitlines()[-1])['roofline']['kernel'].split()[0])")
+python3 tools/pmc_summarize.py "gpurun_out/pmc_$tag" "$kname" > "gpurun_out/pmc_$tag/summary.txt"
 python3 - "$tag" "$*" <<'PY'
-import json, sys
+import hashlib, json, sys
 tag, flags = sys.argv[1], sys.argv[2]
 raw = json.load(open("gpurun_out/pmc_%s/k_trace_traffic_raw.json" % tag))
 line = json.loads(open("gpurun_out/pmc_%s/fetch/bench.json" % tag).read().strip().splitlines()[-1])
 f, w = raw["fetch_kib_per_launch_raw"], raw["write_kib_per_launch_raw"]
-out = {"kernel": "k_trace", "workload": line["config"]["workload_key"], "workload_text": line["config"]["workload"],
+ksha = hashlib.sha256(open("pbrt-r3_amd/csrc/pt_kernels.hip", "rb").read()).hexdigest()[:16]      # bench.py quotes an entry only for the kernel source it was measured on
+out = {"kernel": line["roofline"]["kernel"], "kernels_sha16": ksha, "workload": line["config"]["workload_key"], "workload_text": line["config"]["workload"],
        "measured_on": "bench.py %s --steps 1 --warmup 0 --no-cpu-baseline --no-spp1024 under rocprofv3 --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE; mean over the frame's k_trace launches" % flags,
        "launches_in_pass": line["roofline"]["launches"], "avg_launch_ms_under_pmc": line["roofline"]["avg_launch_ms"],
        "fetch_kib_per_launch_raw": f, "write_kib_per_launch_raw": w, "fetch_factor": 2.0,
