@@ -33,6 +33,9 @@
 #ifndef PT_LOBES_IN_LDS
 #define PT_LOBES_IN_LDS 1       // the lobe-list kernels keep the lobes of the material a wave's lanes share in LDS (shade_body): mixed materials 927 -> 942 Mrays/s
 #endif
+#ifndef PT_TEX_PROGS_GLOBAL
+#define PT_TEX_PROGS_GLOBAL 1       // the texture programs' offsets are read from the material table, not from the per-lane copy (indexed by the job loop: scratch): crown-class 795 -> 813 Mrays/s
+#endif
 #ifndef PT_LIGHTS_IN_LDS
 #define PT_LIGHTS_IN_LDS 8       // the shading kernels keep the light records of scenes with at most this many lights in LDS (0: never); RT1M 1 075 -> 1 081 Mrays/s
 #endif
@@ -2325,13 +2328,18 @@ __device__ __noinline__ void build_lobes_call(const pt_material& in, float a_r, 
 // values are remapped into a3 = {a_r, a_u, a_v}.  k_tex_resolve stops here and hands the values to k_shade_general_res (PtTexRes).
 template <bool INL>
 PT_DEV void textured_params_t(const PtScene& sc, int32_t material, const TexHit& th, PtMatParams& mp, float* a3, V3 n, V2 uv, V3* sh_n, V3* sh_dpdu,
-                              V3 sh_dpdv, V3 sh_dndu, V3 sh_dndv) {
+                              V3 sh_dpdv, V3 sh_dndu, V3 sh_dndv, float* vbuf = nullptr) {
     mp = sc.mat_params[material];
+#if PT_TEX_PROGS_GLOBAL
+    const uint32_t* progs = sc.mat_params[material].prog;          // read where it lies: indexed by the job loop's variable, the copy in `mp` would live in scratch
+#else
+    const uint32_t* progs = mp.prog;
+#endif
     // One call site for every texture program of the hit (the evaluations are independent of one another, so their order is free): jobs 0-2
     // are the bump map's displacement at p + du * dpdu, p + dv * dpdv and p (core/material.rs:31-72), jobs 3-10 the parameters Kd Ks Kr Kt
     // opacity sigma metal-eta metal-k, jobs 11-14 roughness uroughness vroughness eta.
-    float du = 0.0f, dv = 0.0f, disp[3] = {0.0f, 0.0f, 0.0f};
-    if (mp.prog[8]) {
+    float du = 0.0f, dv = 0.0f, disp0 = 0.0f, disp1 = 0.0f;          // (scalars, not an array indexed by the loop variable)
+    if (progs[8]) {
         du = 0.5f * (fabsf(th.dudx) + fabsf(th.dudy));
         if (du == 0.0f) du = 0.0005f;
         dv = 0.5f * (fabsf(th.dvdx) + fabsf(th.dvdy));
@@ -2343,20 +2351,21 @@ PT_DEV void textured_params_t(const PtScene& sc, int32_t material, const TexHit&
 #endif
     for (int j = 0; j < 15; j++) {
         const int k = j < 3 ? 8 : (j < 11 ? j - 3 : j - 2);          // index into PtMatParams::prog
-        const uint32_t pr = mp.prog[k];
+        const uint32_t pr = progs[k];
         if (!pr) continue;
         TexHit ev = th;
         if (j == 0) { ev.p = th.p + du * *sh_dpdu; ev.uv = mk2(uv.x + du, uv.y + 0.0f); }
         else if (j == 1) { ev.p = th.p + dv * sh_dpdv; ev.uv = mk2(uv.x + 0.0f, uv.y + dv); }
         V3 v;
-        if constexpr (INL) v = tex_eval_inl(sc.textures, sc.tex_prog + pr, ev, sc.images);       // k_tex_resolve: the whole texture code inline (pt_texture_calls.inc)
+        if constexpr (INL) v = tex_eval_inl(sc.textures, sc.tex_prog + pr, ev, sc.images, vbuf);       // k_tex_resolve: the whole texture code inline (pt_texture_calls.inc)
         else v = tex_eval(sc.textures, sc.tex_prog + pr, ev, sc.images);
         switch (j) {
-            case 0: case 1: disp[j] = v.x; break;
+            case 0: disp0 = v.x; break;
+            case 1: disp1 = v.x; break;
             case 2: {
                 const float displace = v.x;
-                V3 dpdu = *sh_dpdu + (disp[0] - displace) / du * *sh_n + displace * sh_dndu;
-                V3 dpdv = sh_dpdv + (disp[1] - displace) / dv * *sh_n + displace * sh_dndv;
+                V3 dpdu = *sh_dpdu + (disp0 - displace) / du * *sh_n + displace * sh_dndu;
+                V3 dpdv = sh_dpdv + (disp1 - displace) / dv * *sh_n + displace * sh_dndv;
                 *sh_n = face_forward(normalize(cross(dpdu, dpdv)), n);       // set_shading_geometry(.., false) (surface_interaction.rs:140-161)
                 *sh_dpdu = dpdu;
                 break;
@@ -2923,6 +2932,7 @@ template <bool SPH, bool ALL = false>
 PT_DEV void tex_resolve_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q) {
     const uint32_t begin = ALL ? 0u : Q.counts[PT_Q_TEX_BEGIN], end = ALL ? Q.counts[PT_Q_CUR] : Q.counts[PT_Q_GENERAL_END];
     const uint32_t* list = ALL ? Q.cur : Q.sorted;
+    __shared__ float s_texval[3 * PT_TEX_PROG_MAX][PT_BLOCK];          // the texture interpreter's node values (tex_eval_inl), a column per lane
     for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
         const uint32_t p = list[i];
         const int32_t rec = P.hit_rec[p];
@@ -2961,7 +2971,7 @@ PT_DEV void tex_resolve_body(const PtScene& sc, const PtPaths& P, const PtQueues
         compute_differentials(th, s.p, s.n, s.dpdu, s.dpdv, has_diff, rdf);
         PtMatParams mp;
         float a3[3];
-        textured_params_t<true>(sc, s.material, th, mp, a3, s.n, s.uv, &s.sh_n, &s.sh_dpdu, s.sh_dpdv, s.sh_dndu, s.sh_dndv);
+        textured_params_t<true>(sc, s.material, th, mp, a3, s.n, s.uv, &s.sh_n, &s.sh_dpdu, s.sh_dpdv, s.sh_dndu, s.sh_dndv, &s_texval[0][threadIdx.x]);
         float4* o = P.tex_res + (size_t)p * PT_TEX_RES_F4;
         o[0] = make_float4(mp.m.kd[0], mp.m.kd[1], mp.m.kd[2], mp.m.ks[0]);
         o[1] = make_float4(mp.m.ks[1], mp.m.ks[2], mp.m.kr[0], mp.m.kr[1]);

@@ -139,11 +139,27 @@ PT_DEV V3 mip_triangle(const MipRef& m, uint32_t l, V2 st) {                    
 
 #define PT_TEX_FN __device__ __noinline__
 #define PT_TEXN(x) x
+#define PT_TEX_VBUF_PARAM
+#define PT_TEX_VBUF_DECL V3 val[PT_TEX_PROG_MAX];
+#define PT_TEX_VBUF_GET(s_) val[s_]
+#define PT_TEX_VBUF_SET(i_, v_) val[i_] = (v_)
 #include "pt_texture_calls.inc"
 #undef PT_TEX_FN
 #undef PT_TEXN
+#undef PT_TEX_VBUF_PARAM
+#undef PT_TEX_VBUF_DECL
+#undef PT_TEX_VBUF_GET
+#undef PT_TEX_VBUF_SET
 #define PT_TEX_FN __device__ __forceinline__
 #define PT_TEXN(x) x##_inl
+#define PT_TEX_VBUF_PARAM , float* vbuf
+#define PT_TEX_VBUF_DECL
+#define PT_TEX_VBUF_GET(s_) mk3(vbuf[(3u * (s_)) * PT_BLOCK], vbuf[(3u * (s_) + 1u) * PT_BLOCK], vbuf[(3u * (s_) + 2u) * PT_BLOCK])
+#define PT_TEX_VBUF_SET(i_, v_) do { const V3 v__ = (v_); vbuf[(3u * (i_)) * PT_BLOCK] = v__.x; vbuf[(3u * (i_) + 1u) * PT_BLOCK] = v__.y; vbuf[(3u * (i_) + 2u) * PT_BLOCK] = v__.z; } while (0)
 #include "pt_texture_calls.inc"
 #undef PT_TEX_FN
 #undef PT_TEXN
+#undef PT_TEX_VBUF_PARAM
+#undef PT_TEX_VBUF_DECL
+#undef PT_TEX_VBUF_GET
+#undef PT_TEX_VBUF_SET
