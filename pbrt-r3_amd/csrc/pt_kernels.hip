@@ -2330,11 +2330,9 @@ template <bool INL>
 PT_DEV void textured_params_t(const PtScene& sc, int32_t material, const TexHit& th, PtMatParams& mp, float* a3, V3 n, V2 uv, V3* sh_n, V3* sh_dpdu,
                               V3 sh_dpdv, V3 sh_dndu, V3 sh_dndv, float* vbuf = nullptr) {
     mp = sc.mat_params[material];
-#if PT_TEX_PROGS_GLOBAL
-    const uint32_t* progs = sc.mat_params[material].prog;          // read where it lies: indexed by the job loop's variable, the copy in `mp` would live in scratch
-#else
-    const uint32_t* progs = mp.prog;
-#endif
+    // k_tex_resolve reads the program offsets where they lie: indexed by the job loop's variable, the copy in `mp` lives in scratch (the out-of-line
+    // form, inside the one-kernel textured shading, spills more with it and keeps the copy)
+    const uint32_t* progs = (PT_TEX_PROGS_GLOBAL && INL) ? sc.mat_params[material].prog : mp.prog;
     // One call site for every texture program of the hit (the evaluations are independent of one another, so their order is free): jobs 0-2
     // are the bump map's displacement at p + du * dpdu, p + dv * dpdv and p (core/material.rs:31-72), jobs 3-10 the parameters Kd Ks Kr Kt
     // opacity sigma metal-eta metal-k, jobs 11-14 roughness uroughness vroughness eta.
