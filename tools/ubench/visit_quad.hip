@@ -7,6 +7,9 @@
 //          eight loads fall in ONE line --, does ONE slab test, the hit bits of the quad come from one ballot, ORDER_TABLE
 //          (qbvh_x86.rs:186-204) is a 128-entry LDS table indexed by (hit mask, node_idx) that hands every child its push slot, every
 //          lane pushes its own child at top + slot, and all four lanes keep the ray's stack pointer.
+//   pair   (round 4; round 3's review, item 8) one ray per lane PAIR: lane c owns children 2c and 2c + 1 of the same 32-byte child records -- four dwordx4 per
+//          lane, the pair's eight loads fall in one line: 4 tag look-ups per ray-visit instead of 7 --, TWO slab tests per lane, the order look-up and the
+//          stack bookkeeping paid twice per ray (the quad form: four times), 32 rays per wave instruction.
 // Both walk a synthetic table of random boxes with random rays, so the instruction mix and the memory pattern are the real ones
 // while the "tree" never ends (the next node is a hash of the popped reference).  Reported: ray-visits per second over the chip.
 // What the numbers are for: the quad form cuts the L1 tag look-ups per visit (the resource that bounds k_trace) by ~3.5x, but it
@@ -132,6 +135,60 @@ extern "C" __global__ void __launch_bounds__(BLOCK, 4) k_quad(const char* nodes,
     if (acc == 0xdeadbeefu) out[gid] = acc;
 }
 
+
+// ---- pair form: the quad form's node (4 x {lo.x lo.y lo.z ref | hi.x hi.y hi.z lut}), lane c of a pair owns children 2c and 2c + 1
+extern "C" __global__ void __launch_bounds__(BLOCK, 4) k_pair(const char* nodes, uint32_t n_nodes, uint32_t* out, uint32_t seed) {
+    __shared__ uint32_t s_stack[SLOTS * (BLOCK / 2)];      // one stack per pair (ray)
+    __shared__ uint32_t s_order[128];
+    const uint32_t c = threadIdx.x & 1u, q = threadIdx.x >> 1;
+    if (threadIdx.x < 128) {
+        const uint32_t m = threadIdx.x >> 3, idx = threadIdx.x & 7u;
+        const uint32_t T = (idx >> 2) & 1u, L = (idx >> 1) & 1u, R = idx & 1u;
+        const uint32_t l0 = L ? 0u : 1u, l1 = L ? 1u : 0u, r0 = R ? 2u : 3u, r1 = R ? 3u : 2u;
+        const uint32_t ord[4] = {T ? l0 : r0, T ? l1 : r1, T ? r0 : l0, T ? r1 : l1};
+        uint32_t e = 0, n = 0;
+        for (int k = 0; k < 4; k++) if (m & (1u << ord[k])) { e |= n << (2u * ord[k]); n++; }
+        s_order[threadIdx.x] = e | (n << 8);
+    }
+    __syncthreads();
+    const uint32_t gid = blockIdx.x * BLOCK + threadIdx.x;
+    const Ray r = make_ray((gid >> 1) ^ seed);             // the two lanes of a pair carry the same ray
+    const uint32_t oct3 = r.oct * 3u, ca = c * 4u, cb = c * 4u + 2u, coff = c << 6;
+    const uint32_t pshift = (threadIdx.x & 63u) & ~1u;
+    uint32_t sp = 0, top = __umulhi(hash32((gid >> 1) ^ seed), n_nodes), acc = 0;
+    for (int it = 0; it < ITER; it++) {
+        const uint32_t ref = top;
+        const uint32_t no = (__umulhi(ref, n_nodes) << 7) + coff;
+        const float4 lo0 = *(const float4*)(nodes + no), hi0 = *(const float4*)(nodes + (no + 16u)), lo1 = *(const float4*)(nodes + (no + 32u)), hi1 = *(const float4*)(nodes + (no + 48u));
+#define PSLAB(lo, hi, tn, tf)                                                                                                                                        \
+        const float ax##tn = (lo.x - r.ox) * r.ix, bx##tn = (hi.x - r.ox) * r.ix, ay##tn = (lo.y - r.oy) * r.iy, by##tn = (hi.y - r.oy) * r.iy, az##tn = (lo.z - r.oz) * r.iz, \
+                    bz##tn = (hi.z - r.oz) * r.iz;                                                                                                                   \
+        const float tn = v_max(v_max3(r.tmin, v_min(ax##tn, bx##tn), v_min(ay##tn, by##tn)), v_min(az##tn, bz##tn));                                                   \
+        const float tf = v_min(v_min3(r.tmax, v_max(ax##tn, bx##tn), v_max(ay##tn, by##tn)), v_max(az##tn, bz##tn));
+        PSLAB(lo0, hi0, tn0, tf0)
+        PSLAB(lo1, hi1, tn1, tf1)
+#undef PSLAB
+        const uint32_t ref_a = __float_as_uint(lo0.w), ref_b = __float_as_uint(lo1.w);
+        const bool hit_a = tf0 >= tn0 && ref_a != EMPTY, hit_b = tf1 >= tn1 && ref_b != EMPTY;
+        const unsigned long long Ha = __ballot(hit_a), Hb = __ballot(hit_b);
+        const uint32_t a2 = (uint32_t)(Ha >> pshift) & 3u, b2 = (uint32_t)(Hb >> pshift) & 3u;      // bit 0: lane 0's child (0 / 1), bit 1: lane 1's (2 / 3)
+        const uint32_t m4 = (a2 & 1u) | ((b2 & 1u) << 1) | ((a2 >> 1) << 2) | ((b2 >> 1) << 3);
+        const uint32_t nidx = __builtin_amdgcn_ubfe(__float_as_uint(hi0.w), oct3, 3);
+        const uint32_t e = s_order[(m4 << 3) | nidx];
+        const uint32_t slot_a = __builtin_amdgcn_ubfe(e, ca, 2), slot_b = __builtin_amdgcn_ubfe(e, cb, 2), cnt = e >> 8;
+        if (sp > 0) sp--;
+        if (hit_a) s_stack[((sp + slot_a) & (SLOTS - 1)) * (BLOCK / 2) + q] = ref_a;
+        if (hit_b) s_stack[((sp + slot_b) & (SLOTS - 1)) * (BLOCK / 2) + q] = ref_b;
+        sp = (sp + cnt) & (SLOTS - 1);
+        __builtin_amdgcn_wave_barrier();
+        top = sp > 0 ? s_stack[((sp - 1) & (SLOTS - 1)) * (BLOCK / 2) + q] : EMPTY;
+        acc += cnt;
+        if (top == EMPTY || cnt == 0) top = hash32(ref + it);
+        top = hash32(top);
+    }
+    if (acc == 0xdeadbeefu) out[gid] = acc;
+}
+
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     double mb = argc > 1 ? atof(argv[1]) : 21.0;
@@ -168,11 +225,12 @@ int main(int argc, char** argv) {
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     std::printf("table %.1f MB (%u nodes), %d CUs, %d visits per ray\n", mb, n_nodes, cus, ITER);
     for (int bpc : {2, 4}) {
-        for (int form = 0; form < 2; form++) {
+        for (int form = 0; form < 3; form++) {
             const int blocks = cus * bpc;
             auto launch = [&](uint32_t seed) {
                 if (form == 0) hipLaunchKernelGGL(k_lane, dim3(blocks), dim3(BLOCK), 0, 0, nodes_lane, n_nodes, out, seed);
-                else hipLaunchKernelGGL(k_quad, dim3(blocks), dim3(BLOCK), 0, 0, nodes_quad, n_nodes, out, seed);
+                else if (form == 1) hipLaunchKernelGGL(k_quad, dim3(blocks), dim3(BLOCK), 0, 0, nodes_quad, n_nodes, out, seed);
+                else hipLaunchKernelGGL(k_pair, dim3(blocks), dim3(BLOCK), 0, 0, nodes_quad, n_nodes, out, seed);
             };
             launch(1u);
             (void)hipDeviceSynchronize();
@@ -182,9 +240,10 @@ int main(int argc, char** argv) {
             (void)hipEventSynchronize(e1);
             float ms;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            const double rays = (double)blocks * BLOCK / (form == 0 ? 1 : 4);
+            const double rays = (double)blocks * BLOCK / (form == 0 ? 1 : (form == 1 ? 4 : 2));
             std::printf("%d waves/SIMD  %-28s %8.3f ms  %7.1f G ray-visits/s   (%.0f rays per wave-instruction)  (%s)\n", bpc,
-                        form == 0 ? "lane: one ray per lane" : "quad: one ray per lane quad", ms, rays * ITER / ms / 1e6, form == 0 ? 64.0 : 16.0, hipGetErrorString(hipGetLastError()));
+                        form == 0 ? "lane: one ray per lane" : (form == 1 ? "quad: one ray per lane quad" : "pair: one ray per lane pair"), ms, rays * ITER / ms / 1e6,
+                        form == 0 ? 64.0 : (form == 1 ? 16.0 : 32.0), hipGetErrorString(hipGetLastError()));
         }
     }
     return 0;
