@@ -96,7 +96,7 @@ struct pt_context {
     size_t grid_rows_used = 0, grid_rows_cap = 0, grid_nvox = 0;
     bool grid_lazy = false;
     uint32_t* h_live = nullptr;                        // page-locked: the recursive integrators' live-sample count, read one level behind
-    // k_trace_far (pushed leaves touched: scenes whose rays miss the caches): PBRTGPU_TRACE_FAR 0 never, 1 always, default -1 = decided per scene by
+    // k_trace_far (nodes fetched by lane pairs: scenes whose rays miss the caches): PBRTGPU_TRACE_FAR 0 never, 1 always, default -1 = decided per scene by
     // a timed trial on the scene's own rays -- the first incoherent bounce after an upload is traced twice, once by each kernel
     int trace_far = -1, trace_far_choice = -1;
     DevBuf d_cnt_save;
@@ -1698,8 +1698,8 @@ static pt_status render_tiles(pt_context* ctx, const pt_tile* tiles, uint32_t n_
                 uint32_t* shadow_sorted = nullptr;          // the ordered shadow list for the next traversal launch, if one was made
                 uint32_t* cont_sorted = nullptr;            // the ordered copy of cur for the next traversal launch (sort_cont == 1)
                 uint32_t* cont_spare = ctx->d_csort_ids.as<uint32_t>();
-                // Which traversal kernel: k_trace_far only pays where rays miss the caches -- 16 M sparse triangles +17 %, but a 16 M-triangle scene whose
-                // rays end early -12 %, 3.5 M triangles -7 % -- and neither the scene's size nor its depth tells the two apart.  So a scene larger than
+                // Which traversal kernel: k_trace_far (nodes fetched by lane pairs) only pays where rays miss the caches -- 16 M sparse triangles +15 %, but
+                // 8 M triangles whose rays end early -12 %, RT1M -4 % -- and neither the scene's size nor its depth tells the two apart.  So a scene larger than
                 // the Infinity Cache decides by trial: its first incoherent bounce after an upload (bounce 1 of the first pass: the largest one) is
                 // traced twice, by each kernel, on the same lists; results are identical (the second launch rewrites them), the counters are put back.
                 const char* far_min_env = std::getenv("PBRTGPU_TRACE_FAR_MIN_BYTES");          // (tests: the trial on small scenes)

@@ -43,7 +43,7 @@
 #define PT_TEX_NOUNROLL 0
 #endif
 #ifndef PT_TOUCH_VARIANT
-#define PT_TOUCH_VARIANT 3       // k_trace_far: which pushed children node_step_lean touches (see there; 3 = leaves that are not the next visit)
+#define PT_TOUCH_VARIANT 3       // k_trace_far built with PT_NODE_COOP 0 (its first form): which pushed children node_step_lean touches (see there)
 #endif
 
 // ============================================================ Sobol' sampler
@@ -986,7 +986,7 @@ PT_DEV void node_step_lean(const PtScene& sc, LaneRay& r, TravCtx& c) {
     fs_push4_exec(r.sa, top, c0, c1, c2, c3, e0, e1, e2, e3);
     r.top = top;
     if constexpr (TOUCH != 0) {
-        // k_trace_far, for scenes whose rays miss the caches (chosen per scene by a timed trial, pt_context.cpp).  Every reference pushed here IS
+        // k_trace_far's first form (PT_NODE_COOP 0; superseded by node_step_coop below, which gains more on the same scenes).  Every reference pushed here IS
         // visited later -- the reference's stack holds no distances --, so a pushed LEAF that is not the next visit has its first record's line
         // touched now: one 4-byte load into a register nobody reads.  A leaf round waits for the slowest of up to 64 record fetches, each the
         // first access to a line of its own; touched at push time the line is on its way (or in L2) when the round comes.  Loads return in
@@ -1016,6 +1016,100 @@ PT_DEV void node_step_lean(const PtScene& sc, LaneRay& r, TravCtx& c) {
         if (p3 & me) touch(c3);
     }
 }
+
+#ifndef PT_NODE_COOP
+#define PT_NODE_COOP 1           // k_trace_far fetches nodes pairwise (node_step_coop); 2 = k_trace too (experiment)
+#endif
+#ifndef PT_COOP_TOUCH
+#define PT_COOP_TOUCH 0          // ... and touches pushed leaves as node_step_lean<TOUCH> does (slower with the pairwise fetch: 16 M sparse triangles 440 vs 485 Mrays/s)
+#endif
+#if PT_NODE_COOP
+// k_trace_far's visit, for scenes whose rays miss the caches (chosen per scene by a timed trial, pt_context.cpp): the lean visit with the two lanes of a
+// PAIR fetching each other's node together (tools/ubench/visit_quad.hip `coop`).  Node A belongs to the
+// even lane, node B to the odd one.  In loads 1-3 both lanes read node A (its owner the three near rows, the partner A's three far rows, at the addresses
+// the OWNER computed and handed over by DPP), in loads 4-6 both read node B; the child references each lane fetches for itself.  Six of the seven loads of
+// a visit then see two lanes per 128-byte line -- four tag look-ups per visit instead of seven, still 64 rays per wave.  The odd lanes swap the address
+// registers before and the data registers after the loads (v_swap_b32 under EXEC = odd lanes), so that every lane finds its near rows in x1-3 and its far
+// rows in the PARTNER's x4-6, read through DPP as a source modifier of the slab arithmetic.  A lane whose partner visits a node while it does not helps
+// with the partner's far rows and does nothing else.  m_node = __ballot(w_node).  Measured (Mrays/s at 64 spp, k_trace / this): 16 M sparse triangles
+// 421 / 485, 8 M sparse 525 / 603; where nodes hit the caches the 19 extra instructions per visit cost more than the look-ups save (RT1M 1083 / 1040,
+// 4 M triangles 1288 / 1241), hence the trial.
+#define PT_PAIR_U(x) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0xB1, 0xF, 0xF, false))
+#define PT_PAIR_F(x) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0xB1, 0xF, 0xF, false))
+template <int TOUCH>
+PT_DEV void node_step_coop(const PtScene& sc, LaneRay& r, TravCtx& c, bool w_node, unsigned long long m_node) {
+    constexpr unsigned long long kEven = 0x5555555555555555ull, kOdd = 0xAAAAAAAAAAAAAAAAull;
+    const unsigned long long ev = m_node & kEven, od = m_node & kOdd;
+    const unsigned long long m_y = ev | (ev << 1), m_z = od | (od >> 1);          // the lanes that load from node A / from node B
+    if (__builtin_amdgcn_inverse_ballot_w64(m_y | m_z)) {                           // (closed under lane ^ 1: every DPP source below is an active lane)
+        const uint32_t ref = r.top;
+        const uint32_t no = ref << 7;
+        const char* nb = reinterpret_cast<const char*>(sc.nodes);
+        uint32_t top = PT_EMPTY_REF;
+        const bool in_lds = w_node && no < c.top_bytes;
+        if (w_node) { r.sa -= PT_SLOT; top = lds_load(r.sa); c.n_nodes++; c.n_nodes_lds += in_lds ? 1u : 0u; }
+        const unsigned long long m_lds = __ballot(in_lds), le = m_lds & kEven, lo = m_lds & kOdd;
+        const unsigned long long y_lds = le | (le << 1), z_lds = lo | (lo >> 1);  // node A / node B is one of the top nodes in LDS
+        const uint32_t base = in_lds ? c.top_lds + no - (no >> 3) : no;           // LDS address or byte offset in HBM, the owner knows which
+        uint32_t a1 = base + r.o_nx, a2 = base + r.o_ny, a3 = base + r.o_nz;      // my near rows
+        uint32_t b1 = PT_PAIR_U(base + r.o_fx), b2 = PT_PAIR_U(base + r.o_fy), b3 = PT_PAIR_U(base + r.o_fz);     // my partner's far rows
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[om]\n\tv_swap_b32 %0, %3\n\tv_swap_b32 %1, %4\n\tv_swap_b32 %2, %5\n\ts_mov_b64 exec, %[sv]"
+                     : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b1), "+v"(b2), "+v"(b3), [sv] "=&s"(sv) : [om] "s"(kOdd));
+        float4 x1, x2, x3, x4, x5, x6;
+        uint4 ch;
+        if (__builtin_amdgcn_inverse_ballot_w64(m_y & y_lds)) { x1 = lds_load4(a1); x2 = lds_load4(a2); x3 = lds_load4(a3); }
+        if (__builtin_amdgcn_inverse_ballot_w64(m_z & z_lds)) { x4 = lds_load4(b1); x5 = lds_load4(b2); x6 = lds_load4(b3); }
+        if (in_lds) ch = lds_load4u(base + 96u);
+        if (__builtin_amdgcn_inverse_ballot_w64(m_y & ~y_lds)) {
+            x1 = *reinterpret_cast<const float4*>(nb + a1); x2 = *reinterpret_cast<const float4*>(nb + a2); x3 = *reinterpret_cast<const float4*>(nb + a3);
+        }
+        if (__builtin_amdgcn_inverse_ballot_w64(m_z & ~z_lds)) {
+            x4 = *reinterpret_cast<const float4*>(nb + b1); x5 = *reinterpret_cast<const float4*>(nb + b2); x6 = *reinterpret_cast<const float4*>(nb + b3);
+        }
+        if (__builtin_amdgcn_inverse_ballot_w64(m_node & ~m_lds)) ch = *reinterpret_cast<const uint4*>(nb + (no + 96u));
+        asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[om]\n\t"
+                     "v_swap_b32 %0, %12\n\tv_swap_b32 %1, %13\n\tv_swap_b32 %2, %14\n\tv_swap_b32 %3, %15\n\t"
+                     "v_swap_b32 %4, %16\n\tv_swap_b32 %5, %17\n\tv_swap_b32 %6, %18\n\tv_swap_b32 %7, %19\n\t"
+                     "v_swap_b32 %8, %20\n\tv_swap_b32 %9, %21\n\tv_swap_b32 %10, %22\n\tv_swap_b32 %11, %23\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w), "+v"(x3.x), "+v"(x3.y), "+v"(x3.z), "+v"(x3.w),
+                       "+v"(x4.x), "+v"(x4.y), "+v"(x4.z), "+v"(x4.w), "+v"(x5.x), "+v"(x5.y), "+v"(x5.z), "+v"(x5.w), "+v"(x6.x), "+v"(x6.y), "+v"(x6.z), "+v"(x6.w), [sv] "=&s"(sv)
+                     : [om] "s"(kOdd));
+        const float ox = r.o.x, oy = r.o.y, oz = r.o.z, ix = r.idir.x, iy = r.idir.y, iz = r.idir.z;
+#define PT_SLAB(C) (v_min3(v_min(r.tmax, (PT_PAIR_F(x4.C) - ox) * ix), (PT_PAIR_F(x5.C) - oy) * iy, (PT_PAIR_F(x6.C) - oz) * iz) >= \
+                    v_max3(v_max(r.tmin, (x1.C - ox) * ix), (x2.C - oy) * iy, (x3.C - oz) * iz))
+        const bool h0 = PT_SLAB(x), h1 = PT_SLAB(y), h2 = PT_SLAB(z), h3 = PT_SLAB(w);
+#undef PT_SLAB
+        const bool T = __builtin_amdgcn_ubfe(r.sbits, __builtin_amdgcn_ubfe(ch.x, PT_REF_AXIS_SHIFT, 2), 1) != 0u;
+        const bool L = __builtin_amdgcn_ubfe(r.sbits, __builtin_amdgcn_ubfe(ch.y, PT_REF_AXIS_SHIFT, 2), 1) != 0u;
+        const bool R = __builtin_amdgcn_ubfe(r.sbits, __builtin_amdgcn_ubfe(ch.w, PT_REF_AXIS_SHIFT, 2), 1) != 0u;
+        const uint32_t l0 = L ? ch.x : ch.y, l1 = L ? ch.y : ch.x, r0 = R ? ch.z : ch.w, r1 = R ? ch.w : ch.z;
+        const uint32_t c0 = T ? l0 : r0, c1 = T ? l1 : r1, c2 = T ? r0 : l0, c3 = T ? r1 : l1;
+        // the helping lanes' tests are noise: only the visiting lanes' results count (every push mask below is a select among H0..H3)
+        const unsigned long long H0 = __ballot(h0) & m_node, H1 = __ballot(h1) & m_node, H2 = __ballot(h2) & m_node, H3 = __ballot(h3) & m_node;
+        const unsigned long long Tm = __ballot(T), Lm = __ballot(L), Rm = __ballot(R);
+        const unsigned long long yl = Lm & (H0 ^ H1), el0 = H1 ^ yl, el1 = H0 ^ yl;
+        const unsigned long long yr = Rm & (H2 ^ H3), er0 = H3 ^ yr, er1 = H2 ^ yr;
+        const unsigned long long y0 = Tm & (el0 ^ er0), e0 = er0 ^ y0, e2 = el0 ^ y0;
+        const unsigned long long y1 = Tm & (el1 ^ er1), e1 = er1 ^ y1, e3 = el1 ^ y1;
+        fs_push4_exec(r.sa, top, c0, c1, c2, c3, e0, e1, e2, e3);
+        if (w_node) r.top = top;
+        if constexpr (TOUCH != 0 && PT_COOP_TOUCH) {         // (as in node_step_lean)
+            const unsigned long long p0 = e0 & (e1 | e2 | e3), p1 = e1 & (e2 | e3), p2 = e2 & e3;
+            const char* tb = reinterpret_cast<const char*>(sc.tris);
+            auto touch = [&](uint32_t cref) {
+                if (!(cref & PT_LEAF_BIT)) return;
+                uint32_t v = *reinterpret_cast<const uint32_t*>(tb + (size_t)(cref & PT_LEAF_FIRST_MASK) * 48u);
+                asm volatile("" :: "v"(v));
+            };
+            if (__builtin_amdgcn_inverse_ballot_w64(p0)) touch(c0);
+            if (__builtin_amdgcn_inverse_ballot_w64(p1)) touch(c1);
+            if (__builtin_amdgcn_inverse_ballot_w64(p2)) touch(c2);
+        }
+    }
+}
+#endif
 
 // intersect_simd (qbvh_x86.rs:230-287): closest hit.  Returns record index or -1.
 template <bool SPH, bool INST>
@@ -1456,7 +1550,12 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #if !PT_NODE_STAGED
             if (lean && m_node != 0 && n_parked < PT_LEAF_TRIS_MIN) {
                 PT_PROF_T(t0);
+#if PT_NODE_COOP
+                if constexpr (TOUCH != 0 || PT_NODE_COOP == 2) node_step_coop<TOUCH>(sc, r, c, w_node, m_node);
+                else if (w_node) node_step_lean<TOUCH>(sc, r, c);
+#else
                 if (w_node) node_step_lean<TOUCH>(sc, r, c);
+#endif
                 PT_PROF_T(t1);
 #ifdef PT_PROFILE_PHASES
                 prof[2] += t1 - t0; prof[3] += 1; prof[4] += (unsigned long long)__popcll(m_node);
@@ -1570,7 +1669,7 @@ extern "C" __global__ void __launch_bounds__(PT_TBLOCK, PT_TRACE_DIST_WAVES) k_t
                                                               uint32_t spill_depth, uint32_t* err) {
     trace_body<true, false>(sc, P, Q, cnt, spill, spill_depth, err);
 }
-// the same with pushed leaves touched (node_step_lean<TOUCH>): scenes whose rays miss the caches, chosen per scene by a timed trial (pt_context.cpp)
+// the same with nodes fetched pairwise (node_step_coop): scenes whose rays miss the caches, chosen per scene by a timed trial (pt_context.cpp)
 extern "C" __global__ void __launch_bounds__(PT_TBLOCK, PT_TRACE_DIST_WAVES) k_trace_far(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                                    uint32_t spill_depth, uint32_t* err) {
     trace_body<true, false, false, PT_TOUCH_VARIANT>(sc, P, Q, cnt, spill, spill_depth, err);

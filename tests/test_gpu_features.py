@@ -604,9 +604,9 @@ def test_mesh_light_of_two_thousand_triangles_uses_the_lazy_grid(oracle):
 @pytest.mark.parametrize("name,make", [("cornell", lambda: scenes.cornell_box(res=64, spp=16)), ("materials", lambda: fs.scene_materials_lights("spatial")),
                                        ("rt20k", lambda: scenes.rt1m(20000, res=48, spp=8, max_depth=6)), ("textures", lambda: fs.scene_textures())])
 def test_far_traversal_kernel_changes_nothing(oracle, monkeypatch, name, make, mode):
-    """k_trace_far -- pushed leaves touched ahead of their visit, for scenes whose rays miss the caches -- forced on (PBRTGPU_TRACE_FAR=1), and the
+    """k_trace_far -- a lane pair fetches its two nodes together, for scenes whose rays miss the caches -- forced on (PBRTGPU_TRACE_FAR=1), and the
     timed trial that picks it per scene (forced to run on these small scenes: bounce 1 of the first pass traced twice, once by each kernel,
-    counters put back): per-sample radiance, film and every counter are the oracle's either way -- touching a line changes no result."""
+    counters put back): per-sample radiance, film and every counter are the oracle's either way -- who fetches a row changes no result."""
     if mode == "always":
         monkeypatch.setenv("PBRTGPU_TRACE_FAR", "1")
     else:

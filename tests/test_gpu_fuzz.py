@@ -246,6 +246,30 @@ def fuzz_ctx(pkg):
     ctx.close()
 
 
+@pytest.fixture(scope="module")
+def fuzz_ctx_far(pkg):
+    """A context that traces with k_trace_far -- nodes fetched by lane pairs -- wherever the scene allows it (the switch is read when the context is made)."""
+    import torch  # noqa: F401
+    old = os.environ.get("PBRTGPU_TRACE_FAR")
+    os.environ["PBRTGPU_TRACE_FAR"] = "1"
+    try:
+        ctx = pkg.Context(0)
+    finally:
+        if old is None:
+            del os.environ["PBRTGPU_TRACE_FAR"]
+        else:
+            os.environ["PBRTGPU_TRACE_FAR"] = old
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", _seeds()[:16])
+def test_random_scene_pairwise_node_fetch(fuzz_ctx_far, oracle, seed):
+    """The same scenes through k_trace_far: a lane pair fetches its two nodes together, half of the lanes idle or parked on leaves, nodes in
+    LDS and in HBM side by side in one pair -- whatever the draw produces; everything stays the oracle's."""
+    test_random_scene(fuzz_ctx_far, oracle, seed)
+
+
 @pytest.mark.parametrize("seed", _seeds())
 def test_random_scene(fuzz_ctx, oracle, seed):
     sd, exact_film = random_scene(seed)

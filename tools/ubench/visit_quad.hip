@@ -189,6 +189,73 @@ extern "C" __global__ void __launch_bounds__(BLOCK, 4) k_pair(const char* nodes,
     if (acc == 0xdeadbeefu) out[gid] = acc;
 }
 
+// ---- coop form (round 4): one ray per lane as in `lane`, but the two lanes of a PAIR fetch each other's node together.  Node A belongs to the even
+// lane, node B to the odd one; in loads 1-3 both lanes read from A (the owner its three near rows, the partner A's three far rows, addressed with the
+// OWNER's sign-dependent offsets), in loads 4-6 both read from B; the child references are fetched by each lane for itself.  Six of the seven loads
+// of a visit then see two lanes per 128-byte line: 4 tag look-ups per ray-visit instead of 7, with 64 rays per wave.  Afterwards the odd lanes swap
+// registers X1-3 <-> X4-6 (v_swap_b32 under EXEC = odd lanes), so that every lane finds its near rows in X1-3 and its far rows in the PARTNER's X4-6, which
+// the slab arithmetic reads through DPP (quad_perm [1,0,3,2]) -- a source-operand modifier, no instruction of its own when the compiler folds it.
+#define DPP_SWAP_PAIR(x) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0xB1, 0xF, 0xF, false))
+extern "C" __global__ void __launch_bounds__(BLOCK, 4) k_coop(const char* nodes, uint32_t n_nodes, uint32_t* out, uint32_t seed) {
+    __shared__ uint32_t s_stack[SLOTS * BLOCK];
+    const uint32_t gid = blockIdx.x * BLOCK + threadIdx.x;
+    const Ray r = make_ray(gid ^ seed);
+    const bool odd = (threadIdx.x & 1u) != 0u;
+    const uint32_t ox = (r.oct & 1u) ? 3u : 0u, oy = (r.oct & 2u) ? 3u : 0u, oz = (r.oct & 4u) ? 3u : 0u;
+    const uint32_t o_nx = ox << 4, o_fx = (3u - ox) << 4, o_ny = (1u + oy) << 4, o_fy = (4u - oy) << 4, o_nz = (2u + oz) << 4, o_fz = (5u - oz) << 4;
+    // the partner's far offsets (per-ray constants: refreshed when a lane takes a new ray)
+    const uint32_t p_fx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o_fx, 0xB1, 0xF, 0xF, false), p_fy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o_fy, 0xB1, 0xF, 0xF, false),
+                   p_fz = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o_fz, 0xB1, 0xF, 0xF, false);
+    const uint32_t cAx = odd ? p_fx : o_nx, cAy = odd ? p_fy : o_ny, cAz = odd ? p_fz : o_nz;          // what this lane reads of node A (the even lane's)
+    const uint32_t cBx = odd ? o_nx : p_fx, cBy = odd ? o_ny : p_fy, cBz = odd ? o_nz : p_fz;          // ... of node B (the odd lane's)
+    const unsigned long long odd_mask = 0xAAAAAAAAAAAAAAAAull;
+    uint32_t sp = 0, top = __umulhi(hash32(gid ^ seed), n_nodes), acc = 0;
+    for (int it = 0; it < ITER; it++) {
+        const uint32_t ref = top;
+        const uint32_t no = __umulhi(ref, n_nodes) << 7;
+        if (sp > 0) { sp--; top = s_stack[sp * BLOCK + threadIdx.x]; } else top = EMPTY;
+        const uint32_t no_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)no, 0xB1, 0xF, 0xF, false);
+        const uint32_t bA = odd ? no_p : no, bB = odd ? no : no_p;
+        float4 x1 = *(const float4*)(nodes + (bA + cAx)), x2 = *(const float4*)(nodes + (bA + cAy)), x3 = *(const float4*)(nodes + (bA + cAz));
+        float4 x4 = *(const float4*)(nodes + (bB + cBx)), x5 = *(const float4*)(nodes + (bB + cBy)), x6 = *(const float4*)(nodes + (bB + cBz));
+        const uint4 ch = *(const uint4*)(nodes + (no + 96u));
+        {   // odd lanes: X1-3 <-> X4-6
+            unsigned long long sv;
+            asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[om]\n\t"
+                         "v_swap_b32 %0, %12\n\tv_swap_b32 %1, %13\n\tv_swap_b32 %2, %14\n\tv_swap_b32 %3, %15\n\t"
+                         "v_swap_b32 %4, %16\n\tv_swap_b32 %5, %17\n\tv_swap_b32 %6, %18\n\tv_swap_b32 %7, %19\n\t"
+                         "v_swap_b32 %8, %20\n\tv_swap_b32 %9, %21\n\tv_swap_b32 %10, %22\n\tv_swap_b32 %11, %23\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w), "+v"(x3.x), "+v"(x3.y), "+v"(x3.z), "+v"(x3.w),
+                           "+v"(x4.x), "+v"(x4.y), "+v"(x4.z), "+v"(x4.w), "+v"(x5.x), "+v"(x5.y), "+v"(x5.z), "+v"(x5.w), "+v"(x6.x), "+v"(x6.y), "+v"(x6.z), "+v"(x6.w), [sv] "=&s"(sv)
+                         : [om] "s"(odd_mask));
+        }
+#define CSLAB(C) (v_min3(v_min(r.tmax, (DPP_SWAP_PAIR(x4.C) - r.ox) * r.ix), (DPP_SWAP_PAIR(x5.C) - r.oy) * r.iy, (DPP_SWAP_PAIR(x6.C) - r.oz) * r.iz) >= \
+                  v_max3(v_max(r.tmin, (x1.C - r.ox) * r.ix), (x2.C - r.oy) * r.iy, (x3.C - r.oz) * r.iz))
+        const bool h0 = CSLAB(x), h1 = CSLAB(y), h2 = CSLAB(z), h3 = CSLAB(w);
+#undef CSLAB
+        const bool T = __builtin_amdgcn_ubfe(r.oct, __builtin_amdgcn_ubfe(ch.x, 26, 2), 1) != 0u;
+        const bool L = __builtin_amdgcn_ubfe(r.oct, __builtin_amdgcn_ubfe(ch.y, 26, 2), 1) != 0u;
+        const bool R = __builtin_amdgcn_ubfe(r.oct, __builtin_amdgcn_ubfe(ch.w, 26, 2), 1) != 0u;
+        const uint32_t l0 = L ? ch.x : ch.y, l1 = L ? ch.y : ch.x, r0 = R ? ch.z : ch.w, r1 = R ? ch.w : ch.z;
+        const uint32_t c0 = T ? l0 : r0, c1 = T ? l1 : r1, c2 = T ? r0 : l0, c3 = T ? r1 : l1;
+        const unsigned long long H0 = __ballot(h0), H1 = __ballot(h1), H2 = __ballot(h2), H3 = __ballot(h3), Tm = __ballot(T), Lm = __ballot(L), Rm = __ballot(R);
+        const unsigned long long yl = Lm & (H0 ^ H1), el0 = H1 ^ yl, el1 = H0 ^ yl;
+        const unsigned long long yr = Rm & (H2 ^ H3), er0 = H3 ^ yr, er1 = H2 ^ yr;
+        const unsigned long long y0 = Tm & (el0 ^ er0), e0 = er0 ^ y0, e2 = el0 ^ y0;
+        const unsigned long long y1 = Tm & (el1 ^ er1), e1 = er1 ^ y1, e3 = el1 ^ y1;
+        const unsigned long long me = 1ull << (threadIdx.x & 63u);
+        if (e0 & me) { if (top != EMPTY) { s_stack[sp * BLOCK + threadIdx.x] = top; sp = (sp + 1) & (SLOTS - 1); } top = c0; }
+        if (e1 & me) { if (top != EMPTY) { s_stack[sp * BLOCK + threadIdx.x] = top; sp = (sp + 1) & (SLOTS - 1); } top = c1; }
+        if (e2 & me) { if (top != EMPTY) { s_stack[sp * BLOCK + threadIdx.x] = top; sp = (sp + 1) & (SLOTS - 1); } top = c2; }
+        if (e3 & me) { if (top != EMPTY) { s_stack[sp * BLOCK + threadIdx.x] = top; sp = (sp + 1) & (SLOTS - 1); } top = c3; }
+        acc += (uint32_t)__popcll((e0 | e1 | e2 | e3) & me);
+        if (top == EMPTY) top = hash32(ref + it);
+        top = hash32(top) | 0u;
+    }
+    if (acc == 0xdeadbeefu) out[gid] = acc;
+}
+
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     double mb = argc > 1 ? atof(argv[1]) : 21.0;
@@ -225,12 +292,13 @@ int main(int argc, char** argv) {
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     std::printf("table %.1f MB (%u nodes), %d CUs, %d visits per ray\n", mb, n_nodes, cus, ITER);
     for (int bpc : {2, 4}) {
-        for (int form = 0; form < 3; form++) {
+        for (int form = 0; form < 4; form++) {
             const int blocks = cus * bpc;
             auto launch = [&](uint32_t seed) {
                 if (form == 0) hipLaunchKernelGGL(k_lane, dim3(blocks), dim3(BLOCK), 0, 0, nodes_lane, n_nodes, out, seed);
                 else if (form == 1) hipLaunchKernelGGL(k_quad, dim3(blocks), dim3(BLOCK), 0, 0, nodes_quad, n_nodes, out, seed);
-                else hipLaunchKernelGGL(k_pair, dim3(blocks), dim3(BLOCK), 0, 0, nodes_quad, n_nodes, out, seed);
+                else if (form == 2) hipLaunchKernelGGL(k_pair, dim3(blocks), dim3(BLOCK), 0, 0, nodes_quad, n_nodes, out, seed);
+                else hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(BLOCK), 0, 0, nodes_lane, n_nodes, out, seed);
             };
             launch(1u);
             (void)hipDeviceSynchronize();
@@ -240,10 +308,10 @@ int main(int argc, char** argv) {
             (void)hipEventSynchronize(e1);
             float ms;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            const double rays = (double)blocks * BLOCK / (form == 0 ? 1 : (form == 1 ? 4 : 2));
+            const double rays = (double)blocks * BLOCK / ((form == 0 || form == 3) ? 1 : (form == 1 ? 4 : 2));
             std::printf("%d waves/SIMD  %-28s %8.3f ms  %7.1f G ray-visits/s   (%.0f rays per wave-instruction)  (%s)\n", bpc,
-                        form == 0 ? "lane: one ray per lane" : (form == 1 ? "quad: one ray per lane quad" : "pair: one ray per lane pair"), ms, rays * ITER / ms / 1e6,
-                        form == 0 ? 64.0 : (form == 1 ? 16.0 : 32.0), hipGetErrorString(hipGetLastError()));
+                        form == 0 ? "lane: one ray per lane" : (form == 1 ? "quad: one ray per lane quad" : (form == 2 ? "pair: one ray per lane pair" : "coop: lane form, paired fetch")), ms, rays * ITER / ms / 1e6,
+                        (form == 0 || form == 3) ? 64.0 : (form == 1 ? 16.0 : 32.0), hipGetErrorString(hipGetLastError()));
         }
     }
     return 0;
