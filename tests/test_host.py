@@ -181,7 +181,7 @@ def test_kernel_register_budgets():
     ks = kernel_resources.kernels(pkg.capi.LIB_PATH)
     budgets = {                      # kernel: (registers at most, spilled registers at most, LDS bytes at most)
         "k_trace": (128, 0, 163840),             # four waves per SIMD; ONE 1024-thread block per CU (PT_TRACE_WIDE): its stacks + the shared copy of the tree's top five levels
-        "k_trace_far": (128, 0, 163840),         # the same with pushed leaves touched (scenes whose rays miss the caches)
+        "k_trace_far": (128, 0, 163840),         # the same with nodes fetched by lane pairs (scenes whose rays miss the caches)
         "k_trace_seq": (128, 0, 40960),
         "k_trace_sph_dist": (128, 0, 163840),    # scenes with spheres (config 4's class): the same occupancy step
         "k_shade": (256, 0, 40960),              # two waves per SIMD, nothing in scratch
