@@ -878,7 +878,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     }
     mark("record map + objects");
     t1 = now_ms();
-    ctx->max_stack = bvh.max_stack + max_inner_stack;
+    ctx->max_stack = bvh.max_stack + max_inner_stack + (d->n_instances ? 4u : 0u);      // (+ what a ray leaves behind when it enters an object: the rest of its leaf, its slab interval, the marker)
 
     // ---- shading records ----------------------------------------------------
     tinfo.resize(bvh.tris.size() - 1);

@@ -578,6 +578,7 @@ struct LaneRay {
     uint32_t m_t, m_l, m_r;      // this ray's bit in the node's three order tables (PtNode::order_lut)
     int32_t best;
     uint32_t best_inst;          // INST kernels: instance index + 1 of `best` (0 = a world primitive)
+    uint32_t cur_inst;           // k_trace_inst: instance index + 1 of the object tree this ray is walking right now (0 = the world's)
 };
 PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max) {
     r.o = o;
@@ -587,6 +588,7 @@ PT_DEV void ray_begin(const PtScene& sc, LaneRay& r, V3 o, V3 d, float t_max) {
     if (!(fabsf(r.idir.x) < PT_INF) || !(fabsf(r.idir.y) < PT_INF) || !(fabsf(r.idir.z) < PT_INF)) r.sbits |= 8u;
     r.best = -1;
     r.best_inst = 0;
+    r.cur_inst = 0;
     r.ray_tmax = t_max;
     r.sp = 0;
     r.top = PT_EMPTY_REF;
@@ -746,6 +748,71 @@ template <bool SPH, bool INST>
 PT_DEV void ray_step(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
     if (ray_wants_tri(r)) ray_step_tri<SPH, INST>(sc, r, any_hit, c);
     else ray_step_node(sc, r, c);
+}
+
+// k_trace_inst's leaf step: an instance is ENTERED, not walked.  The blocking form above runs an object's whole tree inside one lane's leaf step while the
+// other 63 lanes of the wave wait (fine for a batch of probe rays, 6x too slow for a frame: 50 instances of a 500 k-triangle object traced at 174 Mrays/s).
+// Here the lane that meets an instance record whose root box it hits pushes what it needs to come back -- the rest of its leaf as a leaf reference, its
+// world-space slab interval, a marker -- turns its ray into the instance-space ray (TransformedPrimitive::intersect, transformed_primitive.rs:26-48: t
+// carries over, the direction is not renormalised) and returns to the wave's phases with the object's root on top of its stack: node visits and leaf walks
+// of object trees then run side by side with everybody else's.  Popping the marker (trace_body) brings the world ray back from the path arrays.  Order of
+// tests, t_max updates and counters are the blocking form's: a leaf cut in two behaves like the whole one because nothing reads the world-space slab
+// interval while the ray is inside the object (a hit among the leaf's earlier records shrinks it before it is saved, a hit inside the object after it is
+// restored, the leaf's later records at their own end).  Objects hold no instances (scene_context.rs:1352-1357), so one level is all there is.
+#define PT_INST_EXIT_REF (PT_LEAF_BIT | PT_LEAF_FIRST_MASK)          // the marker: a leaf reference no scene can hold (fewer than 2^26 - 16 primitives)
+PT_DEV void ray_set_direction_state(LaneRay& r, V3 o, V3 d) {        // what ray_begin derives from (o, d), without touching hit, t_max or stack
+    r.o = o; r.d = d;
+    r.idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.sbits = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+    if (!(fabsf(r.idir.x) < PT_INF) || !(fabsf(r.idir.y) < PT_INF) || !(fabsf(r.idir.z) < PT_INF)) r.sbits |= 8u;
+    ray_precompute(r.rp, o, d);
+}
+template <bool SPH>
+PT_DEV void ray_step_tri_enter(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
+    uint32_t rec = stk_pop(c, r.top, r.sp) & PT_LEAF_FIRST_MASK;
+    bool leaf_hit = false;
+    for (;;) {
+        TriVerts t0 = load_tri(sc.tris, rec);
+        TriHit h;
+        c.n_tris++;
+        bool hit = false;
+        int32_t hit_rec = (int32_t)rec;
+        uint32_t hit_inst = r.cur_inst;
+        const bool last = (t0.flags & PT_TRI_LAST) != 0;
+        if (t0.flags & PT_TRI_INSTANCE) {            // (world leaves only)
+            const uint32_t inst = __float_as_uint(t0.p0.x);
+            const PtInstance& in = sc.instances[inst];
+            V3 o, d;
+            instance_ray(in, r.o, r.d, &o, &d);
+            LaneRay ri;
+            ray_set_direction_state(ri, o, d);
+            ri.ray_tmax = r.ray_tmax;
+            if (in.direct) {                         // a single primitive, wrapped without an accelerator: no root box, not a counted leaf test
+                TriVerts tv = load_tri(sc.tris, in.root_ref);
+                hit = prim_test<SPH>(sc, tv, ri, any_hit, h);
+                hit_rec = (int32_t)in.root_ref; hit_inst = inst + 1u;
+            } else if (box_root_test(in.root_lo, in.root_hi, o, ri.idir, ri.sbits, ri.ray_tmax, ri.tmin, ri.tmax)) {
+                if (leaf_hit) r.tmax = r.ray_tmax;
+                if (!last) stk_push(c, r.top, r.sp, PT_LEAF_BIT | (rec + 1u));
+                stk_push(c, r.top, r.sp, __float_as_uint(r.tmin));
+                stk_push(c, r.top, r.sp, __float_as_uint(r.tmax));
+                stk_push(c, r.top, r.sp, PT_INST_EXIT_REF);
+                r.o = ri.o; r.d = ri.d; r.idir = ri.idir; r.sbits = ri.sbits; r.rp = ri.rp; r.tmin = ri.tmin; r.tmax = ri.tmax;
+                r.cur_inst = inst + 1u;
+                stk_push(c, r.top, r.sp, in.root_ref);
+                return;
+            }
+        } else hit = prim_test<SPH>(sc, t0, r, any_hit, h);
+        if (hit) {
+            r.best = hit_rec; leaf_hit = true;
+            r.best_inst = hit_inst;
+            if (any_hit) { r.sp = 0; r.top = PT_EMPTY_REF; return; }
+            r.ray_tmax = h.t;
+        }
+        if (last) break;
+        rec++;
+    }
+    if (leaf_hit) r.tmax = r.ray_tmax;
 }
 
 // ============================================================ lean node visit (k_trace, k_trace_sph_dist)
@@ -1646,7 +1713,21 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
             prof[12] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[13] += 1; prof[4] += (unsigned long long)__popcll(m_node);
 #endif
         } else {
-            if (w_tri) ray_step_tri<SPH, INST>(sc, r, kind == 2, c);
+            if constexpr (INST) {
+                if (w_tri) {
+                    if (r.top == PT_INST_EXIT_REF) {          // back from an object's tree (ray_step_tri_enter): the world ray again, from where it was handed out
+                        (void)stk_pop(c, r.top, r.sp);
+                        const float w_tmax = __uint_as_float(stk_pop(c, r.top, r.sp)), w_tmin = __uint_as_float(stk_pop(c, r.top, r.sp));
+                        const float4 ro = (kind == 1 ? P.ray_o : (kind == 2 ? P.sh_o : P.pr_o))[p], rd = (kind == 1 ? P.ray_d : (kind == 2 ? P.sh_d : P.pr_d))[p];
+                        const bool hit_inside = r.best >= 0 && r.best_inst == r.cur_inst;      // (an instance is one primitive of the world's tree: entered once per ray)
+                        ray_set_direction_state(r, f4_3(ro), mk3(rd.x, rd.y, rd.z));
+                        r.tmin = w_tmin; r.tmax = hit_inside ? r.ray_tmax : w_tmax;
+                        r.cur_inst = 0;
+                    } else ray_step_tri_enter<SPH>(sc, r, kind == 2, c);
+                }
+            } else {
+                if (w_tri) ray_step_tri<SPH, INST>(sc, r, kind == 2, c);
+            }
 #ifdef PT_PROFILE_PHASES
             prof[7] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[8] += 1; prof[9] += (unsigned long long)__popcll(m_tri);
 #endif
