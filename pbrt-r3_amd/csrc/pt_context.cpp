@@ -752,6 +752,24 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
             ptbvh::parallel_for(d->n_triangles, [&](size_t a, size_t b) { for (size_t t = a; t < b; t++) out[t] = {0u, (uint32_t)t}; });
             return out;
         }
+        if (extra.empty()) {              // triangles only: the list's members counted and written by the host's threads, chunk by chunk, in triangle order
+            const size_t n_chunks = 64, step = ((size_t)d->n_triangles + n_chunks - 1) / n_chunks;
+            std::vector<size_t> cnt_c(n_chunks + 1, 0);
+            ptbvh::parallel_tasks(n_chunks, [&](size_t c) {
+                const size_t a = std::min((size_t)d->n_triangles, c * step), b = std::min((size_t)d->n_triangles, a + step);
+                size_t k = 0;
+                for (size_t t = a; t < b; t++) k += d->meshes[d->tri_mesh[t]].object == tag;
+                cnt_c[c + 1] = k;
+            });
+            for (size_t c = 0; c < n_chunks; c++) cnt_c[c + 1] += cnt_c[c];
+            out.resize(cnt_c[n_chunks]);
+            ptbvh::parallel_tasks(n_chunks, [&](size_t c) {
+                const size_t a = std::min((size_t)d->n_triangles, c * step), b = std::min((size_t)d->n_triangles, a + step);
+                size_t k = cnt_c[c];
+                for (size_t t = a; t < b; t++) if (d->meshes[d->tri_mesh[t]].object == tag) out[k++] = {0u, (uint32_t)t};
+            });
+            return out;
+        }
         size_t e = 0;
         for (uint32_t t = 0; t <= d->n_triangles; t++) {
             while (e < extra.size() && extra[e].before <= t) { out.push_back({extra[e].kind, extra[e].idx}); e++; }
@@ -773,8 +791,15 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
     for (uint32_t k = 0; k < n_objects; k++) {
         ObjectBvh& ob = objs[k];
         ob.list = make_list(k + 1);
-        std::vector<ptbvh::Prim> prims(ob.list.size());
-        for (size_t i = 0; i < ob.list.size(); i++) fill_prim(ob.list[i], &prims[i]);
+        // (the context's primitive buffer, shared with the world list below: uninitialised storage that survives from upload to upload)
+        if (ctx->host_prims_cap < ob.list.size()) {
+            ctx->host_prims.reset();
+            ctx->host_prims.reset(new ptbvh::Prim[ob.list.size()]);
+            ctx->host_prims_cap = ob.list.size();
+        }
+        struct { ptbvh::Prim* p; size_t n; ptbvh::Prim* data() const { return p; } size_t size() const { return n; } bool empty() const { return n == 0; }
+                 ptbvh::Prim& operator[](size_t i) const { return p[i]; } } prims{ctx->host_prims.get(), ob.list.size()};
+        ptbvh::parallel_for(ob.list.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) fill_prim(ob.list[i], &prims[i]); });
         if (prims.size() == 1) {             // a single primitive is wrapped without an accelerator (scene_context.rs:1370-1377)
             ob.direct = true;
             ob.res.tris.assign(1, prims[0].rec);
@@ -851,11 +876,18 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
                 if (ref == PT_EMPTY_REF) return ref;
                 return (ref & PT_LEAF_BIT) ? ((ref & ~PT_LEAF_FIRST_MASK) | ((ref & PT_LEAF_FIRST_MASK) + rec_off[k])) : ref + node_off[k];
             };
-            for (PtNode nd : ob.res.nodes) { for (int c = 0; c < 4; c++) nd.child[c] = shift(nd.child[c]); bvh.nodes.push_back(nd); }
-            for (size_t r = 0; r < ob.res.tris.size(); r++) {
-                bvh.tris.push_back(ob.res.tris[r]);
-                rec_entry.push_back(ob.direct ? ob.list[0] : ob.list[ob.res.tris[r].prim]);
-            }
+            bvh.nodes.resize((size_t)node_off[k] + ob.res.nodes.size());
+            ptbvh::parallel_for(ob.res.nodes.size(), [&](size_t a, size_t b) {
+                for (size_t i = a; i < b; i++) { PtNode nd = ob.res.nodes[i]; for (int c = 0; c < 4; c++) nd.child[c] = shift(nd.child[c]); bvh.nodes[(size_t)node_off[k] + i] = nd; }
+            });
+            bvh.tris.resize((size_t)rec_off[k] + ob.res.tris.size());
+            rec_entry.resize((size_t)rec_off[k] + ob.res.tris.size());
+            ptbvh::parallel_for(ob.res.tris.size(), [&](size_t a, size_t b) {
+                for (size_t r = a; r < b; r++) {
+                    bvh.tris[(size_t)rec_off[k] + r] = ob.res.tris[r];
+                    rec_entry[(size_t)rec_off[k] + r] = ob.direct ? ob.list[0] : ob.list[ob.res.tris[r].prim];
+                }
+            });
             ob.res.root_ref = ob.direct ? rec_off[k] : shift(ob.res.root_ref);
             max_inner_stack = std::max(max_inner_stack, ob.res.max_stack);
             bvh.max_leaf = std::max(bvh.max_leaf, ob.res.max_leaf);
@@ -882,7 +914,8 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
 
     // ---- shading records ----------------------------------------------------
     tinfo.resize(bvh.tris.size() - 1);
-    for (size_t r = 0; r < tinfo.size(); r++) {
+    ptbvh::parallel_for(tinfo.size(), [&](size_t r0_, size_t r1_) {
+    for (size_t r = r0_; r < r1_; r++) {
         PtTriInfo& ti = tinfo[r];
         std::memset(&ti, 0, sizeof(ti));
         ti.light = -1; ti.material = -1;
@@ -900,6 +933,7 @@ pt_status pt_scene_upload(pt_context* ctx, const pt_scene_desc* d) {
         if (!d->UV) mf &= ~PT_MESH_HAS_UV;
         ti.mesh_flags = mf;
     }
+    });
     // one DiffuseAreaLight per emissive world primitive, in primitive order (scene_context.rs:1218-1231); lights inside objects are
     // dropped as in the reference (:1302-1304), instances carry none (TransformedPrimitive::get_area_light)
     for (uint32_t prim = 0; prim < world.size(); prim++) {
