@@ -1248,6 +1248,9 @@ PT_DEV uint32_t wave_ticket(uint32_t* ticket) {
 #ifndef PT_LEAF_MIN
 #define PT_LEAF_MIN 24          // k_trace_seq: leaf phase once this many lanes are parked on a leaf
 #endif
+#ifndef PT_LEAF_MIN_INST
+#define PT_LEAF_MIN_INST 40     // k_trace_inst: a leaf step there may be an instance entry (~300 instructions): wait for more lanes
+#endif
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 4        // waves per SIMD the register allocator must leave room for (k_trace_seq)
 #endif
@@ -1707,7 +1710,7 @@ PT_DEV void trace_body(const PtScene& sc, const PtPaths& P, const PtQueues& Q, P
 #endif
             }
         } else {
-        if (m_node != 0 && __popcll(m_tri) < PT_LEAF_MIN) {
+        if (m_node != 0 && __popcll(m_tri) < (INST ? PT_LEAF_MIN_INST : PT_LEAF_MIN)) {
             if (w_node) ray_step_node(sc, r, c);
 #ifdef PT_PROFILE_PHASES
             prof[12] += (unsigned long long)(__builtin_readcyclecounter() - pt0); prof[13] += 1; prof[4] += (unsigned long long)__popcll(m_node);

@@ -12,17 +12,18 @@ out="gpurun_out/r04_final_$part"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 if [ "$part" = a ]; then
+  # counters first: the bench lines behind them then quote the traffic measured on this very source (bench.py checks the stamp)
+  bash tools/pmc_traffic_workload.sh r04_default && cp gpurun_out/pmc_r04_default/traffic_entry.json "$out/traffic_entry_default.json" && cp gpurun_out/pmc_r04_default/summary.txt "$out/pmc_fetch_write_default.txt" && python3 tools/r04_stamp.py "$out/traffic_entry_default.json"
   timeout -k 10 600 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; exit 1; }
   cut -c1-300 "$out/bench.json"
   timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$out/prof" --output-format csv -- python3 bench.py --no-cpu-baseline --no-spp1024 > "$out/bench_under_rocprof.json" 2> "$out/bench_under_rocprof.err" || { echo "rocprof run failed"; tail -5 "$out/bench_under_rocprof.err"; exit 1; }
   find "$out/prof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$out/kernel_stats.csv"
   find "$out/prof" -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/per_bounce.py {} > "$out/per_bounce.txt"; rm -rf "$out/prof"
   head -8 "$out/kernel_stats.csv" | cut -c1-140
-  bash tools/pmc_traffic_workload.sh r04_default && cp gpurun_out/pmc_r04_default/traffic_entry.json "$out/traffic_entry_default.json" && cp gpurun_out/pmc_r04_default/summary.txt "$out/pmc_fetch_write_default.txt"
 elif [ "$part" = b ]; then
+  PBRTGPU_TRACE_FAR=1 bash tools/pmc_traffic_workload.sh r04_16m_sparse --triangles 16000000 --tri-size 0.00125 && cp gpurun_out/pmc_r04_16m_sparse/traffic_entry.json "$out/traffic_entry_16m_sparse.json" && cp gpurun_out/pmc_r04_16m_sparse/summary.txt "$out/pmc_fetch_write_16m_sparse.txt" && python3 tools/r04_stamp.py "$out/traffic_entry_16m_sparse.json" "PBRTGPU_TRACE_FAR=1 for the whole frame (what the library's trial picks for this scene)"
   timeout -k 10 600 python3 bench.py --triangles 3500000 --materials textured --spp 1024 --steps 1 --warmup 1 --no-spp1024 --cpu-tiles 16 > "$out/bench_crown_class.json" 2> "$out/bench_crown_class.err"
   timeout -k 10 600 python3 bench.py --triangles 16000000 --steps 1 --warmup 1 --no-spp1024 --cpu-tiles 16 > "$out/bench_16m.json" 2> "$out/bench_16m.err"
-  PBRTGPU_TRACE_FAR=1 bash tools/pmc_traffic_workload.sh r04_16m_sparse --triangles 16000000 --tri-size 0.00125 && cp gpurun_out/pmc_r04_16m_sparse/traffic_entry.json "$out/traffic_entry_16m_sparse.json" && cp gpurun_out/pmc_r04_16m_sparse/summary.txt "$out/pmc_fetch_write_16m_sparse.txt"
   timeout -k 10 600 python3 bench.py --triangles 16000000 --tri-size 0.00125 --steps 1 --warmup 1 --no-spp1024 --cpu-tiles 16 > "$out/bench_16m_sparse.json" 2> "$out/bench_16m_sparse.err"
   timeout -k 10 600 python3 bench.py --materials mixed --light sphere --sampler halton --spp 512 --steps 1 --warmup 1 --no-spp1024 --cpu-tiles 16 > "$out/bench_killeroo_class.json" 2> "$out/bench_killeroo_class.err"
   timeout -k 10 600 python3 bench.py --materials mixed --steps 1 --warmup 1 --no-spp1024 --cpu-tiles 16 > "$out/bench_mixed.json" 2> "$out/bench_mixed.err"
