@@ -613,3 +613,38 @@ def golden_tile(info):
     sb = list(info.sample_bounds)
     cx, cy = (sb[0] + sb[2]) // 2, (sb[1] + sb[3]) // 2
     return (cx - 6, cy - 6, cx + 6, cy + 6)
+
+
+def scene_instance_swarm(split="sah", maxnodeprims=4, n_inst=36, res=48, spp=8, depth=6):
+    """What the fixed instancing scene does not reach: world leaves that hold SEVERAL instances, with triangles before, between and behind them (a ray that
+    enters an instance leaves the rest of its leaf on its stack and comes back to it), overlapping instances of a tree deep enough to matter
+    (3 000 triangles, some of them glass), one-triangle objects among them (wrapped without an accelerator: tested on the spot), any-hit rays
+    that end inside an object."""
+    b = base(res=res, spp=spp, depth=depth)
+    b.accelerator_bvh(splitmethod=split, maxnodeprims=maxnodeprims)
+    T = scenes
+    rng = np.random.default_rng(41)
+    n = 3000
+    c = rng.uniform(-0.5, 0.5, (n, 1, 3)).astype(np.float32)
+    verts = (c + rng.uniform(-0.06, 0.06, (n, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    b.object_begin("cloud")
+    b.material_matte((0.6, 0.45, 0.3))
+    b.shape_trianglemesh(verts[:6000], np.arange(6000))
+    b.material_glass()
+    b.shape_trianglemesh(verts[6000:], np.arange(3 * n - 6000))
+    b.object_end()
+    b.object_begin("shard")
+    b.material_mirror()
+    b.shape_trianglemesh([(-0.3, 0.0, 0.0), (0.3, 0.0, 0.1), (0.0, 0.5, 0.05)], [0, 1, 2])
+    b.object_end()
+    room(b)
+    b.material_matte((0.4, 0.4, 0.7))
+    for k in range(n_inst):
+        p = rng.uniform(-1.2, 1.2, 3)
+        sc = float(rng.uniform(0.4, 1.1))
+        m = T.transform_mul(T.transform_translate(float(p[0]), float(p[1]), float(p[2])), T.transform_mul(T.transform_rotate_x(float(rng.uniform(-60, 60))), T.transform_scale(sc, sc * (-1.0 if k % 7 == 3 else 1.0), sc)))
+        b.object_instance("shard" if k % 5 == 4 else "cloud", m)
+        if k % 3 == 0:          # a world triangle between the instances (primitive order = creation order)
+            q = rng.uniform(-1.0, 1.0, 3).astype(np.float32)
+            b.shape_trianglemesh([tuple(q), tuple(q + np.float32([0.3, 0.0, 0.05])), tuple(q + np.float32([0.0, 0.3, 0.1]))], [0, 1, 2])
+    return b.build()

@@ -690,3 +690,20 @@ def test_shadow_ray_sorting_changes_nothing(oracle, monkeypatch, name, make):
         osc.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("split,maxprims", [("sah", 4), ("hlbvh", 4), ("sah", 1), ("middle", 8)])
+def test_rays_enter_instances_and_come_back(oracle, split, maxprims):
+    """k_trace_inst's instance entry (a ray turns into the instance-space ray with the rest of its leaf, its slab interval and a marker left on its
+    stack, and walks the object's tree in the wave's common phases) on a swarm of overlapping instances sharing world leaves with each other and with
+    triangles: hits of plain ray batches (the blocking form), per-sample radiance, film and every counter are the oracle's."""
+    sd = fs.scene_instance_swarm(split, maxprims)
+    ctx = pkg.Context(0)
+    try:
+        ctx.upload(sd)
+        assert sd.desc.n_instances == 36
+        osc = oracle.scene(sd)
+        _compare(ctx, osc, exact_film=True)
+        osc.close()
+    finally:
+        ctx.close()
