@@ -263,7 +263,7 @@ def fuzz_ctx_far(pkg):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", _seeds()[:16])
+@pytest.mark.parametrize("seed", _seeds()[:int(os.environ.get("FUZZ_FAR_N", "16"))])
 def test_random_scene_pairwise_node_fetch(fuzz_ctx_far, oracle, seed):
     """The same scenes through k_trace_far: a lane pair fetches its two nodes together, half of the lanes idle or parked on leaves, nodes in
     LDS and in HBM side by side in one pair -- whatever the draw produces; everything stays the oracle's."""
