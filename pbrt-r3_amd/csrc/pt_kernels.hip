@@ -759,6 +759,9 @@ PT_DEV void ray_step(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
 // tests, t_max updates and counters are the blocking form's: a leaf cut in two behaves like the whole one because nothing reads the world-space slab
 // interval while the ray is inside the object (a hit among the leaf's earlier records shrinks it before it is saved, a hit inside the object after it is
 // restored, the leaf's later records at their own end).  Objects hold no instances (scene_context.rs:1352-1357), so one level is all there is.
+#ifndef PT_INST_LEAF_PREFETCH
+#define PT_INST_LEAF_PREFETCH 0     // the next record asked for before this one is tested: 172 registers (two waves per SIMD) or, held to 168, no faster (637 / 1 060 / 432 against 628 / 1 184 / 440 Mrays/s on three instanced scenes)
+#endif
 #define PT_INST_EXIT_REF (PT_LEAF_BIT | PT_LEAF_FIRST_MASK)          // the marker: a leaf reference no scene can hold (fewer than 2^26 - 16 primitives)
 PT_DEV void ray_set_direction_state(LaneRay& r, V3 o, V3 d) {        // what ray_begin derives from (o, d), without touching hit, t_max or stack
     r.o = o; r.d = d;
@@ -771,8 +774,11 @@ template <bool SPH>
 PT_DEV void ray_step_tri_enter(const PtScene& sc, LaneRay& r, bool any_hit, TravCtx& c) {
     uint32_t rec = stk_pop(c, r.top, r.sp) & PT_LEAF_FIRST_MASK;
     bool leaf_hit = false;
-    for (;;) {
-        TriVerts t0 = load_tri(sc.tris, rec);
+    TriVerts t0 = load_tri(sc.tris, rec);
+    for (;; rec++) {
+#if PT_INST_LEAF_PREFETCH
+        const TriVerts t_next = load_tri(sc.tris, rec + 1u);          // on its way while this record is tested (the array is padded by one record)
+#endif
         TriHit h;
         c.n_tris++;
         bool hit = false;
@@ -810,7 +816,11 @@ PT_DEV void ray_step_tri_enter(const PtScene& sc, LaneRay& r, bool any_hit, Trav
             r.ray_tmax = h.t;
         }
         if (last) break;
-        rec++;
+#if PT_INST_LEAF_PREFETCH
+        t0 = t_next;
+#else
+        t0 = load_tri(sc.tris, rec + 1u);
+#endif
     }
     if (leaf_hit) r.tmax = r.ray_tmax;
 }
@@ -1764,7 +1774,11 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_WAVES) k_trace_s
     trace_body<false, false>(sc, P, Q, cnt, spill, spill_depth, err);
 }
 // scenes with object instances (and possibly spheres): a leaf record may stand for a TransformedPrimitive
-extern "C" __global__ void __launch_bounds__(PT_BLOCK, 2) k_trace_inst(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
+#ifndef PT_TRACE_INST_WAVES
+#define PT_TRACE_INST_WAVES 3      // 164 registers, 14 spilled; at two (154 / 41 as the compiler chose) 615 / 1 130 / 433 Mrays/s on three instanced scenes, here 628 / 1 184 / 440;
+#endif                            // a triangle-only instantiation for scenes without spheres (162, nothing spilled) is no faster: 637 / 1 165 / 444
+
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_TRACE_INST_WAVES) k_trace_inst(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt, uint32_t* spill,
                                                                        uint32_t spill_depth, uint32_t* err) {
     trace_body<false, true, true>(sc, P, Q, cnt, spill, spill_depth, err);
 }
