@@ -153,6 +153,12 @@ def test_stack_spill_build(oracle, tmp_path):
     ctx.film_clear(); ctx.render()
     ox, _, _ = osc.render(threads=8)
     assert rel_l2(ctx.film_rgb(), osc.resolve_rgb(ox)) <= 1e-3
+    osc.close()
+    # ... and rays that enter instances with their way back (the rest of the leaf, the slab interval, the marker) in the HBM part of the stack
+    sd = fs.scene_instance_swarm("sah", 4, n_inst=12, res=32, spp=4)
+    osc = oracle.scene(sd)
+    ctx.upload(sd)
+    _compare(ctx, osc, exact_film=True)
     ctx.close(); osc.close()
 
 
