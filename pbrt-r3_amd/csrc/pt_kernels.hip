@@ -3111,6 +3111,10 @@ extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_s
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_shade_general_inst(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
 }
+// ... without textures and without spheres: the lobe-list kernel with the instance-space reconstruction, nothing else
+extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_WIDE_KERNEL_WAVES) k_shade_general_inst_plain(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
+    shade_body<true, false, false, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_MATTE_END], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET2]);
+}
 // scenes with textured materials (and possibly spheres): lobes are built per hit for the textured ones
 extern "C" __global__ void __launch_bounds__(PT_BLOCK, PT_SHADE_TEX_WAVES) k_shade_general_tex(PtScene sc, PtPaths P, PtQueues Q, PtCounters* cnt) {
     shade_body<true, true, true>(sc, P, Q, cnt, Q.sorted, Q.counts[PT_Q_TEX_BEGIN], Q.counts[PT_Q_GENERAL_END], &Q.counts[PT_Q_TICKET3]);
@@ -4346,7 +4350,7 @@ hipError_t ptk_shade(hipStream_t st, int grid, const PtScene& sc, const PtPaths&
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(PT_SORT_BINS), 0, st, Q);
         hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(PT_BLOCK), 0, st, sc, P, Q);
         if (sc.n_instances) {
-            PT_RUN(k_shade_general_inst);
+            if (!sc.textured && !sc.n_spheres) PT_RUN(k_shade_general_inst_plain); else PT_RUN(k_shade_general_inst);
         } else if (sc.textured) {       // three segments: Matte | other constant materials | textured materials
             matte_sorted();
             general();

@@ -188,6 +188,7 @@ def test_kernel_register_budgets():
         "k_shade": (256, 0, 40960),              # two waves per SIMD, nothing in scratch
         "k_shade_matte_sorted": (256, 0, 40960),
         "k_shade_general": (256, 0, 40960),
+        "k_shade_general_inst_plain": (256, 0, 40960),   # scenes with instances and neither textures nor spheres: the lobe-list kernel + the instance-space reconstruction, nothing spilled
         "k_shade_general_tex": (256, 140, 40960),    # the one-kernel form of the textured segment (PBRTGPU_TEX_SPLIT=0, scenes with instances)
         "k_shade_general_res": (256, 0, 40960),      # the textured segment's shading half: nothing spilled
         "k_tex_resolve": (256, 32, 40960),           # ... and its texture half, the texture code inlined, the interpreter's node values in LDS: 28 registers spilled, 116 B of scratch
