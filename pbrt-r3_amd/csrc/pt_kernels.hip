@@ -1149,7 +1149,7 @@ PT_DEV void node_step_coop(const PtScene& sc, LaneRay& r, TravCtx& c, bool w_nod
                      "v_swap_b32 %0, %12\n\tv_swap_b32 %1, %13\n\tv_swap_b32 %2, %14\n\tv_swap_b32 %3, %15\n\t"
                      "v_swap_b32 %4, %16\n\tv_swap_b32 %5, %17\n\tv_swap_b32 %6, %18\n\tv_swap_b32 %7, %19\n\t"
                      "v_swap_b32 %8, %20\n\tv_swap_b32 %9, %21\n\tv_swap_b32 %10, %22\n\tv_swap_b32 %11, %23\n\t"
-                     "s_mov_b64 exec, %[sv]"
+                     "s_mov_b64 exec, %[sv]\n\ts_nop 1"          // (a DPP read of a register a VALU instruction has just written needs two wait states; the compiler does not see into this block)
                      : "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w), "+v"(x3.x), "+v"(x3.y), "+v"(x3.z), "+v"(x3.w),
                        "+v"(x4.x), "+v"(x4.y), "+v"(x4.z), "+v"(x4.w), "+v"(x5.x), "+v"(x5.y), "+v"(x5.z), "+v"(x5.w), "+v"(x6.x), "+v"(x6.y), "+v"(x6.z), "+v"(x6.w), [sv] "=&s"(sv)
                      : [om] "s"(kOdd));
