@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--light", default="quad", choices=["quad", "sphere"], help="quad = the headline; sphere = an analytic sphere light instead (secondary number: k_trace_sph / k_shade_*_sph)")
     ap.add_argument("--integrator", default="path", choices=["path", "ao", "directlighting", "whitted"],
                     help="path = the headline; ao = Integrator \"ao\" with 64 occlusion rays per camera sample; directlighting / whitted = the recursive integrators (secondary numbers)")
+    ap.add_argument("--instances", type=int, default=0, help="secondary number: the filler triangles as ONE object instanced this many times (k_trace_inst, k_shade_general_inst*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spp1024", action="store_true", help="skip the secondary 1024-spp frame (N=1 only)")
     ap.add_argument("--cpu-tiles", type=int, default=0, help="tiles in the CPU sample (0 = auto, about 15 s)")
@@ -140,7 +141,7 @@ def main():
     t_prog = time.time()
     pkg = importlib.import_module("pbrt-r3_amd")
     t0 = time.time()
-    sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, s=args.tri_size, materials=args.materials, sampler=args.sampler, light=args.light)
+    sd = pkg.scenes.rt1m(args.triangles, res=args.res, spp=args.spp, max_depth=args.max_depth, s=args.tri_size, materials=args.materials, sampler=args.sampler, light=args.light, instances=args.instances)
     if args.integrator == "ao":
         sd.desc.integrator, sd.desc.ao_samples, sd.desc.ao_cos_sample = pkg.capi.PT_INTEGRATOR_AO, 64, 1
     elif args.integrator in ("directlighting", "whitted"):
@@ -300,6 +301,8 @@ def main():
                "sampler": args.sampler, "light": args.light, "integrator": args.integrator}
         if args.tri_size != 0.005:
             key["tri_size"] = args.tri_size
+        if args.instances > 0:
+            key["instances"] = args.instances
         import glob
         import hashlib
         # a PMC measurement describes the kernels it was taken on: entries carry sha256(pt_kernels.hip)[:16], and one taken on other
@@ -332,7 +335,8 @@ def main():
         # fraction can exceed 1; `traffic` (and `hbm_measured`) is what the counters saw leave L2, `l1_req` the bound that holds then.
         roofline = {"bound": "hbm", "achieved": round(alg_gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg_gbps / 8000.0, 4), "traffic": traffic}
         roofline.update({
-                    "kernel": ("k_trace_sph_dist" if args.light == "sphere" else
+                    "kernel": ("k_trace_inst" if args.instances > 0 else
+                               "k_trace_sph_dist" if args.light == "sphere" else
                                "k_trace_far" if os.environ.get("PBRTGPU_TRACE_FAR") == "1" else
                                "k_trace" if (os.environ.get("PBRTGPU_TRACE_FAR") == "0" or scene_bytes <= 256 * 2 ** 20) else
                                "k_trace or k_trace_far (scenes beyond the Infinity Cache: the library's timed trial on the first incoherent bounce picks one)"),
@@ -437,7 +441,7 @@ def main():
         if world == 1 and not args.no_spp1024 and args.spp != 1024:
             # north_star's target sentence quotes 1024 spp for the same scene (BASELINE config 2 says 256; Mrays/s is spp-independent,
             # wall-clock scales): one extra frame at 1024 spp, wall-clock reported beside the headline
-            sd4 = pkg.scenes.rt1m(args.triangles, res=args.res, spp=1024, max_depth=args.max_depth, s=args.tri_size, materials=args.materials, sampler=args.sampler, light=args.light)
+            sd4 = pkg.scenes.rt1m(args.triangles, res=args.res, spp=1024, max_depth=args.max_depth, s=args.tri_size, materials=args.materials, sampler=args.sampler, light=args.light, instances=args.instances)
             sd4.desc.integrator, sd4.desc.ao_samples, sd4.desc.ao_cos_sample = sd.desc.integrator, sd.desc.ao_samples, sd.desc.ao_cos_sample
             sd4.desc.direct_strategy = sd.desc.direct_strategy
             if args.integrator in ("directlighting", "whitted"):
@@ -480,6 +484,8 @@ def main():
             out["config"]["workload"] = out["config"]["workload"].replace("path maxdepth %d" % args.max_depth, "ao nsamples 64 cossample")
             if roofline:
                 roofline["kernel"] = "k_trace (camera rays, then the occlusion rays as shadow work items)"
+        if args.instances > 0:
+            out["config"]["workload"] = out["config"]["workload"].replace("RT1M: ", "RT1M instanced: the filler triangles as one object, %d instances (%d triangles on screen); " % (args.instances, 12 + args.instances * (sd.desc.n_triangles - 12)))
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -767,7 +767,7 @@ def cornell_box(res=512, spp=64, max_depth=5, light_strategy="spatial", sampler=
     return b.build()
 
 
-def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequence=1, sampler="sobol", materials="matte", light="quad"):
+def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequence=1, sampler="sobol", materials="matte", light="quad", instances=0):
     """BASELINE config 2 ("RT1M"): 12-triangle enclosure + light, the rest random matte triangles.
 
     Filler triangle k draws, in order, cx cy cz then v0x..v2z as lerp(uniform_float(), lo, hi)
@@ -787,6 +787,10 @@ def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequ
     _quad(b, (-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1))      # right
     _quad(b, (1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1))          # left
     n_fill = max(0, int(n_triangles) - 12)
+    if instances > 0 and n_fill:
+        # secondary workload (bench.py --instances K): the filler triangles become ONE object, instanced K times on a g x g x g grid of cells
+        # (g = ceil(cbrt(K)), each copy scaled by 1 / g) -- K x n_fill triangles on screen for n_fill in memory; k_trace_inst / k_shade_general_inst*
+        b.object_begin("fill")
     if n_fill:
         u = pcg32_uniform_float(12 * n_fill, seed_sequence).reshape(n_fill, 12)
         one = f32(1.0)
@@ -828,6 +832,18 @@ def rt1m(n_triangles=1000000, res=1024, spp=256, max_depth=8, s=0.005, seed_sequ
                     setm()
                     b.shape_trianglemesh_fast(verts[3 * lo:3 * hi], np.arange(3 * (hi - lo)), twosided=True)
             b.material_matte((0.5, 0.5, 0.5))
+    if instances > 0 and n_fill:
+        b.object_end()
+        g = int(np.ceil(instances ** (1.0 / 3.0) - 1e-9))
+        k = 0
+        for iz in range(g):
+            for iy in range(g):
+                for ix in range(g):
+                    if k < instances:
+                        c = [(-1.0 + (2 * i + 1) / g) * 0.9 for i in (ix, iy, iz)]
+                        b.object_instance("fill", transform_mul(transform_translate(c[0], c[1], c[2]), transform_scale(1.0 / g, 1.0 / g, 1.0 / g)))
+                        k += 1
+        b.material_matte((0.5, 0.5, 0.5))
     b.area_light_source_diffuse(L=(17, 12, 4))
     if light == "sphere":       # secondary workload: an analytic sphere light (the sphere-capable kernel instantiations run)
         t = transform_translate(0.0, 0.85, 0.0)
