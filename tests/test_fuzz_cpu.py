@@ -28,3 +28,34 @@ def test_random_scene_is_deterministic_and_renders(oracle, seed):
         assert (oracle.reference_panics() & 1) == (1 if seed == 970 else 0)        # seed 970: the scene that found quirk Q24
     finally:
         osc.close()
+
+
+def test_instanced_bench_scene_is_the_plain_one_copied(oracle):
+    """bench.py --instances K (scenes.rt1m(instances=K)): the filler triangles become one object, instanced on a g x g x g grid.  With K = 1 the one
+    instance sits under the identity (g = 1: scale 1, centre 0), so the oracle must see exactly the plain scene's image -- through TransformedPrimitive
+    instead of through the world's own tree -- and with K = 8 eight scaled copies: more geometry in the same triangle arrays."""
+    from helpers import pkg
+    plain = pkg.scenes.rt1m(2012, res=24, spp=2, max_depth=4)
+    one = pkg.scenes.rt1m(2012, res=24, spp=2, max_depth=4, instances=1)
+    eight = pkg.scenes.rt1m(2012, res=24, spp=2, max_depth=4, instances=8)
+    assert (plain.desc.n_instances, one.desc.n_instances, eight.desc.n_instances) == (0, 1, 8)
+    assert plain.desc.n_triangles == one.desc.n_triangles == eight.desc.n_triangles
+    m = list(one.desc.instances[0].instance_to_world)
+    assert m == [1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+    centres = sorted((round(eight.desc.instances[i].instance_to_world[3], 3), round(eight.desc.instances[i].instance_to_world[7], 3), round(eight.desc.instances[i].instance_to_world[11], 3))
+                     for i in range(8))
+    assert centres == sorted((x, y, z) for x in (-0.45, 0.45) for y in (-0.45, 0.45) for z in (-0.45, 0.45))
+    imgs = []
+    for sd in (plain, one, eight):
+        osc = oracle.scene(sd)
+        x, cnt, _ = osc.render(threads=4)
+        imgs.append((x, cnt))
+        osc.close()
+    # identity instance: the same picture, sample for sample wherever the origin nudge of Transform::transform_ray (the error bound it adds along the
+    # direction) does not send a later bounce to a neighbouring 5 mm triangle: most pixels agree to rounding, the image means closely
+    a, b = imgs[0][0], imgs[1][0]
+    same = np.isclose(a[..., :3], b[..., :3], rtol=1e-3, atol=1e-5).all(axis=-1).mean()
+    assert same > 0.5, same
+    assert abs(a[..., 1].mean() - b[..., 1].mean()) < 0.1 * a[..., 1].mean()
+    assert np.array_equal(a[..., 3], b[..., 3])
+    assert imgs[2][1]["nodes_visited"] > imgs[0][1]["nodes_visited"]
